@@ -1,0 +1,251 @@
+/*
+ * trifinger.h - C ABI of the MI355X-native TriFinger vectorised environment step.
+ *
+ * This is the INNER drop-in boundary: the surface the reference's
+ * task layer reaches through `isaacgym.gymapi` / `gymtorch`, re-cut as a plain C ABI so a
+ * host in any language can bind it (ctypes stub: leibnizgym_amd/_capi.py).
+ * No torch types appear here: every buffer is a raw device pointer owned by the caller.
+ *
+ * Two shared libraries export exactly these symbols with identical signatures:
+ *   leibnizgym_amd/csrc/libtrifinger_hip.so   the product: hand-written HIP kernels for gfx950
+ *   oracle/_build/libtrifinger_oracle.so      TEST INFRASTRUCTURE: scalar C restatement (pointers are
+ *                                             host pointers, the stream argument is ignored)
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   tf_create / tf_destroy      gymapi.acquire_gym, create_sim, prepare_sim, destroy_sim
+ *                               leibnizgym/envs/env_base.py:151,593,598,438
+ *   tf_set_gravity              gymapi set_sim_params          env_base.py:175-193
+ *   tf_bind                     acquire_*_tensor + gymtorch.wrap_tensor (ownership inverted: the caller
+ *                               allocates, the library receives pointers)
+ *                               leibnizgym/envs/trifinger/trifinger_env.py:594-617
+ *   tf_step                     IsaacEnvBase.step body: masked _reset_impl/_goal_reset_impl, _pre_step,
+ *                               control_decimation x simulate, _post_step, step counters, timeout, dones
+ *                               env_base.py:370-399; trifinger_env.py:373-559,959-1265
+ *   tf_reset                    IsaacEnvBase.reset body        env_base.py:322-343
+ *   tf_frame_count              gymapi.get_frame_count         env_base.py:289
+ *   tf_apply_resets             set_dof_state_tensor_indexed / set_actor_root_state_tensor_indexed (mask
+ *                               based, no index lists, no host sync)   trifinger_env.py:419-423,439
+ *   tf_pre_step                 TrifingerEnv._pre_step + set_dof_actuation_force_tensor  trifinger_env.py:442-498
+ *   tf_simulate                 gymapi.simulate (+fetch_results)       env_base.py:336-339,383-387
+ *   tf_post_step                TrifingerEnv._post_step + refresh_*_tensor   trifinger_env.py:500-559,959-994
+ *   tf_finish_step              env_base.py:391-399 (steps += 1, timeout, dones)
+ *
+ * Conventions: every entry returns a TfStatus (0 ok, negative = error; the Python host maps them to the
+ * exception types the reference raises).  No entry allocates device memory or synchronises after tf_bind.
+ * One handle <-> one stream <-> one GPU; handles are thread-compatible, not thread-safe.
+ */
+#ifndef TRIFINGER_H_
+#define TRIFINGER_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TF_API_VERSION 1
+
+typedef enum TfStatus {
+    TF_OK = 0,
+    TF_ERR_INVALID_ARG = -1,     /* NULL pointer, non-positive size ...                          */
+    TF_ERR_COMMAND_MODE = -2,    /* ValueError  trifinger_env.py:476-478,649-651                 */
+    TF_ERR_ROBOT_RESET = -3,     /* ValueError  trifinger_env.py:1142-1144                       */
+    TF_ERR_OBJECT_RESET = -4,    /* ValueError  trifinger_env.py:1174-1177                       */
+    TF_ERR_DIFFICULTY = -5,      /* ValueError  trifinger_env.py:1244-1246                       */
+    TF_ERR_NOT_BOUND = -6,       /* tf_step before tf_bind                                       */
+    TF_ERR_DEVICE = -7,          /* HIP runtime error (tf_last_error_string has the text)        */
+    TF_ERR_UNSUPPORTED = -8      /* valid in the reference, not built yet                        */
+} TfStatus;
+
+/* command_mode (trifinger_env.py:36-37,460-478) */
+enum { TF_CMD_TORQUE = 0, TF_CMD_POSITION = 1, TF_CMD_POSITION_IMPEDANCE = 2 };
+/* reset_distribution.*.type (trifinger_env.py:48-68) */
+enum { TF_RESET_NONE = 0, TF_RESET_DEFAULT = 1, TF_RESET_RANDOM = 2 };
+
+/* reward terms, in the evaluation order of trifinger_env.py:513-550 */
+enum {
+    TF_REW_FINGER_REACH_OBJECT_RATE = 0,
+    TF_REW_FINGER_MOVE_PENALTY = 1,
+    TF_REW_OBJECT_DIST = 2,
+    TF_REW_OBJECT_ROT = 3,
+    TF_REW_OBJECT_ROT_DELTA = 4,
+    TF_REW_OBJECT_MOVE = 5,
+    TF_NUM_REWARD_TERMS = 6
+};
+
+/* Rows of the structure-of-arrays state matrix: float state[TF_STATE_ROWS][num_envs]
+ * (row-major; env i of row r is state[r * num_envs + i]).  Quaternions are xyzw
+ * (leibnizgym/utils/torch_utils.py:99-111). */
+enum {
+    TF_S_Q = 0,          /*  9 joint positions   (finger 0: 0..2, finger 120: 3..5, finger 240: 6..8) */
+    TF_S_QD = 9,         /*  9 joint velocities                                                   */
+    TF_S_CUBE_P = 18,    /*  3 cube position                                                      */
+    TF_S_CUBE_Q = 21,    /*  4 cube orientation                                                   */
+    TF_S_CUBE_V = 25,    /*  3 cube linear velocity                                               */
+    TF_S_CUBE_W = 28,    /*  3 cube angular velocity                                              */
+    TF_S_GOAL_P = 31,    /*  3 goal position      (_object_goal_poses_buf, trifinger_env.py:588)  */
+    TF_S_GOAL_Q = 34,    /*  4 goal orientation                                                   */
+    TF_S_GOAL_W = 38,    /*  3 goal angular velocity (_object_goal_movement_buf[:,3:6], :590)     */
+    TF_S_TIP_P = 41,     /*  9 fingertip positions of the last filled frame (history[0][:, :, 0:3]) */
+    TF_S_TAU = 50,       /*  9 applied joint torque (what set_dof_actuation_force_tensor received) */
+    TF_S_PREV_OBJ_P = 59,/*  3 object position of history[1]; written by the split path only      */
+    TF_S_PREV_OBJ_Q = 62,/*  4 object orientation of history[1]; split path only                  */
+    TF_S_FT = 66,        /* 18 fingertip contact wrench (world frame force 3 + torque 3 per finger about
+                              the tip-link origin, mean over the substeps of the step); split path only */
+    TF_STATE_ROWS = 84
+};
+
+#define TF_OBS_DIM_BASE 32    /* 9 + 9 + 7 + 7; the action slot (9 or 18) follows  trifinger_env.py:280-286 */
+#define TF_STATES_EXTRA 72    /* 6 + 39 + 9 + 18                                   trifinger_env.py:296-300 */
+#define TF_NUM_INFO 16
+
+/* info[] slots written by every step (device floats, no host sync):
+ *   0..5  mean of reward term k over envs (env/rewards/<term>, only meaningful when active)
+ *   6     env/current_position_goal/count        7  env/current_orientation_goal/count
+ *   8     env/average_consecutive_success        9  number of envs reset in this step (diagnostic)
+ *   10    number of envs with a non-finite state caught by the NaN guard (diagnostic)
+ */
+enum { TF_INFO_REW0 = 0, TF_INFO_POS_COUNT = 6, TF_INFO_ORI_COUNT = 7, TF_INFO_SUCCESS_MEAN = 8,
+       TF_INFO_NUM_RESETS = 9, TF_INFO_NUM_NONFINITE = 10 };
+
+typedef struct TfRewardTerm {
+    int32_t activate;
+    float weight;
+    double sched_start;      /* thresh_sched_* (or linear_schedule_* for object_rot_delta); rewards.py:45-47 */
+    double sched_end;
+} TfRewardTerm;
+
+/* Physical model: the build-authored spec of what the reference asks IsaacGym to simulate
+ * (SURVEY.md section 8a-P).  tf_default_model() fills it from the URDF numbers. */
+typedef struct TfModel {
+    /* finger kinematic chain, identical for the three fingers (trifingerpro.urdf:161-190,461-475) */
+    float base_height;            /* 0.29   base_to_upper_holder_joint                              */
+    float base_yaw_cos[3];        /* yaw {0, -120deg, -240deg}                                      */
+    float base_yaw_sin[3];
+    float base_half_yaw_cos[3];   /* cos/sin of yaw/2 (fingertip orientation quaternion)            */
+    float base_half_yaw_sin[3];
+    float j2_origin[3];           /* (0.01685, 0.0505, 0)      in upper frame                        */
+    float j3_origin[3];           /* (0.04922, 0, -0.16)       in middle frame                       */
+    float tip_origin[3];          /* (0.0185, 0, -0.1626)      in lower frame (finger_tip_link)      */
+    /* links 1..3 = upper, middle, lower(+tip merged).  inertia = xx,yy,zz,xy,xz,yz about the COM    */
+    float link_mass[3];
+    float link_com[3][3];
+    float link_inertia[3][6];
+    /* joint properties (trifinger_env.py:149-158,774-787) */
+    float q_lo[3], q_hi[3];
+    float qd_max;                 /* 10 rad/s                                                        */
+    float tau_max;                /* 0.36 Nm                                                         */
+    float link_angular_damping;   /* 0.01 (trifinger_env.py:866)                                     */
+    float q_default[3];           /* (0, 0.9, -1.7)                                                  */
+    /* collision primitives (build's choice; SURVEY 8a-P "measured") */
+    float cap_a[3], cap_b[3];     /* distal-link capsule end points in the lower frame; b = tip sphere centre */
+    float cap_radius;             /* 0.0102                                                          */
+    /* cube (cube_multicolor_rrc.urdf:10-18) */
+    float cube_half;              /* 0.0325 */
+    float cube_mass;              /* 291.3 * 0.065^3 */
+    float cube_inertia;           /* m s^2 / 6 (isotropic)                                           */
+    float cube_linear_damping, cube_angular_damping;
+    /* arena */
+    float wall_radius;            /* inner radius of the boundary annulus (0.192)                    */
+    float wall_height;            /* the vertical part of the wall ends here (0.06)                  */
+    /* materials: PhysX "average" combine of trifinger_env.py:364-365,876-878,914-915,934-936 */
+    float mu_finger_cube, mu_cube_floor, mu_tip_floor, mu_cube_wall;
+    float restitution_finger;     /* average(0.8, 0) */
+    float bounce_threshold;       /* 0.5 m/s  (scripts/rlg_hydra.py:32)                              */
+    float contact_margin;         /* rows are generated for gaps below this                          */
+    float contact_offset;         /* 0.002 (scripts/rlg_hydra.py:30): restitution applies below it   */
+    float erp;                    /* fraction of penetration removed per substep                     */
+    float max_depenetration_velocity;
+} TfModel;
+
+typedef struct TfConfig {
+    int32_t api_version;          /* TF_API_VERSION */
+    int32_t num_envs;             /* envs owned by this handle (this GPU)                            */
+    int32_t env_id_offset;        /* global id of local env 0 (RNG is keyed by global id -> results  */
+    int32_t global_num_envs;      /*   are invariant to the number of GPUs); total over all ranks    */
+    uint64_t seed;
+    /* MDP (trifinger_env.py:28-115) */
+    int32_t command_mode;
+    int32_t normalize_action, normalize_obs, apply_safety_damping;
+    int32_t asymmetric_obs, enable_ft_sensors;
+    int32_t task_difficulty;
+    int32_t episode_length;       /* <= 0: no time-out (None in the reference)                       */
+    int32_t control_decimation;
+    int32_t robot_reset_type;  float dof_pos_stddev, dof_vel_stddev;
+    int32_t object_reset_type;
+    int32_t goal_rotation_activate; float goal_rotation_rate_magnitude;
+    TfRewardTerm reward[TF_NUM_REWARD_TERMS];
+    int32_t finger_reach_norm_p;  /* only p = 2 is built (both shipped configs use 2)               */
+    float object_rot_scale;       /* ObjectRotationReward.scale  rewards.py:109                      */
+    int32_t success_activate; float success_bonus, position_tolerance, orientation_tolerance;
+    /* physics stepping (env_base.py:47-70, scripts/rlg_hydra.py:15-35) */
+    float dt;                     /* seconds per simulate() call                                     */
+    int32_t substeps;             /* solver substeps per simulate()                                  */
+    int32_t solver_iterations;    /* num_position_iterations                                         */
+    float gravity[3];
+    TfModel model;
+} TfConfig;
+
+typedef struct TfBuffers {
+    float* state;            /* [TF_STATE_ROWS][N]  SoA, resident between steps                      */
+    float* action_buf;       /* [N][A] row-major; what the reference calls _action_buf               */
+    float* obs;              /* [N][TF_OBS_DIM_BASE + A] row-major                                   */
+    float* states;           /* [N][obs_dim + 72] row-major; may be NULL when !asymmetric_obs        */
+    float* reward;           /* [N]                                                                  */
+    uint8_t* reset_buf;      /* [N] _reset_buf                                                        */
+    uint8_t* goal_reset_buf; /* [N] _goal_reset_buf                                                   */
+    uint8_t* successes;      /* [N] _successes                                                        */
+    uint8_t* dones;          /* [N] reset_buf & goal_reset_buf (env_base.py:399)                      */
+    int32_t* steps;          /* [N] _steps_count_buf                                                  */
+    uint32_t* reset_count;   /* [N] number of RNG draws consumed (Philox counter high word)           */
+    float* info;             /* [TF_NUM_INFO]                                                         */
+    float* scratch;          /* [tf_scratch_floats(N)] reduction partials                             */
+} TfBuffers;
+
+typedef struct TfHandle_* tf_handle;
+
+int tf_api_version(void);
+const char* tf_backend_name(void);              /* "hip-gfx950" or "oracle-c" */
+const char* tf_last_error_string(void);
+void tf_default_model(TfModel* out);
+int tf_action_dim(int32_t command_mode);        /* 9, 9, 18; negative TfStatus on a bad mode */
+int64_t tf_scratch_floats(int32_t num_envs);
+
+int tf_create(const TfConfig* cfg, tf_handle* out);
+int tf_destroy(tf_handle h);
+int tf_bind(tf_handle h, const TfBuffers* bufs);
+int tf_set_gravity(tf_handle h, const float g[3]);
+int64_t tf_frame_count(tf_handle h);
+int tf_set_frame_count(tf_handle h, int64_t frames);
+
+/* The hot path: one control step for every env of the handle, fused, on `stream` (hipStream_t). */
+int tf_step(tf_handle h, const float* action /* [N][A] row-major, device */, void* stream);
+/* IsaacEnvBase.reset: reset every env, zero action, ONE simulate, fill obs/states. */
+int tf_reset(tf_handle h, void* stream);
+
+/* Split path (same arithmetic, one hook per launch) kept for the parity tests. */
+int tf_apply_resets(tf_handle h, void* stream);       /* masked _reset_impl then _goal_reset_impl */
+int tf_pre_step(tf_handle h, void* stream);            /* action_buf -> state[TF_S_TAU]            */
+int tf_simulate(tf_handle h, void* stream);            /* one simulate(): `substeps` solver steps  */
+int tf_post_step(tf_handle h, void* stream);           /* obs/states, rewards, termination, info   */
+int tf_finish_step(tf_handle h, void* stream);         /* steps += 1, time-out, dones              */
+
+/* Leaf kernels exposed for the golden-vector tests (T7, T11, T12). n rows each. */
+int tf_test_quat_diff_rad(const float* a, const float* b, float* out, int32_t n, void* stream);
+int tf_test_quat_mul(const float* a, const float* b, float* out, int32_t n, void* stream);
+int tf_test_lgsk(const float* x, float scale, float* out, int32_t n, void* stream);
+int tf_test_sample_xy(const float* u_radius, const float* u_theta, float r_max, float* x, float* y, int32_t n, void* stream);
+int tf_test_sample_yaw_quat(const float* u, float* quat, int32_t n, void* stream);
+int tf_test_normalize_quat(const float* normals, float* quat, int32_t n, void* stream);
+/* counter-based RNG: 4 uint32 per (seed, env_id, reset_count, stream_id)  */
+int tf_test_philox(uint64_t seed, const uint32_t* env_id, const uint32_t* counter, uint32_t stream_id,
+                   uint32_t* out4, int32_t n, void* stream);
+/* forward kinematics of one finger: q[n][3] -> tip position in the finger base frame [n][3] and the 3x3
+ * joint-space mass matrix [n][9] (row-major) + bias forces [n][3] for qd[n][3] */
+int tf_test_finger_dynamics(tf_handle h, const float* q, const float* qd, float* tip, float* mass, float* bias,
+                            int32_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIFINGER_H_ */

@@ -1,0 +1,267 @@
+"""Thin owner of the device buffers behind one native handle.
+
+`TrifingerEngine` is the Python face of the inner boundary (include/trifinger.h): it allocates the
+torch tensors the native library works on (ownership is inverted with respect to
+`gymtorch.wrap_tensor`, reference trifinger_env.py:594-617), binds their addresses once, and
+forwards `step`/`reset` to the fused HIP launch on torch's current stream.  No arithmetic of the
+hot path lives here and there is no fallback: without the HIP library (or an injected one in the
+tests) construction fails.
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi as capi
+
+
+def default_reward_terms():
+    """Reward configuration of the env's default dict (reference trifinger_env.py:76-104)."""
+    return {
+        "finger_reach_object_rate": {"activate": True, "weight": -750, "norm_p": 2},
+        "finger_move_penalty": {"activate": True, "weight": -0.1},
+        "object_dist": {"activate": True, "weight": 2000},
+        "object_rot": {"activate": True, "weight": 300},
+        "object_rot_delta": {"activate": True, "weight": -250},
+        "object_move": {"activate": True, "weight": -750},
+    }
+
+
+# defaults of each term's constructor (reference rewards.py:40-47,70,105-115,155-163,193-201,241-243)
+_TERM_DEFAULT_WEIGHT = {
+    "finger_reach_object_rate": -250, "finger_move_penalty": -1.0e-4, "object_dist": 2000,
+    "object_rot": 100, "object_rot_delta": 100, "object_move": -750,
+}
+
+
+def fill_reward_terms(cfg, reward_terms):
+    """Copy a reference-style `reward_terms` dict into TfConfig (names: rewards.py:267-274)."""
+    for k, name in enumerate(capi.REWARD_TERM_ORDER):
+        kw = dict(reward_terms.get(name, {"activate": False}))
+        term = cfg.reward[k]
+        term.activate = int(bool(kw.get("activate", False)))
+        term.weight = float(kw.get("weight", _TERM_DEFAULT_WEIGHT[name]))
+        if name == "object_rot_delta":
+            term.sched_start = float(kw.get("linear_schedule_start", 0))
+            term.sched_end = float(kw.get("linear_schedule_end", 0))
+        elif name in ("finger_reach_object_rate", "object_dist", "object_rot"):
+            term.sched_start = float(kw.get("thresh_sched_start", 0))
+            term.sched_end = float(kw.get("thresh_sched_end", 0))
+        else:
+            term.sched_start = 0.0
+            term.sched_end = 0.0
+    cfg.finger_reach_norm_p = int(reward_terms.get("finger_reach_object_rate", {}).get("norm_p", 2))
+    cfg.object_rot_scale = float(reward_terms.get("object_rot", {}).get("scale", 1.0))
+
+
+def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, command_mode="position",
+                normalize_action=True, normalize_obs=True, apply_safety_damping=True, asymmetric_obs=False,
+                enable_ft_sensors=False, task_difficulty=1, episode_length=750, control_decimation=1,
+                robot_reset="default", dof_pos_stddev=0.4, dof_vel_stddev=0.2, object_reset="random",
+                goal_rotation=False, goal_rotation_rate=0.5, reward_terms=None, success=None,
+                dt=0.02, substeps=2, solver_iterations=8, gravity=(0.0, 0.0, -9.81), model=None):
+    """Build a TfConfig.  String options are validated here with the reference's ValueErrors."""
+    if command_mode not in capi.COMMAND_MODES:
+        raise ValueError(f"Invalid command mode. Input: {command_mode} not in ['torque', 'position'].")
+    if robot_reset not in capi.RESET_TYPES:
+        raise ValueError(f"Invalid robot initial state distribution. Input: {robot_reset} not in [`default`, `random`].")
+    if object_reset not in capi.RESET_TYPES:
+        raise ValueError(f"Invalid object initial state distribution. Input: {object_reset} "
+                         "not in [`default`, `random`, `none`].")
+    if task_difficulty not in (-1, 1, 2, 3, 4, 5, 6):
+        raise ValueError(f"Invalid difficulty index for task: {task_difficulty}.")
+    cfg = capi.TfConfig()
+    cfg.api_version = capi.TF_API_VERSION
+    cfg.num_envs = int(num_envs)
+    cfg.env_id_offset = int(env_id_offset)
+    cfg.global_num_envs = int(global_num_envs) if global_num_envs else int(num_envs)
+    cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    cfg.command_mode = capi.COMMAND_MODES[command_mode]
+    cfg.normalize_action = int(bool(normalize_action))
+    cfg.normalize_obs = int(bool(normalize_obs))
+    cfg.apply_safety_damping = int(bool(apply_safety_damping))
+    cfg.asymmetric_obs = int(bool(asymmetric_obs))
+    cfg.enable_ft_sensors = int(bool(enable_ft_sensors or asymmetric_obs))   # trifinger_env.py:272-273
+    cfg.task_difficulty = int(task_difficulty)
+    cfg.episode_length = int(episode_length) if episode_length else 0
+    cfg.control_decimation = int(control_decimation)
+    cfg.robot_reset_type = capi.RESET_TYPES[robot_reset]
+    cfg.dof_pos_stddev = float(dof_pos_stddev)
+    cfg.dof_vel_stddev = float(dof_vel_stddev)
+    cfg.object_reset_type = capi.RESET_TYPES[object_reset]
+    cfg.goal_rotation_activate = int(bool(goal_rotation))
+    cfg.goal_rotation_rate_magnitude = float(goal_rotation_rate)
+    fill_reward_terms(cfg, reward_terms if reward_terms is not None else default_reward_terms())
+    s = {"activate": True, "bonus": 5000.0, "position_tolerance": 0.01, "orientation_tolerance": 0.2}
+    s.update(success or {})
+    cfg.success_activate = int(bool(s["activate"]))
+    cfg.success_bonus = float(s["bonus"])
+    cfg.position_tolerance = float(s["position_tolerance"])
+    cfg.orientation_tolerance = float(s["orientation_tolerance"])
+    cfg.dt = float(dt)
+    cfg.substeps = int(substeps)
+    cfg.solver_iterations = int(solver_iterations)
+    for i in range(3):
+        cfg.gravity[i] = float(gravity[i])
+    cfg.model = model if model is not None else lib.default_model()
+    return cfg
+
+
+_STATUS_TO_EXC = {
+    capi.TF_ERR_COMMAND_MODE: (ValueError, "Invalid command mode."),
+    capi.TF_ERR_ROBOT_RESET: (ValueError, "Invalid robot initial state distribution."),
+    capi.TF_ERR_OBJECT_RESET: (ValueError, "Invalid object initial state distribution."),
+    capi.TF_ERR_DIFFICULTY: (ValueError, "Invalid difficulty index for task."),
+    capi.TF_ERR_INVALID_ARG: (ValueError, "invalid argument"),
+    capi.TF_ERR_NOT_BOUND: (RuntimeError, "buffers not bound"),
+    capi.TF_ERR_DEVICE: (RuntimeError, "device error"),
+    capi.TF_ERR_UNSUPPORTED: (NotImplementedError, "configuration not built"),
+}
+
+
+def check(lib, status, what):
+    if status == capi.TF_OK:
+        return
+    exc, msg = _STATUS_TO_EXC.get(status, (RuntimeError, "error"))
+    raise exc(f"{what}: {msg} (status {status}; {lib.last_error()})")
+
+
+class TrifingerEngine:
+    """Buffers + handle for `num_envs` environments on one device."""
+
+    def __init__(self, cfg, device="cuda:0", lib=None):
+        self.device = torch.device(device)
+        if lib is None:
+            if self.device.type != "cuda":
+                raise RuntimeError(
+                    "the TriFinger step runs only as HIP kernels on an MI355X: device must be 'cuda:N' "
+                    f"(got '{device}'); there is no CPU path in this package")
+            lib = capi.load_hip_library()
+        self.lib = lib
+        self.cfg = cfg
+        n = cfg.num_envs
+        self.num_envs = n
+        self.action_dim = lib.tf_action_dim(cfg.command_mode)
+        check(lib, min(self.action_dim, 0), "tf_action_dim")
+        self.obs_dim = 32 + self.action_dim
+        self.states_dim = self.obs_dim + 72 if cfg.asymmetric_obs else 0
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.state = torch.zeros((capi.TF_STATE_ROWS, n), **f32)
+        self.state[capi.S_CUBE_Q + 3] = 1.0     # identity quaternions (xyzw)
+        self.state[capi.S_GOAL_Q + 3] = 1.0
+        self.state[capi.S_PREV_OBJ_Q + 3] = 1.0
+        self.action_buf = torch.zeros((n, self.action_dim), **f32)
+        self.obs = torch.zeros((n, self.obs_dim), **f32)
+        self.states = torch.zeros((n, self.states_dim), **f32)
+        self.reward = torch.zeros((n,), **f32)
+        self.reset_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
+        self.goal_reset_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
+        self.successes = torch.zeros((n,), dtype=torch.bool, device=dev)
+        self.dones = torch.zeros((n,), dtype=torch.bool, device=dev)
+        self.steps = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.reset_count = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.info = torch.zeros((capi.TF_NUM_INFO,), **f32)
+        self.scratch = torch.zeros((int(lib.tf_scratch_floats(n)),), **f32)
+        self._handle = C.c_void_p()
+        check(lib, lib.tf_create(C.byref(cfg), C.byref(self._handle)), "tf_create")
+        b = capi.TfBuffers()
+        b.state = self.state.data_ptr()
+        b.action_buf = self.action_buf.data_ptr()
+        b.obs = self.obs.data_ptr()
+        b.states = self.states.data_ptr() if self.states_dim else None
+        b.reward = self.reward.data_ptr()
+        b.reset_buf = self.reset_buf.data_ptr()
+        b.goal_reset_buf = self.goal_reset_buf.data_ptr()
+        b.successes = self.successes.data_ptr()
+        b.dones = self.dones.data_ptr()
+        b.steps = self.steps.data_ptr()
+        b.reset_count = self.reset_count.data_ptr()
+        b.info = self.info.data_ptr()
+        b.scratch = self.scratch.data_ptr()
+        self._bufs = b
+        check(lib, lib.tf_bind(self._handle, C.byref(b)), "tf_bind")
+        self._is_cuda = dev.type == "cuda"
+        if self._is_cuda:
+            self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _stream(self):
+        if self._is_cuda:
+            return C.c_void_p(torch.cuda.current_stream(self._dev_index).cuda_stream)
+        return None
+
+    def close(self):
+        if self._handle:
+            self.lib.tf_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def frame_count(self):
+        return int(self.lib.tf_frame_count(self._handle))
+
+    @frame_count.setter
+    def frame_count(self, v):
+        check(self.lib, self.lib.tf_set_frame_count(self._handle, int(v)), "tf_set_frame_count")
+
+    def set_gravity(self, g):
+        arr = (C.c_float * 3)(*[float(x) for x in g])
+        check(self.lib, self.lib.tf_set_gravity(self._handle, arr), "tf_set_gravity")
+
+    # -- hot path ---------------------------------------------------------------------------
+    def step(self, action):
+        """One fused control step.  `action`: contiguous float32 [N, A] tensor on the engine's device."""
+        check(self.lib, self.lib.tf_step(self._handle, C.c_void_p(action.data_ptr()), self._stream()), "tf_step")
+
+    def reset(self):
+        check(self.lib, self.lib.tf_reset(self._handle, self._stream()), "tf_reset")
+
+    # -- split path (tests) -----------------------------------------------------------------
+    def apply_resets(self):
+        check(self.lib, self.lib.tf_apply_resets(self._handle, self._stream()), "tf_apply_resets")
+
+    def pre_step(self):
+        check(self.lib, self.lib.tf_pre_step(self._handle, self._stream()), "tf_pre_step")
+
+    def simulate(self):
+        check(self.lib, self.lib.tf_simulate(self._handle, self._stream()), "tf_simulate")
+
+    def post_step(self):
+        check(self.lib, self.lib.tf_post_step(self._handle, self._stream()), "tf_post_step")
+
+    def finish_step(self):
+        check(self.lib, self.lib.tf_finish_step(self._handle, self._stream()), "tf_finish_step")
+
+    # -- named views of the SoA state ---------------------------------------------------------
+    def view(self, row, count):
+        return self.state[row:row + count]
+
+    @property
+    def q(self):
+        return self.state[capi.S_Q:capi.S_Q + 9]
+
+    @property
+    def qd(self):
+        return self.state[capi.S_QD:capi.S_QD + 9]
+
+    @property
+    def cube(self):
+        """[13, N]: position, quaternion (xyzw), linear velocity, angular velocity."""
+        return self.state[capi.S_CUBE_P:capi.S_CUBE_P + 13]
+
+    @property
+    def goal(self):
+        return self.state[capi.S_GOAL_P:capi.S_GOAL_P + 7]
+
+    @property
+    def tip_pos(self):
+        return self.state[capi.S_TIP_P:capi.S_TIP_P + 9]
+
+    @property
+    def tau(self):
+        return self.state[capi.S_TAU:capi.S_TAU + 9]

@@ -1,0 +1,1539 @@
+/*
+ * tf_oracle.c - TEST INFRASTRUCTURE.  Scalar C restatement of the TriFinger env-step hot path.
+ *
+ * This file is the ORACLE of the repository ("Oracle").  It is NOT part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built from
+ * it.  The product (leibnizgym_amd/csrc/trifinger_hip.hip) never includes, links or calls it.
+ *
+ * What it restates, and how each part is pinned:
+ *   - task layer (reference arithmetic visible): leibnizgym/envs/env_base.py:345-401,
+ *     leibnizgym/envs/trifinger/trifinger_env.py:373-559,959-1265, rewards.py, sample.py,
+ *     leibnizgym/utils/torch_utils.py.  PINNED against tests/golden/{name}.npz, which were produced by
+ *     importing the reference's own functions (tests/golden/make_golden.py).
+ *   - physics (reference arithmetic NOT visible: it lives in the closed-source IsaacGym/PhysX binary,
+ *     "NVIDIA IsaacGym Preview Release 2", README.md:17, not under /root/reference, no version pin):
+ *     PARITY UNPINNED.  The algorithm below is this build's own spec (DESIGN.md section "Physics spec"),
+ *     written from the URDF numbers and the solver settings the reference asks for, and is checked
+ *     against analytic known answers (tests/test_physics_analytic.py), not against IsaacGym.
+ *
+ * Arithmetic contract shared with the HIP kernels: fp32, IEEE add/mul/div/sqrt only, no FMA contraction
+ * (-ffp-contract=off on both sides), own polynomial sin/cos/exp/asin/log, fixed evaluation order.  The
+ * HIP path is therefore expected to match this file BIT FOR BIT on per-env outputs.
+ *
+ * Build: oracle/Makefile -> oracle/_build/libtrifinger_oracle.so   (gcc -O2 -ffp-contract=off)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/trifinger.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------ */
+/* deterministic elementary functions (coefficients: Cephes single-precision minimax polynomials)    */
+/* ------------------------------------------------------------------------------------------------ */
+static inline float f_min(float a, float b) { return (a < b) ? a : b; }
+static inline float f_max(float a, float b) { return (a > b) ? a : b; }
+static inline float f_clamp(float x, float lo, float hi) { return f_max(f_min(x, hi), lo); }
+static inline float f_abs(float a) { return (a < 0.0f) ? -a : a; }
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static void tf_sincos(float x, float* s_out, float* c_out) {
+    /* Cody-Waite reduction by pi/2, |x| < ~1e4 */
+    float k = rintf(x * 0.63661977236758134f);
+    int n = (int)k;
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.0f;
+    switch (n & 3) {
+        case 0: *s_out = ps; *c_out = pc; break;
+        case 1: *s_out = pc; *c_out = -ps; break;
+        case 2: *s_out = -ps; *c_out = -pc; break;
+        default: *s_out = -pc; *c_out = ps; break;
+    }
+}
+
+static float tf_exp(float x) {
+    x = f_clamp(x, -87.0f, 88.0f);
+    float k = rintf(x * 1.44269504088896341f);
+    int n = (int)k;
+    float r = x - k * 0.693359375f;
+    r = r - k * -2.12194440e-4f;
+    float z = r * r;
+    float p = ((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r
+               + 1.6666665459e-1f) * r + 5.0000001201e-1f;
+    float e = p * z + r + 1.0f;
+    return e * u2f((uint32_t)(n + 127) << 23);
+}
+
+static float tf_asin(float x) {
+    float a = f_abs(x);
+    a = f_min(a, 1.0f);
+    int big = a > 0.5f;
+    float z, y;
+    if (big) {
+        z = 0.5f * (1.0f - a);
+        y = sqrtf(z);
+    } else {
+        z = a * a;
+        y = a;
+    }
+    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
+               + 1.6666752422e-1f) * z * y + y;
+    if (big) p = 1.5707963267948966f - (p + p);
+    return (x < 0.0f) ? -p : p;
+}
+
+static float tf_log(float x) {
+    /* x > 0, normal.  Cephes logf. */
+    uint32_t u = f2u(x);
+    int e = (int)((u >> 23) & 0xff) - 126;
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u); /* [0.5, 1) */
+    if (m < 0.707106781186547524f) {
+        e = e - 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+                   + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+               + 3.3333331174e-1f) * m * z;
+    float fe = (float)e;
+    y = y + fe * -2.12194440e-4f;
+    y = y - 0.5f * z;
+    float r = m + y;
+    r = r + fe * 0.693359375f;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11; Random123)                                                   */
+/* ------------------------------------------------------------------------------------------------ */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; } /* [0,1) 24 bit */
+
+/* RNG stream tags (counter word 2) */
+enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4 };
+
+static void rng4(uint64_t seed, uint32_t env_gid, uint32_t count, uint32_t tag, float u[4]) {
+    uint32_t r[4];
+    philox4x32_10(env_gid, count, tag, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    for (int i = 0; i < 4; ++i) u[i] = u01(r[i]);
+}
+
+/* two uniforms -> two standard normals (Box-Muller) */
+static void box_muller(float ua, float ub, float* n0, float* n1) {
+    float r = sqrtf(-2.0f * tf_log(1.0f - ua));
+    float s, c;
+    tf_sincos(6.2831855f * ub, &s, &c);
+    *n0 = r * c;
+    *n1 = r * s;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* quaternion helpers (xyzw) - leibnizgym/utils/torch_utils.py:83-150                                */
+/* ------------------------------------------------------------------------------------------------ */
+static void quat_mul(const float a[4], const float b[4], float o[4]) {
+    /* 8-multiplication form, torch_utils.py:99-111 */
+    float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];
+    float x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+    float ww = (z1 + x1) * (x2 + y2);
+    float yy = (w1 - y1) * (w2 + z2);
+    float zz = (w1 + y1) * (w2 - z2);
+    float xx = ww + yy + zz;
+    float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+    o[3] = qq - ww + (z1 - y1) * (y2 - z2);
+    o[0] = qq - xx + (x1 + w1) * (x2 + w2);
+    o[1] = qq - yy + (w1 - x1) * (y2 + z2);
+    o[2] = qq - zz + (z1 + y1) * (w2 - x2);
+}
+
+static float quat_diff_rad(const float a[4], const float b[4]) {
+    /* torch_utils.py:131-150: 2 asin(min(|(a * conj(b)).xyz|, 1)) */
+    float bc[4] = {-b[0], -b[1], -b[2], b[3]};
+    float m[4];
+    quat_mul(a, bc, m);
+    float nrm = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    return 2.0f * tf_asin(f_min(nrm, 1.0f));
+}
+
+static float lgsk(float x, float scale) {
+    /* rewards.py:20-34 */
+    float s = x * scale;
+    return 1.0f / (tf_exp(s) + 2.0f + tf_exp(-s));
+}
+
+static void quat_to_rot(const float q[4], float R[9]) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float xx = x * x, yy = y * y, zz = z * z;
+    float xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy - wz);        R[2] = 2.0f * (xz + wy);
+    R[3] = 2.0f * (xy + wz);        R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz - wx);
+    R[6] = 2.0f * (xz - wy);        R[7] = 2.0f * (yz + wx);        R[8] = 1.0f - 2.0f * (xx + yy);
+}
+
+/* q <- normalize(q + 0.5 h (w,0) * q) */
+static void quat_integrate(float q[4], const float w[3], float h) {
+    float hx = 0.5f * h * w[0], hy = 0.5f * h * w[1], hz = 0.5f * h * w[2];
+    float x = q[0], y = q[1], z = q[2], s = q[3];
+    float nx = x + (hx * s + hy * z - hz * y);
+    float ny = y + (hy * s + hz * x - hx * z);
+    float nz = z + (hz * s + hx * y - hy * x);
+    float ns = s - (hx * x + hy * y + hz * z);
+    float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + ns * ns);
+    q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* handle                                                                                            */
+/* ------------------------------------------------------------------------------------------------ */
+#define MAX_OBS 50
+#define MAX_STATES 122
+
+struct TfHandle_ {
+    TfConfig cfg;
+    TfBuffers buf;
+    int bound;
+    int64_t frame_count;
+    int action_dim, obs_dim, states_dim;
+    float act_lo[18], act_hi[18];
+    float obs_off[MAX_OBS], obs_inv[MAX_OBS];
+    float st_off[MAX_STATES], st_inv[MAX_STATES];
+    float kp[9], kd[9], ks[9];
+};
+
+static char g_err[256] = "";
+
+int tf_api_version(void) { return TF_API_VERSION; }
+const char* tf_backend_name(void) { return "oracle-c"; }
+const char* tf_last_error_string(void) { return g_err; }
+int64_t tf_scratch_floats(int32_t num_envs) { (void)num_envs; return 16; }
+
+int tf_action_dim(int32_t mode) {
+    if (mode == TF_CMD_TORQUE || mode == TF_CMD_POSITION) return 9;
+    if (mode == TF_CMD_POSITION_IMPEDANCE) return 18;
+    return TF_ERR_COMMAND_MODE;
+}
+
+void tf_default_model(TfModel* m) {
+    memset(m, 0, sizeof(*m));
+    m->base_height = 0.29f;                                  /* trifingerpro.urdf:51-55 */
+    const double yaw[3] = {0.0, -2.09439510239, -4.18879020479}; /* :461-475 */
+    for (int f = 0; f < 3; ++f) {
+        m->base_yaw_cos[f] = (float)cos(yaw[f]);
+        m->base_yaw_sin[f] = (float)sin(yaw[f]);
+    }
+    m->base_yaw_cos[0] = 1.0f; m->base_yaw_sin[0] = 0.0f;
+    for (int f = 0; f < 3; ++f) {
+        m->base_half_yaw_cos[f] = (float)cos(0.5 * yaw[f]);
+        m->base_half_yaw_sin[f] = (float)sin(0.5 * yaw[f]);
+    }
+    m->base_half_yaw_cos[0] = 1.0f; m->base_half_yaw_sin[0] = 0.0f;
+    m->j2_origin[0] = 0.01685f; m->j2_origin[1] = 0.0505f; m->j2_origin[2] = 0.0f;      /* :180 */
+    m->j3_origin[0] = 0.04922f; m->j3_origin[1] = 0.0f;    m->j3_origin[2] = -0.16f;    /* :187 */
+    m->tip_origin[0] = 0.0185f; m->tip_origin[1] = 0.0f;   m->tip_origin[2] = -0.1626f; /* :164 */
+    /* upper  (:94-98) */
+    m->link_mass[0] = 0.26f;
+    m->link_com[0][0] = 0.0f; m->link_com[0][1] = 0.06f; m->link_com[0][2] = 0.0f;
+    m->link_inertia[0][0] = 0.000459333333333f; m->link_inertia[0][1] = 6.93333333333e-05f;
+    m->link_inertia[0][2] = 0.000459333333333f;
+    /* middle (:114-118) */
+    m->link_mass[1] = 0.25f;
+    m->link_com[1][0] = 0.028f; m->link_com[1][1] = 0.0f; m->link_com[1][2] = -0.08f;
+    m->link_inertia[1][0] = 0.000441666666667f; m->link_inertia[1][1] = 0.000441666666667f;
+    m->link_inertia[1][2] = 6.66666666667e-05f;
+    /* lower (:134-138) merged with the rigidly attached tip (:155-164), in double precision */
+    {
+        const double ml = 0.021, mt = 0.031;
+        const double cl[3] = {0.0, 0.0, -0.06}, ct[3] = {0.0185, 0.0, -0.1626};
+        const double Il[3] = {3.5e-05, 3.5e-05, 1.4e-06}, It = 5.16666666667e-07;
+        double mm = ml + mt, c[3];
+        for (int i = 0; i < 3; ++i) c[i] = (ml * cl[i] + mt * ct[i]) / mm;
+        double I[6] = {Il[0] + It, Il[1] + It, Il[2] + It, 0.0, 0.0, 0.0};
+        const double* cs[2] = {cl, ct};
+        const double ms[2] = {ml, mt};
+        for (int b = 0; b < 2; ++b) {
+            double d[3] = {cs[b][0] - c[0], cs[b][1] - c[1], cs[b][2] - c[2]};
+            double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            I[0] += ms[b] * (d2 - d[0] * d[0]);
+            I[1] += ms[b] * (d2 - d[1] * d[1]);
+            I[2] += ms[b] * (d2 - d[2] * d[2]);
+            I[3] += -ms[b] * d[0] * d[1];
+            I[4] += -ms[b] * d[0] * d[2];
+            I[5] += -ms[b] * d[1] * d[2];
+        }
+        m->link_mass[2] = (float)mm;
+        for (int i = 0; i < 3; ++i) m->link_com[2][i] = (float)c[i];
+        for (int i = 0; i < 6; ++i) m->link_inertia[2][i] = (float)I[i];
+    }
+    for (int i = 0; i < 3; ++i) { /* trifinger_env.py:156-158 */
+        static const float lo[3] = {-0.33f, 0.0f, -2.7f}, hi[3] = {1.0f, 1.57f, 0.0f}, df[3] = {0.0f, 0.9f, -1.7f};
+        m->q_lo[i] = lo[i]; m->q_hi[i] = hi[i]; m->q_default[i] = df[i];
+    }
+    m->qd_max = 10.0f;                    /* trifinger_env.py:151 */
+    m->tau_max = 0.36f;                   /* :149 */
+    m->link_angular_damping = 0.01f;      /* :866 */
+    m->cap_a[0] = 0.0135f; m->cap_a[1] = 0.0f; m->cap_a[2] = 0.0f;
+    m->cap_b[0] = 0.0185f; m->cap_b[1] = 0.0f; m->cap_b[2] = -0.1592f; /* tip origin + (0,0,0.0034) */
+    m->cap_radius = 0.0102f;
+    m->cube_half = 0.0325f;               /* trifinger_env.py:143 */
+    m->cube_mass = (float)(291.3 * 0.065 * 0.065 * 0.065);
+    m->cube_inertia = (float)(291.3 * 0.065 * 0.065 * 0.065 * 0.065 * 0.065 / 6.0);
+    m->cube_linear_damping = 0.0f;
+    m->cube_angular_damping = 0.05f;
+    m->wall_radius = 0.192f;
+    m->wall_height = 0.06f;
+    m->mu_finger_cube = 1.0f;             /* avg(1.0, 1.0) */
+    m->mu_cube_floor = 0.55f;             /* avg(1.0, 0.1) */
+    m->mu_tip_floor = 0.55f;
+    m->mu_cube_wall = 1.0f;
+    m->restitution_finger = 0.4f;         /* avg(0.8, 0.0) */
+    m->bounce_threshold = 0.5f;
+    m->contact_margin = 0.04f;
+    m->contact_offset = 0.002f;
+    m->erp = 0.2f;
+    m->max_depenetration_velocity = 1000.0f;
+}
+
+/* scale tables: trifinger_env.py:153-213 (limits), :655-710 (concatenation order) */
+static void build_tables(struct TfHandle_* h) {
+    const TfConfig* c = &h->cfg;
+    static const float q_lo[3] = {-0.33f, 0.0f, -2.7f}, q_hi[3] = {1.0f, 1.57f, 0.0f};
+    static const float kd[3] = {0.1f, 0.3f, 0.001f}, ks[3] = {0.08f, 0.08f, 0.04f};
+    int A = h->action_dim;
+    for (int j = 0; j < 9; ++j) {
+        h->kp[j] = 10.0f; h->kd[j] = kd[j % 3]; h->ks[j] = ks[j % 3];
+    }
+    for (int j = 0; j < A; ++j) {
+        if (c->command_mode == TF_CMD_TORQUE) { h->act_lo[j] = -0.36f; h->act_hi[j] = 0.36f; }
+        else if (j < 9) { h->act_lo[j] = q_lo[j % 3]; h->act_hi[j] = q_hi[j % 3]; }
+        else { h->act_lo[j] = 1.0f; h->act_hi[j] = 50.0f; }
+    }
+    float lo[MAX_STATES], hi[MAX_STATES];
+    int k = 0;
+    for (int j = 0; j < 9; ++j) { lo[k] = q_lo[j % 3]; hi[k] = q_hi[j % 3]; ++k; }
+    for (int j = 0; j < 9; ++j) { lo[k] = -10.0f; hi[k] = 10.0f; ++k; }
+    for (int rep = 0; rep < 2; ++rep) {
+        lo[k] = -0.3f; hi[k] = 0.3f; ++k; lo[k] = -0.3f; hi[k] = 0.3f; ++k; lo[k] = 0.0f; hi[k] = 0.3f; ++k;
+        for (int j = 0; j < 4; ++j) { lo[k] = -1.0f; hi[k] = 1.0f; ++k; }
+    }
+    for (int j = 0; j < A; ++j) {
+        if (c->normalize_action) { lo[k] = -1.0f; hi[k] = 1.0f; }
+        else { lo[k] = h->act_lo[j]; hi[k] = h->act_hi[j]; }
+        ++k;
+    }
+    h->obs_dim = k;
+    for (int j = 0; j < 6; ++j) { lo[k] = -0.5f; hi[k] = 0.5f; ++k; }
+    for (int f = 0; f < 3; ++f) {
+        lo[k] = -0.4f; hi[k] = 0.4f; ++k; lo[k] = -0.4f; hi[k] = 0.4f; ++k; lo[k] = 0.0f; hi[k] = 0.5f; ++k;
+        for (int j = 0; j < 4; ++j) { lo[k] = -1.0f; hi[k] = 1.0f; ++k; }
+        for (int j = 0; j < 6; ++j) { lo[k] = -0.2f; hi[k] = 0.2f; ++k; }
+    }
+    for (int j = 0; j < 9; ++j) { lo[k] = -0.36f; hi[k] = 0.36f; ++k; }
+    for (int j = 0; j < 18; ++j) { lo[k] = -1.0f; hi[k] = 1.0f; ++k; }
+    h->states_dim = k;
+    for (int j = 0; j < h->states_dim; ++j) {
+        float off = (lo[j] + hi[j]) * 0.5f;
+        float inv = 1.0f / (hi[j] - lo[j]);
+        h->st_off[j] = off; h->st_inv[j] = inv;
+        if (j < h->obs_dim) { h->obs_off[j] = off; h->obs_inv[j] = inv; }
+    }
+}
+
+int tf_create(const TfConfig* cfg, tf_handle* out) {
+    if (!cfg || !out) return TF_ERR_INVALID_ARG;
+    if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
+    if (tf_action_dim(cfg->command_mode) < 0) return TF_ERR_COMMAND_MODE;
+    if (cfg->robot_reset_type < 0 || cfg->robot_reset_type > 2) return TF_ERR_ROBOT_RESET;
+    if (cfg->object_reset_type < 0 || cfg->object_reset_type > 2) return TF_ERR_OBJECT_RESET;
+    int d = cfg->task_difficulty;
+    if (!(d == -1 || (d >= 1 && d <= 6))) return TF_ERR_DIFFICULTY;
+    if (cfg->finger_reach_norm_p != 2) return TF_ERR_UNSUPPORTED;
+    if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
+        return TF_ERR_INVALID_ARG;
+    struct TfHandle_* h = (struct TfHandle_*)calloc(1, sizeof(*h));
+    if (!h) return TF_ERR_INVALID_ARG;
+    h->cfg = *cfg;
+    if (h->cfg.global_num_envs <= 0) h->cfg.global_num_envs = cfg->num_envs;
+    h->action_dim = tf_action_dim(cfg->command_mode);
+    build_tables(h);
+    *out = h;
+    return TF_OK;
+}
+
+int tf_destroy(tf_handle h) { free(h); return TF_OK; }
+
+int tf_bind(tf_handle h, const TfBuffers* b) {
+    if (!h || !b) return TF_ERR_INVALID_ARG;
+    if (!b->state || !b->action_buf || !b->obs || !b->reward || !b->reset_buf || !b->goal_reset_buf ||
+        !b->successes || !b->dones || !b->steps || !b->reset_count || !b->info || !b->scratch)
+        return TF_ERR_INVALID_ARG;
+    if (h->cfg.asymmetric_obs && !b->states) return TF_ERR_INVALID_ARG;
+    h->buf = *b;
+    h->bound = 1;
+    return TF_OK;
+}
+
+int tf_set_gravity(tf_handle h, const float g[3]) {
+    if (!h || !g) return TF_ERR_INVALID_ARG;
+    for (int i = 0; i < 3; ++i) h->cfg.gravity[i] = g[i];
+    return TF_OK;
+}
+int64_t tf_frame_count(tf_handle h) { return h ? h->frame_count : -1; }
+int tf_set_frame_count(tf_handle h, int64_t f) { if (!h) return TF_ERR_INVALID_ARG; h->frame_count = f; return TF_OK; }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* finger kinematics and dynamics, in the finger base frame (world = Rz(yaw) * base + (0,0,H))        */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    float s1, c1, s2, c2, s23, c23;
+    float p2[3], p3[3];   /* joint-2 / joint-3 origins */
+    float ax[3];          /* axis of joints 2 and 3: R1 * e_x */
+    float Minv[6];        /* 00 01 02 11 12 22 */
+} FK;
+
+/* link k (1..3) frame -> base frame rotation of u */
+static inline void rot_link(const FK* k, int link, const float u[3], float o[3]) {
+    float wx = u[0], wy = u[1], wz = u[2];
+    if (link >= 2) {
+        float ca = (link == 2) ? k->c2 : k->c23, sa = (link == 2) ? k->s2 : k->s23;
+        float ty = ca * u[1] - sa * u[2];
+        float tz = sa * u[1] + ca * u[2];
+        wy = ty; wz = tz;
+    }
+    o[0] = k->c1 * wx + k->s1 * wz;
+    o[1] = wy;
+    o[2] = k->c1 * wz - k->s1 * wx;
+}
+/* base frame -> link k frame */
+static inline void rot_link_T(const FK* k, int link, const float v[3], float o[3]) {
+    float wx = k->c1 * v[0] - k->s1 * v[2];
+    float wy = v[1];
+    float wz = k->s1 * v[0] + k->c1 * v[2];
+    if (link >= 2) {
+        float ca = (link == 2) ? k->c2 : k->c23, sa = (link == 2) ? k->s2 : k->s23;
+        float ty = ca * wy + sa * wz;
+        float tz = ca * wz - sa * wy;
+        wy = ty; wz = tz;
+    }
+    o[0] = wx; o[1] = wy; o[2] = wz;
+}
+static inline void cross3(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+/* symmetric inertia (xx yy zz xy xz yz) times vector */
+static inline void sym_mul(const float I[6], const float v[3], float o[3]) {
+    o[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
+    o[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
+    o[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+}
+
+static void fk_setup(const TfModel* m, const float q[3], FK* k) {
+    tf_sincos(q[0], &k->s1, &k->c1);
+    tf_sincos(q[1], &k->s2, &k->c2);
+    tf_sincos(q[1] + q[2], &k->s23, &k->c23);
+    k->ax[0] = k->c1; k->ax[1] = 0.0f; k->ax[2] = -k->s1;
+    rot_link(k, 1, m->j2_origin, k->p2);
+    float t[3];
+    rot_link(k, 2, m->j3_origin, t);
+    k->p3[0] = k->p2[0] + t[0]; k->p3[1] = k->p2[1] + t[1]; k->p3[2] = k->p2[2] + t[2];
+}
+
+/* lever arms of the three joints for a base-frame point P: L_j = a_j x (P - p_j) */
+static inline void levers(const FK* k, const float P[3], float L1[3], float L2[3], float L3[3]) {
+    L1[0] = P[2]; L1[1] = 0.0f; L1[2] = -P[0];
+    float r2[3] = {P[0] - k->p2[0], P[1] - k->p2[1], P[2] - k->p2[2]};
+    float r3[3] = {P[0] - k->p3[0], P[1] - k->p3[1], P[2] - k->p3[2]};
+    cross3(k->ax, r2, L2);
+    cross3(k->ax, r3, L3);
+}
+
+/* joint-space mass matrix M (00 01 02 11 12 22) and bias h = C(q,qd) qd + g(q).  grav = gravity vector. */
+static void finger_dynamics(const TfModel* m, const FK* k, const float qd[3], const float grav[3], float M[6],
+                            float bias[3]) {
+    float c1[3], c2[3], c3[3], t[3];
+    rot_link(k, 1, m->link_com[0], c1);
+    rot_link(k, 2, m->link_com[1], t);
+    c2[0] = k->p2[0] + t[0]; c2[1] = k->p2[1] + t[1]; c2[2] = k->p2[2] + t[2];
+    rot_link(k, 3, m->link_com[2], t);
+    c3[0] = k->p3[0] + t[0]; c3[1] = k->p3[1] + t[1]; c3[2] = k->p3[2] + t[2];
+    /* COM Jacobian columns */
+    float a1L[3], a2L[3], a3L[3];       /* link1: col0 ; */
+    float b1L[3], b2L[3], b3L[3];
+    float e1L[3], e2L[3], e3L[3];
+    levers(k, c1, a1L, a2L, a3L);       /* only a1L used */
+    levers(k, c2, b1L, b2L, b3L);       /* b1L, b2L used */
+    levers(k, c3, e1L, e2L, e3L);       /* all used */
+    float m1 = m->link_mass[0], m2 = m->link_mass[1], m3 = m->link_mass[2];
+    const float* I1 = m->link_inertia[0];
+    const float* I2 = m->link_inertia[1];
+    const float* I3 = m->link_inertia[2];
+    /* angular terms: local joint-1 axis in link k is (0, ca, -sa); joint-2/3 axis is e_x */
+    float u2I = k->c2 * k->c2 * I2[1] - 2.0f * k->c2 * k->s2 * I2[5] + k->s2 * k->s2 * I2[2];
+    float u3I = k->c23 * k->c23 * I3[1] - 2.0f * k->c23 * k->s23 * I3[5] + k->s23 * k->s23 * I3[2];
+    float u2x = k->c2 * I2[3] - k->s2 * I2[4];
+    float u3x = k->c23 * I3[3] - k->s23 * I3[4];
+    M[0] = m1 * dot3(a1L, a1L) + m2 * dot3(b1L, b1L) + m3 * dot3(e1L, e1L) + I1[1] + u2I + u3I;
+    M[1] = m2 * dot3(b1L, b2L) + m3 * dot3(e1L, e2L) + u2x + u3x;
+    M[2] = m3 * dot3(e1L, e3L) + u3x;
+    M[3] = m2 * dot3(b2L, b2L) + m3 * dot3(e2L, e2L) + I2[0] + I3[0];
+    M[4] = m3 * dot3(e2L, e3L) + I3[0];
+    M[5] = m3 * dot3(e3L, e3L) + I3[0];
+    /* RNEA with zero joint acceleration, base acceleration = -gravity */
+    float w1[3] = {0.0f, qd[0], 0.0f};
+    float w2[3] = {w1[0] + k->ax[0] * qd[1], w1[1] + k->ax[1] * qd[1], w1[2] + k->ax[2] * qd[1]};
+    float w3[3] = {w2[0] + k->ax[0] * qd[2], w2[1] + k->ax[1] * qd[2], w2[2] + k->ax[2] * qd[2]};
+    float axq2[3] = {k->ax[0] * qd[1], k->ax[1] * qd[1], k->ax[2] * qd[1]};
+    float axq3[3] = {k->ax[0] * qd[2], k->ax[1] * qd[2], k->ax[2] * qd[2]};
+    float dw2[3], dw3[3];
+    cross3(w1, axq2, dw2);                         /* dw1 = 0 */
+    cross3(w2, axq3, t);
+    dw3[0] = dw2[0] + t[0]; dw3[1] = dw2[1] + t[1]; dw3[2] = dw2[2] + t[2];
+    float a0[3] = {-grav[0], -grav[1], -grav[2]};
+    /* acceleration of joint origins */
+    float u[3], v[3];
+    float ap2[3], ap3[3];
+    cross3(w1, k->p2, u); cross3(w1, u, v);        /* w1 x (w1 x p2), dw1 = 0 */
+    ap2[0] = a0[0] + v[0]; ap2[1] = a0[1] + v[1]; ap2[2] = a0[2] + v[2];
+    float d23[3] = {k->p3[0] - k->p2[0], k->p3[1] - k->p2[1], k->p3[2] - k->p2[2]};
+    cross3(dw2, d23, t); cross3(w2, d23, u); cross3(w2, u, v);
+    ap3[0] = ap2[0] + t[0] + v[0]; ap3[1] = ap2[1] + t[1] + v[1]; ap3[2] = ap2[2] + t[2] + v[2];
+    /* COM accelerations -> inertial forces */
+    float F1[3], F2[3], F3[3], N1[3], N2[3], N3[3];
+    cross3(w1, c1, u); cross3(w1, u, v);
+    F1[0] = m1 * (a0[0] + v[0]); F1[1] = m1 * (a0[1] + v[1]); F1[2] = m1 * (a0[2] + v[2]);
+    float r2c[3] = {c2[0] - k->p2[0], c2[1] - k->p2[1], c2[2] - k->p2[2]};
+    cross3(dw2, r2c, t); cross3(w2, r2c, u); cross3(w2, u, v);
+    F2[0] = m2 * (ap2[0] + t[0] + v[0]); F2[1] = m2 * (ap2[1] + t[1] + v[1]); F2[2] = m2 * (ap2[2] + t[2] + v[2]);
+    float r3c[3] = {c3[0] - k->p3[0], c3[1] - k->p3[1], c3[2] - k->p3[2]};
+    cross3(dw3, r3c, t); cross3(w3, r3c, u); cross3(w3, u, v);
+    F3[0] = m3 * (ap3[0] + t[0] + v[0]); F3[1] = m3 * (ap3[1] + t[1] + v[1]); F3[2] = m3 * (ap3[2] + t[2] + v[2]);
+    /* N_k = R (I (R^T dw)) + w x R (I (R^T w)) */
+    float wl[3], Iw[3], Iww[3], dl[3], Id[3], Idw[3];
+    rot_link_T(k, 1, w1, wl); sym_mul(I1, wl, Iw); rot_link(k, 1, Iw, Iww);
+    cross3(w1, Iww, N1);                                                     /* dw1 = 0 */
+    rot_link_T(k, 2, w2, wl); sym_mul(I2, wl, Iw); rot_link(k, 2, Iw, Iww);
+    rot_link_T(k, 2, dw2, dl); sym_mul(I2, dl, Id); rot_link(k, 2, Id, Idw);
+    cross3(w2, Iww, t);
+    N2[0] = Idw[0] + t[0]; N2[1] = Idw[1] + t[1]; N2[2] = Idw[2] + t[2];
+    rot_link_T(k, 3, w3, wl); sym_mul(I3, wl, Iw); rot_link(k, 3, Iw, Iww);
+    rot_link_T(k, 3, dw3, dl); sym_mul(I3, dl, Id); rot_link(k, 3, Id, Idw);
+    cross3(w3, Iww, t);
+    N3[0] = Idw[0] + t[0]; N3[1] = Idw[1] + t[1]; N3[2] = Idw[2] + t[2];
+    /* backward pass: moments about joint origins */
+    float n3[3], n2[3], n1[3], f2[3];
+    cross3(r3c, F3, t);
+    n3[0] = N3[0] + t[0]; n3[1] = N3[1] + t[1]; n3[2] = N3[2] + t[2];
+    f2[0] = F2[0] + F3[0]; f2[1] = F2[1] + F3[1]; f2[2] = F2[2] + F3[2];
+    cross3(r2c, F2, t); cross3(d23, F3, u);
+    n2[0] = N2[0] + t[0] + n3[0] + u[0]; n2[1] = N2[1] + t[1] + n3[1] + u[1]; n2[2] = N2[2] + t[2] + n3[2] + u[2];
+    cross3(c1, F1, t); cross3(k->p2, f2, u);
+    n1[0] = N1[0] + t[0] + n2[0] + u[0]; n1[1] = N1[1] + t[1] + n2[1] + u[1]; n1[2] = N1[2] + t[2] + n2[2] + u[2];
+    bias[0] = n1[1];
+    bias[1] = dot3(k->ax, n2);
+    bias[2] = dot3(k->ax, n3);
+}
+
+static void inv3sym(const float M[6], float Mi[6]) {
+    float A = M[3] * M[5] - M[4] * M[4];
+    float B = M[2] * M[4] - M[1] * M[5];
+    float C = M[1] * M[4] - M[2] * M[3];
+    float det = M[0] * A + M[1] * B + M[2] * C;
+    float rd = 1.0f / det;
+    Mi[0] = A * rd; Mi[1] = B * rd; Mi[2] = C * rd;
+    Mi[3] = (M[0] * M[5] - M[2] * M[2]) * rd;
+    Mi[4] = (M[1] * M[2] - M[0] * M[4]) * rd;
+    Mi[5] = (M[0] * M[3] - M[1] * M[1]) * rd;
+}
+static inline void sym3_mul(const float S[6], const float v[3], float o[3]) { /* S = 00 01 02 11 12 22 */
+    o[0] = S[0] * v[0] + S[1] * v[1] + S[2] * v[2];
+    o[1] = S[1] * v[0] + S[3] * v[1] + S[4] * v[2];
+    o[2] = S[2] * v[0] + S[4] * v[1] + S[5] * v[2];
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* per-env working state                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    float q[9], qd[9];
+    float cp[3], cq[4], cv[3], cw[3];
+    float gp[3], gq[4], gw[3];
+    float tau[9];
+    float ft[18];      /* accumulated fingertip wrench (world), summed over substeps */
+} Env;
+
+/* one contact between finger f and something: three rows (normal + two tangents) */
+typedef struct {
+    int active;
+    float Jf[3][3];    /* row d: J^T dir_d (joint space) */
+    float Wf[3][3];    /* Minv Jf */
+    float dir[3][3];   /* world directions n, t1, t2 (cube side)            */
+    float rxd[3][3];   /* r_c x dir_d                                       */
+    float Dinv[3];
+    float bias;
+    float mu;
+    float arm[3];      /* world contact point - tip-link origin (for the wrench sensor) */
+    float lam[3];
+} FingerContact;
+
+typedef struct {
+    int active;
+    float r[3];
+    float dir[3][3];
+    float rxd[3][3];
+    float Dinv[3];
+    float bias;
+    float mu;
+    float lam[3];
+} CubeContact;
+
+static void base_to_world(const TfModel* m, int f, const float b[3], float w[3]) {
+    float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
+    w[0] = c * b[0] - s * b[1];
+    w[1] = s * b[0] + c * b[1];
+    w[2] = b[2] + m->base_height;
+}
+static void dir_world_to_base(const TfModel* m, int f, const float w[3], float b[3]) {
+    float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
+    b[0] = c * w[0] + s * w[1];
+    b[1] = c * w[1] - s * w[0];
+    b[2] = w[2];
+}
+static void dir_base_to_world(const TfModel* m, int f, const float b[3], float w[3]) {
+    float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
+    w[0] = c * b[0] - s * b[1];
+    w[1] = s * b[0] + c * b[1];
+    w[2] = b[2];
+}
+
+static void tangent_basis(const float n[3], float t1[3], float t2[3]) {
+    if (f_abs(n[2]) < 0.9f) {
+        float inv = 1.0f / sqrtf(n[0] * n[0] + n[1] * n[1]);
+        t1[0] = -n[1] * inv; t1[1] = n[0] * inv; t1[2] = 0.0f;
+    } else {
+        float inv = 1.0f / sqrtf(n[1] * n[1] + n[2] * n[2]);
+        t1[0] = 0.0f; t1[1] = -n[2] * inv; t1[2] = n[1] * inv;
+    }
+    cross3(n, t1, t2);
+}
+
+/* normal-row bias from gap and approach speed (DESIGN.md "contact rows") */
+static float contact_bias(const TfModel* m, float gap, float vn0, float h, float restitution) {
+    float inv_h = 1.0f / h;
+    float b;
+    if (gap >= 0.0f) b = gap * inv_h;
+    else b = f_max(m->erp * gap * inv_h, -m->max_depenetration_velocity);
+    if (restitution > 0.0f && gap < m->contact_offset && vn0 < -m->bounce_threshold) b = f_min(b, restitution * vn0);
+    return b;
+}
+
+/* Rows of one finger contact once point P (base frame), world normal n and cube arm r_c are known. */
+static void finger_rows(const TfModel* m, int f, const FK* k, const float Pb[3], const float n_w[3],
+                        const float rc[3], int with_cube, FingerContact* c) {
+    float t1[3], t2[3];
+    tangent_basis(n_w, t1, t2);
+    const float* dw[3] = {n_w, t1, t2};
+    float L1[3], L2[3], L3[3];
+    levers(k, Pb, L1, L2, L3);
+    for (int d = 0; d < 3; ++d) {
+        float db[3];
+        dir_world_to_base(m, f, dw[d], db);
+        c->dir[d][0] = dw[d][0]; c->dir[d][1] = dw[d][1]; c->dir[d][2] = dw[d][2];
+        c->Jf[d][0] = dot3(L1, db); c->Jf[d][1] = dot3(L2, db); c->Jf[d][2] = dot3(L3, db);
+        sym3_mul(k->Minv, c->Jf[d], c->Wf[d]);
+        float D = dot3(c->Jf[d], c->Wf[d]);
+        if (with_cube) {
+            cross3(rc, dw[d], c->rxd[d]);
+            D = D + 1.0f / m->cube_mass + dot3(c->rxd[d], c->rxd[d]) / m->cube_inertia;
+        } else {
+            c->rxd[d][0] = 0.0f; c->rxd[d][1] = 0.0f; c->rxd[d][2] = 0.0f;
+        }
+        c->Dinv[d] = 1.0f / D;
+    }
+}
+
+static void cube_corner(const float R[9], float hc, int k, float sk, int idx, float y[3], float r[3]) {
+    int a = (k + 1) % 3, b = (k + 2) % 3;
+    if (a > b) { int t = a; a = b; b = t; }
+    y[k] = sk * hc;
+    y[a] = (idx & 1) ? hc : -hc;
+    y[b] = (idx & 2) ? hc : -hc;
+    r[0] = R[0] * y[0] + R[1] * y[1] + R[2] * y[2];
+    r[1] = R[3] * y[0] + R[4] * y[1] + R[5] * y[2];
+    r[2] = R[6] * y[0] + R[7] * y[1] + R[8] * y[2];
+}
+
+static void cube_rows(const TfModel* m, CubeContact* c) {
+    for (int d = 0; d < 3; ++d) {
+        cross3(c->r, c->dir[d], c->rxd[d]);
+        float D = 1.0f / m->cube_mass + dot3(c->rxd[d], c->rxd[d]) / m->cube_inertia;
+        c->Dinv[d] = 1.0f / D;
+    }
+}
+
+/* One solver substep of length h for one env. */
+static void substep(const struct TfHandle_* H, Env* e, float h) {
+    const TfConfig* cfg = &H->cfg;
+    const TfModel* m = &cfg->model;
+    FK fk[3];
+    float vq[9];                 /* joint velocities being solved */
+    float v[3], w[3];            /* cube velocities being solved  */
+    /* ---- free motion ---- */
+    for (int f = 0; f < 3; ++f) {
+        float M[6], bias[3], rhs[3], acc[3];
+        fk_setup(m, &e->q[3 * f], &fk[f]);
+        finger_dynamics(m, &fk[f], &e->qd[3 * f], cfg->gravity, M, bias);
+        inv3sym(M, fk[f].Minv);
+        for (int j = 0; j < 3; ++j) rhs[j] = e->tau[3 * f + j] - bias[j];
+        sym3_mul(fk[f].Minv, rhs, acc);
+        float damp = 1.0f - h * m->link_angular_damping;
+        for (int j = 0; j < 3; ++j) vq[3 * f + j] = (e->qd[3 * f + j] + h * acc[j]) * damp;
+    }
+    {
+        float dl = 1.0f - h * m->cube_linear_damping, da = 1.0f - h * m->cube_angular_damping;
+        for (int i = 0; i < 3; ++i) {
+            v[i] = (e->cv[i] + h * cfg->gravity[i]) * dl;
+            w[i] = e->cw[i] * da;
+        }
+    }
+    /* ---- contact generation (positions at the start of the substep) ---- */
+    float R[9];
+    quat_to_rot(e->cq, R);
+    const float hc = m->cube_half;
+    FingerContact fc[3], tf_[3];
+    CubeContact cf[4], cwl[4];
+    float tip_origin_w[3][3];
+    for (int f = 0; f < 3; ++f) {
+        const FK* k = &fk[f];
+        float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3];
+        rot_link(k, 3, m->cap_a, t);
+        Ab[0] = k->p3[0] + t[0]; Ab[1] = k->p3[1] + t[1]; Ab[2] = k->p3[2] + t[2];
+        rot_link(k, 3, m->cap_b, t);
+        Bb[0] = k->p3[0] + t[0]; Bb[1] = k->p3[1] + t[1]; Bb[2] = k->p3[2] + t[2];
+        rot_link(k, 3, m->tip_origin, t);
+        To[0] = k->p3[0] + t[0]; To[1] = k->p3[1] + t[1]; To[2] = k->p3[2] + t[2];
+        base_to_world(m, f, Ab, Aw);
+        base_to_world(m, f, Bb, Bw);
+        base_to_world(m, f, To, tip_origin_w[f]);
+        /* --- capsule (distal link) vs cube: closest points by alternating projection, cube frame --- */
+        FingerContact* c = &fc[f];
+        memset(c, 0, sizeof(*c));
+        float da[3] = {Aw[0] - e->cp[0], Aw[1] - e->cp[1], Aw[2] - e->cp[2]};
+        float db[3] = {Bw[0] - e->cp[0], Bw[1] - e->cp[1], Bw[2] - e->cp[2]};
+        float a[3], b[3];
+        for (int i = 0; i < 3; ++i) {                       /* R^T d */
+            a[i] = R[i] * da[0] + R[3 + i] * da[1] + R[6 + i] * da[2];
+            b[i] = R[i] * db[0] + R[3 + i] * db[1] + R[6 + i] * db[2];
+        }
+        float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+        float inv_dd = 1.0f / dot3(d, d);
+        float s = 1.0f, x[3], y[3];
+        for (int it = 0; it < 4; ++it) {
+            for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+            float ya[3] = {y[0] - a[0], y[1] - a[1], y[2] - a[2]};
+            s = f_clamp(dot3(ya, d) * inv_dd, 0.0f, 1.0f);
+        }
+        for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+        float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
+        float dist2 = dot3(ev, ev);
+        float nc[3], gap;
+        if (dist2 > 1e-12f) {
+            float dist = sqrtf(dist2);
+            float inv = 1.0f / dist;
+            nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
+            gap = dist - m->cap_radius;
+        } else {
+            /* capsule axis inside the box: push out through the nearest face */
+            int bi = 0;
+            float best = f_abs(x[0]) - hc;
+            for (int i = 1; i < 3; ++i) {
+                float p = f_abs(x[i]) - hc;
+                if (p > best) { best = p; bi = i; }
+            }
+            nc[0] = 0.0f; nc[1] = 0.0f; nc[2] = 0.0f;
+            float sg = (x[bi] < 0.0f) ? -1.0f : 1.0f;
+            nc[bi] = sg;
+            y[bi] = sg * hc;
+            gap = best - m->cap_radius;
+        }
+        if (gap < m->contact_margin) {
+            float n_w[3], rc[3], xw[3];
+            for (int i = 0; i < 3; ++i) {
+                n_w[i] = R[3 * i] * nc[0] + R[3 * i + 1] * nc[1] + R[3 * i + 2] * nc[2];
+                rc[i] = R[3 * i] * y[0] + R[3 * i + 1] * y[1] + R[3 * i + 2] * y[2];
+                xw[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
+            }
+            /* finger-side contact point (world, relative to the cube centre): axis point minus r n */
+            float Pw[3] = {e->cp[0] + xw[0] - m->cap_radius * n_w[0], e->cp[1] + xw[1] - m->cap_radius * n_w[1],
+                           e->cp[2] + xw[2] - m->cap_radius * n_w[2]};
+            float Pr[3] = {Pw[0], Pw[1], Pw[2] - m->base_height};
+            float Pb[3];
+            dir_world_to_base(m, f, Pr, Pb);
+            c->active = 1;
+            c->mu = m->mu_finger_cube;
+            finger_rows(m, f, k, Pb, n_w, rc, 1, c);
+            for (int i = 0; i < 3; ++i) c->arm[i] = Pw[i] - tip_origin_w[f][i];
+            float vn0 = dot3(c->Jf[0], &vq[3 * f]) - (dot3(c->dir[0], v) + dot3(c->rxd[0], w));
+            c->bias = contact_bias(m, gap, vn0, h, m->restitution_finger);
+        }
+        /* --- tip sphere vs floor --- */
+        FingerContact* g = &tf_[f];
+        memset(g, 0, sizeof(*g));
+        float gapf = Bw[2] - m->cap_radius;
+        if (gapf < m->contact_margin) {
+            float n_w[3] = {0.0f, 0.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
+            float Pb[3] = {Bb[0], Bb[1], Bb[2] - m->cap_radius};
+            float Pw[3] = {Bw[0], Bw[1], Bw[2] - m->cap_radius};
+            g->active = 1;
+            g->mu = m->mu_tip_floor;
+            finger_rows(m, f, k, Pb, n_w, zero, 0, g);
+            for (int i = 0; i < 3; ++i) g->arm[i] = Pw[i] - tip_origin_w[f][i];
+            float vn0 = dot3(g->Jf[0], &vq[3 * f]);
+            g->bias = contact_bias(m, gapf, vn0, h, m->restitution_finger);
+        }
+    }
+    /* --- cube vs floor: the four corners of the face that points down most --- */
+    {
+        int k = 0;
+        float best = f_abs(R[6]);
+        if (f_abs(R[7]) > best) { best = f_abs(R[7]); k = 1; }
+        if (f_abs(R[8]) > best) { best = f_abs(R[8]); k = 2; }
+        float sk = (R[6 + k] > 0.0f) ? -1.0f : 1.0f;
+        for (int i = 0; i < 4; ++i) {
+            CubeContact* c = &cf[i];
+            memset(c, 0, sizeof(*c));
+            float y[3];
+            cube_corner(R, hc, k, sk, i, y, c->r);
+            float gap = e->cp[2] + c->r[2];
+            if (gap < m->contact_margin) {
+                c->active = 1;
+                c->mu = m->mu_cube_floor;
+                c->dir[0][2] = 1.0f; c->dir[1][0] = 1.0f; c->dir[2][1] = 1.0f;
+                cube_rows(m, c);
+                float vn0 = dot3(c->dir[0], v) + dot3(c->rxd[0], w);
+                c->bias = contact_bias(m, gap, vn0, h, 0.0f);
+            }
+        }
+    }
+    /* --- cube vs boundary wall: the four corners of the face that points outward most --- */
+    {
+        float rho_c = sqrtf(e->cp[0] * e->cp[0] + e->cp[1] * e->cp[1]);
+        int any = rho_c > 1e-6f;
+        float dx = 0.0f, dy = 0.0f;
+        if (any) { float inv = 1.0f / rho_c; dx = e->cp[0] * inv; dy = e->cp[1] * inv; }
+        float pr[3];
+        for (int i = 0; i < 3; ++i) pr[i] = R[i] * dx + R[3 + i] * dy;
+        int k = 0;
+        float best = f_abs(pr[0]);
+        if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
+        if (f_abs(pr[2]) > best) { best = f_abs(pr[2]); k = 2; }
+        float sk = (pr[k] < 0.0f) ? -1.0f : 1.0f;
+        for (int i = 0; i < 4; ++i) {
+            CubeContact* c = &cwl[i];
+            memset(c, 0, sizeof(*c));
+            float y[3];
+            cube_corner(R, hc, k, sk, i, y, c->r);
+            float px = e->cp[0] + c->r[0], py = e->cp[1] + c->r[1];
+            float rho = sqrtf(px * px + py * py);
+            float gap = m->wall_radius - rho;
+            if (any && gap < m->contact_margin && rho > 1e-6f) {
+                float inv = 1.0f / rho;
+                c->active = 1;
+                c->mu = m->mu_cube_wall;
+                c->dir[0][0] = -px * inv; c->dir[0][1] = -py * inv;
+                c->dir[1][0] = py * inv;  c->dir[1][1] = -px * inv;
+                c->dir[2][2] = 1.0f;
+                cube_rows(m, c);
+                float vn0 = dot3(c->dir[0], v) + dot3(c->rxd[0], w);
+                c->bias = contact_bias(m, gap, vn0, h, 0.0f);
+            }
+        }
+    }
+    /* --- joint limit / velocity limit rows --- */
+    float vlo[9], vhi[9], lim_dinv[9], lim_lam[9];
+    {
+        float inv_h = 1.0f / h;
+        for (int j = 0; j < 9; ++j) {
+            int f = j / 3, jj = j % 3;
+            static const int diag[3] = {0, 3, 5};
+            vlo[j] = f_clamp((m->q_lo[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
+            vhi[j] = f_clamp((m->q_hi[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
+            lim_dinv[j] = 1.0f / fk[f].Minv[diag[jj]];
+            lim_lam[j] = 0.0f;
+        }
+    }
+    /* ---- projected Gauss-Seidel ---- */
+    const float inv_m = 1.0f / m->cube_mass, inv_I = 1.0f / m->cube_inertia;
+    for (int it = 0; it < cfg->solver_iterations; ++it) {
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int f = 0; f < 3; ++f) {
+                FingerContact* c = (pass == 0) ? &fc[f] : &tf_[f];
+                if (!c->active) continue;
+                float* vf = &vq[3 * f];
+                for (int d = 0; d < 3; ++d) {
+                    float vrel = dot3(c->Jf[d], vf);
+                    if (pass == 0) vrel = vrel - (dot3(c->dir[d], v) + dot3(c->rxd[d], w));
+                    float lam_new;
+                    if (d == 0) lam_new = f_max(c->lam[0] - c->Dinv[0] * (vrel + c->bias), 0.0f);
+                    else {
+                        float lim = c->mu * c->lam[0];
+                        lam_new = f_clamp(c->lam[d] - c->Dinv[d] * vrel, -lim, lim);
+                    }
+                    float dl = lam_new - c->lam[d];
+                    c->lam[d] = lam_new;
+                    vf[0] = vf[0] + c->Wf[d][0] * dl; vf[1] = vf[1] + c->Wf[d][1] * dl; vf[2] = vf[2] + c->Wf[d][2] * dl;
+                    if (pass == 0) {
+                        float s = dl * inv_m, q = dl * inv_I;
+                        v[0] = v[0] - c->dir[d][0] * s; v[1] = v[1] - c->dir[d][1] * s; v[2] = v[2] - c->dir[d][2] * s;
+                        w[0] = w[0] - c->rxd[d][0] * q; w[1] = w[1] - c->rxd[d][1] * q; w[2] = w[2] - c->rxd[d][2] * q;
+                    }
+                }
+            }
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = 0; i < 4; ++i) {
+                CubeContact* c = (pass == 0) ? &cf[i] : &cwl[i];
+                if (!c->active) continue;
+                for (int d = 0; d < 3; ++d) {
+                    float vrel = dot3(c->dir[d], v) + dot3(c->rxd[d], w);
+                    float lam_new;
+                    if (d == 0) lam_new = f_max(c->lam[0] - c->Dinv[0] * (vrel + c->bias), 0.0f);
+                    else {
+                        float lim = c->mu * c->lam[0];
+                        lam_new = f_clamp(c->lam[d] - c->Dinv[d] * vrel, -lim, lim);
+                    }
+                    float dl = lam_new - c->lam[d];
+                    c->lam[d] = lam_new;
+                    float s = dl * inv_m, q = dl * inv_I;
+                    v[0] = v[0] + c->dir[d][0] * s; v[1] = v[1] + c->dir[d][1] * s; v[2] = v[2] + c->dir[d][2] * s;
+                    w[0] = w[0] + c->rxd[d][0] * q; w[1] = w[1] + c->rxd[d][1] * q; w[2] = w[2] + c->rxd[d][2] * q;
+                }
+            }
+        }
+        for (int j = 0; j < 9; ++j) {
+            int f = j / 3, jj = j % 3;
+            static const int col[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+            static const int diag[3] = {0, 3, 5};
+            const float* Mi = fk[f].Minv;
+            float v0 = vq[j] - Mi[diag[jj]] * lim_lam[j];
+            float tgt = f_clamp(v0, vlo[j], vhi[j]);
+            float lam_new = (tgt - v0) * lim_dinv[j];
+            float dl = lam_new - lim_lam[j];
+            lim_lam[j] = lam_new;
+            vq[3 * f + 0] = vq[3 * f + 0] + Mi[col[jj][0]] * dl;
+            vq[3 * f + 1] = vq[3 * f + 1] + Mi[col[jj][1]] * dl;
+            vq[3 * f + 2] = vq[3 * f + 2] + Mi[col[jj][2]] * dl;
+        }
+    }
+    /* ---- fingertip wrench sensor: contact impulses / h, world frame, about the tip-link origin ---- */
+    {
+        float inv_h = 1.0f / h;
+        for (int f = 0; f < 3; ++f) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const FingerContact* c = (pass == 0) ? &fc[f] : &tf_[f];
+                if (!c->active) continue;
+                float F[3];
+                for (int i = 0; i < 3; ++i)
+                    F[i] = (c->dir[0][i] * c->lam[0] + c->dir[1][i] * c->lam[1] + c->dir[2][i] * c->lam[2]) * inv_h;
+                float T[3];
+                cross3(c->arm, F, T);
+                for (int i = 0; i < 3; ++i) { e->ft[6 * f + i] += F[i]; e->ft[6 * f + 3 + i] += T[i]; }
+            }
+        }
+    }
+    /* ---- integrate ---- */
+    for (int j = 0; j < 9; ++j) {
+        e->qd[j] = vq[j];
+        e->q[j] = f_clamp(e->q[j] + h * vq[j], m->q_lo[j % 3], m->q_hi[j % 3]);
+    }
+    for (int i = 0; i < 3; ++i) {
+        e->cv[i] = v[i]; e->cw[i] = w[i];
+        e->cp[i] = e->cp[i] + h * v[i];
+    }
+    quat_integrate(e->cq, e->cw, h);
+    if (cfg->goal_rotation_activate) quat_integrate(e->gq, e->gw, h);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* SoA <-> Env                                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+#define ST(h, row, i) ((h)->buf.state[(size_t)(row) * (size_t)(h)->cfg.num_envs + (size_t)(i)])
+
+static void env_load(const struct TfHandle_* h, int i, Env* e) {
+    for (int j = 0; j < 9; ++j) { e->q[j] = ST(h, TF_S_Q + j, i); e->qd[j] = ST(h, TF_S_QD + j, i); e->tau[j] = ST(h, TF_S_TAU + j, i); }
+    for (int j = 0; j < 3; ++j) {
+        e->cp[j] = ST(h, TF_S_CUBE_P + j, i); e->cv[j] = ST(h, TF_S_CUBE_V + j, i); e->cw[j] = ST(h, TF_S_CUBE_W + j, i);
+        e->gp[j] = ST(h, TF_S_GOAL_P + j, i); e->gw[j] = ST(h, TF_S_GOAL_W + j, i);
+    }
+    for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
+    for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
+}
+static void env_store(const struct TfHandle_* h, int i, const Env* e) {
+    for (int j = 0; j < 9; ++j) { ST(h, TF_S_Q + j, i) = e->q[j]; ST(h, TF_S_QD + j, i) = e->qd[j]; ST(h, TF_S_TAU + j, i) = e->tau[j]; }
+    for (int j = 0; j < 3; ++j) {
+        ST(h, TF_S_CUBE_P + j, i) = e->cp[j]; ST(h, TF_S_CUBE_V + j, i) = e->cv[j]; ST(h, TF_S_CUBE_W + j, i) = e->cw[j];
+        ST(h, TF_S_GOAL_P + j, i) = e->gp[j]; ST(h, TF_S_GOAL_W + j, i) = e->gw[j];
+    }
+    for (int j = 0; j < 4; ++j) { ST(h, TF_S_CUBE_Q + j, i) = e->cq[j]; ST(h, TF_S_GOAL_Q + j, i) = e->gq[j]; }
+    for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* task layer                                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+/* sample.py:22-34 */
+static void sample_xy(float u_r, float u_t, float r_max, float* x, float* y) {
+    float radius = sqrtf(u_r) * r_max;
+    float s, c;
+    tf_sincos(6.2831855f * u_t, &s, &c);
+    *x = radius * c;
+    *y = radius * s;
+}
+/* sample.py:77-84 via torch_utils.py:153-180 with roll = pitch = 0 */
+static void sample_yaw_quat(float u, float q[4]) {
+    float s, c;
+    tf_sincos((6.2831855f * u) * 0.5f, &s, &c);
+    q[0] = 0.0f; q[1] = 0.0f; q[2] = s; q[3] = c;
+}
+/* sample.py:55-65: normalize(randn(4)), eps 1e-12 */
+static void normalize_quat(const float n[4], float q[4]) {
+    float nrm = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3]);
+    float inv = 1.0f / f_max(nrm, 1e-12f);
+    for (int i = 0; i < 4; ++i) q[i] = n[i] * inv;
+}
+
+#define CUBE_RADIUS_3D 0.05629165f      /* CuboidalObject(0.065).radius_3d,  envs/trifinger/utils.py:122-131 */
+#define CUBE_MAX_COM_DIST 0.13870835f   /* ARENA_RADIUS - radius_3d                                            */
+#define CUBE_MIN_HEIGHT 0.0325f
+#define CUBE_MAX_HEIGHT 0.1f
+
+/* trifinger_env.py:1194-1265 */
+static void sample_goal(const struct TfHandle_* h, uint32_t gid, uint32_t count, Env* e) {
+    const TfConfig* c = &h->cfg;
+    int d = c->task_difficulty;
+    float u[4];
+    rng4(c->seed, gid, count, RNG_GOAL_POS, u);
+    float x = 0.0f, y = 0.0f, z;
+    float quat[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, &x, &y);
+    if (d == -1 || d == 1) z = CUBE_MIN_HEIGHT;
+    else if (d == 2 || d == 6) z = CUBE_MIN_HEIGHT + 0.05f;
+    else if (d == 3) z = 0.0675f * u[2] + CUBE_MIN_HEIGHT;           /* (max_height - min_height) in double, then fp32 */
+    else z = 0.04370835f * u[2] + CUBE_RADIUS_3D;                    /* (max_height - radius_3d) */
+    if (d == -1) sample_yaw_quat(u[3], quat);
+    if (d == 4 || d == 5 || d == 6) {
+        float v[4], n[4];
+        rng4(c->seed, gid, count, RNG_GOAL_QUAT, v);
+        box_muller(v[0], v[1], &n[0], &n[1]);
+        box_muller(v[2], v[3], &n[2], &n[3]);
+        normalize_quat(n, quat);
+    }
+    if (c->goal_rotation_activate) {     /* sample.py:67-75 */
+        float v[4], n[4];
+        rng4(c->seed, gid, count, RNG_GOAL_ANGVEL, v);
+        box_muller(v[0], v[1], &n[0], &n[1]);
+        box_muller(v[2], v[3], &n[2], &n[3]);
+        float nrm = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        float mag = n[3] * c->goal_rotation_rate_magnitude;
+        for (int i = 0; i < 3; ++i) e->gw[i] = mag * (n[i] / nrm);
+    } else {
+        e->gw[0] = 0.0f; e->gw[1] = 0.0f; e->gw[2] = 0.0f;
+    }
+    e->gp[0] = x; e->gp[1] = y; e->gp[2] = z;
+    for (int i = 0; i < 4; ++i) e->gq[i] = quat[i];
+}
+
+/* masked _reset_impl then _goal_reset_impl (env_base.py:370-379; trifinger_env.py:373-440).
+ * Returns 1 if the env was reset (its action row must be zeroed). */
+static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all) {
+    const TfConfig* c = &h->cfg;
+    const TfModel* m = &c->model;
+    uint32_t gid = (uint32_t)(c->env_id_offset + i);
+    int did_reset = 0;
+    if (force_all || h->buf.reset_buf[i]) {
+        did_reset = 1;
+        uint32_t count = h->buf.reset_count[i];
+        h->buf.reset_buf[i] = 0;
+        h->buf.steps[i] = 0;
+        h->buf.successes[i] = 0;
+        if (c->robot_reset_type == TF_RESET_DEFAULT) {
+            for (int j = 0; j < 9; ++j) { e->q[j] = m->q_default[j % 3]; e->qd[j] = 0.0f; }
+        } else if (c->robot_reset_type == TF_RESET_RANDOM) {   /* trifinger_env.py:1125-1141 */
+            float n[20];
+            for (int b = 0; b < 5; ++b) rng4(c->seed, gid, count, RNG_ROBOT + (uint32_t)b, &n[4 * b]);
+            for (int j = 0; j < 9; ++j) {
+                e->q[j] = m->q_default[j % 3] + c->dof_pos_stddev * (2.0f * n[j] - 1.0f);
+                e->qd[j] = 0.0f + c->dof_vel_stddev * (2.0f * n[9 + j] - 1.0f);
+            }
+        }
+        if (c->object_reset_type == TF_RESET_DEFAULT) {
+            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = CUBE_MIN_HEIGHT;
+            e->cq[0] = 0.0f; e->cq[1] = 0.0f; e->cq[2] = 0.0f; e->cq[3] = 1.0f;
+            for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
+        } else if (c->object_reset_type == TF_RESET_RANDOM) {  /* trifinger_env.py:1169-1173 */
+            float u[4];
+            rng4(c->seed, gid, count, RNG_OBJECT, u);
+            sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, &e->cp[0], &e->cp[1]);
+            e->cp[2] = 0.065f / 2.0f;
+            sample_yaw_quat(u[2], e->cq);
+            for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
+        }
+        sample_goal(h, gid, count, e);
+        h->buf.reset_count[i] = count + 1u;
+    }
+    if (!force_all && h->buf.goal_reset_buf[i]) {
+        uint32_t count = h->buf.reset_count[i];
+        h->buf.goal_reset_buf[i] = 0;
+        sample_goal(h, gid, count, e);
+        h->buf.reset_count[i] = count + 1u;
+    }
+    return did_reset;
+}
+
+/* trifinger_env.py:442-494 */
+static void compute_torque(const struct TfHandle_* h, const float* act, const float q[9], const float qd[9],
+                           float tau[9]) {
+    const TfConfig* c = &h->cfg;
+    int A = h->action_dim;
+    float at[18];
+    for (int j = 0; j < A; ++j) {
+        if (c->normalize_action) {     /* torch_utils.py:39-57 */
+            float off = (h->act_lo[j] + h->act_hi[j]) * 0.5f;
+            at[j] = act[j] * (h->act_hi[j] - h->act_lo[j]) * 0.5f + off;
+        } else at[j] = act[j];
+    }
+    for (int j = 0; j < 9; ++j) {
+        float t;
+        if (c->command_mode == TF_CMD_TORQUE) t = at[j];
+        else if (c->command_mode == TF_CMD_POSITION) { t = h->kp[j] * (at[j] - q[j]); t = t - h->kd[j] * qd[j]; }
+        else { t = at[9 + j] * (at[j] - q[j]); t = t - h->kd[j] * qd[j]; }
+        t = f_max(f_min(t, 0.36f), -0.36f);
+        if (c->apply_safety_damping) {
+            t = t - h->ks[j] * qd[j];
+            t = f_max(f_min(t, 0.36f), -0.36f);
+        }
+        tau[j] = t;
+    }
+}
+
+typedef struct {
+    float c_reach, c_move_pen, dt, c_dist, rot_num, rot_scale, w_rot, rot_delta_sched, w_rot_delta, w_move;
+} RewardCoef;
+
+static double sched_window(const TfRewardTerm* t, double step) {
+    if (t->sched_start != t->sched_end) return (t->sched_start <= step && step <= t->sched_end) ? 1.0 : 0.0;
+    return 1.0;
+}
+/* scalar prefactors exactly as python evaluates them in double before they meet an fp32 tensor */
+static void reward_coefs(const struct TfHandle_* h, RewardCoef* rc) {
+    const TfConfig* c = &h->cfg;
+    double step = (double)h->frame_count * (double)c->global_num_envs;   /* env_base.py:287-289 */
+    double dt = (double)c->dt;
+    const TfRewardTerm* T = c->reward;
+    rc->c_reach = (float)((double)T[TF_REW_FINGER_REACH_OBJECT_RATE].weight * sched_window(&T[TF_REW_FINGER_REACH_OBJECT_RATE], step));
+    rc->c_move_pen = T[TF_REW_FINGER_MOVE_PENALTY].weight;
+    rc->dt = c->dt;
+    rc->c_dist = (float)((double)T[TF_REW_OBJECT_DIST].weight * dt * sched_window(&T[TF_REW_OBJECT_DIST], step));
+    rc->rot_num = (float)(sched_window(&T[TF_REW_OBJECT_ROT], step) * dt);
+    rc->rot_scale = c->object_rot_scale;
+    rc->w_rot = T[TF_REW_OBJECT_ROT].weight;
+    {
+        const TfRewardTerm* t = &T[TF_REW_OBJECT_ROT_DELTA];   /* rewards.py:14-17 */
+        double s = 1.0;
+        if (t->sched_start != t->sched_end) {
+            s = (step - t->sched_start) / (t->sched_end - t->sched_start);
+            s = (s < 0.0) ? 0.0 : ((s > 1.0) ? 1.0 : s);
+        }
+        rc->rot_delta_sched = (float)s;
+        rc->w_rot_delta = t->weight;
+    }
+    rc->w_move = T[TF_REW_OBJECT_MOVE].weight;
+}
+
+static float norm3d(const float a[3], const float b[3]) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+/* fingertip link state in the world frame: position, quaternion (xyzw), linear and angular velocity */
+static void tip_state(const TfModel* m, int f, const float q[3], const float qd[3], float out[13]) {
+    FK k;
+    fk_setup(m, q, &k);
+    float t[3], To[3];
+    rot_link(&k, 3, m->tip_origin, t);
+    To[0] = k.p3[0] + t[0]; To[1] = k.p3[1] + t[1]; To[2] = k.p3[2] + t[2];
+    base_to_world(m, f, To, &out[0]);
+    /* orientation: Rz(yaw) Ry(q1) Rx(q2+q3) */
+    float sy, cy, sx, cx;
+    tf_sincos(0.5f * q[0], &sy, &cy);
+    tf_sincos(0.5f * (q[1] + q[2]), &sx, &cx);
+    float qyx[4] = {cy * sx, sy * cx, -(sy * sx), cy * cx};   /* qy * qx */
+    float qz[4] = {0.0f, 0.0f, m->base_half_yaw_sin[f], m->base_half_yaw_cos[f]};
+    quat_mul(qz, qyx, &out[3]);
+    float L1[3], L2[3], L3[3], vb[3], wb[3];
+    levers(&k, To, L1, L2, L3);
+    for (int i = 0; i < 3; ++i) vb[i] = L1[i] * qd[0] + L2[i] * qd[1] + L3[i] * qd[2];
+    wb[0] = k.ax[0] * qd[1] + k.ax[0] * qd[2];
+    wb[1] = qd[0];
+    wb[2] = k.ax[2] * qd[1] + k.ax[2] * qd[2];
+    dir_base_to_world(m, f, vb, &out[7]);
+    dir_base_to_world(m, f, wb, &out[10]);
+}
+
+/* per-env accumulators for the info scalars */
+typedef struct { double rew[6]; double pos_cnt, ori_cnt, succ, resets, nonfinite; } Stats;
+
+/* trifinger_env.py:500-559 + 959-1099 for one env.  prev_obj = history[1] pose (7).  */
+static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float prev_obj[7], const RewardCoef* rc,
+                          int with_reward, Stats* st) {
+    const TfConfig* c = &h->cfg;
+    const TfModel* m = &c->model;
+    int A = h->action_dim, OD = h->obs_dim, SD = h->states_dim;
+    float tips[3][13];
+    for (int f = 0; f < 3; ++f) tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
+    /* NaN guard: a non-finite env is flagged for reset and parked at the default pose */
+    {
+        float acc = 0.0f;
+        for (int j = 0; j < 9; ++j) acc = acc + e->q[j] * 0.0f + e->qd[j] * 0.0f;
+        for (int j = 0; j < 3; ++j) acc = acc + e->cp[j] * 0.0f + e->cv[j] * 0.0f + e->cw[j] * 0.0f;
+        for (int j = 0; j < 4; ++j) acc = acc + e->cq[j] * 0.0f;
+        if (!(acc == 0.0f)) {
+            for (int j = 0; j < 9; ++j) { e->q[j] = m->q_default[j % 3]; e->qd[j] = 0.0f; }
+            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = CUBE_MIN_HEIGHT;
+            e->cq[0] = 0.0f; e->cq[1] = 0.0f; e->cq[2] = 0.0f; e->cq[3] = 1.0f;
+            for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
+            for (int j = 0; j < 18; ++j) e->ft[j] = 0.0f;
+            for (int f = 0; f < 3; ++f) tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
+            h->buf.reset_buf[i] = 1;
+            st->nonfinite += 1.0;
+        }
+    }
+    /* observations (trifinger_env.py:996-1019) and states (:1021-1051) */
+    float raw[MAX_STATES];
+    int k = 0;
+    for (int j = 0; j < 9; ++j) raw[k++] = e->q[j];
+    for (int j = 0; j < 9; ++j) raw[k++] = e->qd[j];
+    for (int j = 0; j < 3; ++j) raw[k++] = e->cp[j];
+    for (int j = 0; j < 4; ++j) raw[k++] = e->cq[j];
+    for (int j = 0; j < 3; ++j) raw[k++] = e->gp[j];
+    for (int j = 0; j < 4; ++j) raw[k++] = e->gq[j];
+    const float* act = &h->buf.action_buf[(size_t)i * (size_t)A];
+    for (int j = 0; j < A; ++j) raw[k++] = act[j];
+    float* obs = &h->buf.obs[(size_t)i * (size_t)OD];
+    for (int j = 0; j < OD; ++j) obs[j] = c->normalize_obs ? (2.0f * (raw[j] - h->obs_off[j])) * h->obs_inv[j] : raw[j];
+    if (c->asymmetric_obs) {
+        for (int j = 0; j < 3; ++j) raw[k++] = e->cv[j];
+        for (int j = 0; j < 3; ++j) raw[k++] = e->cw[j];
+        for (int f = 0; f < 3; ++f) for (int j = 0; j < 13; ++j) raw[k++] = tips[f][j];
+        for (int j = 0; j < 9; ++j) raw[k++] = c->enable_ft_sensors ? e->tau[j] : 0.0f;
+        {
+            /* wrench: mean over the substeps of this step, rotated into the tip-link frame */
+            float inv_n = 1.0f / (float)(c->substeps * c->control_decimation);
+            for (int f = 0; f < 3; ++f) {
+                FK kk;
+                fk_setup(m, &e->q[3 * f], &kk);
+                for (int half = 0; half < 2; ++half) {
+                    float wv[3] = {e->ft[6 * f + 3 * half] * inv_n, e->ft[6 * f + 3 * half + 1] * inv_n,
+                                   e->ft[6 * f + 3 * half + 2] * inv_n};
+                    float bv[3], lv[3];
+                    dir_world_to_base(m, f, wv, bv);
+                    rot_link_T(&kk, 3, bv, lv);
+                    for (int j = 0; j < 3; ++j) raw[k++] = c->enable_ft_sensors ? lv[j] : 0.0f;
+                }
+            }
+        }
+        float* sts = &h->buf.states[(size_t)i * (size_t)SD];
+        for (int j = 0; j < SD; ++j) sts[j] = c->normalize_obs ? (2.0f * (raw[j] - h->st_off[j])) * h->st_inv[j] : raw[j];
+    }
+    /* history bookkeeping: previous fingertip positions are whatever the last filled frame left */
+    float tip_prev[9];
+    for (int j = 0; j < 9; ++j) tip_prev[j] = ST(h, TF_S_TIP_P + j, i);
+    for (int f = 0; f < 3; ++f) for (int j = 0; j < 3; ++j) ST(h, TF_S_TIP_P + 3 * f + j, i) = tips[f][j];
+    if (!with_reward) return;
+    /* rewards (rewards.py; evaluation order trifinger_env.py:513-550) */
+    float r[6];
+    {
+        float s = 0.0f;
+        for (int f = 0; f < 3; ++f) {
+            float cur = norm3d(tips[f], e->cp);
+            float prv = norm3d(&tip_prev[3 * f], prev_obj);
+            s = s + (cur - prv);
+        }
+        r[0] = rc->c_reach * s;
+    }
+    {
+        float s = 0.0f;
+        for (int f = 0; f < 3; ++f) for (int j = 0; j < 3; ++j) {
+            float vel = (tips[f][j] - tip_prev[3 * f + j]) / rc->dt;
+            s = s + vel * vel;
+        }
+        r[1] = rc->c_move_pen * s;
+    }
+    float dist = norm3d(e->cp, e->gp);
+    r[2] = rc->c_dist * lgsk(dist, 50.0f);
+    float ang = quat_diff_rad(e->cq, e->gq);
+    r[3] = rc->w_rot * (rc->rot_num / (rc->rot_scale * f_abs(ang) + rc->rot_scale));
+    float ang_prev = quat_diff_rad(&prev_obj[3], e->gq);
+    r[4] = rc->w_rot_delta * (rc->rot_delta_sched * (f_abs(ang) - f_abs(ang_prev)));
+    r[5] = rc->w_move * (dist - norm3d(prev_obj, e->gp));
+    float total = 0.0f;
+    for (int t = 0; t < 6; ++t) if (c->reward[t].activate) { total = total + r[t]; st->rew[t] += (double)r[t]; }
+    /* termination (trifinger_env.py:1053-1099) */
+    int pos_ok = dist <= c->position_tolerance;
+    int ori_ok = ang <= c->orientation_tolerance;
+    st->pos_cnt += pos_ok; st->ori_cnt += ori_ok;
+    int done;
+    if (c->task_difficulty < 4) done = pos_ok;
+    else if (c->task_difficulty == 4) done = pos_ok && ori_ok;
+    else done = ori_ok;
+    int succ = h->buf.successes[i] != 0;
+    if (c->success_activate) {
+        if (done) total = total + c->success_bonus;
+        h->buf.goal_reset_buf[i] = (uint8_t)done;
+        succ = succ || done;
+    } else {
+        succ = (h->buf.goal_reset_buf[i] != 0) && succ;
+    }
+    h->buf.successes[i] = (uint8_t)succ;
+    st->succ += succ;
+    h->buf.reward[i] = total;
+}
+
+/* env_base.py:391-399 */
+static void finish_env(const struct TfHandle_* h, int i) {
+    int s = h->buf.steps[i] + 1;
+    h->buf.steps[i] = s;
+    if (h->cfg.episode_length > 0 && s >= h->cfg.episode_length) h->buf.reset_buf[i] = 1;
+    h->buf.dones[i] = (uint8_t)(h->buf.reset_buf[i] && h->buf.goal_reset_buf[i]);
+}
+
+static void write_info(const struct TfHandle_* h, const Stats* st) {
+    float n = (float)h->cfg.num_envs;
+    for (int t = 0; t < 6; ++t) h->buf.info[t] = (float)(st->rew[t] / (double)n);
+    h->buf.info[TF_INFO_POS_COUNT] = (float)st->pos_cnt;
+    h->buf.info[TF_INFO_ORI_COUNT] = (float)st->ori_cnt;
+    h->buf.info[TF_INFO_SUCCESS_MEAN] = (float)(st->succ / (double)n);
+    h->buf.info[TF_INFO_NUM_RESETS] = (float)st->resets;
+    h->buf.info[TF_INFO_NUM_NONFINITE] = (float)st->nonfinite;
+}
+
+static void stats_add(Stats* a, const Stats* b) {
+    for (int t = 0; t < 6; ++t) a->rew[t] += b->rew[t];
+    a->pos_cnt += b->pos_cnt; a->ori_cnt += b->ori_cnt; a->succ += b->succ; a->resets += b->resets;
+    a->nonfinite += b->nonfinite;
+}
+
+/* fused step / reset */
+static int run_step(tf_handle h, const float* action, int is_reset) {
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->bound) return TF_ERR_NOT_BOUND;
+    if (!is_reset && !action) return TF_ERR_INVALID_ARG;
+    const TfConfig* c = &h->cfg;
+    int N = c->num_envs, A = h->action_dim;
+    int nsim = is_reset ? 1 : c->control_decimation;
+    h->frame_count += nsim;
+    RewardCoef rc;
+    reward_coefs(h, &rc);
+    float hsub = c->dt / (float)c->substeps;
+    Stats total;
+    memset(&total, 0, sizeof(total));
+#pragma omp parallel
+    {
+        Stats local;
+        memset(&local, 0, sizeof(local));
+#pragma omp for schedule(static)
+        for (int i = 0; i < N; ++i) {
+            Env e;
+            env_load(h, i, &e);
+            float* abuf = &h->buf.action_buf[(size_t)i * (size_t)A];
+            if (is_reset) { for (int j = 0; j < A; ++j) abuf[j] = 0.0f; }   /* env_base.py:332-334 acts on the buffer */
+            else { for (int j = 0; j < A; ++j) abuf[j] = action[(size_t)i * (size_t)A + j]; }
+            if (apply_resets(h, i, &e, is_reset)) {
+                for (int j = 0; j < A; ++j) abuf[j] = 0.0f;                  /* trifinger_env.py:387 */
+                local.resets += 1.0;
+            }
+            compute_torque(h, abuf, e.q, e.qd, e.tau);
+            float prev_obj[7] = {e.cp[0], e.cp[1], e.cp[2], e.cq[0], e.cq[1], e.cq[2], e.cq[3]};
+            for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
+            for (int s = 0; s < nsim * c->substeps; ++s) substep(h, &e, hsub);
+            post_step_env(h, i, &e, prev_obj, &rc, !is_reset, &local);
+            env_store(h, i, &e);
+            if (!is_reset) finish_env(h, i);
+        }
+#pragma omp critical
+        stats_add(&total, &local);
+    }
+    write_info(h, &total);
+    return TF_OK;
+}
+
+int tf_step(tf_handle h, const float* action, void* stream) { (void)stream; return run_step(h, action, 0); }
+int tf_reset(tf_handle h, void* stream) { (void)stream; return run_step(h, NULL, 1); }
+
+/* ---- split path ---- */
+int tf_apply_resets(tf_handle h, void* stream) {
+    (void)stream;
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->bound) return TF_ERR_NOT_BOUND;
+    int A = h->action_dim;
+    for (int i = 0; i < h->cfg.num_envs; ++i) {
+        Env e;
+        env_load(h, i, &e);
+        if (apply_resets(h, i, &e, 0)) for (int j = 0; j < A; ++j) h->buf.action_buf[(size_t)i * (size_t)A + j] = 0.0f;
+        env_store(h, i, &e);
+    }
+    return TF_OK;
+}
+int tf_pre_step(tf_handle h, void* stream) {
+    (void)stream;
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->bound) return TF_ERR_NOT_BOUND;
+    int A = h->action_dim;
+    for (int i = 0; i < h->cfg.num_envs; ++i) {
+        Env e;
+        env_load(h, i, &e);
+        compute_torque(h, &h->buf.action_buf[(size_t)i * (size_t)A], e.q, e.qd, e.tau);
+        for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
+        env_store(h, i, &e);
+        for (int j = 0; j < 3; ++j) ST(h, TF_S_PREV_OBJ_P + j, i) = e.cp[j];
+        for (int j = 0; j < 4; ++j) ST(h, TF_S_PREV_OBJ_Q + j, i) = e.cq[j];
+    }
+    return TF_OK;
+}
+int tf_simulate(tf_handle h, void* stream) {
+    (void)stream;
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->bound) return TF_ERR_NOT_BOUND;
+    h->frame_count += 1;
+    float hsub = h->cfg.dt / (float)h->cfg.substeps;
+    for (int i = 0; i < h->cfg.num_envs; ++i) {
+        Env e;
+        env_load(h, i, &e);
+        for (int s = 0; s < h->cfg.substeps; ++s) substep(h, &e, hsub);
+        env_store(h, i, &e);
+    }
+    return TF_OK;
+}
+int tf_post_step(tf_handle h, void* stream) {
+    (void)stream;
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->bound) return TF_ERR_NOT_BOUND;
+    RewardCoef rc;
+    reward_coefs(h, &rc);
+    Stats st;
+    memset(&st, 0, sizeof(st));
+    for (int i = 0; i < h->cfg.num_envs; ++i) {
+        Env e;
+        env_load(h, i, &e);
+        float prev_obj[7];
+        for (int j = 0; j < 3; ++j) prev_obj[j] = ST(h, TF_S_PREV_OBJ_P + j, i);
+        for (int j = 0; j < 4; ++j) prev_obj[3 + j] = ST(h, TF_S_PREV_OBJ_Q + j, i);
+        post_step_env(h, i, &e, prev_obj, &rc, 1, &st);
+        env_store(h, i, &e);
+    }
+    write_info(h, &st);
+    return TF_OK;
+}
+int tf_finish_step(tf_handle h, void* stream) {
+    (void)stream;
+    if (!h) return TF_ERR_INVALID_ARG;
+    if (!h->bound) return TF_ERR_NOT_BOUND;
+    for (int i = 0; i < h->cfg.num_envs; ++i) finish_env(h, i);
+    return TF_OK;
+}
+
+/* ---- leaf entries for the golden tests ---- */
+int tf_test_quat_diff_rad(const float* a, const float* b, float* out, int32_t n, void* s) {
+    (void)s;
+    for (int i = 0; i < n; ++i) out[i] = quat_diff_rad(&a[4 * i], &b[4 * i]);
+    return TF_OK;
+}
+int tf_test_quat_mul(const float* a, const float* b, float* out, int32_t n, void* s) {
+    (void)s;
+    for (int i = 0; i < n; ++i) quat_mul(&a[4 * i], &b[4 * i], &out[4 * i]);
+    return TF_OK;
+}
+int tf_test_lgsk(const float* x, float scale, float* out, int32_t n, void* s) {
+    (void)s;
+    for (int i = 0; i < n; ++i) out[i] = lgsk(x[i], scale);
+    return TF_OK;
+}
+int tf_test_sample_xy(const float* ur, const float* ut, float r_max, float* x, float* y, int32_t n, void* s) {
+    (void)s;
+    for (int i = 0; i < n; ++i) sample_xy(ur[i], ut[i], r_max, &x[i], &y[i]);
+    return TF_OK;
+}
+int tf_test_sample_yaw_quat(const float* u, float* quat, int32_t n, void* s) {
+    (void)s;
+    for (int i = 0; i < n; ++i) sample_yaw_quat(u[i], &quat[4 * i]);
+    return TF_OK;
+}
+int tf_test_normalize_quat(const float* nn, float* quat, int32_t n, void* s) {
+    (void)s;
+    for (int i = 0; i < n; ++i) normalize_quat(&nn[4 * i], &quat[4 * i]);
+    return TF_OK;
+}
+int tf_test_philox(uint64_t seed, const uint32_t* env_id, const uint32_t* counter, uint32_t tag, uint32_t* out4,
+                   int32_t n, void* s) {
+    (void)s;
+    for (int i = 0; i < n; ++i)
+        philox4x32_10(env_id[i], counter[i], tag, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &out4[4 * i]);
+    return TF_OK;
+}
+int tf_test_finger_dynamics(tf_handle h, const float* q, const float* qd, float* tip, float* mass, float* bias,
+                            int32_t n, void* s) {
+    (void)s;
+    if (!h) return TF_ERR_INVALID_ARG;
+    const TfModel* m = &h->cfg.model;
+    for (int i = 0; i < n; ++i) {
+        FK k;
+        float M[6], t[3];
+        fk_setup(m, &q[3 * i], &k);
+        finger_dynamics(m, &k, &qd[3 * i], h->cfg.gravity, M, &bias[3 * i]);
+        rot_link(&k, 3, m->tip_origin, t);
+        for (int j = 0; j < 3; ++j) tip[3 * i + j] = k.p3[j] + t[j];
+        float* o = &mass[9 * i];
+        o[0] = M[0]; o[1] = M[1]; o[2] = M[2]; o[3] = M[1]; o[4] = M[3]; o[5] = M[4]; o[6] = M[2]; o[7] = M[4]; o[8] = M[5];
+    }
+    return TF_OK;
+}
+
+/* extra oracle-only leaf functions used by tests/test_oracle_math.py */
+void tfo_sincos(const float* x, float* s, float* c, int32_t n) { for (int i = 0; i < n; ++i) tf_sincos(x[i], &s[i], &c[i]); }
+void tfo_exp(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = tf_exp(x[i]); }
+void tfo_asin(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = tf_asin(x[i]); }
+void tfo_log(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = tf_log(x[i]); }
+void tfo_philox_raw(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}

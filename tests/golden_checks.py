@@ -1,0 +1,345 @@
+"""Checks of a trifinger C-ABI library against the committed golden fixtures (tests/golden/*.npz).
+
+Every function takes `(lib, device)`: the oracle on 'cpu' (CPU suite: pins the oracle) or the HIP
+library on 'cuda:0' (GPU suite: pins the product).  All calls go through the C ABI.
+
+Tolerances (fp32): abs 2e-6 / rel 1e-5 unless noted; quat_diff_rad near pi 2e-3 (asin slope);
+samplers 2e-6 (own sincos vs torch's).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from leibnizgym_amd import _capi as capi
+from leibnizgym_amd.engine import TrifingerEngine, make_config
+from oracle_util import golden
+
+ATOL, RTOL = 2e-6, 1e-5
+
+
+def T(a, device, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device).contiguous()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def sync(device):
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+
+
+def close(a, b, atol=ATOL, rtol=RTOL, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert np.all(err <= 0), f"{what}: max excess {err.max():.3e}, max abs diff {np.abs(a - b).max():.3e}"
+
+
+# ---------------------------------------------------------------------------------------------
+def check_math(lib, device):
+    g = golden("math")
+    a, b = T(g["quat_a"], device), T(g["quat_b"], device)
+    n = a.shape[0]
+    out4 = torch.empty_like(a)
+    assert lib.tf_test_quat_mul(P(a), P(b), P(out4), n, None) == 0
+    sync(device)
+    close(out4.cpu().numpy(), g["quat_mul"], what="quat_mul")
+    out1 = torch.empty(n, device=device)
+    assert lib.tf_test_quat_diff_rad(P(a), P(b), P(out1), n, None) == 0
+    sync(device)
+    got, want = out1.cpu().numpy(), g["quat_diff_rad"]
+    near_pi = want > 3.0
+    close(got[~near_pi], want[~near_pi], atol=5e-6, what="quat_diff_rad")
+    close(got[near_pi], want[near_pi], atol=2e-3, what="quat_diff_rad near pi")
+    # yaw-only euler rows == sample_yaw_quat(u) with yaw = 2 pi u
+    rpy = g["euler_rpy"][:8]
+    u = T(rpy[:, 2] / np.float32(6.2831855), device)
+    q = torch.empty(8, 4, device=device)
+    assert lib.tf_test_sample_yaw_quat(P(u), P(q), 8, None) == 0
+    sync(device)
+    close(q.cpu().numpy(), g["euler_quat"][:8], atol=1e-6, what="quaternion_from_euler_xyz (yaw)")
+
+
+def check_lgsk(lib, device):
+    g = golden("rewards")
+    x = T(g["lgsk_x"], device)
+    y = torch.empty_like(x)
+    for scale, key in ((50.0, "lgsk_y50"), (3.0, "lgsk_y3")):
+        assert lib.tf_test_lgsk(P(x), scale, P(y), x.numel(), None) == 0
+        sync(device)
+        close(y.cpu().numpy(), g[key], atol=1e-12, rtol=2e-5, what=f"lgsk scale {scale}")
+
+
+def check_samplers(lib, device):
+    g = golden("samplers")
+    n = g["xy_x"].shape[0]
+    ur, ut = T(g["xy_u_radius"], device), T(g["xy_u_theta"], device)
+    x, y = torch.empty(n, device=device), torch.empty(n, device=device)
+    assert lib.tf_test_sample_xy(P(ur), P(ut), float(g["xy_rmax"]), P(x), P(y), n, None) == 0
+    sync(device)
+    close(x.cpu().numpy(), g["xy_x"], atol=2e-7, rtol=2e-6, what="random_xy.x")
+    close(y.cpu().numpy(), g["xy_y"], atol=2e-7, rtol=2e-6, what="random_xy.y")
+    u = T(g["yaw_u"], device)
+    q = torch.empty(n, 4, device=device)
+    assert lib.tf_test_sample_yaw_quat(P(u), P(q), n, None) == 0
+    sync(device)
+    close(q.cpu().numpy(), g["yaw_quat"], atol=1e-6, what="random_yaw_orientation")
+    nrm = T(g["ori_normals"], device)
+    assert lib.tf_test_normalize_quat(P(nrm), P(q), n, None) == 0
+    sync(device)
+    close(q.cpu().numpy(), g["ori_quat"], atol=2e-7, rtol=2e-6, what="random_orientation")
+
+
+# ---------------------------------------------------------------------------------------------
+def _engine(lib, device, n, **kw):
+    kw.setdefault("success", {"activate": False})
+    cfg = make_config(lib, n, **kw)
+    return TrifingerEngine(cfg, device=device, lib=lib)
+
+
+def check_torque(lib, device):
+    """T4: (action, q, qd) -> applied torque, 3 command modes x normalize x safety damping."""
+    g = golden("torque")
+    n = g["q"].shape[0]
+    for mode in ("torque", "position", "position_impedance"):
+        for norm in (1, 0):
+            for safe in (0, 1):
+                eng = _engine(lib, device, n, command_mode=mode, normalize_action=bool(norm),
+                              apply_safety_damping=bool(safe))
+                eng.q.copy_(T(g["q"].T, device))
+                eng.qd.copy_(T(g["qd"].T, device))
+                eng.action_buf.copy_(T(g[f"{mode}_action"], device))
+                eng.pre_step()
+                sync(device)
+                close(eng.tau.T.cpu().numpy(), g[f"{mode}_norm{norm}_safe{safe}"], atol=1e-6,
+                      what=f"torque {mode} norm={norm} safe={safe}")
+                eng.close()
+
+
+def check_obs(lib, device):
+    """T5: obs[41|50] / states[113|122] assembly + scale tables, for the slots that are inputs of the
+    native step (q, qd, object pose/vel, goal, last action, dof force).  Fingertip slots are produced by
+    the build's own FK and are checked in test_physics_analytic.py; here they are compared after
+    re-normalising the FK tips with the golden scale table."""
+    g = golden("obs")
+    n = g["q"].shape[0]
+    for mode in ("torque", "position", "position_impedance"):
+        for na in (1, 0):
+            for norm_obs in (True, False):
+                eng = _engine(lib, device, n, command_mode=mode, normalize_action=bool(na), normalize_obs=norm_obs,
+                              asymmetric_obs=True)
+                tag = f"{mode}_na{na}"
+                eng.q.copy_(T(g["q"].T, device))
+                eng.qd.copy_(T(g["qd"].T, device))
+                eng.cube.copy_(T(g["obj"].T, device))
+                eng.goal.copy_(T(g["goal"].T, device))
+                eng.action_buf.copy_(T(g[f"{mode}_action"], device))
+                eng.tau.copy_(T(g["dof_force"].T, device))
+                eng.view(capi.S_PREV_OBJ_P, 7).copy_(T(g["obj"][:, :7].T, device))
+                eng.post_step()
+                sync(device)
+                obs = eng.obs.cpu().numpy()
+                sts = eng.states.cpu().numpy()
+                want_obs = g[f"{tag}_obs_norm"] if norm_obs else g[f"{tag}_obs_raw"]
+                want_sts = g[f"{tag}_states_norm"] if norm_obs else g[f"{tag}_states_raw"]
+                od = want_obs.shape[1]
+                close(obs, want_obs, atol=2e-6, what=f"obs {tag} norm_obs={norm_obs}")
+                # states: common prefix, object velocity, dof force
+                close(sts[:, :od + 6], want_sts[:, :od + 6], atol=2e-6, what=f"states[:obs+6] {tag}")
+                close(sts[:, od + 45:od + 54], want_sts[:, od + 45:od + 54], atol=2e-6, what=f"states dof force {tag}")
+                # fingertip block: the scale table must be the golden one -> unscale with golden table gives raw FK
+                if norm_obs:
+                    lo, hi = g[f"{tag}_states_lo"], g[f"{tag}_states_hi"]
+                    raw = sts * (hi - lo) * 0.5 + (lo + hi) * 0.5
+                    eng2 = _engine(lib, device, n, command_mode=mode, normalize_action=bool(na), normalize_obs=False,
+                                   asymmetric_obs=True)
+                    eng2.state.copy_(eng.state)
+                    eng2.action_buf.copy_(eng.action_buf)
+                    eng2.post_step()
+                    sync(device)
+                    close(raw[:, od + 6:od + 45], eng2.states.cpu().numpy()[:, od + 6:od + 45], atol=5e-6,
+                          what=f"fingertip block scale table {tag}")
+                    eng2.close()
+                eng.close()
+
+
+REWARD_CFGS = {
+    "d1": {
+        "finger_move_penalty": {"activate": True, "weight": -0.1},
+        "finger_reach_object_rate": {"activate": True, "norm_p": 2, "weight": -750},
+        "object_dist": {"activate": True, "weight": 2000},
+        "object_rot": {"activate": False, "weight": 300},
+        "object_rot_delta": {"activate": False, "weight": -250},
+        "object_move": {"activate": False, "weight": -750},
+    },
+    "d4": {
+        "finger_move_penalty": {"activate": True, "weight": -0.1},
+        "finger_reach_object_rate": {"activate": True, "norm_p": 2, "weight": -250,
+                                     "thresh_sched_start": 0, "thresh_sched_end": 1e7},
+        "object_dist": {"activate": True, "weight": 2000, "thresh_sched_start": 0, "thresh_sched_end": 10e10},
+        "object_rot": {"activate": True, "weight": 2000, "epsilon": 0.01, "scale": 3.0,
+                       "thresh_sched_start": 1e7, "thresh_sched_end": 1e10},
+        "object_rot_delta": {"activate": False, "weight": -250},
+        "object_move": {"activate": False, "weight": -750},
+    },
+    "envdef": {
+        "finger_reach_object_rate": {"activate": True, "weight": -750, "norm_p": 2},
+        "finger_move_penalty": {"activate": True, "weight": -0.1},
+        "object_dist": {"activate": True, "weight": 2000},
+        "object_rot": {"activate": True, "weight": 300},
+        "object_rot_delta": {"activate": True, "weight": -250},
+        "object_move": {"activate": True, "weight": -750},
+    },
+    "linsched": {
+        "finger_reach_object_rate": {"activate": True, "weight": -750, "norm_p": 2},
+        "finger_move_penalty": {"activate": True, "weight": -0.1},
+        "object_dist": {"activate": True, "weight": 2000},
+        "object_rot": {"activate": True, "weight": 300, "scale": 1.0},
+        "object_rot_delta": {"activate": True, "weight": -250,
+                             "linear_schedule_start": 5e6, "linear_schedule_end": 1.5e7},
+        "object_move": {"activate": True, "weight": -750},
+    },
+}
+
+
+def check_rewards(lib, device):
+    """T6/T7: per-env total reward and per-term means for 4 configs x 5 schedule points.
+
+    Object terms (object_dist, object_rot, object_rot_delta, object_move) are compared directly with
+    the golden values of the imported reference terms.  The two fingertip terms take FK tips and are
+    covered by `check_finger_rewards`."""
+    g = golden("rewards")
+    obj, obj_prev, goal = g["obj"], g["obj_prev"], g["goal"]
+    n = obj.shape[0]
+    steps = g["sched_steps"]
+    order = list(capi.REWARD_TERM_ORDER)
+    assert [str(s) for s in g["term_order"]] == order
+    for cname, terms in REWARD_CFGS.items():
+        per_all, means_all = g[f"{cname}_per_term"], g[f"{cname}_means"]
+        for si, step in enumerate(steps):
+            # object-only config: switch the two finger terms off, keep every object term as configured
+            obj_terms = {k: dict(v) for k, v in terms.items()}
+            obj_terms["finger_reach_object_rate"]["activate"] = False
+            obj_terms["finger_move_penalty"]["activate"] = False
+            # env_steps_count = frame_count * global_num_envs (env_base.py:287-289): with global_num_envs=1 the
+            # frame counter itself is the schedule step
+            cfg = make_config(lib, n, command_mode="torque", reward_terms=obj_terms, dt=float(g["dt"]),
+                              success={"activate": False}, global_num_envs=1)
+            eng = TrifingerEngine(cfg, device=device, lib=lib)
+            eng.cube.copy_(T(obj.T, device))
+            eng.goal.copy_(T(goal.T, device))
+            eng.view(capi.S_PREV_OBJ_P, 7).copy_(T(obj_prev[:, :7].T, device))
+            eng.frame_count = int(step)
+            eng.post_step()
+            sync(device)
+            want = np.zeros(n, dtype=np.float64)
+            for k, name in enumerate(order):
+                if obj_terms[name]["activate"]:
+                    want += per_all[si, k].astype(np.float64)
+            close(eng.reward.cpu().numpy(), want, atol=2e-4, rtol=2e-5, what=f"object rewards {cname} step={step}")
+            info = eng.info.cpu().numpy()
+            for k, name in enumerate(order):
+                if obj_terms[name]["activate"]:
+                    close(info[k], means_all[si, k], atol=2e-4, rtol=2e-5, what=f"mean {name} {cname} step={step}")
+            eng.close()
+
+
+def check_finger_rewards(lib, device):
+    """T7 fingertip terms with FK-produced tips: the golden per-term values are reproduced by feeding
+    the golden (tips - tips_prev) displacement through the previous-tip history."""
+    g = golden("rewards")
+    tips, tips_prev = g["tips"][:, :, 0:3], g["tips_prev"][:, :, 0:3]
+    obj, obj_prev = g["obj"], g["obj_prev"]
+    n = obj.shape[0]
+    terms = {k: dict(v) for k, v in REWARD_CFGS["d1"].items()}
+    terms["object_dist"]["activate"] = False
+    cfg = make_config(lib, n, command_mode="torque", reward_terms=terms, dt=float(g["dt"]),
+                      success={"activate": False}, robot_reset="default")
+    eng = TrifingerEngine(cfg, device=device, lib=lib)
+    rng = np.random.default_rng(5)
+    q = np.tile(np.array([0.0, 0.9, -1.7], dtype=np.float32), (n, 3)) + rng.uniform(-0.3, 0.3, (n, 9)).astype(np.float32)
+    eng.q.copy_(T(q.T, device))
+    eng.post_step()                       # first call: leaves FK tips in the history row
+    sync(device)
+    fk_tips = eng.tip_pos.T.cpu().numpy().reshape(n, 3, 3).copy()
+    # previous tips = fk_tips - golden displacement; object placed so that tip-object offsets equal golden ones
+    disp = (tips - tips_prev).astype(np.float32)
+    prev = (fk_tips - disp).astype(np.float32)
+    eng.tip_pos.copy_(T(prev.reshape(n, 9).T, device))
+    eng.cube.copy_(T(obj.T, device))
+    eng.view(capi.S_PREV_OBJ_P, 7).copy_(T(obj_prev[:, :7].T, device))
+    eng.post_step()
+    sync(device)
+    o, op = obj[:, 0:3].astype(np.float64), obj_prev[:, 0:3].astype(np.float64)
+    cur = np.linalg.norm(fk_tips.astype(np.float64) - o[:, None, :], axis=-1)
+    prv = np.linalg.norm(prev.astype(np.float64) - op[:, None, :], axis=-1)
+    reach = -750.0 * (cur - prv).sum(-1)
+    move = -0.1 * (((fk_tips.astype(np.float64) - prev.astype(np.float64)) / 0.02) ** 2).sum((-1, -2))
+    close(eng.reward.cpu().numpy(), reach + move, atol=5e-3, rtol=5e-5, what="finger terms (formula)")
+    # finger_move_penalty depends only on the displacement -> equals the golden term up to the fp32
+    # rounding of (fk - (fk - disp)) ~ 1e-7 m, amplified by (1/dt)^2 * 2 * v
+    got_move = eng.reward.cpu().numpy().astype(np.float64) - reach
+    close(got_move, g["d1_per_term"][0, 1], atol=5e-3, rtol=5e-3, what="finger_move_penalty vs imported reference term")
+    eng.close()
+
+
+def check_termination(lib, device):
+    """T8: flags, counts, bonus, successes for difficulty {1,4,5} x activate {T,F}."""
+    g = golden("termination")
+    n = g["obj_p"].shape[0]
+    none = {k: {"activate": False} for k in capi.REWARD_TERM_ORDER}
+    for diff in (1, 4, 5):
+        for act in (1, 0):
+            cfg = make_config(lib, n, command_mode="torque", task_difficulty=diff, reward_terms=none,
+                              success={"activate": bool(act), "bonus": float(g["bonus"]),
+                                       "position_tolerance": float(g["pos_tol"]),
+                                       "orientation_tolerance": float(g["ori_tol"])})
+            eng = TrifingerEngine(cfg, device=device, lib=lib)
+            eng.view(capi.S_CUBE_P, 3).copy_(T(g["obj_p"].T, device))
+            eng.view(capi.S_CUBE_Q, 4).copy_(T(g["obj_q"].T, device))
+            eng.view(capi.S_GOAL_P, 3).copy_(T(g["goal_p"].T, device))
+            eng.view(capi.S_GOAL_Q, 4).copy_(T(g["goal_q"].T, device))
+            eng.view(capi.S_PREV_OBJ_P, 3).copy_(T(g["obj_p"].T, device))
+            eng.view(capi.S_PREV_OBJ_Q, 4).copy_(T(g["obj_q"].T, device))
+            eng.successes.copy_(torch.as_tensor(g["successes_in"]).to(device))
+            eng.goal_reset_buf.copy_(torch.as_tensor(g["goal_reset_in"]).to(device))
+            eng.post_step()
+            sync(device)
+            tag = f"d{diff}_act{act}"
+            # the golden adds the bonus to a random reward_in; all reward terms are off here -> bonus only
+            want_bonus = g[f"{tag}_reward"] - g["reward_in"]
+            close(eng.reward.cpu().numpy(), want_bonus, atol=1e-3, what=f"bonus {tag}")
+            assert np.array_equal(eng.goal_reset_buf.cpu().numpy(), g[f"{tag}_goal_reset"]), tag
+            assert np.array_equal(eng.successes.cpu().numpy(), g[f"{tag}_successes"]), tag
+            info = eng.info.cpu().numpy()
+            assert info[capi.INFO_POS_COUNT] == float(g["pos_count"])
+            assert info[capi.INFO_ORI_COUNT] == float(g["ori_count"])
+            close(info[capi.INFO_SUCCESS_MEAN], g[f"{tag}_succ_mean"], atol=1e-6, what=f"succ mean {tag}")
+            eng.close()
+
+
+def check_constants(lib, device):
+    """T13: sampling radii/heights used by the native resets equal CuboidalObject(0.065)'s numbers."""
+    g = golden("constants")
+    n = 4096
+    for diff, zlo, zhi in ((1, g["min_height"], g["min_height"]), (3, g["min_height"], g["max_height"]),
+                           (4, g["radius_3d"], g["max_height"]), (2, 0.0825, 0.0825)):
+        cfg = make_config(lib, n, command_mode="torque", task_difficulty=diff, seed=11)
+        eng = TrifingerEngine(cfg, device=device, lib=lib)
+        eng.reset()
+        sync(device)
+        goal = eng.goal.cpu().numpy()
+        rad = np.hypot(goal[0], goal[1])
+        if diff == 2:
+            assert np.all(rad == 0)
+        else:
+            assert rad.max() <= float(g["max_com_distance"]) * (1 + 1e-6)
+            assert rad.max() > 0.98 * float(g["max_com_distance"])
+        assert goal[2].min() >= float(zlo) - 1e-7 and goal[2].max() <= float(zhi) + 1e-7
+        cube = eng.cube.cpu().numpy()
+        # after one simulate the cube has barely moved from its spawn pose
+        assert np.hypot(cube[0], cube[1]).max() <= float(g["max_com_distance"]) + 2e-3
+        eng.close()
