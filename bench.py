@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the fused TriFinger step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
+one process per GPU, envs sharded with no data-path collective (weak scaling: every rank steps
+`--envs` environments; RNG is keyed by global env id).  RCCL is used only for the timing barrier and the
+max-over-ranks reduction of the elapsed time.
+
+A "step" is one control step (tf_step: masked resets, torque law, decimation x substeps of physics,
+obs/states/rewards/termination) over the rank's whole batch, with synthetic random actions
+2*U[0,1)-1 that are already resident in HBM (a ring of pre-generated action tensors).
+
+Workload = BASELINE.json configs[2]: trifinger_difficulty_4, 65536 envs per GPU, torque mode, Hydra
+defaults of scripts/rlg_hydra.py:58-118 + difficulty-4 reward schedule (:140-182), asymmetric obs on
+(the shipped resources/config/rlg/asymm.yaml default), episode_length 750.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel k_step vs the HBM roofline, as the north star
+asks; the kernel is FP32-issue bound) and `cpu_baseline` (this repo's CPU oracle on the
+host cores - the reference's IsaacGym CPU pipeline cannot be run).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from leibnizgym_amd.engine import TrifingerEngine, make_config  # noqa: E402
+from leibnizgym_amd import _capi  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
+BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs
+FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
+
+D4_REWARDS = {                   # scripts/rlg_hydra.py:140-174
+    "finger_move_penalty": {"activate": True, "weight": -0.1},
+    "finger_reach_object_rate": {"activate": True, "norm_p": 2, "weight": -250,
+                                 "thresh_sched_start": 0, "thresh_sched_end": 1e7},
+    "object_dist": {"activate": True, "weight": 2000, "thresh_sched_start": 0, "thresh_sched_end": 10e10},
+    "object_rot": {"activate": True, "weight": 2000, "epsilon": 0.01, "scale": 3.0,
+                   "thresh_sched_start": 1e7, "thresh_sched_end": 1e10},
+    "object_rot_delta": {"activate": False, "weight": -250},
+    "object_move": {"activate": False, "weight": -750},
+}
+D4_SUCCESS = {"activate": False, "bonus": 5000.0, "orientation_tolerance": 0.25, "position_tolerance": 0.02}
+
+
+def workload_kwargs(asym):
+    return dict(command_mode="torque", task_difficulty=4, asymmetric_obs=asym, normalize_action=True,
+                normalize_obs=True, apply_safety_damping=True, episode_length=750, control_decimation=1,
+                robot_reset="default", object_reset="random", reward_terms=D4_REWARDS, success=D4_SUCCESS,
+                dt=0.02, substeps=2, solver_iterations=8)
+
+
+def cpu_baseline(asym, budget_s=12.0):
+    """Time the CPU oracle (same algorithm, scalar C, OpenMP over envs) on a bounded sample of the workload."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s"], stdout=subprocess.DEVNULL)
+    so = os.path.join(REPO, "oracle", "_build", "libtrifinger_oracle_omp.so")
+    lib = _capi.TfLib(so)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(1)
+    n = 8192
+    eng = TrifingerEngine(make_config(lib, n, seed=7, **workload_kwargs(asym)), device="cpu", lib=lib)
+    eng.reset()
+    acts = [(torch.rand(n, 9) * 2 - 1).contiguous() for _ in range(4)]
+    eng.step(acts[0])                                   # warm-up
+    t0 = time.perf_counter()
+    eng.step(acts[1])
+    one = time.perf_counter() - t0
+    steps = max(3, min(400, int(budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for k in range(steps):
+        eng.step(acts[k % 4])
+    el = time.perf_counter() - t0
+    eng.close()
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {steps} steps of the same workload, OpenMP static schedule over envs "
+                      f"({cores} threads), {el:.1f} s; reference IsaacGym CPU pipeline not available, "
+                      f"baseline is this repo's CPU oracle (oracle/tf_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--symmetric", action="store_true", help="asymmetric_obs=False (obs only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == max(1, args.gpus) or not distributed, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path in the product)"
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    asym = not args.symmetric
+    n = args.envs
+    lib = _capi.load_hip_library()
+    cfg = make_config(lib, n, seed=7, env_id_offset=rank * n, global_num_envs=world * n, **workload_kwargs(asym))
+    eng = TrifingerEngine(cfg, device=dev, lib=lib)
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    ring = [(torch.rand(n, eng.action_dim, device=dev, generator=gen) * 2 - 1).contiguous() for _ in range(16)]
+    eng.reset()
+    for k in range(args.warmup):
+        eng.step(ring[k % len(ring)])
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.enable_kernel_timing(min(args.steps, 8192))
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        eng.step(ring[k % len(ring)])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = eng.kernel_time_ms()
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on what was just timed: finite state, resets happened if steps crossed an episode boundary
+    assert torch.isfinite(eng.state).all(), "non-finite state after the timed region"
+
+    total_env_steps = world * n * args.steps
+    value = total_env_steps / elapsed
+    kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
+    bytes_per_launch = BYTES_PER_ENV_STEP[asym] * n
+    achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
+    out = {
+        "metric": "env-steps/sec (whole node), trifinger_difficulty_4 @65536 envs, 1/2/4/8 GPUs",
+        "value": value,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"trifinger_difficulty_4, {n} envs/GPU x {world} GPU, torque mode, random actions 2*U-1, "
+                        f"asymmetric_obs={asym}, episode_length 750, dt 0.02, 2 substeps, 8 solver iterations, "
+                        f"control_decimation 1 (BASELINE.json configs[2])",
+            "envs_per_gpu": n,
+            "global_envs": world * n,
+            "asymmetric_obs": asym,
+            "parallelism": f"env-shard x{world} (no data-path collective)",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "k_step<9,false>",
+            "kernel_avg_us": kern_avg_s * 1e6,
+            "kernel_launches_timed": kern_n,
+            "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP[asym],
+            "note": "north star asks for the HBM fraction; the kernel is FP32-issue/latency bound "
+                    "(<=9x9 per-env algebra, no MFMA): see fp32_frac_est",
+            "fp32_frac_est": (FLOP_PER_ENV_STEP * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(asym)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

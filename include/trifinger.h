@@ -88,8 +88,8 @@ enum {
     TF_S_GOAL_W = 38,    /*  3 goal angular velocity (_object_goal_movement_buf[:,3:6], :590)     */
     TF_S_TIP_P = 41,     /*  9 fingertip positions of the last filled frame (history[0][:, :, 0:3]) */
     TF_S_TAU = 50,       /*  9 applied joint torque (what set_dof_actuation_force_tensor received) */
-    TF_S_PREV_OBJ_P = 59,/*  3 object position of history[1]; written by the split path only      */
-    TF_S_PREV_OBJ_Q = 62,/*  4 object orientation of history[1]; split path only                  */
+    TF_S_PREV_OBJ_P = 59,/*  3 object position of history[1]: the pose the step's physics started from */
+    TF_S_PREV_OBJ_Q = 62,/*  4 object orientation of history[1]                                   */
     TF_S_FT = 66,        /* 18 fingertip contact wrench (world frame force 3 + torque 3 per finger about
                               the tip-link origin, mean over the substeps of the step); split path only */
     TF_STATE_ROWS = 84
@@ -222,6 +222,12 @@ int tf_set_frame_count(tf_handle h, int64_t frames);
 int tf_step(tf_handle h, const float* action /* [N][A] row-major, device */, void* stream);
 /* IsaacEnvBase.reset: reset every env, zero action, ONE simulate, fill obs/states. */
 int tf_reset(tf_handle h, void* stream);
+
+/* Optional measurement hook used by bench.py: bracket the fused step kernel (only that kernel) with a pair of
+ * events recorded on its launch stream, for up to `max_launches` launches (0 disables).  tf_kernel_time_ms
+ * waits for the recorded events and returns the summed kernel duration and the number of launches summed. */
+int tf_enable_kernel_timing(tf_handle h, int32_t max_launches);
+int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches);
 
 /* Split path (same arithmetic, one hook per launch) kept for the parity tests. */
 int tf_apply_resets(tf_handle h, void* stream);       /* masked _reset_impl then _goal_reset_impl */

@@ -118,6 +118,8 @@ SYMBOLS = {
     "tf_set_frame_count": (C.c_int, [_P, C.c_int64]),
     "tf_step": (C.c_int, [_P, _P, _P]),
     "tf_reset": (C.c_int, [_P, _P]),
+    "tf_enable_kernel_timing": (C.c_int, [_P, C.c_int32]),
+    "tf_kernel_time_ms": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tf_apply_resets": (C.c_int, [_P, _P]),
     "tf_pre_step": (C.c_int, [_P, _P]),
     "tf_simulate": (C.c_int, [_P, _P]),

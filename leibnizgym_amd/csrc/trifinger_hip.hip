@@ -1,0 +1,2124 @@
+// trifinger_hip.hip - MI355X (gfx950) kernels + C ABI of the TriFinger vectorised environment step.
+//
+// The hot path of pairlab/leibnizgym (IsaacEnvBase.step -> TrifingerEnv hooks -> gymapi.simulate;
+// reference leibnizgym/envs/env_base.py:345-401, leibnizgym/envs/trifinger/trifinger_env.py:373-559,959-1265)
+// as ONE fused launch per control step:
+//
+//   masked reset / goal reset (Philox4x32-10 keyed by global env id)  ->  PD/torque law  ->
+//   decimation x substeps x { 3 x 3-DoF articulated forward dynamics + free cube, contact generation,
+//   projected Gauss-Seidel over contact + joint-limit rows, symplectic Euler }  ->
+//   fingertip FK, obs[41]/states[113] assembly + normalisation, six reward terms, termination,
+//   step counters / time-out / dones, wave-reduced episode statistics.
+//
+// Execution model (CDNA4): one environment per lane, one 64-lane wavefront per workgroup, state in HBM
+// as structure-of-arrays rows [field][env] so that every global access of a wave is one coalesced 256-B
+// line.  Per-env matrices are at most 3x3 / 6x6: no MFMA.  The finger contact Jacobian rows (J, M^-1 J^T,
+// directions) are staged in LDS as [slot][lane] (bank = lane: conflict free) and re-read by every solver
+// iteration; everything else lives in VGPRs (the kernel is compiled for 1 wave per SIMD: at 65536 envs the
+// chip holds exactly one wave per SIMD, so the register file is there to be used).  The row-major API
+// tensors (action [N,A], obs [N,41], states [N,113]) are transposed through LDS so global traffic stays
+// coalesced (dwordx4).  Episode statistics are reduced with wave shuffles into per-wave partials and
+// folded by a one-block kernel: no atomics, no host sync, deterministic.
+//
+// Arithmetic contract (shared with the CPU oracle used by the tests): fp32 IEEE add/mul/div/sqrt, no FMA
+// contraction (-ffp-contract=off), own polynomial sin/cos/exp/asin/log, fixed evaluation order.  Per-env
+// outputs are expected to be bit-identical to the oracle's.
+//
+// Physics is this build's own spec (the reference's lives in closed-source PhysX): DESIGN.md "Physics spec".
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+
+#include "../../include/trifinger.h"
+
+#define WAVE 64
+#define MAX_STATES 122
+
+// ------------------------------------------------------------------------------------------------------
+// device-side parameter block (kernel argument, lives in SGPRs / scalar cache)
+// ------------------------------------------------------------------------------------------------------
+struct RewardCoef {
+    float c_reach, c_move_pen, dt, c_dist, rot_num, rot_scale, w_rot, rot_delta_sched, w_rot_delta, w_move;
+};
+
+struct DevParams {
+    // buffers
+    float* state;
+    float* action_buf;
+    float* obs;
+    float* states;
+    float* reward;
+    uint8_t* reset_buf;
+    uint8_t* goal_reset_buf;
+    uint8_t* successes;
+    uint8_t* dones;
+    int32_t* steps;
+    uint32_t* reset_count;
+    float* info;
+    float* scratch;
+    const float* tables;      // [4][MAX_STATES]: obs/states offset, obs/states 1/range ; then act_lo/hi, kp kd ks
+    // sizes
+    int32_t N, A, OD, SD;
+    int32_t env_id_offset;
+    uint32_t seed_lo, seed_hi;
+    // MDP
+    int32_t command_mode, normalize_action, normalize_obs, apply_safety_damping, asymmetric_obs, enable_ft;
+    int32_t task_difficulty, episode_length;
+    int32_t robot_reset_type, object_reset_type, goal_rotation_activate;
+    float dof_pos_stddev, dof_vel_stddev, goal_rate;
+    int32_t rew_active[6];
+    int32_t success_activate;
+    float success_bonus, pos_tol, ori_tol;
+    // stepping
+    int32_t substeps, iters, control_decimation;
+    float dt, hsub;
+    float grav[3];
+    TfModel m;
+};
+
+// what changes every launch travels by value; everything else is read through a pointer to constant
+// device memory so that the ~200 scalars of DevParams are fetched (scalar cache) where they are used
+// instead of being pinned in SGPRs for the whole kernel
+struct StepArgs {
+    RewardCoef rc;
+    int32_t nsim;
+};
+
+// table rows
+#define TAB_OFF 0
+#define TAB_INV (MAX_STATES)
+#define TAB_ACT_LO (2 * MAX_STATES)
+#define TAB_ACT_HI (2 * MAX_STATES + 18)
+#define TAB_KP (2 * MAX_STATES + 36)
+#define TAB_KD (2 * MAX_STATES + 45)
+#define TAB_KS (2 * MAX_STATES + 54)
+#define TAB_FLOATS (2 * MAX_STATES + 63)
+
+// ------------------------------------------------------------------------------------------------------
+// deterministic elementary functions (Cephes single-precision polynomials; identical to the oracle's)
+// ------------------------------------------------------------------------------------------------------
+#define DEV __device__ __forceinline__
+
+DEV float f_min(float a, float b) { return (a < b) ? a : b; }
+DEV float f_max(float a, float b) { return (a > b) ? a : b; }
+DEV float f_clamp(float x, float lo, float hi) { return f_max(f_min(x, hi), lo); }
+DEV float f_abs(float a) { return (a < 0.0f) ? -a : a; }
+
+DEV void tf_sincos(float x, float& s_out, float& c_out) {
+    float k = __builtin_rintf(x * 0.63661977236758134f);
+    int n = (int)k;
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.0f;
+    int q = n & 3;
+    float s = (q & 1) ? pc : ps;
+    float c = (q & 1) ? ps : pc;
+    s_out = (q & 2) ? -s : s;
+    c_out = (q == 1 || q == 2) ? -c : c;
+}
+
+DEV float tf_exp(float x) {
+    x = f_clamp(x, -87.0f, 88.0f);
+    float k = __builtin_rintf(x * 1.44269504088896341f);
+    int n = (int)k;
+    float r = x - k * 0.693359375f;
+    r = r - k * -2.12194440e-4f;
+    float z = r * r;
+    float p = ((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r
+               + 1.6666665459e-1f) * r + 5.0000001201e-1f;
+    float e = p * z + r + 1.0f;
+    return e * __uint_as_float((uint32_t)(n + 127) << 23);
+}
+
+DEV float tf_asin(float x) {
+    float a = f_abs(x);
+    a = f_min(a, 1.0f);
+    bool big = a > 0.5f;
+    float z = big ? 0.5f * (1.0f - a) : a * a;
+    float y = big ? __builtin_sqrtf(z) : a;
+    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
+               + 1.6666752422e-1f) * z * y + y;
+    if (big) p = 1.5707963267948966f - (p + p);
+    return (x < 0.0f) ? -p : p;
+}
+
+DEV float tf_log(float x) {
+    uint32_t u = __float_as_uint(x);
+    int e = (int)((u >> 23) & 0xff) - 126;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e = e - 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+                   + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+               + 3.3333331174e-1f) * m * z;
+    float fe = (float)e;
+    y = y + fe * -2.12194440e-4f;
+    y = y - 0.5f * z;
+    float r = m + y;
+    r = r + fe * 0.693359375f;
+    return r;
+}
+
+DEV float f_sqrt(float x) { return __builtin_sqrtf(x); }
+// Hide a value from the optimiser.  hipcc folds (0.0f - y) into -y, which turns +0 into -0 when y == +0
+// (normalised action slot of a freshly reset env); an opaque operand keeps the IEEE subtraction.
+DEV float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+
+// ------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11) - counter = (global env id, reset count, stream tag, 0)
+// ------------------------------------------------------------------------------------------------------
+DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
+enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4 };
+DEV void rng4(const DevParams& P, uint32_t gid, uint32_t count, uint32_t tag, float u[4]) {
+    uint32_t r[4];
+    philox4x32_10(gid, count, tag, 0u, P.seed_lo, P.seed_hi, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = u01(r[i]);
+}
+DEV void box_muller(float ua, float ub, float& n0, float& n1) {
+    float r = f_sqrt(-2.0f * tf_log(1.0f - ua));
+    float s, c;
+    tf_sincos(6.2831855f * ub, s, c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// small vector helpers
+// ------------------------------------------------------------------------------------------------------
+DEV void cross3(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+DEV float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+DEV void sym_mul(const float I[6], const float v[3], float o[3]) {   // xx yy zz xy xz yz
+    o[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
+    o[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
+    o[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+}
+DEV void sym3_mul(const float S[6], const float v[3], float o[3]) {  // 00 01 02 11 12 22
+    o[0] = S[0] * v[0] + S[1] * v[1] + S[2] * v[2];
+    o[1] = S[1] * v[0] + S[3] * v[1] + S[4] * v[2];
+    o[2] = S[2] * v[0] + S[4] * v[1] + S[5] * v[2];
+}
+
+// quaternions (xyzw): reference leibnizgym/utils/torch_utils.py:83-150
+DEV void quat_mul(const float a[4], const float b[4], float o[4]) {
+    float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];
+    float x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+    float ww = (z1 + x1) * (x2 + y2);
+    float yy = (w1 - y1) * (w2 + z2);
+    float zz = (w1 + y1) * (w2 - z2);
+    float xx = ww + yy + zz;
+    float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+    o[3] = qq - ww + (z1 - y1) * (y2 - z2);
+    o[0] = qq - xx + (x1 + w1) * (x2 + w2);
+    o[1] = qq - yy + (w1 - x1) * (y2 + z2);
+    o[2] = qq - zz + (z1 + y1) * (w2 - x2);
+}
+DEV float quat_diff_rad(const float a[4], const float b[4]) {
+    float bc[4] = {-b[0], -b[1], -b[2], b[3]};
+    float m[4];
+    quat_mul(a, bc, m);
+    float nrm = f_sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    return 2.0f * tf_asin(f_min(nrm, 1.0f));
+}
+DEV float lgsk(float x, float scale) {      // reference rewards.py:20-34
+    float s = x * scale;
+    return 1.0f / (tf_exp(s) + 2.0f + tf_exp(-s));
+}
+DEV void quat_to_rot(const float q[4], float R[9]) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float xx = x * x, yy = y * y, zz = z * z;
+    float xy = x * y, xz = x * z, yz = y * z;
+    float wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy - wz);        R[2] = 2.0f * (xz + wy);
+    R[3] = 2.0f * (xy + wz);        R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz - wx);
+    R[6] = 2.0f * (xz - wy);        R[7] = 2.0f * (yz + wx);        R[8] = 1.0f - 2.0f * (xx + yy);
+}
+DEV void quat_integrate(float q[4], const float w[3], float h) {
+    float hx = 0.5f * h * w[0], hy = 0.5f * h * w[1], hz = 0.5f * h * w[2];
+    float x = q[0], y = q[1], z = q[2], s = q[3];
+    float nx = x + (hx * s + hy * z - hz * y);
+    float ny = y + (hy * s + hz * x - hx * z);
+    float nz = z + (hz * s + hx * y - hy * x);
+    float ns = s - (hx * x + hy * y + hz * z);
+    float inv = 1.0f / f_sqrt(nx * nx + ny * ny + nz * nz + ns * ns);
+    q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// finger kinematics / dynamics in the finger base frame (world = Rz(yaw) base + (0,0,H))
+// ------------------------------------------------------------------------------------------------------
+struct FK {
+    float s1, c1, s2, c2, s23, c23;
+    float p2[3], p3[3];
+    float ax[3];
+    float Minv[6];
+};
+
+template <int LINK> DEV void rot_link(const FK& k, const float u[3], float o[3]) {
+    float wx = u[0], wy = u[1], wz = u[2];
+    if (LINK >= 2) {
+        float ca = (LINK == 2) ? k.c2 : k.c23, sa = (LINK == 2) ? k.s2 : k.s23;
+        float ty = ca * u[1] - sa * u[2];
+        float tz = sa * u[1] + ca * u[2];
+        wy = ty; wz = tz;
+    }
+    o[0] = k.c1 * wx + k.s1 * wz;
+    o[1] = wy;
+    o[2] = k.c1 * wz - k.s1 * wx;
+}
+template <int LINK> DEV void rot_link_T(const FK& k, const float v[3], float o[3]) {
+    float wx = k.c1 * v[0] - k.s1 * v[2];
+    float wy = v[1];
+    float wz = k.s1 * v[0] + k.c1 * v[2];
+    if (LINK >= 2) {
+        float ca = (LINK == 2) ? k.c2 : k.c23, sa = (LINK == 2) ? k.s2 : k.s23;
+        float ty = ca * wy + sa * wz;
+        float tz = ca * wz - sa * wy;
+        wy = ty; wz = tz;
+    }
+    o[0] = wx; o[1] = wy; o[2] = wz;
+}
+
+DEV void fk_setup(const TfModel& m, const float q[3], FK& k) {
+    tf_sincos(q[0], k.s1, k.c1);
+    tf_sincos(q[1], k.s2, k.c2);
+    tf_sincos(q[1] + q[2], k.s23, k.c23);
+    k.ax[0] = k.c1; k.ax[1] = 0.0f; k.ax[2] = -k.s1;
+    rot_link<1>(k, m.j2_origin, k.p2);
+    float t[3];
+    rot_link<2>(k, m.j3_origin, t);
+    k.p3[0] = k.p2[0] + t[0]; k.p3[1] = k.p2[1] + t[1]; k.p3[2] = k.p2[2] + t[2];
+}
+
+DEV void levers(const FK& k, const float P[3], float L1[3], float L2[3], float L3[3]) {
+    L1[0] = P[2]; L1[1] = 0.0f; L1[2] = -P[0];
+    float r2[3] = {P[0] - k.p2[0], P[1] - k.p2[1], P[2] - k.p2[2]};
+    float r3[3] = {P[0] - k.p3[0], P[1] - k.p3[1], P[2] - k.p3[2]};
+    cross3(k.ax, r2, L2);
+    cross3(k.ax, r3, L3);
+}
+
+DEV void finger_dynamics(const TfModel& m, const FK& k, const float qd[3], const float grav[3], float M[6], float bias[3]) {
+    float c1[3], c2[3], c3[3], t[3];
+    rot_link<1>(k, m.link_com[0], c1);
+    rot_link<2>(k, m.link_com[1], t);
+    c2[0] = k.p2[0] + t[0]; c2[1] = k.p2[1] + t[1]; c2[2] = k.p2[2] + t[2];
+    rot_link<3>(k, m.link_com[2], t);
+    c3[0] = k.p3[0] + t[0]; c3[1] = k.p3[1] + t[1]; c3[2] = k.p3[2] + t[2];
+    float a1L[3], a2L[3], a3L[3], b1L[3], b2L[3], b3L[3], e1L[3], e2L[3], e3L[3];
+    levers(k, c1, a1L, a2L, a3L);
+    levers(k, c2, b1L, b2L, b3L);
+    levers(k, c3, e1L, e2L, e3L);
+    float m1 = m.link_mass[0], m2 = m.link_mass[1], m3 = m.link_mass[2];
+    const float* I1 = m.link_inertia[0];
+    const float* I2 = m.link_inertia[1];
+    const float* I3 = m.link_inertia[2];
+    float u2I = k.c2 * k.c2 * I2[1] - 2.0f * k.c2 * k.s2 * I2[5] + k.s2 * k.s2 * I2[2];
+    float u3I = k.c23 * k.c23 * I3[1] - 2.0f * k.c23 * k.s23 * I3[5] + k.s23 * k.s23 * I3[2];
+    float u2x = k.c2 * I2[3] - k.s2 * I2[4];
+    float u3x = k.c23 * I3[3] - k.s23 * I3[4];
+    M[0] = m1 * dot3(a1L, a1L) + m2 * dot3(b1L, b1L) + m3 * dot3(e1L, e1L) + I1[1] + u2I + u3I;
+    M[1] = m2 * dot3(b1L, b2L) + m3 * dot3(e1L, e2L) + u2x + u3x;
+    M[2] = m3 * dot3(e1L, e3L) + u3x;
+    M[3] = m2 * dot3(b2L, b2L) + m3 * dot3(e2L, e2L) + I2[0] + I3[0];
+    M[4] = m3 * dot3(e2L, e3L) + I3[0];
+    M[5] = m3 * dot3(e3L, e3L) + I3[0];
+    float w1[3] = {0.0f, qd[0], 0.0f};
+    float w2[3] = {w1[0] + k.ax[0] * qd[1], w1[1] + k.ax[1] * qd[1], w1[2] + k.ax[2] * qd[1]};
+    float w3[3] = {w2[0] + k.ax[0] * qd[2], w2[1] + k.ax[1] * qd[2], w2[2] + k.ax[2] * qd[2]};
+    float axq2[3] = {k.ax[0] * qd[1], k.ax[1] * qd[1], k.ax[2] * qd[1]};
+    float axq3[3] = {k.ax[0] * qd[2], k.ax[1] * qd[2], k.ax[2] * qd[2]};
+    float dw2[3], dw3[3];
+    cross3(w1, axq2, dw2);
+    cross3(w2, axq3, t);
+    dw3[0] = dw2[0] + t[0]; dw3[1] = dw2[1] + t[1]; dw3[2] = dw2[2] + t[2];
+    float a0[3] = {-grav[0], -grav[1], -grav[2]};
+    float u[3], v[3], ap2[3], ap3[3];
+    cross3(w1, k.p2, u); cross3(w1, u, v);
+    ap2[0] = a0[0] + v[0]; ap2[1] = a0[1] + v[1]; ap2[2] = a0[2] + v[2];
+    float d23[3] = {k.p3[0] - k.p2[0], k.p3[1] - k.p2[1], k.p3[2] - k.p2[2]};
+    cross3(dw2, d23, t); cross3(w2, d23, u); cross3(w2, u, v);
+    ap3[0] = ap2[0] + t[0] + v[0]; ap3[1] = ap2[1] + t[1] + v[1]; ap3[2] = ap2[2] + t[2] + v[2];
+    float F1[3], F2[3], F3[3], N1[3], N2[3], N3[3];
+    cross3(w1, c1, u); cross3(w1, u, v);
+    F1[0] = m1 * (a0[0] + v[0]); F1[1] = m1 * (a0[1] + v[1]); F1[2] = m1 * (a0[2] + v[2]);
+    float r2c[3] = {c2[0] - k.p2[0], c2[1] - k.p2[1], c2[2] - k.p2[2]};
+    cross3(dw2, r2c, t); cross3(w2, r2c, u); cross3(w2, u, v);
+    F2[0] = m2 * (ap2[0] + t[0] + v[0]); F2[1] = m2 * (ap2[1] + t[1] + v[1]); F2[2] = m2 * (ap2[2] + t[2] + v[2]);
+    float r3c[3] = {c3[0] - k.p3[0], c3[1] - k.p3[1], c3[2] - k.p3[2]};
+    cross3(dw3, r3c, t); cross3(w3, r3c, u); cross3(w3, u, v);
+    F3[0] = m3 * (ap3[0] + t[0] + v[0]); F3[1] = m3 * (ap3[1] + t[1] + v[1]); F3[2] = m3 * (ap3[2] + t[2] + v[2]);
+    float wl[3], Iw[3], Iww[3], dl[3], Id[3], Idw[3];
+    rot_link_T<1>(k, w1, wl); sym_mul(I1, wl, Iw); rot_link<1>(k, Iw, Iww);
+    cross3(w1, Iww, N1);
+    rot_link_T<2>(k, w2, wl); sym_mul(I2, wl, Iw); rot_link<2>(k, Iw, Iww);
+    rot_link_T<2>(k, dw2, dl); sym_mul(I2, dl, Id); rot_link<2>(k, Id, Idw);
+    cross3(w2, Iww, t);
+    N2[0] = Idw[0] + t[0]; N2[1] = Idw[1] + t[1]; N2[2] = Idw[2] + t[2];
+    rot_link_T<3>(k, w3, wl); sym_mul(I3, wl, Iw); rot_link<3>(k, Iw, Iww);
+    rot_link_T<3>(k, dw3, dl); sym_mul(I3, dl, Id); rot_link<3>(k, Id, Idw);
+    cross3(w3, Iww, t);
+    N3[0] = Idw[0] + t[0]; N3[1] = Idw[1] + t[1]; N3[2] = Idw[2] + t[2];
+    float n3[3], n2[3], n1[3], f2[3];
+    cross3(r3c, F3, t);
+    n3[0] = N3[0] + t[0]; n3[1] = N3[1] + t[1]; n3[2] = N3[2] + t[2];
+    f2[0] = F2[0] + F3[0]; f2[1] = F2[1] + F3[1]; f2[2] = F2[2] + F3[2];
+    cross3(r2c, F2, t); cross3(d23, F3, u);
+    n2[0] = N2[0] + t[0] + n3[0] + u[0]; n2[1] = N2[1] + t[1] + n3[1] + u[1]; n2[2] = N2[2] + t[2] + n3[2] + u[2];
+    cross3(c1, F1, t); cross3(k.p2, f2, u);
+    n1[0] = N1[0] + t[0] + n2[0] + u[0]; n1[1] = N1[1] + t[1] + n2[1] + u[1]; n1[2] = N1[2] + t[2] + n2[2] + u[2];
+    bias[0] = n1[1];
+    bias[1] = dot3(k.ax, n2);
+    bias[2] = dot3(k.ax, n3);
+}
+
+DEV void inv3sym(const float M[6], float Mi[6]) {
+    float A = M[3] * M[5] - M[4] * M[4];
+    float B = M[2] * M[4] - M[1] * M[5];
+    float C = M[1] * M[4] - M[2] * M[3];
+    float det = M[0] * A + M[1] * B + M[2] * C;
+    float rd = 1.0f / det;
+    Mi[0] = A * rd; Mi[1] = B * rd; Mi[2] = C * rd;
+    Mi[3] = (M[0] * M[5] - M[2] * M[2]) * rd;
+    Mi[4] = (M[1] * M[2] - M[0] * M[4]) * rd;
+    Mi[5] = (M[0] * M[3] - M[1] * M[1]) * rd;
+}
+
+template <int F> DEV void base_to_world(const TfModel& m, const float b[3], float w[3]) {
+    float c = m.base_yaw_cos[F], s = m.base_yaw_sin[F];
+    w[0] = c * b[0] - s * b[1];
+    w[1] = s * b[0] + c * b[1];
+    w[2] = b[2] + m.base_height;
+}
+template <int F> DEV void dir_world_to_base(const TfModel& m, const float w[3], float b[3]) {
+    float c = m.base_yaw_cos[F], s = m.base_yaw_sin[F];
+    b[0] = c * w[0] + s * w[1];
+    b[1] = c * w[1] - s * w[0];
+    b[2] = w[2];
+}
+template <int F> DEV void dir_base_to_world(const TfModel& m, const float b[3], float w[3]) {
+    float c = m.base_yaw_cos[F], s = m.base_yaw_sin[F];
+    w[0] = c * b[0] - s * b[1];
+    w[1] = s * b[0] + c * b[1];
+    w[2] = b[2];
+}
+
+DEV void tangent_basis(const float n[3], float t1[3], float t2[3]) {
+    if (f_abs(n[2]) < 0.9f) {
+        float inv = 1.0f / f_sqrt(n[0] * n[0] + n[1] * n[1]);
+        t1[0] = -n[1] * inv; t1[1] = n[0] * inv; t1[2] = 0.0f;
+    } else {
+        float inv = 1.0f / f_sqrt(n[1] * n[1] + n[2] * n[2]);
+        t1[0] = 0.0f; t1[1] = -n[2] * inv; t1[2] = n[1] * inv;
+    }
+    cross3(n, t1, t2);
+}
+
+DEV float contact_bias(const TfModel& m, float gap, float vn0, float h, float restitution) {
+    float inv_h = 1.0f / h;
+    float b;
+    if (gap >= 0.0f) b = gap * inv_h;
+    else b = f_max(m.erp * gap * inv_h, -m.max_depenetration_velocity);
+    if (restitution > 0.0f && gap < m.contact_offset && vn0 < -m.bounce_threshold) b = f_min(b, restitution * vn0);
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-env working state (registers)
+// ------------------------------------------------------------------------------------------------------
+struct Env {
+    float q[9], qd[9];
+    float cp[3], cq[4], cv[3], cw[3];
+    float gp[3], gq[4], gw[3];
+    float tau[9];
+    float ft[18];
+};
+
+// LDS layout, floats per lane: finger-cube contact f at FC_BASE(f): Jf[3][3] Wf[3][3] dir[3][3] r[3] (30);
+// tip-floor contact f at TF_BASE(f): Jf[3][3] Wf[3][3] (18).  Stored [slot][lane].
+#define FC_BASE(f) ((f) * 30)
+#define TF_BASE(f) (90 + (f) * 18)
+#define LDS_SLOTS 144
+#define LDS_FLOATS (LDS_SLOTS * WAVE)
+
+struct FingerContactRegs {   // the small per-contact scalars stay in VGPRs
+    bool active;
+    float Dinv[3];
+    float bias;
+    float arm[3];
+    float lam[3];
+};
+struct CubeContactRegs {
+    bool active;
+    float r[3];
+    float n[2];          // wall contacts: horizontal inward normal; unused for floor contacts
+    float Dinv[3];
+    float bias;
+    float lam[3];
+};
+
+#define LDS_AT(slot) lds[(slot) * WAVE + lane]
+
+// rows of one finger contact: point Pb (base frame), world normal, cube arm rc.  Writes J / W / dir / r to LDS.
+template <int F, bool WITH_CUBE>
+DEV void finger_rows(const TfModel& m, const FK& k, const float Pb[3], const float n_w[3], const float rc[3],
+                     float* lds, int lane, int base, FingerContactRegs& c, float Jn[3], float dirn[3], float rxdn[3]) {
+    float t1[3], t2[3];
+    tangent_basis(n_w, t1, t2);
+    float L1[3], L2[3], L3[3];
+    levers(k, Pb, L1, L2, L3);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float* dw = (d == 0) ? n_w : ((d == 1) ? t1 : t2);
+        float db[3], Jf[3], Wf[3];
+        dir_world_to_base<F>(m, dw, db);
+        Jf[0] = dot3(L1, db); Jf[1] = dot3(L2, db); Jf[2] = dot3(L3, db);
+        sym3_mul(k.Minv, Jf, Wf);
+        float D = dot3(Jf, Wf);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            LDS_AT(base + d * 3 + j) = Jf[j];
+            LDS_AT(base + 9 + d * 3 + j) = Wf[j];
+        }
+        if (WITH_CUBE) {
+            float rxd[3];
+            cross3(rc, dw, rxd);
+            D = D + 1.0f / m.cube_mass + dot3(rxd, rxd) / m.cube_inertia;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) LDS_AT(base + 18 + d * 3 + j) = dw[j];
+            if (d == 0) { rxdn[0] = rxd[0]; rxdn[1] = rxd[1]; rxdn[2] = rxd[2]; }
+        }
+        if (d == 0) { Jn[0] = Jf[0]; Jn[1] = Jf[1]; Jn[2] = Jf[2]; dirn[0] = dw[0]; dirn[1] = dw[1]; dirn[2] = dw[2]; }
+        c.Dinv[d] = 1.0f / D;
+    }
+    if (WITH_CUBE) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) LDS_AT(base + 27 + j) = rc[j];
+    }
+}
+
+DEV void cube_corner(const float R[9], float hc, int k, float sk, int idx, float r[3]) {
+    // axes a < b are the two that are not k
+    float y[3];
+    float sa = (idx & 1) ? hc : -hc;
+    float sb = (idx & 2) ? hc : -hc;
+    float fk_ = sk * hc;
+    y[0] = (k == 0) ? fk_ : sa;
+    y[1] = (k == 1) ? fk_ : ((k == 0) ? sa : sb);
+    y[2] = (k == 2) ? fk_ : sb;
+    r[0] = R[0] * y[0] + R[1] * y[1] + R[2] * y[2];
+    r[1] = R[3] * y[0] + R[4] * y[1] + R[5] * y[2];
+    r[2] = R[6] * y[0] + R[7] * y[1] + R[8] * y[2];
+}
+
+// one PGS row update on cube velocities; returns via references
+DEV void cube_row(float vrel_bias, float Dinv, float lo, float hi, float& lam, const float dir[3], const float rxd[3],
+                  float inv_m, float inv_I, float v[3], float w[3], float sign) {
+    float lam_new = f_clamp(lam - Dinv * vrel_bias, lo, hi);
+    float dl = lam_new - lam;
+    lam = lam_new;
+    float s = dl * inv_m, q = dl * inv_I;
+    if (sign > 0.0f) {
+        v[0] = v[0] + dir[0] * s; v[1] = v[1] + dir[1] * s; v[2] = v[2] + dir[2] * s;
+        w[0] = w[0] + rxd[0] * q; w[1] = w[1] + rxd[1] * q; w[2] = w[2] + rxd[2] * q;
+    } else {
+        v[0] = v[0] - dir[0] * s; v[1] = v[1] - dir[1] * s; v[2] = v[2] - dir[2] * s;
+        w[0] = w[0] - rxd[0] * q; w[1] = w[1] - rxd[1] * q; w[2] = w[2] - rxd[2] * q;
+    }
+}
+
+// ---- contact generation for finger F (capsule vs cube, tip vs floor) ----
+template <int F>
+DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const float R[9], const float* vq,
+                         const float v[3], const float w[3], float h, float* lds, int lane,
+                         FingerContactRegs& c, FingerContactRegs& g) {
+    const TfModel& m = P.m;
+    const float hc = m.cube_half;
+    float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3], Tw[3];
+    rot_link<3>(k, m.cap_a, t);
+    Ab[0] = k.p3[0] + t[0]; Ab[1] = k.p3[1] + t[1]; Ab[2] = k.p3[2] + t[2];
+    rot_link<3>(k, m.cap_b, t);
+    Bb[0] = k.p3[0] + t[0]; Bb[1] = k.p3[1] + t[1]; Bb[2] = k.p3[2] + t[2];
+    rot_link<3>(k, m.tip_origin, t);
+    To[0] = k.p3[0] + t[0]; To[1] = k.p3[1] + t[1]; To[2] = k.p3[2] + t[2];
+    base_to_world<F>(m, Ab, Aw);
+    base_to_world<F>(m, Bb, Bw);
+    base_to_world<F>(m, To, Tw);
+    // capsule (distal link) vs cube: closest points by alternating projection in the cube frame
+    c.active = false;
+    c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
+    c.bias = 0.0f;
+    c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
+    c.arm[0] = 0.0f; c.arm[1] = 0.0f; c.arm[2] = 0.0f;
+    float da[3] = {Aw[0] - e.cp[0], Aw[1] - e.cp[1], Aw[2] - e.cp[2]};
+    float db[3] = {Bw[0] - e.cp[0], Bw[1] - e.cp[1], Bw[2] - e.cp[2]};
+    float a[3], b[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = R[i] * da[0] + R[3 + i] * da[1] + R[6 + i] * da[2];
+        b[i] = R[i] * db[0] + R[3 + i] * db[1] + R[6 + i] * db[2];
+    }
+    float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    float inv_dd = 1.0f / dot3(d, d);
+    float s = 1.0f, x[3], y[3];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+        float ya[3] = {y[0] - a[0], y[1] - a[1], y[2] - a[2]};
+        s = f_clamp(dot3(ya, d) * inv_dd, 0.0f, 1.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+    float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
+    float dist2 = dot3(ev, ev);
+    float nc[3], gap;
+    if (dist2 > 1e-12f) {
+        float dist = f_sqrt(dist2);
+        float inv = 1.0f / dist;
+        nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
+        gap = dist - m.cap_radius;
+    } else {
+        int bi = 0;
+        float best = f_abs(x[0]) - hc;
+        float p1 = f_abs(x[1]) - hc;
+        if (p1 > best) { best = p1; bi = 1; }
+        float p2 = f_abs(x[2]) - hc;
+        if (p2 > best) { best = p2; bi = 2; }
+        float xb = (bi == 0) ? x[0] : ((bi == 1) ? x[1] : x[2]);
+        float sg = (xb < 0.0f) ? -1.0f : 1.0f;
+        nc[0] = (bi == 0) ? sg : 0.0f; nc[1] = (bi == 1) ? sg : 0.0f; nc[2] = (bi == 2) ? sg : 0.0f;
+        y[0] = (bi == 0) ? sg * hc : y[0]; y[1] = (bi == 1) ? sg * hc : y[1]; y[2] = (bi == 2) ? sg * hc : y[2];
+        gap = best - m.cap_radius;
+    }
+    if (gap < m.contact_margin) {
+        float n_w[3], rc[3], xw[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            n_w[i] = R[3 * i] * nc[0] + R[3 * i + 1] * nc[1] + R[3 * i + 2] * nc[2];
+            rc[i] = R[3 * i] * y[0] + R[3 * i + 1] * y[1] + R[3 * i + 2] * y[2];
+            xw[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
+        }
+        float Pw[3] = {e.cp[0] + xw[0] - m.cap_radius * n_w[0], e.cp[1] + xw[1] - m.cap_radius * n_w[1],
+                       e.cp[2] + xw[2] - m.cap_radius * n_w[2]};
+        float Pr[3] = {Pw[0], Pw[1], Pw[2] - m.base_height};
+        float Pb[3];
+        dir_world_to_base<F>(m, Pr, Pb);
+        c.active = true;
+        float Jn[3], dirn[3], rxdn[3];
+        finger_rows<F, true>(m, k, Pb, n_w, rc, lds, lane, FC_BASE(F), c, Jn, dirn, rxdn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c.arm[i] = Pw[i] - Tw[i];
+        float vn0 = dot3(Jn, &vq[3 * F]) - (dot3(dirn, v) + dot3(rxdn, w));
+        c.bias = contact_bias(m, gap, vn0, h, m.restitution_finger);
+    }
+    // tip sphere vs floor
+    g.active = false;
+    g.lam[0] = 0.0f; g.lam[1] = 0.0f; g.lam[2] = 0.0f;
+    g.bias = 0.0f;
+    g.Dinv[0] = 0.0f; g.Dinv[1] = 0.0f; g.Dinv[2] = 0.0f;
+    g.arm[0] = 0.0f; g.arm[1] = 0.0f; g.arm[2] = 0.0f;
+    float gapf = Bw[2] - m.cap_radius;
+    if (gapf < m.contact_margin) {
+        float n_w[3] = {0.0f, 0.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
+        float Pb[3] = {Bb[0], Bb[1], Bb[2] - m.cap_radius};
+        float Pw[3] = {Bw[0], Bw[1], Bw[2] - m.cap_radius};
+        g.active = true;
+        float Jn[3], dirn[3], rxdn[3];
+        finger_rows<F, false>(m, k, Pb, n_w, zero, lds, lane, TF_BASE(F), g, Jn, dirn, rxdn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g.arm[i] = Pw[i] - Tw[i];
+        float vn0 = dot3(Jn, &vq[3 * F]);
+        g.bias = contact_bias(m, gapf, vn0, h, m.restitution_finger);
+    }
+}
+
+// PGS rows of the finger-cube contact of finger F (reads J/W/dir/r from LDS)
+template <int F>
+DEV void solve_finger_cube(const TfModel& m, FingerContactRegs& c, const float* lds, int lane, float* vq, float v[3],
+                           float w[3], float inv_m, float inv_I) {
+    if (!c.active) return;
+    float* vf = &vq[3 * F];
+    float rc[3] = {LDS_AT(FC_BASE(F) + 27), LDS_AT(FC_BASE(F) + 28), LDS_AT(FC_BASE(F) + 29)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float Jf[3], Wf[3], dir[3], rxd[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jf[j] = LDS_AT(FC_BASE(F) + d * 3 + j);
+            Wf[j] = LDS_AT(FC_BASE(F) + 9 + d * 3 + j);
+            dir[j] = LDS_AT(FC_BASE(F) + 18 + d * 3 + j);
+        }
+        cross3(rc, dir, rxd);
+        float vrel = dot3(Jf, vf);
+        vrel = vrel - (dot3(dir, v) + dot3(rxd, w));
+        float lam_new;
+        if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
+        else {
+            float lim = m.mu_finger_cube * c.lam[0];
+            lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
+        }
+        float dl = lam_new - c.lam[d];
+        c.lam[d] = lam_new;
+        vf[0] = vf[0] + Wf[0] * dl; vf[1] = vf[1] + Wf[1] * dl; vf[2] = vf[2] + Wf[2] * dl;
+        float s = dl * inv_m, q = dl * inv_I;
+        v[0] = v[0] - dir[0] * s; v[1] = v[1] - dir[1] * s; v[2] = v[2] - dir[2] * s;
+        w[0] = w[0] - rxd[0] * q; w[1] = w[1] - rxd[1] * q; w[2] = w[2] - rxd[2] * q;
+    }
+}
+template <int F>
+DEV void solve_tip_floor(const TfModel& m, FingerContactRegs& c, const float* lds, int lane, float* vq) {
+    if (!c.active) return;
+    float* vf = &vq[3 * F];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float Jf[3], Wf[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jf[j] = LDS_AT(TF_BASE(F) + d * 3 + j);
+            Wf[j] = LDS_AT(TF_BASE(F) + 9 + d * 3 + j);
+        }
+        float vrel = dot3(Jf, vf);
+        float lam_new;
+        if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
+        else {
+            float lim = m.mu_tip_floor * c.lam[0];
+            lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
+        }
+        float dl = lam_new - c.lam[d];
+        c.lam[d] = lam_new;
+        vf[0] = vf[0] + Wf[0] * dl; vf[1] = vf[1] + Wf[1] * dl; vf[2] = vf[2] + Wf[2] * dl;
+    }
+}
+
+// wrench of one finger contact, world frame, about the tip-link origin
+template <bool WITH_CUBE>
+DEV void add_wrench(const FingerContactRegs& c, const float* lds, int lane, int base, float inv_h, float* ft) {
+    if (!c.active) return;
+    float F[3];
+    if (WITH_CUBE) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            F[i] = (LDS_AT(base + 18 + i) * c.lam[0] + LDS_AT(base + 21 + i) * c.lam[1] + LDS_AT(base + 24 + i) * c.lam[2]) * inv_h;
+    } else {
+        // floor contact directions are constants: n = +z, t1 = -y, t2 = +x
+        const float n_w[3] = {0.0f, 0.0f, 1.0f};
+        float t1[3], t2[3];
+        tangent_basis(n_w, t1, t2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) F[i] = (n_w[i] * c.lam[0] + t1[i] * c.lam[1] + t2[i] * c.lam[2]) * inv_h;
+    }
+    float T[3];
+    cross3(c.arm, F, T);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ft[i] += F[i]; ft[3 + i] += T[i]; }
+}
+
+// One solver substep of length h for the env held by this lane.  WRENCH: accumulate the fingertip contact
+// wrench (only the asymmetric `states` vector consumes it).
+template <bool WRENCH>
+DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
+    const TfModel& m = P.m;
+    FK fk0, fk1, fk2;
+    float vq[9];
+    float v[3], w[3];
+    // ---- free motion ----
+    {
+        float damp = 1.0f - h * m.link_angular_damping;
+#define FREE_MOTION(F, fk)                                                                       \
+        {                                                                                        \
+            float M[6], bias[3], rhs[3], acc[3];                                                 \
+            fk_setup(m, &e.q[3 * F], fk);                                                        \
+            finger_dynamics(m, fk, &e.qd[3 * F], P.grav, M, bias);                               \
+            inv3sym(M, fk.Minv);                                                                 \
+            for (int j = 0; j < 3; ++j) rhs[j] = e.tau[3 * F + j] - bias[j];                     \
+            sym3_mul(fk.Minv, rhs, acc);                                                         \
+            for (int j = 0; j < 3; ++j) vq[3 * F + j] = (e.qd[3 * F + j] + h * acc[j]) * damp;   \
+        }
+        FREE_MOTION(0, fk0)
+        FREE_MOTION(1, fk1)
+        FREE_MOTION(2, fk2)
+#undef FREE_MOTION
+        float dl = 1.0f - h * m.cube_linear_damping, da = 1.0f - h * m.cube_angular_damping;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i] = (e.cv[i] + h * P.grav[i]) * dl;
+            w[i] = e.cw[i] * da;
+        }
+    }
+    // ---- contact generation ----
+    float R[9];
+    quat_to_rot(e.cq, R);
+    const float hc = m.cube_half;
+    FingerContactRegs fc0, fc1, fc2, tf0, tf1, tf2;
+    finger_contacts<0>(P, e, fk0, R, vq, v, w, h, lds, lane, fc0, tf0);
+    finger_contacts<1>(P, e, fk1, R, vq, v, w, h, lds, lane, fc1, tf1);
+    finger_contacts<2>(P, e, fk2, R, vq, v, w, h, lds, lane, fc2, tf2);
+    CubeContactRegs cf[4], cwl[4];
+    const float inv_m = 1.0f / m.cube_mass, inv_I = 1.0f / m.cube_inertia;
+    {   // cube vs floor: corners of the face that points down most
+        int k = 0;
+        float best = f_abs(R[6]);
+        if (f_abs(R[7]) > best) { best = f_abs(R[7]); k = 1; }
+        if (f_abs(R[8]) > best) { best = f_abs(R[8]); k = 2; }
+        float rk = (k == 0) ? R[6] : ((k == 1) ? R[7] : R[8]);
+        float sk = (rk > 0.0f) ? -1.0f : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            CubeContactRegs& c = cf[i];
+            c.active = false;
+            c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
+            c.bias = 0.0f; c.n[0] = 0.0f; c.n[1] = 0.0f;
+            c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
+            cube_corner(R, hc, k, sk, i, c.r);
+            float gap = e.cp[2] + c.r[2];
+            if (gap < m.contact_margin) {
+                c.active = true;
+                const float dn[3] = {0.0f, 0.0f, 1.0f}, dx[3] = {1.0f, 0.0f, 0.0f}, dy[3] = {0.0f, 1.0f, 0.0f};
+                float rxn[3], rxx[3], rxy[3];
+                cross3(c.r, dn, rxn); cross3(c.r, dx, rxx); cross3(c.r, dy, rxy);
+                c.Dinv[0] = 1.0f / (1.0f / m.cube_mass + dot3(rxn, rxn) / m.cube_inertia);
+                c.Dinv[1] = 1.0f / (1.0f / m.cube_mass + dot3(rxx, rxx) / m.cube_inertia);
+                c.Dinv[2] = 1.0f / (1.0f / m.cube_mass + dot3(rxy, rxy) / m.cube_inertia);
+                float vn0 = dot3(dn, v) + dot3(rxn, w);
+                c.bias = contact_bias(m, gap, vn0, h, 0.0f);
+            }
+        }
+    }
+    {   // cube vs boundary wall: corners of the face that points outward most
+        float rho_c = f_sqrt(e.cp[0] * e.cp[0] + e.cp[1] * e.cp[1]);
+        bool any = rho_c > 1e-6f;
+        float dx = 0.0f, dy = 0.0f;
+        if (any) { float inv = 1.0f / rho_c; dx = e.cp[0] * inv; dy = e.cp[1] * inv; }
+        float pr[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pr[i] = R[i] * dx + R[3 + i] * dy;
+        int k = 0;
+        float best = f_abs(pr[0]);
+        if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
+        if (f_abs(pr[2]) > best) { best = f_abs(pr[2]); k = 2; }
+        float pk = (k == 0) ? pr[0] : ((k == 1) ? pr[1] : pr[2]);
+        float sk = (pk < 0.0f) ? -1.0f : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            CubeContactRegs& c = cwl[i];
+            c.active = false;
+            c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
+            c.bias = 0.0f; c.n[0] = 0.0f; c.n[1] = 0.0f;
+            c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
+            cube_corner(R, hc, k, sk, i, c.r);
+            float px = e.cp[0] + c.r[0], py = e.cp[1] + c.r[1];
+            float rho = f_sqrt(px * px + py * py);
+            float gap = m.wall_radius - rho;
+            if (any && gap < m.contact_margin && rho > 1e-6f) {
+                float inv = 1.0f / rho;
+                c.active = true;
+                c.n[0] = -px * inv; c.n[1] = -py * inv;
+                const float dn[3] = {c.n[0], c.n[1], 0.0f}, dt[3] = {py * inv, -px * inv, 0.0f}, dz[3] = {0.0f, 0.0f, 1.0f};
+                float rxn[3], rxt[3], rxz[3];
+                cross3(c.r, dn, rxn); cross3(c.r, dt, rxt); cross3(c.r, dz, rxz);
+                c.Dinv[0] = 1.0f / (1.0f / m.cube_mass + dot3(rxn, rxn) / m.cube_inertia);
+                c.Dinv[1] = 1.0f / (1.0f / m.cube_mass + dot3(rxt, rxt) / m.cube_inertia);
+                c.Dinv[2] = 1.0f / (1.0f / m.cube_mass + dot3(rxz, rxz) / m.cube_inertia);
+                float vn0 = dot3(dn, v) + dot3(rxn, w);
+                c.bias = contact_bias(m, gap, vn0, h, 0.0f);
+            }
+        }
+    }
+    // ---- joint / velocity limit rows ----
+    float vlo[9], vhi[9], lim_dinv[9], lim_lam[9];
+    {
+        float inv_h = 1.0f / h;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int f = j / 3, jj = j % 3;
+            const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
+            const FK& k = (f == 0) ? fk0 : ((f == 1) ? fk1 : fk2);
+            vlo[j] = f_clamp((m.q_lo[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
+            vhi[j] = f_clamp((m.q_hi[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
+            lim_dinv[j] = 1.0f / k.Minv[dg];
+            lim_lam[j] = 0.0f;
+        }
+    }
+    __syncthreads();   // LDS rows written above are read below (same lane; barrier keeps the phases ordered)
+    // ---- projected Gauss-Seidel ----
+    for (int it = 0; it < P.iters; ++it) {
+        solve_finger_cube<0>(m, fc0, lds, lane, vq, v, w, inv_m, inv_I);
+        solve_finger_cube<1>(m, fc1, lds, lane, vq, v, w, inv_m, inv_I);
+        solve_finger_cube<2>(m, fc2, lds, lane, vq, v, w, inv_m, inv_I);
+        solve_tip_floor<0>(m, tf0, lds, lane, vq);
+        solve_tip_floor<1>(m, tf1, lds, lane, vq);
+        solve_tip_floor<2>(m, tf2, lds, lane, vq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            CubeContactRegs& c = cf[i];
+            if (c.active) {
+                const float dn[3] = {0.0f, 0.0f, 1.0f}, dx[3] = {1.0f, 0.0f, 0.0f}, dy[3] = {0.0f, 1.0f, 0.0f};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float* dir = (d == 0) ? dn : ((d == 1) ? dx : dy);
+                    float rxd[3];
+                    cross3(c.r, dir, rxd);
+                    float vrel = dot3(dir, v) + dot3(rxd, w);
+                    float lam_new;
+                    if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
+                    else {
+                        float lim = m.mu_cube_floor * c.lam[0];
+                        lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
+                    }
+                    float dl = lam_new - c.lam[d];
+                    c.lam[d] = lam_new;
+                    float s = dl * inv_m, q = dl * inv_I;
+                    v[0] = v[0] + dir[0] * s; v[1] = v[1] + dir[1] * s; v[2] = v[2] + dir[2] * s;
+                    w[0] = w[0] + rxd[0] * q; w[1] = w[1] + rxd[1] * q; w[2] = w[2] + rxd[2] * q;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            CubeContactRegs& c = cwl[i];
+            if (c.active) {
+                const float dn[3] = {c.n[0], c.n[1], 0.0f}, dt[3] = {-c.n[1], c.n[0], 0.0f}, dz[3] = {0.0f, 0.0f, 1.0f};
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float* dir = (d == 0) ? dn : ((d == 1) ? dt : dz);
+                    float rxd[3];
+                    cross3(c.r, dir, rxd);
+                    float vrel = dot3(dir, v) + dot3(rxd, w);
+                    float lam_new;
+                    if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
+                    else {
+                        float lim = m.mu_cube_wall * c.lam[0];
+                        lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
+                    }
+                    float dl = lam_new - c.lam[d];
+                    c.lam[d] = lam_new;
+                    float s = dl * inv_m, q = dl * inv_I;
+                    v[0] = v[0] + dir[0] * s; v[1] = v[1] + dir[1] * s; v[2] = v[2] + dir[2] * s;
+                    w[0] = w[0] + rxd[0] * q; w[1] = w[1] + rxd[1] * q; w[2] = w[2] + rxd[2] * q;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int f = j / 3, jj = j % 3;
+            const FK& k = (f == 0) ? fk0 : ((f == 1) ? fk1 : fk2);
+            const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
+            const int c0 = (jj == 0) ? 0 : ((jj == 1) ? 1 : 2);
+            const int c1 = (jj == 0) ? 1 : ((jj == 1) ? 3 : 4);
+            const int c2 = (jj == 0) ? 2 : ((jj == 1) ? 4 : 5);
+            float v0 = vq[j] - k.Minv[dg] * lim_lam[j];
+            float tgt = f_clamp(v0, vlo[j], vhi[j]);
+            float lam_new = (tgt - v0) * lim_dinv[j];
+            float dl = lam_new - lim_lam[j];
+            lim_lam[j] = lam_new;
+            vq[3 * f + 0] = vq[3 * f + 0] + k.Minv[c0] * dl;
+            vq[3 * f + 1] = vq[3 * f + 1] + k.Minv[c1] * dl;
+            vq[3 * f + 2] = vq[3 * f + 2] + k.Minv[c2] * dl;
+        }
+    }
+    // ---- fingertip wrench sensor ----
+    if (WRENCH) {
+        float inv_h = 1.0f / h;
+        add_wrench<true>(fc0, lds, lane, FC_BASE(0), inv_h, &e.ft[0]);
+        add_wrench<false>(tf0, lds, lane, TF_BASE(0), inv_h, &e.ft[0]);
+        add_wrench<true>(fc1, lds, lane, FC_BASE(1), inv_h, &e.ft[6]);
+        add_wrench<false>(tf1, lds, lane, TF_BASE(1), inv_h, &e.ft[6]);
+        add_wrench<true>(fc2, lds, lane, FC_BASE(2), inv_h, &e.ft[12]);
+        add_wrench<false>(tf2, lds, lane, TF_BASE(2), inv_h, &e.ft[12]);
+    }
+    __syncthreads();
+    // ---- integrate ----
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        e.qd[j] = vq[j];
+        e.q[j] = f_clamp(e.q[j] + h * vq[j], m.q_lo[j % 3], m.q_hi[j % 3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        e.cv[i] = v[i]; e.cw[i] = w[i];
+        e.cp[i] = e.cp[i] + h * v[i];
+    }
+    quat_integrate(e.cq, e.cw, h);
+}
+
+// the moving goal (goal_movement.rotation) is a free body nothing interacts with: its orientation is
+// integrated with the same substep sequence, outside the contact solve
+DEV void goal_advance(const DevParams& P, Env& e, int nsub, float h) {
+    if (P.goal_rotation_activate) {
+        for (int s = 0; s < nsub; ++s) quat_integrate(e.gq, e.gw, h);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SoA <-> registers
+// ------------------------------------------------------------------------------------------------------
+#define ST(row) P.state[(size_t)(row) * (size_t)P.N + (size_t)i]
+
+DEV void load_goal(const DevParams& P, int i, Env& e) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { e.gp[j] = ST(TF_S_GOAL_P + j); e.gw[j] = ST(TF_S_GOAL_W + j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e.gq[j] = ST(TF_S_GOAL_Q + j);
+}
+DEV void store_goal(const DevParams& P, int i, const Env& e, bool pred) {
+    if (!pred) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ST(TF_S_GOAL_P + j) = e.gp[j]; ST(TF_S_GOAL_W + j) = e.gw[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ST(TF_S_GOAL_Q + j) = e.gq[j];
+}
+DEV void load_dyn(const DevParams& P, int i, Env& e) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { e.q[j] = ST(TF_S_Q + j); e.qd[j] = ST(TF_S_QD + j); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { e.cp[j] = ST(TF_S_CUBE_P + j); e.cv[j] = ST(TF_S_CUBE_V + j); e.cw[j] = ST(TF_S_CUBE_W + j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e.cq[j] = ST(TF_S_CUBE_Q + j);
+}
+DEV void store_dyn(const DevParams& P, int i, const Env& e, bool valid) {
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { ST(TF_S_Q + j) = e.q[j]; ST(TF_S_QD + j) = e.qd[j]; ST(TF_S_TAU + j) = e.tau[j]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ST(TF_S_CUBE_P + j) = e.cp[j]; ST(TF_S_CUBE_V + j) = e.cv[j]; ST(TF_S_CUBE_W + j) = e.cw[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ST(TF_S_CUBE_Q + j) = e.cq[j];
+}
+DEV void load_split_extras(const DevParams& P, int i, Env& e) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) e.tau[j] = ST(TF_S_TAU + j);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) e.ft[j] = ST(TF_S_FT + j);
+}
+DEV void store_ft(const DevParams& P, int i, const Env& e, bool valid) {
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) ST(TF_S_FT + j) = e.ft[j];
+}
+DEV void store_prev_obj(const DevParams& P, int i, const Env& e, bool valid) {
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ST(TF_S_PREV_OBJ_P + j) = e.cp[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ST(TF_S_PREV_OBJ_Q + j) = e.cq[j];
+}
+DEV void load_prev_obj(const DevParams& P, int i, float prev_obj[7]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) prev_obj[j] = ST(TF_S_PREV_OBJ_P + j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) prev_obj[3 + j] = ST(TF_S_PREV_OBJ_Q + j);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// task layer
+// ------------------------------------------------------------------------------------------------------
+DEV void sample_xy(float u_r, float u_t, float r_max, float& x, float& y) {   // reference sample.py:22-34
+    float radius = f_sqrt(u_r) * r_max;
+    float s, c;
+    tf_sincos(6.2831855f * u_t, s, c);
+    x = radius * c;
+    y = radius * s;
+}
+DEV void sample_yaw_quat(float u, float q[4]) {                                 // sample.py:77-84
+    float s, c;
+    tf_sincos((6.2831855f * u) * 0.5f, s, c);
+    q[0] = 0.0f; q[1] = 0.0f; q[2] = s; q[3] = c;
+}
+DEV void normalize_quat(const float n[4], float q[4]) {                         // sample.py:55-65
+    float nrm = f_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3]);
+    float inv = 1.0f / f_max(nrm, 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = n[i] * inv;
+}
+
+#define CUBE_RADIUS_3D 0.05629165f      // CuboidalObject(0.065).radius_3d, reference envs/trifinger/utils.py:122-131
+#define CUBE_MAX_COM_DIST 0.13870835f
+#define CUBE_MIN_HEIGHT 0.0325f
+
+DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, Env& e) {   // trifinger_env.py:1194-1265
+    int d = P.task_difficulty;
+    float u[4];
+    rng4(P, gid, count, RNG_GOAL_POS, u);
+    float x = 0.0f, y = 0.0f, z;
+    float quat[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, x, y);
+    if (d == -1 || d == 1) z = CUBE_MIN_HEIGHT;
+    else if (d == 2 || d == 6) z = CUBE_MIN_HEIGHT + 0.05f;
+    else if (d == 3) z = 0.0675f * u[2] + CUBE_MIN_HEIGHT;
+    else z = 0.04370835f * u[2] + CUBE_RADIUS_3D;
+    if (d == -1) sample_yaw_quat(u[3], quat);
+    if (d == 4 || d == 5 || d == 6) {
+        float v[4], n[4];
+        rng4(P, gid, count, RNG_GOAL_QUAT, v);
+        box_muller(v[0], v[1], n[0], n[1]);
+        box_muller(v[2], v[3], n[2], n[3]);
+        normalize_quat(n, quat);
+    }
+    if (P.goal_rotation_activate) {
+        float v[4], n[4];
+        rng4(P, gid, count, RNG_GOAL_ANGVEL, v);
+        box_muller(v[0], v[1], n[0], n[1]);
+        box_muller(v[2], v[3], n[2], n[3]);
+        float nrm = f_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        float mag = n[3] * P.goal_rate;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) e.gw[i] = mag * (n[i] / nrm);
+    } else {
+        e.gw[0] = 0.0f; e.gw[1] = 0.0f; e.gw[2] = 0.0f;
+    }
+    e.gp[0] = x; e.gp[1] = y; e.gp[2] = z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.gq[i] = quat[i];
+}
+
+// masked _reset_impl then _goal_reset_impl (env_base.py:370-379; trifinger_env.py:373-440)
+DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_all, bool& goal_changed) {
+    const TfModel& m = P.m;
+    uint32_t gid = (uint32_t)(P.env_id_offset + i);
+    bool did_reset = false;
+    bool rflag = force_all || (P.reset_buf[i] != 0);
+    bool gflag = !force_all && (P.goal_reset_buf[i] != 0);
+    uint32_t count = P.reset_count[i];
+    if (rflag) {
+        did_reset = true;
+        if (P.robot_reset_type == TF_RESET_DEFAULT) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { e.q[j] = m.q_default[j % 3]; e.qd[j] = 0.0f; }
+        } else if (P.robot_reset_type == TF_RESET_RANDOM) {
+            float n[20];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) rng4(P, gid, count, RNG_ROBOT + (uint32_t)b, &n[4 * b]);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                e.q[j] = m.q_default[j % 3] + P.dof_pos_stddev * (2.0f * n[j] - 1.0f);
+                e.qd[j] = 0.0f + P.dof_vel_stddev * (2.0f * n[9 + j] - 1.0f);
+            }
+        }
+        if (P.object_reset_type == TF_RESET_DEFAULT) {
+            e.cp[0] = 0.0f; e.cp[1] = 0.0f; e.cp[2] = CUBE_MIN_HEIGHT;
+            e.cq[0] = 0.0f; e.cq[1] = 0.0f; e.cq[2] = 0.0f; e.cq[3] = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { e.cv[k] = 0.0f; e.cw[k] = 0.0f; }
+        } else if (P.object_reset_type == TF_RESET_RANDOM) {
+            float u[4];
+            rng4(P, gid, count, RNG_OBJECT, u);
+            sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, e.cp[0], e.cp[1]);
+            e.cp[2] = 0.065f / 2.0f;
+            sample_yaw_quat(u[2], e.cq);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { e.cv[k] = 0.0f; e.cw[k] = 0.0f; }
+        }
+        sample_goal(P, gid, count, e);
+        count = count + 1u;
+    }
+    if (gflag) {
+        sample_goal(P, gid, count, e);
+        count = count + 1u;
+    }
+    if (valid) {
+        if (rflag) { P.reset_buf[i] = 0; P.steps[i] = 0; P.successes[i] = 0; }
+        if (gflag) P.goal_reset_buf[i] = 0;
+        if (rflag || gflag) P.reset_count[i] = count;
+    }
+    goal_changed = rflag || gflag;
+    return did_reset;
+}
+
+// trifinger_env.py:442-494
+template <int A>
+DEV void compute_torque(const DevParams& P, const float* act, const float q[9], const float qd[9], float tau[9]) {
+    float at[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        if (P.normalize_action) {
+            float lo = P.tables[TAB_ACT_LO + j], hi = P.tables[TAB_ACT_HI + j];
+            float off = (lo + hi) * 0.5f;
+            at[j] = act[j] * (hi - lo) * 0.5f + off;
+        } else at[j] = act[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        float t;
+        float kd = P.tables[TAB_KD + j];
+        if (P.command_mode == TF_CMD_TORQUE) t = at[j];
+        else if (P.command_mode == TF_CMD_POSITION) { t = P.tables[TAB_KP + j] * (at[j] - q[j]); t = t - kd * qd[j]; }
+        else { t = at[(A == 18) ? 9 + j : j] * (at[j] - q[j]); t = t - kd * qd[j]; }
+        t = f_max(f_min(t, 0.36f), -0.36f);
+        if (P.apply_safety_damping) {
+            t = t - P.tables[TAB_KS + j] * qd[j];
+            t = f_max(f_min(t, 0.36f), -0.36f);
+        }
+        tau[j] = t;
+    }
+}
+
+DEV float norm3d(const float a[3], const float b[3]) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return f_sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+template <int F> DEV void tip_state(const TfModel& m, const float q[3], const float qd[3], float out[13]) {
+    FK k;
+    fk_setup(m, q, k);
+    float t[3], To[3];
+    rot_link<3>(k, m.tip_origin, t);
+    To[0] = k.p3[0] + t[0]; To[1] = k.p3[1] + t[1]; To[2] = k.p3[2] + t[2];
+    base_to_world<F>(m, To, &out[0]);
+    float sy, cy, sx, cx;
+    tf_sincos(0.5f * q[0], sy, cy);
+    tf_sincos(0.5f * (q[1] + q[2]), sx, cx);
+    float qyx[4] = {cy * sx, sy * cx, -(sy * sx), cy * cx};
+    float qz[4] = {0.0f, 0.0f, m.base_half_yaw_sin[F], m.base_half_yaw_cos[F]};
+    quat_mul(qz, qyx, &out[3]);
+    float L1[3], L2[3], L3[3], vb[3], wb[3];
+    levers(k, To, L1, L2, L3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vb[i] = L1[i] * qd[0] + L2[i] * qd[1] + L3[i] * qd[2];
+    wb[0] = k.ax[0] * qd[1] + k.ax[0] * qd[2];
+    wb[1] = qd[0];
+    wb[2] = k.ax[2] * qd[1] + k.ax[2] * qd[2];
+    dir_base_to_world<F>(m, vb, &out[7]);
+    dir_base_to_world<F>(m, wb, &out[10]);
+}
+
+template <int F> DEV void wrench_local(const DevParams& P, const Env& e, float inv_n, float out[6]) {
+    FK kk;
+    fk_setup(P.m, &e.q[3 * F], kk);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float wv[3] = {e.ft[6 * F + 3 * half] * inv_n, e.ft[6 * F + 3 * half + 1] * inv_n, e.ft[6 * F + 3 * half + 2] * inv_n};
+        float bv[3], lv[3];
+        dir_world_to_base<F>(P.m, wv, bv);
+        rot_link_T<3>(kk, bv, lv);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[3 * half + j] = P.enable_ft ? lv[j] : 0.0f;
+    }
+}
+
+// cooperative, coalesced store of a [64][W] tile staged in LDS as lds[lane * W + j]
+DEV void store_tile(float* __restrict__ dst, const float* lds, int wave_first_env, int n_valid, int W, int lane) {
+    const int total = n_valid * W;                       // floats in this wave's tile
+    float* base = dst + (size_t)wave_first_env * (size_t)W;   // 64*W*4-byte multiple: 16-B aligned
+    const int total4 = total >> 2;
+    for (int idx = lane; idx < total4; idx += WAVE) {
+        float4 vv = *reinterpret_cast<const float4*>(&lds[idx * 4]);
+        *reinterpret_cast<float4*>(&base[idx * 4]) = vv;
+    }
+    for (int idx = (total4 << 2) + lane; idx < total; idx += WAVE) base[idx] = lds[idx];
+}
+
+struct LaneStats { float rew[6]; float pos_cnt, ori_cnt, succ, resets, nonfinite; };
+
+DEV float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = x + __shfl_xor(x, off, WAVE);
+    return x;
+}
+
+
+// trifinger_env.py:500-559 + 959-1099 for the env of this lane.  prev_obj = history[1] pose (7).
+template <int A>
+DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool valid, int wave_first, int n_valid, Env& e,
+                       const float* act, const float prev_obj[7], bool with_reward, float* lds, int lane, LaneStats& st) {
+    const TfModel& m = P.m;
+    constexpr int OD = TF_OBS_DIM_BASE + A;
+    constexpr int SD = OD + TF_STATES_EXTRA;
+    float tips0[13], tips1[13], tips2[13];
+    tip_state<0>(m, &e.q[0], &e.qd[0], tips0);
+    tip_state<1>(m, &e.q[3], &e.qd[3], tips1);
+    tip_state<2>(m, &e.q[6], &e.qd[6], tips2);
+    {   // NaN guard: a non-finite env is flagged for reset and parked at the default pose
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc = acc + e.q[j] * 0.0f + e.qd[j] * 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc = acc + e.cp[j] * 0.0f + e.cv[j] * 0.0f + e.cw[j] * 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = acc + e.cq[j] * 0.0f;
+        if (!(acc == 0.0f)) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { e.q[j] = m.q_default[j % 3]; e.qd[j] = 0.0f; }
+            e.cp[0] = 0.0f; e.cp[1] = 0.0f; e.cp[2] = CUBE_MIN_HEIGHT;
+            e.cq[0] = 0.0f; e.cq[1] = 0.0f; e.cq[2] = 0.0f; e.cq[3] = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { e.cv[k] = 0.0f; e.cw[k] = 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
+            tip_state<0>(m, &e.q[0], &e.qd[0], tips0);
+            tip_state<1>(m, &e.q[3], &e.qd[3], tips1);
+            tip_state<2>(m, &e.q[6], &e.qd[6], tips2);
+            if (valid) P.reset_buf[i] = 1;
+            st.nonfinite += valid ? 1.0f : 0.0f;
+        }
+    }
+    // ---- observations: stage [lane][OD] in LDS, then one coalesced tile store ----
+    const float* off = P.tables + TAB_OFF;
+    const float* inv = P.tables + TAB_INV;
+    const bool nrm = P.normalize_obs != 0;
+#define EMIT(W, col, val)                                                               \
+    {                                                                                   \
+        float x_ = (val);                                                               \
+        lds[lane * (W) + (col)] = nrm ? (2.0f * (x_ - off[col])) * inv[col] : x_;       \
+    }
+#define EMIT_COMMON(W)                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 9; ++j) EMIT(W, j, e.q[j])                   \
+    _Pragma("unroll") for (int j = 0; j < 9; ++j) EMIT(W, 9 + j, e.qd[j])              \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) EMIT(W, 18 + j, e.cp[j])             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) EMIT(W, 21 + j, e.cq[j])             \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) EMIT(W, 25 + j, e.gp[j])             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) EMIT(W, 28 + j, e.gq[j])             \
+    _Pragma("unroll") for (int j = 0; j < A; ++j) EMIT(W, 32 + j, opaque(act[j]))
+    __syncthreads();
+    EMIT_COMMON(OD)
+    __syncthreads();
+    store_tile(P.obs, lds, wave_first, n_valid, OD, lane);
+    __syncthreads();
+    if (P.asymmetric_obs) {
+        EMIT_COMMON(SD)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) EMIT(SD, OD + j, e.cv[j])
+#pragma unroll
+        for (int j = 0; j < 3; ++j) EMIT(SD, OD + 3 + j, e.cw[j])
+#pragma unroll
+        for (int j = 0; j < 13; ++j) EMIT(SD, OD + 6 + j, tips0[j])
+#pragma unroll
+        for (int j = 0; j < 13; ++j) EMIT(SD, OD + 19 + j, tips1[j])
+#pragma unroll
+        for (int j = 0; j < 13; ++j) EMIT(SD, OD + 32 + j, tips2[j])
+#pragma unroll
+        for (int j = 0; j < 9; ++j) EMIT(SD, OD + 45 + j, (P.enable_ft ? e.tau[j] : 0.0f))
+        float inv_n = 1.0f / (float)(P.substeps * P.control_decimation);
+        float wl[6];
+        wrench_local<0>(P, e, inv_n, wl);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) EMIT(SD, OD + 54 + j, wl[j])
+        wrench_local<1>(P, e, inv_n, wl);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) EMIT(SD, OD + 60 + j, wl[j])
+        wrench_local<2>(P, e, inv_n, wl);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) EMIT(SD, OD + 66 + j, wl[j])
+        __syncthreads();
+        store_tile(P.states, lds, wave_first, n_valid, SD, lane);
+        __syncthreads();
+    }
+#undef EMIT_COMMON
+#undef EMIT
+    // ---- history: previous fingertip positions are whatever the last filled frame left ----
+    float tip_prev[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) tip_prev[j] = ST(TF_S_TIP_P + j);
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { ST(TF_S_TIP_P + j) = tips0[j]; ST(TF_S_TIP_P + 3 + j) = tips1[j]; ST(TF_S_TIP_P + 6 + j) = tips2[j]; }
+    }
+    if (!with_reward) return;
+    // ---- rewards (reference rewards.py; order of trifinger_env.py:513-550) ----
+    float r[6];
+    {
+        float s = 0.0f;
+        s = s + (norm3d(tips0, e.cp) - norm3d(&tip_prev[0], prev_obj));
+        s = s + (norm3d(tips1, e.cp) - norm3d(&tip_prev[3], prev_obj));
+        s = s + (norm3d(tips2, e.cp) - norm3d(&tip_prev[6], prev_obj));
+        r[0] = rc.c_reach * s;
+    }
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { float vel = (tips0[j] - tip_prev[j]) / rc.dt; s = s + vel * vel; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { float vel = (tips1[j] - tip_prev[3 + j]) / rc.dt; s = s + vel * vel; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { float vel = (tips2[j] - tip_prev[6 + j]) / rc.dt; s = s + vel * vel; }
+        r[1] = rc.c_move_pen * s;
+    }
+    float dist = norm3d(e.cp, e.gp);
+    r[2] = rc.c_dist * lgsk(dist, 50.0f);
+    float ang = quat_diff_rad(e.cq, e.gq);
+    r[3] = rc.w_rot * (rc.rot_num / (rc.rot_scale * f_abs(ang) + rc.rot_scale));
+    float ang_prev = quat_diff_rad(&prev_obj[3], e.gq);
+    r[4] = rc.w_rot_delta * (rc.rot_delta_sched * (f_abs(ang) - f_abs(ang_prev)));
+    r[5] = rc.w_move * (dist - norm3d(prev_obj, e.gp));
+    float total = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        if (P.rew_active[t]) { total = total + r[t]; st.rew[t] += valid ? r[t] : 0.0f; }
+    }
+    // ---- termination (trifinger_env.py:1053-1099) ----
+    bool pos_ok = dist <= P.pos_tol;
+    bool ori_ok = ang <= P.ori_tol;
+    st.pos_cnt += (valid && pos_ok) ? 1.0f : 0.0f;
+    st.ori_cnt += (valid && ori_ok) ? 1.0f : 0.0f;
+    bool done;
+    if (P.task_difficulty < 4) done = pos_ok;
+    else if (P.task_difficulty == 4) done = pos_ok && ori_ok;
+    else done = ori_ok;
+    bool succ = P.successes[i] != 0;
+    if (P.success_activate) {
+        if (done) total = total + P.success_bonus;
+        if (valid) P.goal_reset_buf[i] = (uint8_t)done;
+        succ = succ || done;
+    } else {
+        succ = (P.goal_reset_buf[i] != 0) && succ;
+    }
+    if (valid) {
+        P.successes[i] = (uint8_t)succ;
+        P.reward[i] = total;
+    }
+    st.succ += (valid && succ) ? 1.0f : 0.0f;
+}
+
+DEV void finish_env(const DevParams& P, int i, bool valid) {     // env_base.py:391-399
+    if (!valid) return;
+    int s = P.steps[i] + 1;
+    P.steps[i] = s;
+    uint8_t rb = P.reset_buf[i];
+    if (P.episode_length > 0 && s >= P.episode_length) { rb = 1; P.reset_buf[i] = 1; }
+    P.dones[i] = (uint8_t)(rb && P.goal_reset_buf[i]);
+}
+
+DEV void stats_zero(LaneStats& st) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t) st.rew[t] = 0.0f;
+    st.pos_cnt = 0.0f; st.ori_cnt = 0.0f; st.succ = 0.0f; st.resets = 0.0f; st.nonfinite = 0.0f;
+}
+DEV void stats_publish(const DevParams& P, const LaneStats& st, int lane) {
+    float* out = P.scratch + (size_t)blockIdx.x * 16;
+    float vals[11];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) vals[t] = st.rew[t];
+    vals[6] = st.pos_cnt; vals[7] = st.ori_cnt; vals[8] = st.succ; vals[9] = st.resets; vals[10] = st.nonfinite;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        float s = wave_sum(vals[k]);
+        if (lane == 0) out[k] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// kernels.  One 64-lane wave per workgroup, one env per lane.  __launch_bounds__(64, 1): 1 wave/SIMD is
+// all the chip ever holds at <= 65536 envs, so let the allocator use the whole VGPR file.
+// Per-env data that is cold while the contact solve runs (goal pose, last action, previous object pose)
+// is parked in its coalesced SoA rows in HBM/L2 and re-read afterwards, not carried in registers.
+// ------------------------------------------------------------------------------------------------------
+#define LANE_SETUP                                                     \
+    const DevParams& P = *Pp;                                          \
+    const int lane = threadIdx.x;                                      \
+    const int wave_first = blockIdx.x * WAVE;                          \
+    const int i_raw = wave_first + lane;                               \
+    const bool valid = i_raw < P.N;                                    \
+    const int i = valid ? i_raw : (P.N - 1);                           \
+    const int n_valid = (P.N - wave_first < WAVE) ? (P.N - wave_first) : WAVE; \
+    (void)n_valid; (void)i; (void)valid;
+
+// fused control step (IS_RESET=false) or IsaacEnvBase.reset (IS_RESET=true)
+template <int A, bool IS_RESET, bool ASYM>
+__global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ Pp, const StepArgs sa,
+                                                  const float* __restrict__ action) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    LANE_SETUP
+    Env e;
+    float n_resets = 0.0f;
+    // ---- phase A: action tile, masked resets, torque law ----
+    {
+        float act[A];
+        if (!IS_RESET) {
+            // action tile [n_valid][A] is contiguous: coalesced dword loads into LDS, each lane picks its row
+            const float* src = action + (size_t)wave_first * (size_t)A;
+            const int total = n_valid * A;
+            for (int idx = lane; idx < total; idx += WAVE) lds[idx] = src[idx];
+            __syncthreads();
+            const int row = valid ? lane : (n_valid - 1);
+#pragma unroll
+            for (int j = 0; j < A; ++j) act[j] = lds[row * A + j];
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int j = 0; j < A; ++j) act[j] = 0.0f;
+        }
+        load_dyn(P, i, e);
+        load_goal(P, i, e);
+        bool goal_changed;
+        bool did_reset = apply_resets(P, i, valid, e, IS_RESET, goal_changed);
+        store_goal(P, i, e, valid && goal_changed);
+        if (did_reset) {
+#pragma unroll
+            for (int j = 0; j < A; ++j) act[j] = 0.0f;          // trifinger_env.py:387
+            n_resets = valid ? 1.0f : 0.0f;
+        }
+        // _action_buf (what the observation reports as the last command): transposed back through LDS
+#pragma unroll
+        for (int j = 0; j < A; ++j) lds[lane * A + j] = act[j];
+        __syncthreads();
+        store_tile(P.action_buf, lds, wave_first, n_valid, A, lane);
+        __syncthreads();
+        compute_torque<A>(P, act, e.q, e.qd, e.tau);
+        store_prev_obj(P, i, e, valid);                         // history[1] of the object (trifinger_env.py:975)
+    }
+    // ---- phase B: physics ----
+#pragma unroll
+    for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
+    const int nsub = sa.nsim * P.substeps;
+    for (int s = 0; s < nsub; ++s) substep<ASYM>(P, e, P.hsub, lds, lane);
+    // ---- phase C: observations, rewards, termination, counters ----
+    __syncthreads();
+    {
+        LaneStats st;
+        stats_zero(st);
+        st.resets = n_resets;
+        float act[A], prev_obj[7];
+        const int row = valid ? i : (P.N - 1);
+#pragma unroll
+        for (int j = 0; j < A; ++j) act[j] = P.action_buf[(size_t)row * A + j];
+        load_prev_obj(P, i, prev_obj);
+        load_goal(P, i, e);
+        goal_advance(P, e, nsub, P.hsub);
+        post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st);
+        store_dyn(P, i, e, valid);
+        if (P.goal_rotation_activate) store_goal(P, i, e, valid);
+        if (!IS_RESET) finish_env(P, i, valid);
+        stats_publish(P, st, lane);
+    }
+}
+
+// fold the per-wave partials into info[] (deterministic order)
+__global__ void __launch_bounds__(256) k_reduce_stats(const DevParams* __restrict__ Pp, int n_waves) {
+    const DevParams& P = *Pp;
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    for (int k = 0; k < 11; ++k) {
+        float s = 0.0f;
+        for (int w = t; w < n_waves; w += 256) s = s + P.scratch[(size_t)w * 16 + k];
+        red[t] = s;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (t < off) red[t] = red[t] + red[t + off];
+            __syncthreads();
+        }
+        if (t == 0) {
+            float total = red[0];
+            float n = (float)P.N;
+            float out;
+            if (k < 6 || k == 8) out = total / n;
+            else out = total;
+            const int slot = (k < 6) ? k : ((k == 6) ? TF_INFO_POS_COUNT : ((k == 7) ? TF_INFO_ORI_COUNT :
+                             ((k == 8) ? TF_INFO_SUCCESS_MEAN : ((k == 9) ? TF_INFO_NUM_RESETS : TF_INFO_NUM_NONFINITE))));
+            P.info[slot] = out;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- split path: one hook per launch (parity tests) ----
+template <int A>
+__global__ void __launch_bounds__(WAVE, 1) k_apply_resets(const DevParams* __restrict__ Pp) {
+    __shared__ __attribute__((aligned(16))) float lds[WAVE * 18];
+    LANE_SETUP
+    Env e;
+    load_dyn(P, i, e);
+    load_goal(P, i, e);
+    bool goal_changed;
+    bool did = apply_resets(P, i, valid, e, false, goal_changed);
+    float act[A];
+    const int row = valid ? i : (P.N - 1);
+#pragma unroll
+    for (int j = 0; j < A; ++j) act[j] = did ? 0.0f : P.action_buf[(size_t)row * A + j];
+#pragma unroll
+    for (int j = 0; j < A; ++j) lds[lane * A + j] = act[j];
+    __syncthreads();
+    store_tile(P.action_buf, lds, wave_first, n_valid, A, lane);
+    load_split_extras(P, i, e);
+    store_dyn(P, i, e, valid);
+    store_goal(P, i, e, valid);
+}
+
+template <int A>
+__global__ void __launch_bounds__(WAVE, 1) k_pre_step(const DevParams* __restrict__ Pp) {
+    LANE_SETUP
+    Env e;
+    load_dyn(P, i, e);
+    float act[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) act[j] = P.action_buf[(size_t)i * A + j];
+    compute_torque<A>(P, act, e.q, e.qd, e.tau);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
+    store_dyn(P, i, e, valid);
+    store_ft(P, i, e, valid);
+    store_prev_obj(P, i, e, valid);
+}
+
+__global__ void __launch_bounds__(WAVE, 1) k_simulate(const DevParams* __restrict__ Pp) {
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    LANE_SETUP
+    Env e;
+    load_dyn(P, i, e);
+    load_split_extras(P, i, e);
+    for (int s = 0; s < P.substeps; ++s) substep<true>(P, e, P.hsub, lds, lane);
+    store_dyn(P, i, e, valid);
+    store_ft(P, i, e, valid);
+    if (P.goal_rotation_activate) {
+        load_goal(P, i, e);
+        goal_advance(P, e, P.substeps, P.hsub);
+        store_goal(P, i, e, valid);
+    }
+}
+
+template <int A>
+__global__ void __launch_bounds__(WAVE, 1) k_post_step(const DevParams* __restrict__ Pp, const StepArgs sa) {
+    __shared__ __attribute__((aligned(16))) float lds[WAVE * MAX_STATES];
+    LANE_SETUP
+    LaneStats st;
+    stats_zero(st);
+    Env e;
+    load_dyn(P, i, e);
+    load_goal(P, i, e);
+    load_split_extras(P, i, e);
+    float act[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) act[j] = P.action_buf[(size_t)i * A + j];
+    float prev_obj[7];
+    load_prev_obj(P, i, prev_obj);
+    post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, true, lds, lane, st);
+    store_dyn(P, i, e, valid);
+    store_ft(P, i, e, valid);
+    stats_publish(P, st, lane);
+}
+
+__global__ void __launch_bounds__(WAVE, 1) k_finish(const DevParams* __restrict__ Pp) {
+    LANE_SETUP
+    finish_env(P, i, valid);
+}
+
+// ---- leaf kernels for the golden tests ----
+__global__ void k_test_quat_diff(const float* a, const float* b, float* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float qa[4] = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+    float qb[4] = {b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]};
+    out[i] = quat_diff_rad(qa, qb);
+}
+__global__ void k_test_quat_mul(const float* a, const float* b, float* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float qa[4] = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+    float qb[4] = {b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]};
+    float o[4];
+    quat_mul(qa, qb, o);
+    for (int j = 0; j < 4; ++j) out[4 * i + j] = o[j];
+}
+__global__ void k_test_lgsk(const float* x, float scale, float* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = lgsk(x[i], scale);
+}
+__global__ void k_test_sample_xy(const float* ur, const float* ut, float r_max, float* x, float* y, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float xx, yy;
+    sample_xy(ur[i], ut[i], r_max, xx, yy);
+    x[i] = xx; y[i] = yy;
+}
+__global__ void k_test_yaw(const float* u, float* q, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[4];
+    sample_yaw_quat(u[i], o);
+    for (int j = 0; j < 4; ++j) q[4 * i + j] = o[j];
+}
+__global__ void k_test_normq(const float* nn, float* q, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float in[4] = {nn[4 * i], nn[4 * i + 1], nn[4 * i + 2], nn[4 * i + 3]}, o[4];
+    normalize_quat(in, o);
+    for (int j = 0; j < 4; ++j) q[4 * i + j] = o[j];
+}
+__global__ void k_test_philox(uint32_t k0, uint32_t k1, const uint32_t* env_id, const uint32_t* counter, uint32_t tag,
+                              uint32_t* out4, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r[4];
+    philox4x32_10(env_id[i], counter[i], tag, 0u, k0, k1, r);
+    for (int j = 0; j < 4; ++j) out4[4 * i + j] = r[j];
+}
+__global__ void k_test_finger_dyn(const DevParams* __restrict__ Pp, const float* q, const float* qd, float* tip, float* mass, float* bias, int n) {
+    const DevParams& P = *Pp;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    FK k;
+    float M[6], t[3], b[3];
+    float qq[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]}, qv[3] = {qd[3 * i], qd[3 * i + 1], qd[3 * i + 2]};
+    fk_setup(P.m, qq, k);
+    finger_dynamics(P.m, k, qv, P.grav, M, b);
+    rot_link<3>(k, P.m.tip_origin, t);
+    for (int j = 0; j < 3; ++j) { tip[3 * i + j] = k.p3[j] + t[j]; bias[3 * i + j] = b[j]; }
+    float* o = &mass[9 * i];
+    o[0] = M[0]; o[1] = M[1]; o[2] = M[2]; o[3] = M[1]; o[4] = M[3]; o[5] = M[4]; o[6] = M[2]; o[7] = M[4]; o[8] = M[5];
+}
+
+// ======================================================================================================
+// host side: handle + C ABI
+// ======================================================================================================
+struct TfHandle_ {
+    TfConfig cfg;
+    DevParams dp;            // host mirror of *d_params
+    DevParams* d_params;     // device copy read by the kernels
+    StepArgs sa;
+    int bound;
+    int64_t frame_count;
+    int action_dim;
+    float* d_tables;
+    // optional kernel timing (bench.py): event pairs around the fused step kernel
+    hipEvent_t* ev;          // [2 * ev_cap]
+    int ev_cap, ev_used;
+};
+
+static thread_local char g_err[512] = "";
+static void free_events(TfHandle_* h);
+
+static int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return TF_ERR_DEVICE;
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);    \
+    } while (0)
+
+extern "C" {
+
+int tf_api_version(void) { return TF_API_VERSION; }
+const char* tf_backend_name(void) { return "hip-gfx950"; }
+const char* tf_last_error_string(void) { return g_err; }
+int64_t tf_scratch_floats(int32_t num_envs) { return (int64_t)((num_envs + WAVE - 1) / WAVE) * 16; }
+
+int tf_action_dim(int32_t mode) {
+    if (mode == TF_CMD_TORQUE || mode == TF_CMD_POSITION) return 9;
+    if (mode == TF_CMD_POSITION_IMPEDANCE) return 18;
+    return TF_ERR_COMMAND_MODE;
+}
+
+// Physical model from the URDF numbers (reference resources/assets/trifinger/robot_properties_fingers/urdf/pro/
+// trifingerpro.urdf and objects/urdf/cube_multicolor_rrc.urdf).
+void tf_default_model(TfModel* m) {
+    memset(m, 0, sizeof(*m));
+    m->base_height = 0.29f;
+    const double yaw[3] = {0.0, -2.09439510239, -4.18879020479};
+    for (int f = 0; f < 3; ++f) {
+        m->base_yaw_cos[f] = (float)cos(yaw[f]);
+        m->base_yaw_sin[f] = (float)sin(yaw[f]);
+        m->base_half_yaw_cos[f] = (float)cos(0.5 * yaw[f]);
+        m->base_half_yaw_sin[f] = (float)sin(0.5 * yaw[f]);
+    }
+    m->base_yaw_cos[0] = 1.0f; m->base_yaw_sin[0] = 0.0f;
+    m->base_half_yaw_cos[0] = 1.0f; m->base_half_yaw_sin[0] = 0.0f;
+    m->j2_origin[0] = 0.01685f; m->j2_origin[1] = 0.0505f; m->j2_origin[2] = 0.0f;
+    m->j3_origin[0] = 0.04922f; m->j3_origin[1] = 0.0f;    m->j3_origin[2] = -0.16f;
+    m->tip_origin[0] = 0.0185f; m->tip_origin[1] = 0.0f;   m->tip_origin[2] = -0.1626f;
+    m->link_mass[0] = 0.26f;
+    m->link_com[0][1] = 0.06f;
+    m->link_inertia[0][0] = 0.000459333333333f; m->link_inertia[0][1] = 6.93333333333e-05f; m->link_inertia[0][2] = 0.000459333333333f;
+    m->link_mass[1] = 0.25f;
+    m->link_com[1][0] = 0.028f; m->link_com[1][2] = -0.08f;
+    m->link_inertia[1][0] = 0.000441666666667f; m->link_inertia[1][1] = 0.000441666666667f; m->link_inertia[1][2] = 6.66666666667e-05f;
+    {   // distal link: lower link merged with the rigidly attached tip link (parallel-axis, double precision)
+        const double mass[2] = {0.021, 0.031};
+        const double com[2][3] = {{0.0, 0.0, -0.06}, {0.0185, 0.0, -0.1626}};
+        const double diag[2][3] = {{3.5e-05, 3.5e-05, 1.4e-06}, {5.16666666667e-07, 5.16666666667e-07, 5.16666666667e-07}};
+        double mm = mass[0] + mass[1], c[3], I[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; ++i) c[i] = (mass[0] * com[0][i] + mass[1] * com[1][i]) / mm;
+        I[0] = diag[0][0] + diag[1][0]; I[1] = diag[0][1] + diag[1][1]; I[2] = diag[0][2] + diag[1][2];
+        for (int b = 0; b < 2; ++b) {
+            double d[3] = {com[b][0] - c[0], com[b][1] - c[1], com[b][2] - c[2]};
+            double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            I[0] += mass[b] * (d2 - d[0] * d[0]);
+            I[1] += mass[b] * (d2 - d[1] * d[1]);
+            I[2] += mass[b] * (d2 - d[2] * d[2]);
+            I[3] += -mass[b] * d[0] * d[1];
+            I[4] += -mass[b] * d[0] * d[2];
+            I[5] += -mass[b] * d[1] * d[2];
+        }
+        m->link_mass[2] = (float)mm;
+        for (int i = 0; i < 3; ++i) m->link_com[2][i] = (float)c[i];
+        for (int i = 0; i < 6; ++i) m->link_inertia[2][i] = (float)I[i];
+    }
+    const float lo[3] = {-0.33f, 0.0f, -2.7f}, hi[3] = {1.0f, 1.57f, 0.0f}, df[3] = {0.0f, 0.9f, -1.7f};
+    for (int i = 0; i < 3; ++i) { m->q_lo[i] = lo[i]; m->q_hi[i] = hi[i]; m->q_default[i] = df[i]; }
+    m->qd_max = 10.0f;
+    m->tau_max = 0.36f;
+    m->link_angular_damping = 0.01f;
+    m->cap_a[0] = 0.0135f;
+    m->cap_b[0] = 0.0185f; m->cap_b[2] = -0.1592f;
+    m->cap_radius = 0.0102f;
+    m->cube_half = 0.0325f;
+    m->cube_mass = (float)(291.3 * 0.065 * 0.065 * 0.065);
+    m->cube_inertia = (float)(291.3 * 0.065 * 0.065 * 0.065 * 0.065 * 0.065 / 6.0);
+    m->cube_linear_damping = 0.0f;
+    m->cube_angular_damping = 0.05f;
+    m->wall_radius = 0.192f;
+    m->wall_height = 0.06f;
+    m->mu_finger_cube = 1.0f;
+    m->mu_cube_floor = 0.55f;
+    m->mu_tip_floor = 0.55f;
+    m->mu_cube_wall = 1.0f;
+    m->restitution_finger = 0.4f;
+    m->bounce_threshold = 0.5f;
+    m->contact_margin = 0.04f;
+    m->contact_offset = 0.002f;
+    m->erp = 0.2f;
+    m->max_depenetration_velocity = 1000.0f;
+}
+
+// scale tables: reference trifinger_env.py:153-213 (limits) and :655-710 (concatenation order)
+static void build_tables(const TfConfig* c, int A, float* tab, int* obs_dim, int* states_dim) {
+    const float q_lo[3] = {-0.33f, 0.0f, -2.7f}, q_hi[3] = {1.0f, 1.57f, 0.0f};
+    const float kd[3] = {0.1f, 0.3f, 0.001f}, ks[3] = {0.08f, 0.08f, 0.04f};
+    float lo[MAX_STATES], hi[MAX_STATES];
+    float* act_lo = tab + TAB_ACT_LO;
+    float* act_hi = tab + TAB_ACT_HI;
+    for (int j = 0; j < 9; ++j) { tab[TAB_KP + j] = 10.0f; tab[TAB_KD + j] = kd[j % 3]; tab[TAB_KS + j] = ks[j % 3]; }
+    for (int j = 0; j < 18; ++j) { act_lo[j] = 0.0f; act_hi[j] = 0.0f; }
+    for (int j = 0; j < A; ++j) {
+        if (c->command_mode == TF_CMD_TORQUE) { act_lo[j] = -0.36f; act_hi[j] = 0.36f; }
+        else if (j < 9) { act_lo[j] = q_lo[j % 3]; act_hi[j] = q_hi[j % 3]; }
+        else { act_lo[j] = 1.0f; act_hi[j] = 50.0f; }
+    }
+    int k = 0;
+    for (int j = 0; j < 9; ++j) { lo[k] = q_lo[j % 3]; hi[k] = q_hi[j % 3]; ++k; }
+    for (int j = 0; j < 9; ++j) { lo[k] = -10.0f; hi[k] = 10.0f; ++k; }
+    for (int rep = 0; rep < 2; ++rep) {
+        lo[k] = -0.3f; hi[k] = 0.3f; ++k; lo[k] = -0.3f; hi[k] = 0.3f; ++k; lo[k] = 0.0f; hi[k] = 0.3f; ++k;
+        for (int j = 0; j < 4; ++j) { lo[k] = -1.0f; hi[k] = 1.0f; ++k; }
+    }
+    for (int j = 0; j < A; ++j) {
+        if (c->normalize_action) { lo[k] = -1.0f; hi[k] = 1.0f; }
+        else { lo[k] = act_lo[j]; hi[k] = act_hi[j]; }
+        ++k;
+    }
+    *obs_dim = k;
+    for (int j = 0; j < 6; ++j) { lo[k] = -0.5f; hi[k] = 0.5f; ++k; }
+    for (int f = 0; f < 3; ++f) {
+        lo[k] = -0.4f; hi[k] = 0.4f; ++k; lo[k] = -0.4f; hi[k] = 0.4f; ++k; lo[k] = 0.0f; hi[k] = 0.5f; ++k;
+        for (int j = 0; j < 4; ++j) { lo[k] = -1.0f; hi[k] = 1.0f; ++k; }
+        for (int j = 0; j < 6; ++j) { lo[k] = -0.2f; hi[k] = 0.2f; ++k; }
+    }
+    for (int j = 0; j < 9; ++j) { lo[k] = -0.36f; hi[k] = 0.36f; ++k; }
+    for (int j = 0; j < 18; ++j) { lo[k] = -1.0f; hi[k] = 1.0f; ++k; }
+    *states_dim = k;
+    for (int j = 0; j < MAX_STATES; ++j) { tab[TAB_OFF + j] = 0.0f; tab[TAB_INV + j] = 1.0f; }
+    for (int j = 0; j < k; ++j) {
+        tab[TAB_OFF + j] = (lo[j] + hi[j]) * 0.5f;
+        tab[TAB_INV + j] = 1.0f / (hi[j] - lo[j]);
+    }
+}
+
+int tf_create(const TfConfig* cfg, tf_handle* out) {
+    if (!cfg || !out) return TF_ERR_INVALID_ARG;
+    if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
+    if (tf_action_dim(cfg->command_mode) < 0) return TF_ERR_COMMAND_MODE;
+    if (cfg->robot_reset_type < 0 || cfg->robot_reset_type > 2) return TF_ERR_ROBOT_RESET;
+    if (cfg->object_reset_type < 0 || cfg->object_reset_type > 2) return TF_ERR_OBJECT_RESET;
+    int d = cfg->task_difficulty;
+    if (!(d == -1 || (d >= 1 && d <= 6))) return TF_ERR_DIFFICULTY;
+    if (cfg->finger_reach_norm_p != 2) return TF_ERR_UNSUPPORTED;
+    if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
+        return TF_ERR_INVALID_ARG;
+    TfHandle_* h = new TfHandle_();
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    if (h->cfg.global_num_envs <= 0) h->cfg.global_num_envs = cfg->num_envs;
+    h->action_dim = tf_action_dim(cfg->command_mode);
+    float tab[TAB_FLOATS];
+    int od = 0, sd = 0;
+    build_tables(&h->cfg, h->action_dim, tab, &od, &sd);
+    hipError_t e = hipMalloc((void**)&h->d_tables, sizeof(tab));
+    if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(tables)"); }
+    e = hipMemcpy(h->d_tables, tab, sizeof(tab), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(h->d_tables); delete h; return hip_fail(e, "hipMemcpy(tables)"); }
+    DevParams& P = h->dp;
+    P.tables = h->d_tables;
+    P.N = cfg->num_envs; P.A = h->action_dim; P.OD = od; P.SD = sd;
+    P.env_id_offset = cfg->env_id_offset;
+    P.seed_lo = (uint32_t)cfg->seed; P.seed_hi = (uint32_t)(cfg->seed >> 32);
+    P.command_mode = cfg->command_mode; P.normalize_action = cfg->normalize_action; P.normalize_obs = cfg->normalize_obs;
+    P.apply_safety_damping = cfg->apply_safety_damping; P.asymmetric_obs = cfg->asymmetric_obs; P.enable_ft = cfg->enable_ft_sensors;
+    P.task_difficulty = cfg->task_difficulty; P.episode_length = cfg->episode_length;
+    P.robot_reset_type = cfg->robot_reset_type; P.object_reset_type = cfg->object_reset_type;
+    P.goal_rotation_activate = cfg->goal_rotation_activate;
+    P.dof_pos_stddev = cfg->dof_pos_stddev; P.dof_vel_stddev = cfg->dof_vel_stddev; P.goal_rate = cfg->goal_rotation_rate_magnitude;
+    for (int t = 0; t < 6; ++t) P.rew_active[t] = cfg->reward[t].activate;
+    P.success_activate = cfg->success_activate; P.success_bonus = cfg->success_bonus;
+    P.pos_tol = cfg->position_tolerance; P.ori_tol = cfg->orientation_tolerance;
+    P.substeps = cfg->substeps; P.iters = cfg->solver_iterations; P.control_decimation = cfg->control_decimation;
+    P.dt = cfg->dt; P.hsub = cfg->dt / (float)cfg->substeps;
+    for (int i = 0; i < 3; ++i) P.grav[i] = cfg->gravity[i];
+    P.m = cfg->model;
+    e = hipMalloc((void**)&h->d_params, sizeof(DevParams));
+    if (e != hipSuccess) { (void)hipFree(h->d_tables); delete h; return hip_fail(e, "hipMalloc(params)"); }
+    e = hipMemcpy(h->d_params, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(h->d_tables); (void)hipFree(h->d_params); delete h; return hip_fail(e, "hipMemcpy(params)"); }
+    *out = h;
+    return TF_OK;
+}
+
+int tf_destroy(tf_handle h) {
+    if (!h) return TF_OK;
+    if (h->d_tables) (void)hipFree(h->d_tables);
+    if (h->d_params) (void)hipFree(h->d_params);
+    free_events(h);
+    delete h;
+    return TF_OK;
+}
+
+int tf_bind(tf_handle h, const TfBuffers* b) {
+    if (!h || !b) return TF_ERR_INVALID_ARG;
+    if (!b->state || !b->action_buf || !b->obs || !b->reward || !b->reset_buf || !b->goal_reset_buf ||
+        !b->successes || !b->dones || !b->steps || !b->reset_count || !b->info || !b->scratch)
+        return TF_ERR_INVALID_ARG;
+    if (h->cfg.asymmetric_obs && !b->states) return TF_ERR_INVALID_ARG;
+    DevParams& P = h->dp;
+    P.state = b->state; P.action_buf = b->action_buf; P.obs = b->obs; P.states = b->states; P.reward = b->reward;
+    P.reset_buf = b->reset_buf; P.goal_reset_buf = b->goal_reset_buf; P.successes = b->successes; P.dones = b->dones;
+    P.steps = b->steps; P.reset_count = b->reset_count; P.info = b->info; P.scratch = b->scratch;
+    HIP_TRY(hipMemcpy(h->d_params, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice));
+    h->bound = 1;
+    return TF_OK;
+}
+
+int tf_set_gravity(tf_handle h, const float g[3]) {
+    if (!h || !g) return TF_ERR_INVALID_ARG;
+    for (int i = 0; i < 3; ++i) { h->cfg.gravity[i] = g[i]; h->dp.grav[i] = g[i]; }
+    // cold path: a blocking copy is fine (and orders after any step already queued on the null stream)
+    HIP_TRY(hipMemcpy(h->d_params, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice));
+    return TF_OK;
+}
+int64_t tf_frame_count(tf_handle h) { return h ? h->frame_count : -1; }
+int tf_set_frame_count(tf_handle h, int64_t f) { if (!h) return TF_ERR_INVALID_ARG; h->frame_count = f; return TF_OK; }
+
+}  // extern "C"
+
+static double sched_window(const TfRewardTerm* t, double step) {
+    if (t->sched_start != t->sched_end) return (t->sched_start <= step && step <= t->sched_end) ? 1.0 : 0.0;
+    return 1.0;
+}
+// scalar prefactors exactly as python evaluates them in double before they meet an fp32 tensor
+// (reference rewards.py:50-63,117-139,165-184,203-235,245-263; env_base.py:287-289)
+static void reward_coefs(TfHandle_* h) {
+    const TfConfig* c = &h->cfg;
+    RewardCoef* rc = &h->sa.rc;
+    double step = (double)h->frame_count * (double)c->global_num_envs;
+    double dt = (double)c->dt;
+    const TfRewardTerm* T = c->reward;
+    rc->c_reach = (float)((double)T[TF_REW_FINGER_REACH_OBJECT_RATE].weight * sched_window(&T[TF_REW_FINGER_REACH_OBJECT_RATE], step));
+    rc->c_move_pen = T[TF_REW_FINGER_MOVE_PENALTY].weight;
+    rc->dt = c->dt;
+    rc->c_dist = (float)((double)T[TF_REW_OBJECT_DIST].weight * dt * sched_window(&T[TF_REW_OBJECT_DIST], step));
+    rc->rot_num = (float)(sched_window(&T[TF_REW_OBJECT_ROT], step) * dt);
+    rc->rot_scale = c->object_rot_scale;
+    rc->w_rot = T[TF_REW_OBJECT_ROT].weight;
+    const TfRewardTerm* t = &T[TF_REW_OBJECT_ROT_DELTA];
+    double s = 1.0;
+    if (t->sched_start != t->sched_end) {
+        s = (step - t->sched_start) / (t->sched_end - t->sched_start);
+        s = (s < 0.0) ? 0.0 : ((s > 1.0) ? 1.0 : s);
+    }
+    rc->rot_delta_sched = (float)s;
+    rc->w_rot_delta = t->weight;
+    rc->w_move = T[TF_REW_OBJECT_MOVE].weight;
+}
+
+static inline int n_waves(const TfHandle_* h) { return (h->cfg.num_envs + WAVE - 1) / WAVE; }
+
+#define CHECK_HANDLE(h)                         \
+    if (!(h)) return TF_ERR_INVALID_ARG;        \
+    if (!(h)->bound) return TF_ERR_NOT_BOUND;
+
+#define LAUNCH_CHECK(what)                                         \
+    do {                                                           \
+        hipError_t e_ = hipGetLastError();                         \
+        if (e_ != hipSuccess) return hip_fail(e_, what);           \
+    } while (0)
+
+static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStream_t s) {
+    const int nsim = is_reset ? 1 : h->cfg.control_decimation;
+    h->frame_count += nsim;
+    h->sa.nsim = nsim;
+    reward_coefs(h);
+    dim3 grid(n_waves(h)), block(WAVE);
+    const bool timed = !is_reset && h->ev && h->ev_used < h->ev_cap;
+    if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], s));
+    const bool asym = h->cfg.asymmetric_obs != 0;
+#define LAUNCH_STEP(AA, RR, SS) hipLaunchKernelGGL((k_step<AA, RR, SS>), grid, block, 0, s, h->d_params, h->sa, action)
+    if (h->action_dim == 9) {
+        if (is_reset) { if (asym) LAUNCH_STEP(9, true, true); else LAUNCH_STEP(9, true, false); }
+        else { if (asym) LAUNCH_STEP(9, false, true); else LAUNCH_STEP(9, false, false); }
+    } else {
+        if (is_reset) { if (asym) LAUNCH_STEP(18, true, true); else LAUNCH_STEP(18, true, false); }
+        else { if (asym) LAUNCH_STEP(18, false, true); else LAUNCH_STEP(18, false, false); }
+    }
+#undef LAUNCH_STEP
+    LAUNCH_CHECK("k_step");
+    if (timed) { HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], s)); h->ev_used += 1; }
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, s, h->d_params, n_waves(h));
+    LAUNCH_CHECK("k_reduce_stats");
+    return TF_OK;
+}
+
+extern "C" {
+
+int tf_step(tf_handle h, const float* action, void* stream) {
+    CHECK_HANDLE(h)
+    if (!action) return TF_ERR_INVALID_ARG;
+    return launch_step(h, action, false, (hipStream_t)stream);
+}
+int tf_reset(tf_handle h, void* stream) {
+    CHECK_HANDLE(h)
+    return launch_step(h, nullptr, true, (hipStream_t)stream);
+}
+
+static void free_events(TfHandle_* h) {
+    if (h->ev) {
+        for (int i = 0; i < 2 * h->ev_cap; ++i) (void)hipEventDestroy(h->ev[i]);
+        delete[] h->ev;
+    }
+    h->ev = nullptr; h->ev_cap = 0; h->ev_used = 0;
+}
+int tf_enable_kernel_timing(tf_handle h, int32_t max_launches) {
+    if (!h) return TF_ERR_INVALID_ARG;
+    free_events(h);
+    if (max_launches <= 0) return TF_OK;
+    h->ev = new hipEvent_t[2 * (size_t)max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
+    h->ev_cap = max_launches;
+    return TF_OK;
+}
+int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {
+    if (!h || !total_ms || !launches) return TF_ERR_INVALID_ARG;
+    double sum = 0.0;
+    for (int i = 0; i < h->ev_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        sum += (double)ms;
+    }
+    *total_ms = sum;
+    *launches = h->ev_used;
+    return TF_OK;
+}
+
+int tf_apply_resets(tf_handle h, void* stream) {
+    CHECK_HANDLE(h)
+    dim3 grid(n_waves(h)), block(WAVE);
+    if (h->action_dim == 9) hipLaunchKernelGGL(k_apply_resets<9>, grid, block, 0, (hipStream_t)stream, h->d_params);
+    else hipLaunchKernelGGL(k_apply_resets<18>, grid, block, 0, (hipStream_t)stream, h->d_params);
+    LAUNCH_CHECK("k_apply_resets");
+    return TF_OK;
+}
+int tf_pre_step(tf_handle h, void* stream) {
+    CHECK_HANDLE(h)
+    dim3 grid(n_waves(h)), block(WAVE);
+    if (h->action_dim == 9) hipLaunchKernelGGL(k_pre_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params);
+    else hipLaunchKernelGGL(k_pre_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params);
+    LAUNCH_CHECK("k_pre_step");
+    return TF_OK;
+}
+int tf_simulate(tf_handle h, void* stream) {
+    CHECK_HANDLE(h)
+    h->frame_count += 1;
+    hipLaunchKernelGGL(k_simulate, dim3(n_waves(h)), dim3(WAVE), 0, (hipStream_t)stream, h->d_params);
+    LAUNCH_CHECK("k_simulate");
+    return TF_OK;
+}
+int tf_post_step(tf_handle h, void* stream) {
+    CHECK_HANDLE(h)
+    reward_coefs(h);
+    dim3 grid(n_waves(h)), block(WAVE);
+    if (h->action_dim == 9) hipLaunchKernelGGL(k_post_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
+    else hipLaunchKernelGGL(k_post_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
+    LAUNCH_CHECK("k_post_step");
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, h->d_params, n_waves(h));
+    LAUNCH_CHECK("k_reduce_stats");
+    return TF_OK;
+}
+int tf_finish_step(tf_handle h, void* stream) {
+    CHECK_HANDLE(h)
+    hipLaunchKernelGGL(k_finish, dim3(n_waves(h)), dim3(WAVE), 0, (hipStream_t)stream, h->d_params);
+    LAUNCH_CHECK("k_finish");
+    return TF_OK;
+}
+
+#define LEAF_GRID(n) dim3(((n) + 255) / 256), dim3(256), 0, (hipStream_t)stream
+int tf_test_quat_diff_rad(const float* a, const float* b, float* out, int32_t n, void* stream) {
+    hipLaunchKernelGGL(k_test_quat_diff, LEAF_GRID(n), a, b, out, n);
+    LAUNCH_CHECK("k_test_quat_diff");
+    return TF_OK;
+}
+int tf_test_quat_mul(const float* a, const float* b, float* out, int32_t n, void* stream) {
+    hipLaunchKernelGGL(k_test_quat_mul, LEAF_GRID(n), a, b, out, n);
+    LAUNCH_CHECK("k_test_quat_mul");
+    return TF_OK;
+}
+int tf_test_lgsk(const float* x, float scale, float* out, int32_t n, void* stream) {
+    hipLaunchKernelGGL(k_test_lgsk, LEAF_GRID(n), x, scale, out, n);
+    LAUNCH_CHECK("k_test_lgsk");
+    return TF_OK;
+}
+int tf_test_sample_xy(const float* ur, const float* ut, float r_max, float* x, float* y, int32_t n, void* stream) {
+    hipLaunchKernelGGL(k_test_sample_xy, LEAF_GRID(n), ur, ut, r_max, x, y, n);
+    LAUNCH_CHECK("k_test_sample_xy");
+    return TF_OK;
+}
+int tf_test_sample_yaw_quat(const float* u, float* quat, int32_t n, void* stream) {
+    hipLaunchKernelGGL(k_test_yaw, LEAF_GRID(n), u, quat, n);
+    LAUNCH_CHECK("k_test_yaw");
+    return TF_OK;
+}
+int tf_test_normalize_quat(const float* nn, float* quat, int32_t n, void* stream) {
+    hipLaunchKernelGGL(k_test_normq, LEAF_GRID(n), nn, quat, n);
+    LAUNCH_CHECK("k_test_normq");
+    return TF_OK;
+}
+int tf_test_philox(uint64_t seed, const uint32_t* env_id, const uint32_t* counter, uint32_t tag, uint32_t* out4,
+                   int32_t n, void* stream) {
+    hipLaunchKernelGGL(k_test_philox, LEAF_GRID(n), (uint32_t)seed, (uint32_t)(seed >> 32), env_id, counter, tag, out4, n);
+    LAUNCH_CHECK("k_test_philox");
+    return TF_OK;
+}
+int tf_test_finger_dynamics(tf_handle h, const float* q, const float* qd, float* tip, float* mass, float* bias,
+                            int32_t n, void* stream) {
+    if (!h) return TF_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_test_finger_dyn, LEAF_GRID(n), h->d_params, q, qd, tip, mass, bias, n);
+    LAUNCH_CHECK("k_test_finger_dyn");
+    return TF_OK;
+}
+
+}  // extern "C"

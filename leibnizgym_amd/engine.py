@@ -221,6 +221,15 @@ class TrifingerEngine:
     def reset(self):
         check(self.lib, self.lib.tf_reset(self._handle, self._stream()), "tf_reset")
 
+    def enable_kernel_timing(self, max_launches):
+        check(self.lib, self.lib.tf_enable_kernel_timing(self._handle, int(max_launches)), "tf_enable_kernel_timing")
+
+    def kernel_time_ms(self):
+        """(summed duration of the timed fused-step kernels in ms, number of launches); synchronises."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        check(self.lib, self.lib.tf_kernel_time_ms(self._handle, C.byref(ms), C.byref(n)), "tf_kernel_time_ms")
+        return ms.value, n.value
+
     # -- split path (tests) -----------------------------------------------------------------
     def apply_resets(self):
         check(self.lib, self.lib.tf_apply_resets(self._handle, self._stream()), "tf_apply_resets")

@@ -22,7 +22,9 @@
  *
  * Build: oracle/Makefile -> oracle/_build/libtrifinger_oracle.so   (gcc -O2 -ffp-contract=off)
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -228,6 +230,9 @@ struct TfHandle_ {
     float obs_off[MAX_OBS], obs_inv[MAX_OBS];
     float st_off[MAX_STATES], st_inv[MAX_STATES];
     float kp[9], kd[9], ks[9];
+    int timing_on;
+    double timed_ms;
+    int64_t timed_launches;
 };
 
 static char g_err[256] = "";
@@ -999,14 +1004,14 @@ static void env_load(const struct TfHandle_* h, int i, Env* e) {
     for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
     for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
 }
-static void env_store(const struct TfHandle_* h, int i, const Env* e) {
+static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_ft) {
     for (int j = 0; j < 9; ++j) { ST(h, TF_S_Q + j, i) = e->q[j]; ST(h, TF_S_QD + j, i) = e->qd[j]; ST(h, TF_S_TAU + j, i) = e->tau[j]; }
     for (int j = 0; j < 3; ++j) {
         ST(h, TF_S_CUBE_P + j, i) = e->cp[j]; ST(h, TF_S_CUBE_V + j, i) = e->cv[j]; ST(h, TF_S_CUBE_W + j, i) = e->cw[j];
         ST(h, TF_S_GOAL_P + j, i) = e->gp[j]; ST(h, TF_S_GOAL_W + j, i) = e->gw[j];
     }
     for (int j = 0; j < 4; ++j) { ST(h, TF_S_CUBE_Q + j, i) = e->cq[j]; ST(h, TF_S_GOAL_Q + j, i) = e->gq[j]; }
-    for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
+    if (store_ft) for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1385,10 +1390,12 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
             }
             compute_torque(h, abuf, e.q, e.qd, e.tau);
             float prev_obj[7] = {e.cp[0], e.cp[1], e.cp[2], e.cq[0], e.cq[1], e.cq[2], e.cq[3]};
+            for (int j = 0; j < 3; ++j) ST(h, TF_S_PREV_OBJ_P + j, i) = e.cp[j];   /* history[1] of the object */
+            for (int j = 0; j < 4; ++j) ST(h, TF_S_PREV_OBJ_Q + j, i) = e.cq[j];
             for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
             for (int s = 0; s < nsim * c->substeps; ++s) substep(h, &e, hsub);
             post_step_env(h, i, &e, prev_obj, &rc, !is_reset, &local);
-            env_store(h, i, &e);
+            env_store(h, i, &e, 0);      /* the wrench accumulator rows belong to the split path */
             if (!is_reset) finish_env(h, i);
         }
 #pragma omp critical
@@ -1398,7 +1405,28 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
     return TF_OK;
 }
 
-int tf_step(tf_handle h, const float* action, void* stream) { (void)stream; return run_step(h, action, 0); }
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+int tf_enable_kernel_timing(tf_handle h, int32_t max_launches) {
+    if (!h) return TF_ERR_INVALID_ARG;
+    h->timing_on = max_launches > 0; h->timed_ms = 0.0; h->timed_launches = 0;
+    return TF_OK;
+}
+int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {
+    if (!h || !total_ms || !launches) return TF_ERR_INVALID_ARG;
+    *total_ms = h->timed_ms; *launches = h->timed_launches;
+    return TF_OK;
+}
+int tf_step(tf_handle h, const float* action, void* stream) {
+    (void)stream;
+    double t0 = (h && h->timing_on) ? now_ms() : 0.0;
+    int rc = run_step(h, action, 0);
+    if (h && h->timing_on) { h->timed_ms += now_ms() - t0; h->timed_launches += 1; }
+    return rc;
+}
 int tf_reset(tf_handle h, void* stream) { (void)stream; return run_step(h, NULL, 1); }
 
 /* ---- split path ---- */
@@ -1411,7 +1439,7 @@ int tf_apply_resets(tf_handle h, void* stream) {
         Env e;
         env_load(h, i, &e);
         if (apply_resets(h, i, &e, 0)) for (int j = 0; j < A; ++j) h->buf.action_buf[(size_t)i * (size_t)A + j] = 0.0f;
-        env_store(h, i, &e);
+        env_store(h, i, &e, 1);
     }
     return TF_OK;
 }
@@ -1425,7 +1453,7 @@ int tf_pre_step(tf_handle h, void* stream) {
         env_load(h, i, &e);
         compute_torque(h, &h->buf.action_buf[(size_t)i * (size_t)A], e.q, e.qd, e.tau);
         for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
-        env_store(h, i, &e);
+        env_store(h, i, &e, 1);
         for (int j = 0; j < 3; ++j) ST(h, TF_S_PREV_OBJ_P + j, i) = e.cp[j];
         for (int j = 0; j < 4; ++j) ST(h, TF_S_PREV_OBJ_Q + j, i) = e.cq[j];
     }
@@ -1441,7 +1469,7 @@ int tf_simulate(tf_handle h, void* stream) {
         Env e;
         env_load(h, i, &e);
         for (int s = 0; s < h->cfg.substeps; ++s) substep(h, &e, hsub);
-        env_store(h, i, &e);
+        env_store(h, i, &e, 1);
     }
     return TF_OK;
 }
@@ -1460,7 +1488,7 @@ int tf_post_step(tf_handle h, void* stream) {
         for (int j = 0; j < 3; ++j) prev_obj[j] = ST(h, TF_S_PREV_OBJ_P + j, i);
         for (int j = 0; j < 4; ++j) prev_obj[3 + j] = ST(h, TF_S_PREV_OBJ_Q + j, i);
         post_step_env(h, i, &e, prev_obj, &rc, 1, &st);
-        env_store(h, i, &e);
+        env_store(h, i, &e, 1);
     }
     write_info(h, &st);
     return TF_OK;

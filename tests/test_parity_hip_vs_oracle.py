@@ -1,0 +1,87 @@
+"""GPU suite: the HIP path must reproduce the oracle BIT FOR BIT on every per-env output (state, obs,
+states, reward, flags, counters) along seeded rollouts with resets, goal resets and contacts; the eleven
+reduced info scalars agree to fp32 summation-order tolerance (rtol 2e-5)."""
+import pytest
+import torch
+
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("cfg_name", list(pu.CONFIGS))
+def test_rollout_bit_exact(hip, oracle, cfg_name):
+    n, steps = 1000, 130          # 1000 = 15 full waves + a ragged one; 130 steps > 3 episodes of 40
+    got = pu.rollout(hip, DEV, n, steps, cfg_name)
+    want = pu.rollout(oracle, "cpu", n, steps, cfg_name)
+    for t, (a, b) in enumerate(zip(got, want)):
+        pu.assert_bit_equal(a, b, f"{cfg_name} step {t}")
+
+
+@pytest.mark.parametrize("n", [1, 4, 63, 64, 65])
+def test_ragged_sizes(hip, oracle, n):
+    got = pu.rollout(hip, DEV, n, 45, "d4_torque_asym")
+    want = pu.rollout(oracle, "cpu", n, 45, "d4_torque_asym")
+    for t, (a, b) in enumerate(zip(got, want)):
+        pu.assert_bit_equal(a, b, f"N={n} step {t}")
+
+
+def test_split_path_equals_fused(hip):
+    """tf_apply_resets/pre_step/simulate/post_step/finish_step == tf_step on the GPU."""
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    n = 777
+    kw = dict(pu.CONFIGS["envdefault_position"])
+    engs = [TrifingerEngine(make_config(hip, n, seed=5, episode_length=30, **kw), device=DEV, lib=hip)
+            for _ in range(2)]
+    for e in engs:
+        e.reset()
+    for t in range(70):
+        act = pu.actions_for(t, n, 9, 5).to(DEV)
+        engs[0].step(act)
+        e = engs[1]
+        e.action_buf.copy_(act)
+        e.apply_resets()
+        e.pre_step()
+        e.simulate()
+        e.post_step()
+        e.finish_step()
+        torch.cuda.synchronize()
+        # rows 66.. (wrench accumulators) are written by the split path only;
+        # info[9] (number of resets) is only counted by the fused kernel
+        a, b = pu.snapshot(engs[0]), pu.snapshot(engs[1])
+        a["info"][9] = b["info"][9] = 0.0
+        pu.assert_bit_equal(a, b, f"split vs fused step {t}", skip_rows=slice(66, 84))
+
+
+def test_full_size_properties(hip):
+    """BASELINE config 3 size (65536 envs): size-independent invariants over 60 steps."""
+    from leibnizgym_amd import _capi as capi
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    n = 65536
+    kw = dict(pu.CONFIGS["d4_torque_asym"])
+    eng = TrifingerEngine(make_config(hip, n, seed=7, episode_length=25, **kw), device=DEV, lib=hip)
+    eng.reset()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    total_resets = 0.0
+    for t in range(60):
+        eng.step(torch.rand(n, 9, device=DEV, generator=g) * 2 - 1)
+        total_resets += float(eng.info[capi.INFO_NUM_RESETS])
+    torch.cuda.synchronize()
+    st = eng.state
+    assert torch.isfinite(st).all() and torch.isfinite(eng.obs).all() and torch.isfinite(eng.states).all()
+    qn = st[capi.S_CUBE_Q:capi.S_CUBE_Q + 4].norm(dim=0)
+    assert (qn - 1).abs().max() < 1e-5                                  # unit quaternions
+    q = st[capi.S_Q:capi.S_Q + 9]
+    lo = torch.tensor([-0.33, 0.0, -2.7] * 3, device=DEV)[:, None]
+    hi = torch.tensor([1.0, 1.57, 0.0] * 3, device=DEV)[:, None]
+    assert (q >= lo).all() and (q <= hi).all()                          # joint limits
+    assert st[capi.S_QD:capi.S_QD + 9].abs().max() <= 10.0 + 1e-4       # velocity limit
+    assert st[capi.S_TAU:capi.S_TAU + 9].abs().max() <= 0.36 + 1e-7     # torque limit
+    assert st[capi.S_CUBE_P + 2].min() > 0.0325 - 3e-3                  # cube never sinks through the floor
+    assert torch.hypot(st[capi.S_CUBE_P], st[capi.S_CUBE_P + 1]).max() < 0.2   # stays inside the arena
+    assert int(eng.steps.max()) <= 25 and total_resets == 2 * n         # every env timed out exactly twice
+    assert float(eng.info[capi.INFO_NUM_NONFINITE]) == 0.0
+    obs_q = eng.obs[:, 0:9].T * (hi - lo) * 0.5 + (hi + lo) * 0.5       # obs is the normalised state
+    assert (obs_q - q).abs().max() < 1e-5
+    eng.close()
