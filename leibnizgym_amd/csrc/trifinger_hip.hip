@@ -1510,31 +1510,29 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
     }
 }
 
-// fold the per-wave partials into info[] (deterministic order)
+// fold the per-wave partials into info[] (deterministic order): one block per statistic
 __global__ void __launch_bounds__(256) k_reduce_stats(const DevParams* __restrict__ Pp, int n_waves) {
     const DevParams& P = *Pp;
     __shared__ float red[256];
     const int t = threadIdx.x;
-    for (int k = 0; k < 11; ++k) {
-        float s = 0.0f;
-        for (int w = t; w < n_waves; w += 256) s = s + P.scratch[(size_t)w * 16 + k];
-        red[t] = s;
+    const int k = blockIdx.x;
+    float s = 0.0f;
+    for (int w = t; w < n_waves; w += 256) s = s + P.scratch[(size_t)w * 16 + k];
+    red[t] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off) red[t] = red[t] + red[t + off];
         __syncthreads();
-        for (int off = 128; off >= 1; off >>= 1) {
-            if (t < off) red[t] = red[t] + red[t + off];
-            __syncthreads();
-        }
-        if (t == 0) {
-            float total = red[0];
-            float n = (float)P.N;
-            float out;
-            if (k < 6 || k == 8) out = total / n;
-            else out = total;
-            const int slot = (k < 6) ? k : ((k == 6) ? TF_INFO_POS_COUNT : ((k == 7) ? TF_INFO_ORI_COUNT :
-                             ((k == 8) ? TF_INFO_SUCCESS_MEAN : ((k == 9) ? TF_INFO_NUM_RESETS : TF_INFO_NUM_NONFINITE))));
-            P.info[slot] = out;
-        }
-        __syncthreads();
+    }
+    if (t == 0) {
+        float total = red[0];
+        float n = (float)P.N;
+        float out;
+        if (k < 6 || k == 8) out = total / n;
+        else out = total;
+        const int slot = (k < 6) ? k : ((k == 6) ? TF_INFO_POS_COUNT : ((k == 7) ? TF_INFO_ORI_COUNT :
+                         ((k == 8) ? TF_INFO_SUCCESS_MEAN : ((k == 9) ? TF_INFO_NUM_RESETS : TF_INFO_NUM_NONFINITE))));
+        P.info[slot] = out;
     }
 }
 
@@ -1988,7 +1986,7 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
 #undef LAUNCH_STEP
     LAUNCH_CHECK("k_step");
     if (timed) { HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], s)); h->ev_used += 1; }
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, s, h->d_params, n_waves(h));
+    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(256), 0, s, h->d_params, n_waves(h));
     LAUNCH_CHECK("k_reduce_stats");
     return TF_OK;
 }
@@ -2065,7 +2063,7 @@ int tf_post_step(tf_handle h, void* stream) {
     if (h->action_dim == 9) hipLaunchKernelGGL(k_post_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
     else hipLaunchKernelGGL(k_post_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
     LAUNCH_CHECK("k_post_step");
-    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, h->d_params, n_waves(h));
+    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(256), 0, (hipStream_t)stream, h->d_params, n_waves(h));
     LAUNCH_CHECK("k_reduce_stats");
     return TF_OK;
 }
