@@ -1,0 +1,94 @@
+"""The C-ABI libraries load (no GPU needed) and export every symbol include/trifinger.h declares; the ctypes
+mirrors of the structs have the C compiler's sizes; both libraries ship the same default model."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from leibnizgym_amd import _capi as capi
+from oracle_util import REPO
+
+HEADER = os.path.join(REPO, "include", "trifinger.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", src)))
+
+
+def hip_lib():
+    path = capi.hip_library_path()
+    if not os.path.isfile(path):
+        subprocess.check_call(["make", "-C", os.path.dirname(path), "-s"])
+    return capi.TfLib(path)
+
+
+def test_header_and_binding_agree():
+    names = declared_functions()
+    assert len(names) >= 25
+    assert sorted(capi.SYMBOLS) == names, set(names) ^ set(capi.SYMBOLS)
+
+
+def test_hip_library_exports_every_symbol():
+    lib = hip_lib()                      # TfLib raises if a symbol is missing
+    assert lib.backend == "hip-gfx950"
+    assert lib.tf_api_version() == capi.TF_API_VERSION
+    assert lib.tf_action_dim(0) == 9 and lib.tf_action_dim(2) == 18 and lib.tf_action_dim(7) == capi.TF_ERR_COMMAND_MODE
+    assert lib.tf_scratch_floats(65536) == 1024 * 16
+
+
+def test_oracle_library_exports_every_symbol(oracle):
+    assert oracle.backend == "oracle-c"
+
+
+def test_struct_sizes_match_the_c_compiler():
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "trifinger.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu\n", sizeof(TfRewardTerm), sizeof(TfModel), sizeof(TfConfig), sizeof(TfBuffers),
+           offsetof(TfConfig, model), offsetof(TfConfig, reward));
+    return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "s.c"), os.path.join(d, "s")
+        open(src, "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), "-o", exe, src])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [int(x) for x in out]
+    assert sizes == [C.sizeof(capi.TfRewardTerm), C.sizeof(capi.TfModel), C.sizeof(capi.TfConfig),
+                     C.sizeof(capi.TfBuffers), capi.TfConfig.model.offset, capi.TfConfig.reward.offset]
+
+
+def test_default_models_are_identical(oracle):
+    a, b = hip_lib().default_model(), oracle.default_model()
+    assert bytes(a) == bytes(b)
+    assert abs(a.cube_mass - 291.3 * 0.065 ** 3) < 1e-7          # cube_multicolor_rrc.urdf: density x volume
+    assert abs(a.link_mass[2] - 0.052) < 1e-7                     # lower link + tip link
+
+
+def test_product_fails_loudly_without_a_gpu_device():
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    lib = hip_lib()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        TrifingerEngine(make_config(lib, 4), device="cpu")
+    missing = os.path.join(REPO, "leibnizgym_amd", "csrc", "does_not_exist.so")
+    with pytest.raises(capi.TfLibraryError, match="no fallback"):
+        capi.TfLib(missing)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "leibnizgym_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                for line in text.splitlines():
+                    code = line.split("#")[0].split("//")[0]
+                    assert "oracle_util" not in code and "tf_oracle" not in code and "libtrifinger_oracle" not in code, \
+                        (f, line)

@@ -1,0 +1,247 @@
+"""Host-side API and step sequencing (T1-T3, T14, T15 and the quirk list of SURVEY.md 8a-Q), run on the CPU with
+the oracle library injected through the test hook `lib=` (the product never loads it by itself).
+
+Known answers are hand-derived from the cited reference lines; nothing here depends on the physics details.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from leibnizgym_amd.config import compose, gym_config
+from leibnizgym_amd.envs import IsaacEnvBase, TrifingerEnv
+from leibnizgym_amd.utils.errors import InvalidTaskNameError
+from leibnizgym_amd.utils.rlg_train import RlGamesGpuEnvAdapter
+from leibnizgym_amd.wrappers import VecTaskPython
+
+
+def make_env(oracle, **cfg):
+    base = {"num_instances": 4, "command_mode": "torque"}
+    base.update(cfg)
+    return TrifingerEnv(config=base, device="cpu", verbose=False, lib=oracle)
+
+
+def test_shapes_specs_and_getters(oracle):
+    env = make_env(oracle, asymmetric_obs=True)
+    assert isinstance(env, IsaacEnvBase)
+    assert env.get_num_instances() == 4
+    assert env.get_obs_dim() == 41 and env.get_state_dim() == 113 and env.get_action_dim() == 9
+    assert tuple(env.get_obs_shape()) == (4, 41) and tuple(env.get_action_shape()) == (4, 9)
+    assert sum(env.obs_spec.values()) == 41 and sum(env.state_spec.values()) == 113
+    assert env.config["enable_ft_sensors"] is True                       # forced by asymmetric_obs (:272-273)
+    env2 = make_env(oracle, command_mode="position_impedance")
+    assert env2.get_action_dim() == 18 and env2.get_obs_dim() == 50 and env2.get_state_dim() == 0
+    # scale tables (trifinger_env.py:663-710)
+    assert env._observations_scale.low.shape[0] == 41 and env._states_scale.high.shape[0] == 113
+    assert torch.equal(env._action_scale.high, torch.full((9,), 0.36))
+
+
+def test_reset_and_step_contract(oracle):
+    env = make_env(oracle)
+    assert env.env_steps_count == 0
+    obs = env.reset()
+    assert obs.shape == (4, 41) and obs.data_ptr() != env.obs_buf.data_ptr()          # reset returns a clone
+    assert env.env_steps_count == 4                                                   # one simulate x 4 instances
+    assert int(env._steps_count_buf.sum()) == 0
+    out = env.step(torch.zeros(4, 9))
+    obs2, rew, dones, info = out
+    assert obs2.data_ptr() == env.obs_buf.data_ptr()                                  # step returns the live buffer
+    assert rew.shape == (4,) and dones.dtype == torch.bool and dones.shape == (4,)
+    assert env.env_steps_count == 8 and env._steps_count_buf.tolist() == [1, 1, 1, 1]
+    keys = set(info)
+    assert {"env/current_position_goal/count", "env/current_orientation_goal/count",
+            "env/average_consecutive_success", "env/rewards/object_dist"} <= keys
+    # numpy actions are accepted (env_base.py:361-362)
+    env.step(np.zeros((4, 9), dtype=np.float32))
+    assert env._steps_count_buf.tolist() == [2, 2, 2, 2]
+
+
+def test_invalid_inputs_raise_like_the_reference(oracle):
+    env = make_env(oracle)
+    env.reset()
+    with pytest.raises(ValueError, match="Invalid shape for tensor `action`"):
+        env.step(torch.zeros(4, 8))
+    with pytest.raises(ValueError, match="Invalid command mode"):
+        make_env(oracle, command_mode="velocity")
+    with pytest.raises(ValueError, match="Invalid difficulty index"):
+        make_env(oracle, task_difficulty=7)
+    with pytest.raises(ValueError, match="Invalid robot initial state distribution"):
+        make_env(oracle, reset_distribution={"robot_initial_state": {"type": "gaussian"}})
+    with pytest.raises(ValueError, match="Invalid object initial state distribution"):
+        make_env(oracle, reset_distribution={"object_initial_state": {"type": "grid"}})
+    with pytest.raises(ValueError, match="Invalid physics engine backend"):
+        make_env(oracle, physics_engine="bullet")
+    with pytest.raises(ValueError, match="Invalid physics up-axis"):
+        make_env(oracle, sim={"up_axis": "x"})
+    with pytest.raises(RuntimeError, match="MI355X"):
+        TrifingerEnv(config={"num_instances": 2, "command_mode": "torque"}, device="cpu", verbose=False)
+
+
+def test_timeout_reset_sequencing(oracle):
+    """Quirks 1-3: time-out uses steps >= episode_length after the increment; the reset happens at the START of
+    the next step, before physics, and zeroes that env's action for the step (env_base.py:370-395)."""
+    env = make_env(oracle, episode_length=3, termination_conditions={"success": {"activate": False}})
+    env.reset()
+    act = torch.full((4, 9), 0.5)
+    for k in range(1, 4):
+        _, _, dones, _ = env.step(act)
+        assert env._steps_count_buf.tolist() == [k] * 4
+        assert env._reset_buf.tolist() == [k >= 3] * 4
+        assert not dones.any()                       # quirk 2: dones = reset & goal_reset, never true here
+        assert torch.equal(env.action_buf, act)
+    counts_before = env._engine.reset_count.clone()
+    env.step(act)                                    # reset applied first, then one physics step
+    assert env._steps_count_buf.tolist() == [1] * 4 and not env._reset_buf.any()
+    assert torch.equal(env.action_buf, torch.zeros(4, 9))      # trifinger_env.py:387
+    assert torch.equal(env.obs_buf[:, 32:41], torch.zeros(4, 9))   # normalised zero action in the observation
+    assert (env._engine.reset_count == counts_before + 1).all()
+    q = env._dof_position
+    assert (q - torch.tensor([0.0, 0.9, -1.7] * 3)).abs().max() < 0.15   # default pose + one step of sag
+    assert env.dones_buf.data_ptr() == env._reset_buf.data_ptr()    # quirk: dones_buf IS the reset buffer (:281-284)
+
+
+def test_partial_reset_only_touches_flagged_envs(oracle):
+    env = make_env(oracle, episode_length=0)
+    env.reset()
+    env.step(torch.zeros(4, 9))
+    before = env._engine.state.clone()
+    env._reset_buf[2] = True
+    goal_before = env._object_goal_poses_buf.clone()
+    env.step(torch.full((4, 9), 0.3))
+    assert env.action_buf[2].abs().max() == 0 and (env.action_buf[[0, 1, 3]] == 0.3).all()
+    g = env._object_goal_poses_buf
+    assert torch.equal(g[[0, 1, 3]], goal_before[[0, 1, 3]]) and not torch.equal(g[2], goal_before[2])
+    assert env._engine.reset_count.tolist() == [1, 1, 2, 1]
+    assert env._steps_count_buf.tolist() == [2, 2, 1, 2]
+    assert before.shape == env._engine.state.shape
+
+
+def test_success_goal_reset_and_dones(oracle):
+    """Success termination on: goal_reset_buf = hit, bonus added, successes |= hit, goal resampled next step
+    (trifinger_env.py:1088-1094, 425-440); dones only when a time-out coincides with a hit."""
+    env = make_env(oracle, episode_length=2, task_difficulty=1,
+                   termination_conditions={"success": {"activate": True, "bonus": 123.0, "position_tolerance": 10.0,
+                                                       "orientation_tolerance": 10.0}},
+                   reward_terms={k: {"activate": False} for k in
+                                 ("finger_reach_object_rate", "finger_move_penalty", "object_dist", "object_rot",
+                                  "object_rot_delta", "object_move")})
+    env.reset()
+    _, rew, dones, info = env.step(torch.zeros(4, 9))
+    assert torch.equal(rew, torch.full((4,), 123.0))                    # huge tolerance: every env hits
+    assert env._goal_reset_buf.all() and env._successes.all() and not dones.any()
+    assert float(info["env/average_consecutive_success"]) == 1.0
+    assert float(info["env/current_position_goal/count"]) == 4.0
+    goal0 = env._object_goal_poses_buf.clone()
+    _, _, dones, _ = env.step(torch.zeros(4, 9))                        # goal resampled at the start of this step
+    assert not torch.equal(env._object_goal_poses_buf, goal0)
+    assert dones.all()                                                  # steps == 2 -> time-out AND goal hit
+    assert env._engine.reset_count.tolist() == [2] * 4                  # reset() + one goal reset
+
+
+def test_reward_schedule_follows_env_steps_count(oracle):
+    """object_rot switches on when env_steps_count >= 1e7 (difficulty-4 schedule, scripts/rlg_hydra.py:160-167)."""
+    cfg = gym_config("trifinger_difficulty_4")
+    cfg.update(num_instances=4, seed=1, physics_engine="physx")
+    cfg["sim"]["use_gpu_pipeline"] = True
+    env = TrifingerEnv(config=cfg, device="cpu", verbose=False, lib=oracle)
+    env.reset()
+    _, _, _, info = env.step(torch.zeros(4, 9))
+    assert float(info["env/rewards/object_rot"]) == 0.0
+    assert float(info["env/rewards/finger_reach_object_rate"]) != 0.0
+    env._engine.frame_count = 2_500_000                                 # 2.5e6 frames x 4 envs = 1e7
+    _, _, _, info = env.step(torch.zeros(4, 9))
+    assert float(info["env/rewards/object_rot"]) > 0.0
+    assert float(info["env/rewards/finger_reach_object_rate"]) == 0.0   # its window [0, 1e7] just closed
+    assert env.env_steps_count == 4 * 2_500_001
+
+
+def test_control_decimation_repeats_simulate(oracle):
+    # safety damping off: the torque of a zero action is then exactly zero, whatever the joint velocity
+    a = make_env(oracle, control_decimation=1, episode_length=0, apply_safety_damping=False)
+    b = make_env(oracle, control_decimation=5, episode_length=0, apply_safety_damping=False)   # reference tests use 5
+    a.reset(), b.reset()
+    b.step(torch.zeros(4, 9))
+    assert b.env_steps_count == (1 + 5) * 4
+    for _ in range(5):
+        a.step(torch.zeros(4, 9))
+    # same physics sequence (zero torque) -> same cube state; fingers too
+    assert torch.allclose(a._engine.cube, b._engine.cube, atol=1e-6)
+    assert torch.allclose(a._engine.q, b._engine.q, atol=1e-6)
+
+
+def test_vec_task_clamps_and_spaces(oracle):
+    env = make_env(oracle, asymmetric_obs=True)
+    vec = VecTaskPython(env, rl_device="cpu", clip_obs=5.0, clip_actions=1.0)
+    assert (vec.num_envs, vec.num_obs, vec.num_states, vec.num_actions) == (4, 41, 113, 9)
+    assert vec.observation_space.shape == (41,) and float(vec.observation_space.high[0]) == 5.0
+    assert vec.action_space.shape == (9,) and float(vec.action_space.low[0]) == -1.0
+    obs = vec.reset()
+    assert obs.abs().max() <= 5.0
+    big = torch.full((4, 9), 7.0)
+    obs, rew, done, info = vec.step(big)
+    assert torch.equal(env.action_buf, torch.ones(4, 9))                # clipped before the task sees it
+    assert obs.abs().max() <= 5.0 and vec.get_state().abs().max() <= 5.0
+    assert "Number of observations: 41" in str(vec)
+    with pytest.raises(AssertionError):
+        VecTaskPython(object(), rl_device="cpu")
+
+
+def test_rl_games_adapter_contract(oracle):
+    env = make_env(oracle, asymmetric_obs=True)
+    ad = RlGamesGpuEnvAdapter("rlgpu", 4, env=VecTaskPython(env, rl_device="cpu"))
+    assert ad.use_global_obs and set(ad.full_state) == {"obs", "states"}
+    info = ad.get_env_info()
+    assert set(info) == {"num_envs", "action_space", "observation_space", "state_space"} and info["num_envs"] == 4
+    first = ad.reset()
+    out, rew, done, extra = ad.step(torch.zeros(4, 9))
+    assert out is first is ad.full_state                                 # the SAME dict object every call
+    assert out["obs"].shape == (4, 41) and out["states"].shape == (4, 113)
+    assert isinstance(extra, list) and extra[0] == [] and "env/average_consecutive_success" in extra[1]
+    sym = RlGamesGpuEnvAdapter("rlgpu", 4, env=VecTaskPython(make_env(oracle), rl_device="cpu"))
+    assert not sym.use_global_obs and torch.is_tensor(sym.reset())
+    assert ad.get_number_of_agents() == 1
+
+
+def test_dump_config_and_seed(oracle, tmp_path):
+    env = make_env(oracle)
+    path = os.path.join(tmp_path, "sub", "env_config")
+    env.dump_config(path)
+    import yaml
+    d = yaml.safe_load(open(path + ".yaml"))
+    assert d["num_instances"] == 4 and d["command_mode"] == "torque" and d["sim"]["dt"] == 0.02
+    TrifingerEnv.seed(3)
+    a = torch.rand(2)
+    TrifingerEnv.seed(3)
+    assert torch.equal(a, torch.rand(2))
+    env.render(), env.close()
+
+
+def test_same_seed_same_trajectory_and_two_instances_coexist(oracle):
+    a, b = make_env(oracle, seed=11), make_env(oracle, seed=11)
+    c = make_env(oracle, seed=12)
+    oa, ob, oc = a.reset(), b.reset(), c.reset()
+    assert torch.equal(oa, ob) and not torch.equal(oa, oc)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(5):
+        act = torch.rand(4, 9, generator=g) * 2 - 1
+        ra = a.step(act)[1].clone()
+        rb = b.step(act)[1].clone()
+        assert torch.equal(ra, rb)
+
+
+def test_hydra_schema_loader():
+    cfg = compose(["gym=trifinger_difficulty_4", "args.num_envs=8192", "args.headless=True", "args.seed=3"])
+    g = cfg["gym"]
+    assert g["task_difficulty"] == 4 and g["num_instances"] == 8192 and g["seed"] == 3
+    assert g["asymmetric_obs"] is True                                   # copied from rlg.asymmetric_obs (:266)
+    assert g["sim"]["use_gpu_pipeline"] is True and g["physics_engine"] == "physx"
+    assert g["reward_terms"]["object_rot"]["thresh_sched_start"] == 1e7
+    assert g["termination_conditions"]["success"]["position_tolerance"] == 0.02
+    assert cfg["rlg"]["params"]["config"]["num_actors"] == 8192 and cfg["args"]["train"] is True
+    d1 = compose([])["gym"]
+    assert d1["task_difficulty"] == 1 and d1["num_instances"] == 256 and d1["command_mode"] == "torque"
+    with pytest.raises(KeyError):
+        gym_config("trifinger_difficulty_9")
+    with pytest.raises(InvalidTaskNameError):
+        raise InvalidTaskNameError("Foo")
