@@ -101,6 +101,8 @@ struct StepArgs {
 // ------------------------------------------------------------------------------------------------------
 #define DEV __device__ __forceinline__
 
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
 DEV float f_min(float a, float b) { return (a < b) ? a : b; }
 DEV float f_max(float a, float b) { return (a > b) ? a : b; }
 DEV float f_clamp(float x, float lo, float hi) { return f_max(f_min(x, hi), lo); }
@@ -211,20 +213,20 @@ DEV void box_muller(float ua, float ub, float& n0, float& n1) {
 // small vector helpers
 // ------------------------------------------------------------------------------------------------------
 DEV void cross3(const float a[3], const float b[3], float o[3]) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
+    o[0] = FMA(a[1], b[2], -(a[2] * b[1]));
+    o[1] = FMA(a[2], b[0], -(a[0] * b[2]));
+    o[2] = FMA(a[0], b[1], -(a[1] * b[0]));
 }
-DEV float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+DEV float dot3(const float a[3], const float b[3]) { return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0])); }
 DEV void sym_mul(const float I[6], const float v[3], float o[3]) {   // xx yy zz xy xz yz
-    o[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
-    o[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
-    o[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+    o[0] = FMA(I[4], v[2], FMA(I[3], v[1], I[0] * v[0]));
+    o[1] = FMA(I[5], v[2], FMA(I[1], v[1], I[3] * v[0]));
+    o[2] = FMA(I[2], v[2], FMA(I[5], v[1], I[4] * v[0]));
 }
 DEV void sym3_mul(const float S[6], const float v[3], float o[3]) {  // 00 01 02 11 12 22
-    o[0] = S[0] * v[0] + S[1] * v[1] + S[2] * v[2];
-    o[1] = S[1] * v[0] + S[3] * v[1] + S[4] * v[2];
-    o[2] = S[2] * v[0] + S[4] * v[1] + S[5] * v[2];
+    o[0] = FMA(S[2], v[2], FMA(S[1], v[1], S[0] * v[0]));
+    o[1] = FMA(S[4], v[2], FMA(S[3], v[1], S[1] * v[0]));
+    o[2] = FMA(S[5], v[2], FMA(S[4], v[1], S[2] * v[0]));
 }
 
 // quaternions (xyzw): reference leibnizgym/utils/torch_utils.py:83-150
@@ -286,22 +288,22 @@ template <int LINK> DEV void rot_link(const FK& k, const float u[3], float o[3])
     float wx = u[0], wy = u[1], wz = u[2];
     if (LINK >= 2) {
         float ca = (LINK == 2) ? k.c2 : k.c23, sa = (LINK == 2) ? k.s2 : k.s23;
-        float ty = ca * u[1] - sa * u[2];
-        float tz = sa * u[1] + ca * u[2];
+        float ty = FMA(ca, u[1], -(sa * u[2]));
+        float tz = FMA(sa, u[1], ca * u[2]);
         wy = ty; wz = tz;
     }
-    o[0] = k.c1 * wx + k.s1 * wz;
+    o[0] = FMA(k.c1, wx, k.s1 * wz);
     o[1] = wy;
-    o[2] = k.c1 * wz - k.s1 * wx;
+    o[2] = FMA(k.c1, wz, -(k.s1 * wx));
 }
 template <int LINK> DEV void rot_link_T(const FK& k, const float v[3], float o[3]) {
-    float wx = k.c1 * v[0] - k.s1 * v[2];
+    float wx = FMA(k.c1, v[0], -(k.s1 * v[2]));
     float wy = v[1];
-    float wz = k.s1 * v[0] + k.c1 * v[2];
+    float wz = FMA(k.s1, v[0], k.c1 * v[2]);
     if (LINK >= 2) {
         float ca = (LINK == 2) ? k.c2 : k.c23, sa = (LINK == 2) ? k.s2 : k.s23;
-        float ty = ca * wy + sa * wz;
-        float tz = ca * wz - sa * wy;
+        float ty = FMA(ca, wy, sa * wz);
+        float tz = FMA(ca, wz, -(sa * wy));
         wy = ty; wz = tz;
     }
     o[0] = wx; o[1] = wy; o[2] = wz;
@@ -414,36 +416,47 @@ DEV void inv3sym(const float M[6], float Mi[6]) {
 
 template <int F> DEV void base_to_world(const TfModel& m, const float b[3], float w[3]) {
     float c = m.base_yaw_cos[F], s = m.base_yaw_sin[F];
-    w[0] = c * b[0] - s * b[1];
-    w[1] = s * b[0] + c * b[1];
+    w[0] = FMA(c, b[0], -(s * b[1]));
+    w[1] = FMA(s, b[0], c * b[1]);
     w[2] = b[2] + m.base_height;
 }
 template <int F> DEV void dir_world_to_base(const TfModel& m, const float w[3], float b[3]) {
     float c = m.base_yaw_cos[F], s = m.base_yaw_sin[F];
-    b[0] = c * w[0] + s * w[1];
-    b[1] = c * w[1] - s * w[0];
+    b[0] = FMA(c, w[0], s * w[1]);
+    b[1] = FMA(c, w[1], -(s * w[0]));
     b[2] = w[2];
 }
 template <int F> DEV void dir_base_to_world(const TfModel& m, const float b[3], float w[3]) {
     float c = m.base_yaw_cos[F], s = m.base_yaw_sin[F];
-    w[0] = c * b[0] - s * b[1];
-    w[1] = s * b[0] + c * b[1];
+    w[0] = FMA(c, b[0], -(s * b[1]));
+    w[1] = FMA(s, b[0], c * b[1]);
     w[2] = b[2];
+}
+
+// o = R v and o = R^T v for a row-major 3x3
+DEV void mat3_mul(const float R[9], const float v[3], float o[3]) {
+    o[0] = FMA(R[2], v[2], FMA(R[1], v[1], R[0] * v[0]));
+    o[1] = FMA(R[5], v[2], FMA(R[4], v[1], R[3] * v[0]));
+    o[2] = FMA(R[8], v[2], FMA(R[7], v[1], R[6] * v[0]));
+}
+DEV void mat3T_mul(const float R[9], const float v[3], float o[3]) {
+    o[0] = FMA(R[6], v[2], FMA(R[3], v[1], R[0] * v[0]));
+    o[1] = FMA(R[7], v[2], FMA(R[4], v[1], R[1] * v[0]));
+    o[2] = FMA(R[8], v[2], FMA(R[5], v[1], R[2] * v[0]));
 }
 
 DEV void tangent_basis(const float n[3], float t1[3], float t2[3]) {
     if (f_abs(n[2]) < 0.9f) {
-        float inv = 1.0f / f_sqrt(n[0] * n[0] + n[1] * n[1]);
+        float inv = 1.0f / f_sqrt(FMA(n[0], n[0], n[1] * n[1]));
         t1[0] = -n[1] * inv; t1[1] = n[0] * inv; t1[2] = 0.0f;
     } else {
-        float inv = 1.0f / f_sqrt(n[1] * n[1] + n[2] * n[2]);
+        float inv = 1.0f / f_sqrt(FMA(n[1], n[1], n[2] * n[2]));
         t1[0] = 0.0f; t1[1] = -n[2] * inv; t1[2] = n[1] * inv;
     }
     cross3(n, t1, t2);
 }
 
-DEV float contact_bias(const TfModel& m, float gap, float vn0, float h, float restitution) {
-    float inv_h = 1.0f / h;
+DEV float contact_bias(const TfModel& m, float gap, float vn0, float inv_h, float restitution) {
     float b;
     if (gap >= 0.0f) b = gap * inv_h;
     else b = f_max(m.erp * gap * inv_h, -m.max_depenetration_velocity);
@@ -462,7 +475,7 @@ struct Env {
     float ft[18];
 };
 
-// LDS layout, floats per lane: finger-cube contact f at FC_BASE(f): Jf[3][3] Wf[3][3] dir[3][3] r[3] (30);
+// LDS layout, floats per lane: finger-cube contact f at FC_BASE(f): Jf[3][3] Wf[3][3] dir[3][3] rc[3] (30);
 // tip-floor contact f at TF_BASE(f): Jf[3][3] Wf[3][3] (18).  Stored [slot][lane].
 #define FC_BASE(f) ((f) * 30)
 #define TF_BASE(f) (90 + (f) * 18)
@@ -476,10 +489,11 @@ struct FingerContactRegs {   // the small per-contact scalars stay in VGPRs
     float arm[3];
     float lam[3];
 };
+// one cube corner against the floor or the wall.  Rows are always evaluated (no branch): an inactive contact has
+// Dinv = 0 and bias = 0, so its impulses stay exactly zero.
 struct CubeContactRegs {
-    bool active;
     float r[3];
-    float n[2];          // wall contacts: horizontal inward normal; unused for floor contacts
+    float n[2];          // wall contacts: horizontal inward normal
     float Dinv[3];
     float bias;
     float lam[3];
@@ -487,10 +501,11 @@ struct CubeContactRegs {
 
 #define LDS_AT(slot) lds[(slot) * WAVE + lane]
 
-// rows of one finger contact: point Pb (base frame), world normal, cube arm rc.  Writes J / W / dir / r to LDS.
+// rows of one finger contact: point Pb (base frame), world normal, cube arm rc.  Writes J / W / dir / rc to LDS.
 template <int F, bool WITH_CUBE>
 DEV void finger_rows(const TfModel& m, const FK& k, const float Pb[3], const float n_w[3], const float rc[3],
-                     float* lds, int lane, int base, FingerContactRegs& c, float Jn[3], float dirn[3], float rxdn[3]) {
+                     float inv_m, float inv_I, float* lds, int lane, int base, FingerContactRegs& c, float Jn[3],
+                     float dirn[3]) {
     float t1[3], t2[3];
     tangent_basis(n_w, t1, t2);
     float L1[3], L2[3], L3[3];
@@ -511,10 +526,9 @@ DEV void finger_rows(const TfModel& m, const FK& k, const float Pb[3], const flo
         if (WITH_CUBE) {
             float rxd[3];
             cross3(rc, dw, rxd);
-            D = D + 1.0f / m.cube_mass + dot3(rxd, rxd) / m.cube_inertia;
+            D = FMA(dot3(rxd, rxd), inv_I, D + inv_m);
 #pragma unroll
             for (int j = 0; j < 3; ++j) LDS_AT(base + 18 + d * 3 + j) = dw[j];
-            if (d == 0) { rxdn[0] = rxd[0]; rxdn[1] = rxd[1]; rxdn[2] = rxd[2]; }
         }
         if (d == 0) { Jn[0] = Jf[0]; Jn[1] = Jf[1]; Jn[2] = Jf[2]; dirn[0] = dw[0]; dirn[1] = dw[1]; dirn[2] = dw[2]; }
         c.Dinv[d] = 1.0f / D;
@@ -534,32 +548,106 @@ DEV void cube_corner(const float R[9], float hc, int k, float sk, int idx, float
     y[0] = (k == 0) ? fk_ : sa;
     y[1] = (k == 1) ? fk_ : ((k == 0) ? sa : sb);
     y[2] = (k == 2) ? fk_ : sb;
-    r[0] = R[0] * y[0] + R[1] * y[1] + R[2] * y[2];
-    r[1] = R[3] * y[0] + R[4] * y[1] + R[5] * y[2];
-    r[2] = R[6] * y[0] + R[7] * y[1] + R[8] * y[2];
+    mat3_mul(R, y, r);
 }
 
-// one PGS row update on cube velocities; returns via references
-DEV void cube_row(float vrel_bias, float Dinv, float lo, float hi, float& lam, const float dir[3], const float rxd[3],
-                  float inv_m, float inv_I, float v[3], float w[3], float sign) {
-    float lam_new = f_clamp(lam - Dinv * vrel_bias, lo, hi);
-    float dl = lam_new - lam;
-    lam = lam_new;
+// ---- PGS row kernels (identical arithmetic in the oracle) ----
+DEV float solve_normal(float& lam, float Dinv, float vrel, float bias) {
+    float ln = f_max(FMA(-Dinv, vrel + bias, lam), 0.0f);
+    float dl = ln - lam;
+    lam = ln;
+    return dl;
+}
+DEV float solve_tangent(float& lam, float Dinv, float vrel, float lim) {
+    float ln = f_clamp(FMA(-Dinv, vrel, lam), -lim, lim);
+    float dl = ln - lam;
+    lam = ln;
+    return dl;
+}
+// axis-aligned rows of a cube corner with arm r: direction +z / +x / +y
+template <int SLOT, bool IS_NORMAL>
+DEV void cube_row_z(CubeContactRegs& c, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    const float* r = c.r;
+    float vrel = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
+    float dl = IS_NORMAL ? solve_normal(c.lam[SLOT], c.Dinv[SLOT], vrel, c.bias)
+                         : solve_tangent(c.lam[SLOT], c.Dinv[SLOT], vrel, mu * c.lam[0]);
     float s = dl * inv_m, q = dl * inv_I;
-    if (sign > 0.0f) {
-        v[0] = v[0] + dir[0] * s; v[1] = v[1] + dir[1] * s; v[2] = v[2] + dir[2] * s;
-        w[0] = w[0] + rxd[0] * q; w[1] = w[1] + rxd[1] * q; w[2] = w[2] + rxd[2] * q;
-    } else {
-        v[0] = v[0] - dir[0] * s; v[1] = v[1] - dir[1] * s; v[2] = v[2] - dir[2] * s;
-        w[0] = w[0] - rxd[0] * q; w[1] = w[1] - rxd[1] * q; w[2] = w[2] - rxd[2] * q;
-    }
+    v[2] = v[2] + s;
+    w[0] = FMA(r[1], q, w[0]);
+    w[1] = FMA(-r[0], q, w[1]);
+}
+template <int SLOT>
+DEV void cube_row_x(CubeContactRegs& c, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    const float* r = c.r;
+    float vrel = FMA(r[2], w[1], FMA(-r[1], w[2], v[0]));
+    float dl = solve_tangent(c.lam[SLOT], c.Dinv[SLOT], vrel, mu * c.lam[0]);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = v[0] + s;
+    w[1] = FMA(r[2], q, w[1]);
+    w[2] = FMA(-r[1], q, w[2]);
+}
+template <int SLOT>
+DEV void cube_row_y(CubeContactRegs& c, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    const float* r = c.r;
+    float vrel = FMA(-r[2], w[0], FMA(r[0], w[2], v[1]));
+    float dl = solve_tangent(c.lam[SLOT], c.Dinv[SLOT], vrel, mu * c.lam[0]);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[1] = v[1] + s;
+    w[0] = FMA(-r[2], q, w[0]);
+    w[2] = FMA(r[0], q, w[2]);
+}
+// wall rows: inward horizontal normal n = (n0, n1, 0) and tangent t = (-n1, n0, 0)
+DEV void wall_arm_n(const CubeContactRegs& c, float a[3]) {
+    const float* r = c.r;
+    a[0] = -(r[2] * c.n[1]);
+    a[1] = r[2] * c.n[0];
+    a[2] = FMA(r[0], c.n[1], -(r[1] * c.n[0]));
+}
+DEV void wall_arm_t(const CubeContactRegs& c, float b[3]) {
+    const float* r = c.r;
+    b[0] = -(r[2] * c.n[0]);
+    b[1] = -(r[2] * c.n[1]);
+    b[2] = FMA(r[0], c.n[0], r[1] * c.n[1]);
+}
+DEV void wall_row_n(CubeContactRegs& c, float inv_m, float inv_I, float v[3], float w[3]) {
+    float a[3];
+    wall_arm_n(c, a);
+    float vrel = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c.n[1], v[1], c.n[0] * v[0]))));
+    float dl = solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = FMA(c.n[0], s, v[0]);
+    v[1] = FMA(c.n[1], s, v[1]);
+    w[0] = FMA(a[0], q, w[0]); w[1] = FMA(a[1], q, w[1]); w[2] = FMA(a[2], q, w[2]);
+}
+DEV void wall_row_t(CubeContactRegs& c, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    float b[3];
+    wall_arm_t(c, b);
+    float vrel = FMA(b[2], w[2], FMA(b[1], w[1], FMA(b[0], w[0], FMA(c.n[0], v[1], -(c.n[1] * v[0])))));
+    float dl = solve_tangent(c.lam[1], c.Dinv[1], vrel, mu * c.lam[0]);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = FMA(-c.n[1], s, v[0]);
+    v[1] = FMA(c.n[0], s, v[1]);
+    w[0] = FMA(b[0], q, w[0]); w[1] = FMA(b[1], q, w[1]); w[2] = FMA(b[2], q, w[2]);
+}
+
+DEV void finger_contact_zero(FingerContactRegs& c) {
+    c.active = false;
+    c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
+    c.bias = 0.0f;
+    c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
+    c.arm[0] = 0.0f; c.arm[1] = 0.0f; c.arm[2] = 0.0f;
+}
+DEV void cube_contact_zero(CubeContactRegs& c) {
+    c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
+    c.bias = 0.0f; c.n[0] = 0.0f; c.n[1] = 0.0f;
+    c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
 }
 
 // ---- contact generation for finger F (capsule vs cube, tip vs floor) ----
 template <int F>
 DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const float R[9], const float* vq,
-                         const float v[3], const float w[3], float h, float* lds, int lane,
-                         FingerContactRegs& c, FingerContactRegs& g) {
+                         const float v[3], const float w[3], float inv_h, float inv_m, float inv_I, float* lds,
+                         int lane, FingerContactRegs& c, FingerContactRegs& g) {
     const TfModel& m = P.m;
     const float hc = m.cube_half;
     float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3], Tw[3];
@@ -573,31 +661,24 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
     base_to_world<F>(m, Bb, Bw);
     base_to_world<F>(m, To, Tw);
     // capsule (distal link) vs cube: closest points by alternating projection in the cube frame
-    c.active = false;
-    c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
-    c.bias = 0.0f;
-    c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
-    c.arm[0] = 0.0f; c.arm[1] = 0.0f; c.arm[2] = 0.0f;
+    finger_contact_zero(c);
     float da[3] = {Aw[0] - e.cp[0], Aw[1] - e.cp[1], Aw[2] - e.cp[2]};
     float db[3] = {Bw[0] - e.cp[0], Bw[1] - e.cp[1], Bw[2] - e.cp[2]};
     float a[3], b[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        a[i] = R[i] * da[0] + R[3 + i] * da[1] + R[6 + i] * da[2];
-        b[i] = R[i] * db[0] + R[3 + i] * db[1] + R[6 + i] * db[2];
-    }
+    mat3T_mul(R, da, a);
+    mat3T_mul(R, db, b);
     float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     float inv_dd = 1.0f / dot3(d, d);
     float s = 1.0f, x[3], y[3];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+        for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
         float ya[3] = {y[0] - a[0], y[1] - a[1], y[2] - a[2]};
         s = f_clamp(dot3(ya, d) * inv_dd, 0.0f, 1.0f);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+    for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
     float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
     float dist2 = dot3(ev, ev);
     float nc[3], gap;
@@ -621,47 +702,42 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
     }
     if (gap < m.contact_margin) {
         float n_w[3], rc[3], xw[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            n_w[i] = R[3 * i] * nc[0] + R[3 * i + 1] * nc[1] + R[3 * i + 2] * nc[2];
-            rc[i] = R[3 * i] * y[0] + R[3 * i + 1] * y[1] + R[3 * i + 2] * y[2];
-            xw[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
-        }
-        float Pw[3] = {e.cp[0] + xw[0] - m.cap_radius * n_w[0], e.cp[1] + xw[1] - m.cap_radius * n_w[1],
-                       e.cp[2] + xw[2] - m.cap_radius * n_w[2]};
+        mat3_mul(R, nc, n_w);
+        mat3_mul(R, y, rc);
+        mat3_mul(R, x, xw);
+        float Pw[3] = {FMA(-m.cap_radius, n_w[0], e.cp[0] + xw[0]), FMA(-m.cap_radius, n_w[1], e.cp[1] + xw[1]),
+                       FMA(-m.cap_radius, n_w[2], e.cp[2] + xw[2])};
         float Pr[3] = {Pw[0], Pw[1], Pw[2] - m.base_height};
         float Pb[3];
         dir_world_to_base<F>(m, Pr, Pb);
         c.active = true;
-        float Jn[3], dirn[3], rxdn[3];
-        finger_rows<F, true>(m, k, Pb, n_w, rc, lds, lane, FC_BASE(F), c, Jn, dirn, rxdn);
+        float Jn[3], dirn[3];
+        finger_rows<F, true>(m, k, Pb, n_w, rc, inv_m, inv_I, lds, lane, FC_BASE(F), c, Jn, dirn);
 #pragma unroll
         for (int i = 0; i < 3; ++i) c.arm[i] = Pw[i] - Tw[i];
-        float vn0 = dot3(Jn, &vq[3 * F]) - (dot3(dirn, v) + dot3(rxdn, w));
-        c.bias = contact_bias(m, gap, vn0, h, m.restitution_finger);
+        float rxn[3];
+        cross3(rc, dirn, rxn);
+        float vn0 = dot3(Jn, &vq[3 * F]) - (dot3(dirn, v) + dot3(rxn, w));
+        c.bias = contact_bias(m, gap, vn0, inv_h, m.restitution_finger);
     }
     // tip sphere vs floor
-    g.active = false;
-    g.lam[0] = 0.0f; g.lam[1] = 0.0f; g.lam[2] = 0.0f;
-    g.bias = 0.0f;
-    g.Dinv[0] = 0.0f; g.Dinv[1] = 0.0f; g.Dinv[2] = 0.0f;
-    g.arm[0] = 0.0f; g.arm[1] = 0.0f; g.arm[2] = 0.0f;
+    finger_contact_zero(g);
     float gapf = Bw[2] - m.cap_radius;
     if (gapf < m.contact_margin) {
         float n_w[3] = {0.0f, 0.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
         float Pb[3] = {Bb[0], Bb[1], Bb[2] - m.cap_radius};
         float Pw[3] = {Bw[0], Bw[1], Bw[2] - m.cap_radius};
         g.active = true;
-        float Jn[3], dirn[3], rxdn[3];
-        finger_rows<F, false>(m, k, Pb, n_w, zero, lds, lane, TF_BASE(F), g, Jn, dirn, rxdn);
+        float Jn[3], dirn[3];
+        finger_rows<F, false>(m, k, Pb, n_w, zero, inv_m, inv_I, lds, lane, TF_BASE(F), g, Jn, dirn);
 #pragma unroll
         for (int i = 0; i < 3; ++i) g.arm[i] = Pw[i] - Tw[i];
         float vn0 = dot3(Jn, &vq[3 * F]);
-        g.bias = contact_bias(m, gapf, vn0, h, m.restitution_finger);
+        g.bias = contact_bias(m, gapf, vn0, inv_h, m.restitution_finger);
     }
 }
 
-// PGS rows of the finger-cube contact of finger F (reads J/W/dir/r from LDS)
+// PGS rows of the finger-cube contact of finger F (reads J/W/dir/rc from LDS)
 template <int F>
 DEV void solve_finger_cube(const TfModel& m, FingerContactRegs& c, const float* lds, int lane, float* vq, float v[3],
                            float w[3], float inv_m, float inv_I) {
@@ -678,20 +754,14 @@ DEV void solve_finger_cube(const TfModel& m, FingerContactRegs& c, const float* 
             dir[j] = LDS_AT(FC_BASE(F) + 18 + d * 3 + j);
         }
         cross3(rc, dir, rxd);
-        float vrel = dot3(Jf, vf);
-        vrel = vrel - (dot3(dir, v) + dot3(rxd, w));
-        float lam_new;
-        if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
-        else {
-            float lim = m.mu_finger_cube * c.lam[0];
-            lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
-        }
-        float dl = lam_new - c.lam[d];
-        c.lam[d] = lam_new;
-        vf[0] = vf[0] + Wf[0] * dl; vf[1] = vf[1] + Wf[1] * dl; vf[2] = vf[2] + Wf[2] * dl;
-        float s = dl * inv_m, q = dl * inv_I;
-        v[0] = v[0] - dir[0] * s; v[1] = v[1] - dir[1] * s; v[2] = v[2] - dir[2] * s;
-        w[0] = w[0] - rxd[0] * q; w[1] = w[1] - rxd[1] * q; w[2] = w[2] - rxd[2] * q;
+        float vrel = dot3(Jf, vf) - (dot3(dir, v) + dot3(rxd, w));
+        float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
+                            : solve_tangent(c.lam[d], c.Dinv[d], vrel, m.mu_finger_cube * c.lam[0]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vf[j] = FMA(Wf[j], dl, vf[j]);
+        float sc = dl * inv_m, q = dl * inv_I;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], q, w[j]); }
     }
 }
 template <int F>
@@ -707,15 +777,10 @@ DEV void solve_tip_floor(const TfModel& m, FingerContactRegs& c, const float* ld
             Wf[j] = LDS_AT(TF_BASE(F) + 9 + d * 3 + j);
         }
         float vrel = dot3(Jf, vf);
-        float lam_new;
-        if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
-        else {
-            float lim = m.mu_tip_floor * c.lam[0];
-            lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
-        }
-        float dl = lam_new - c.lam[d];
-        c.lam[d] = lam_new;
-        vf[0] = vf[0] + Wf[0] * dl; vf[1] = vf[1] + Wf[1] * dl; vf[2] = vf[2] + Wf[2] * dl;
+        float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
+                            : solve_tangent(c.lam[d], c.Dinv[d], vrel, m.mu_tip_floor * c.lam[0]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vf[j] = FMA(Wf[j], dl, vf[j]);
     }
 }
 
@@ -727,14 +792,14 @@ DEV void add_wrench(const FingerContactRegs& c, const float* lds, int lane, int 
     if (WITH_CUBE) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            F[i] = (LDS_AT(base + 18 + i) * c.lam[0] + LDS_AT(base + 21 + i) * c.lam[1] + LDS_AT(base + 24 + i) * c.lam[2]) * inv_h;
+            F[i] = FMA(LDS_AT(base + 24 + i), c.lam[2], FMA(LDS_AT(base + 21 + i), c.lam[1], LDS_AT(base + 18 + i) * c.lam[0])) * inv_h;
     } else {
-        // floor contact directions are constants: n = +z, t1 = -y, t2 = +x
+        // floor contact directions are constants: n = +z, t1 = -y, t2 = +x (tangent_basis of +z)
         const float n_w[3] = {0.0f, 0.0f, 1.0f};
         float t1[3], t2[3];
         tangent_basis(n_w, t1, t2);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) F[i] = (n_w[i] * c.lam[0] + t1[i] * c.lam[1] + t2[i] * c.lam[2]) * inv_h;
+        for (int i = 0; i < 3; ++i) F[i] = FMA(t2[i], c.lam[2], FMA(t1[i], c.lam[1], n_w[i] * c.lam[0])) * inv_h;
     }
     float T[3];
     cross3(c.arm, F, T);
@@ -747,6 +812,8 @@ DEV void add_wrench(const FingerContactRegs& c, const float* lds, int lane, int 
 template <bool WRENCH>
 DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     const TfModel& m = P.m;
+    const float inv_h = 1.0f / h;
+    const float inv_m = 1.0f / m.cube_mass, inv_I = 1.0f / m.cube_inertia;
     FK fk0, fk1, fk2;
     float vq[9];
     float v[3], w[3];
@@ -761,7 +828,7 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
             inv3sym(M, fk.Minv);                                                                 \
             for (int j = 0; j < 3; ++j) rhs[j] = e.tau[3 * F + j] - bias[j];                     \
             sym3_mul(fk.Minv, rhs, acc);                                                         \
-            for (int j = 0; j < 3; ++j) vq[3 * F + j] = (e.qd[3 * F + j] + h * acc[j]) * damp;   \
+            for (int j = 0; j < 3; ++j) vq[3 * F + j] = FMA(h, acc[j], e.qd[3 * F + j]) * damp;  \
         }
         FREE_MOTION(0, fk0)
         FREE_MOTION(1, fk1)
@@ -770,7 +837,7 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
         float dl = 1.0f - h * m.cube_linear_damping, da = 1.0f - h * m.cube_angular_damping;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            v[i] = (e.cv[i] + h * P.grav[i]) * dl;
+            v[i] = FMA(h, P.grav[i], e.cv[i]) * dl;
             w[i] = e.cw[i] * da;
         }
     }
@@ -779,11 +846,10 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     quat_to_rot(e.cq, R);
     const float hc = m.cube_half;
     FingerContactRegs fc0, fc1, fc2, tf0, tf1, tf2;
-    finger_contacts<0>(P, e, fk0, R, vq, v, w, h, lds, lane, fc0, tf0);
-    finger_contacts<1>(P, e, fk1, R, vq, v, w, h, lds, lane, fc1, tf1);
-    finger_contacts<2>(P, e, fk2, R, vq, v, w, h, lds, lane, fc2, tf2);
+    finger_contacts<0>(P, e, fk0, R, vq, v, w, inv_h, inv_m, inv_I, lds, lane, fc0, tf0);
+    finger_contacts<1>(P, e, fk1, R, vq, v, w, inv_h, inv_m, inv_I, lds, lane, fc1, tf1);
+    finger_contacts<2>(P, e, fk2, R, vq, v, w, inv_h, inv_m, inv_I, lds, lane, fc2, tf2);
     CubeContactRegs cf[4], cwl[4];
-    const float inv_m = 1.0f / m.cube_mass, inv_I = 1.0f / m.cube_inertia;
     {   // cube vs floor: corners of the face that points down most
         int k = 0;
         float best = f_abs(R[6]);
@@ -794,33 +860,27 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             CubeContactRegs& c = cf[i];
-            c.active = false;
-            c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
-            c.bias = 0.0f; c.n[0] = 0.0f; c.n[1] = 0.0f;
-            c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
+            cube_contact_zero(c);
             cube_corner(R, hc, k, sk, i, c.r);
             float gap = e.cp[2] + c.r[2];
             if (gap < m.contact_margin) {
-                c.active = true;
-                const float dn[3] = {0.0f, 0.0f, 1.0f}, dx[3] = {1.0f, 0.0f, 0.0f}, dy[3] = {0.0f, 1.0f, 0.0f};
-                float rxn[3], rxx[3], rxy[3];
-                cross3(c.r, dn, rxn); cross3(c.r, dx, rxx); cross3(c.r, dy, rxy);
-                c.Dinv[0] = 1.0f / (1.0f / m.cube_mass + dot3(rxn, rxn) / m.cube_inertia);
-                c.Dinv[1] = 1.0f / (1.0f / m.cube_mass + dot3(rxx, rxx) / m.cube_inertia);
-                c.Dinv[2] = 1.0f / (1.0f / m.cube_mass + dot3(rxy, rxy) / m.cube_inertia);
-                float vn0 = dot3(dn, v) + dot3(rxn, w);
-                c.bias = contact_bias(m, gap, vn0, h, 0.0f);
+                const float* r = c.r;
+                c.Dinv[0] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);
+                c.Dinv[1] = 1.0f / FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m);
+                c.Dinv[2] = 1.0f / FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m);
+                float vn0 = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
+                c.bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
         }
     }
     {   // cube vs boundary wall: corners of the face that points outward most
-        float rho_c = f_sqrt(e.cp[0] * e.cp[0] + e.cp[1] * e.cp[1]);
+        float rho_c = f_sqrt(FMA(e.cp[0], e.cp[0], e.cp[1] * e.cp[1]));
         bool any = rho_c > 1e-6f;
         float dx = 0.0f, dy = 0.0f;
         if (any) { float inv = 1.0f / rho_c; dx = e.cp[0] * inv; dy = e.cp[1] * inv; }
         float pr[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pr[i] = R[i] * dx + R[3 + i] * dy;
+        for (int i = 0; i < 3; ++i) pr[i] = FMA(R[i], dx, R[3 + i] * dy);
         int k = 0;
         float best = f_abs(pr[0]);
         if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
@@ -830,45 +890,39 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             CubeContactRegs& c = cwl[i];
-            c.active = false;
-            c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
-            c.bias = 0.0f; c.n[0] = 0.0f; c.n[1] = 0.0f;
-            c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
+            cube_contact_zero(c);
             cube_corner(R, hc, k, sk, i, c.r);
             float px = e.cp[0] + c.r[0], py = e.cp[1] + c.r[1];
-            float rho = f_sqrt(px * px + py * py);
+            float rho = f_sqrt(FMA(px, px, py * py));
             float gap = m.wall_radius - rho;
             if (any && gap < m.contact_margin && rho > 1e-6f) {
                 float inv = 1.0f / rho;
-                c.active = true;
+                const float* r = c.r;
                 c.n[0] = -px * inv; c.n[1] = -py * inv;
-                const float dn[3] = {c.n[0], c.n[1], 0.0f}, dt[3] = {py * inv, -px * inv, 0.0f}, dz[3] = {0.0f, 0.0f, 1.0f};
-                float rxn[3], rxt[3], rxz[3];
-                cross3(c.r, dn, rxn); cross3(c.r, dt, rxt); cross3(c.r, dz, rxz);
-                c.Dinv[0] = 1.0f / (1.0f / m.cube_mass + dot3(rxn, rxn) / m.cube_inertia);
-                c.Dinv[1] = 1.0f / (1.0f / m.cube_mass + dot3(rxt, rxt) / m.cube_inertia);
-                c.Dinv[2] = 1.0f / (1.0f / m.cube_mass + dot3(rxz, rxz) / m.cube_inertia);
-                float vn0 = dot3(dn, v) + dot3(rxn, w);
-                c.bias = contact_bias(m, gap, vn0, h, 0.0f);
+                float a[3], b[3];
+                wall_arm_n(c, a);
+                wall_arm_t(c, b);
+                c.Dinv[0] = 1.0f / FMA(dot3(a, a), inv_I, inv_m);
+                c.Dinv[1] = 1.0f / FMA(dot3(b, b), inv_I, inv_m);
+                c.Dinv[2] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);
+                float vn0 = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c.n[1], v[1], c.n[0] * v[0]))));
+                c.bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
         }
     }
     // ---- joint / velocity limit rows ----
     float vlo[9], vhi[9], lim_dinv[9], lim_lam[9];
-    {
-        float inv_h = 1.0f / h;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int f = j / 3, jj = j % 3;
-            const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
-            const FK& k = (f == 0) ? fk0 : ((f == 1) ? fk1 : fk2);
-            vlo[j] = f_clamp((m.q_lo[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
-            vhi[j] = f_clamp((m.q_hi[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
-            lim_dinv[j] = 1.0f / k.Minv[dg];
-            lim_lam[j] = 0.0f;
-        }
+    for (int j = 0; j < 9; ++j) {
+        const int f = j / 3, jj = j % 3;
+        const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
+        const FK& k = (f == 0) ? fk0 : ((f == 1) ? fk1 : fk2);
+        vlo[j] = f_clamp((m.q_lo[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
+        vhi[j] = f_clamp((m.q_hi[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
+        lim_dinv[j] = 1.0f / k.Minv[dg];
+        lim_lam[j] = 0.0f;
     }
-    __syncthreads();   // LDS rows written above are read below (same lane; barrier keeps the phases ordered)
+    __syncthreads();   // LDS rows written above are read below (same lane; keeps the phases ordered)
     // ---- projected Gauss-Seidel ----
     for (int it = 0; it < P.iters; ++it) {
         solve_finger_cube<0>(m, fc0, lds, lane, vq, v, w, inv_m, inv_I);
@@ -878,76 +932,37 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
         solve_tip_floor<1>(m, tf1, lds, lane, vq);
         solve_tip_floor<2>(m, tf2, lds, lane, vq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            CubeContactRegs& c = cf[i];
-            if (c.active) {
-                const float dn[3] = {0.0f, 0.0f, 1.0f}, dx[3] = {1.0f, 0.0f, 0.0f}, dy[3] = {0.0f, 1.0f, 0.0f};
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const float* dir = (d == 0) ? dn : ((d == 1) ? dx : dy);
-                    float rxd[3];
-                    cross3(c.r, dir, rxd);
-                    float vrel = dot3(dir, v) + dot3(rxd, w);
-                    float lam_new;
-                    if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
-                    else {
-                        float lim = m.mu_cube_floor * c.lam[0];
-                        lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
-                    }
-                    float dl = lam_new - c.lam[d];
-                    c.lam[d] = lam_new;
-                    float s = dl * inv_m, q = dl * inv_I;
-                    v[0] = v[0] + dir[0] * s; v[1] = v[1] + dir[1] * s; v[2] = v[2] + dir[2] * s;
-                    w[0] = w[0] + rxd[0] * q; w[1] = w[1] + rxd[1] * q; w[2] = w[2] + rxd[2] * q;
-                }
-            }
+        for (int i = 0; i < 4; ++i) {       // cube - floor: rows +z (normal), +x, +y
+            cube_row_z<0, true>(cf[i], m.mu_cube_floor, inv_m, inv_I, v, w);
+            cube_row_x<1>(cf[i], m.mu_cube_floor, inv_m, inv_I, v, w);
+            cube_row_y<2>(cf[i], m.mu_cube_floor, inv_m, inv_I, v, w);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            CubeContactRegs& c = cwl[i];
-            if (c.active) {
-                const float dn[3] = {c.n[0], c.n[1], 0.0f}, dt[3] = {-c.n[1], c.n[0], 0.0f}, dz[3] = {0.0f, 0.0f, 1.0f};
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const float* dir = (d == 0) ? dn : ((d == 1) ? dt : dz);
-                    float rxd[3];
-                    cross3(c.r, dir, rxd);
-                    float vrel = dot3(dir, v) + dot3(rxd, w);
-                    float lam_new;
-                    if (d == 0) lam_new = f_max(c.lam[0] - c.Dinv[0] * (vrel + c.bias), 0.0f);
-                    else {
-                        float lim = m.mu_cube_wall * c.lam[0];
-                        lam_new = f_clamp(c.lam[d] - c.Dinv[d] * vrel, -lim, lim);
-                    }
-                    float dl = lam_new - c.lam[d];
-                    c.lam[d] = lam_new;
-                    float s = dl * inv_m, q = dl * inv_I;
-                    v[0] = v[0] + dir[0] * s; v[1] = v[1] + dir[1] * s; v[2] = v[2] + dir[2] * s;
-                    w[0] = w[0] + rxd[0] * q; w[1] = w[1] + rxd[1] * q; w[2] = w[2] + rxd[2] * q;
-                }
-            }
+        for (int i = 0; i < 4; ++i) {       // cube - wall: rows n (normal), t, +z
+            wall_row_n(cwl[i], inv_m, inv_I, v, w);
+            wall_row_t(cwl[i], m.mu_cube_wall, inv_m, inv_I, v, w);
+            cube_row_z<2, false>(cwl[i], m.mu_cube_wall, inv_m, inv_I, v, w);
         }
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
+        for (int j = 0; j < 9; ++j) {       // joint limits + velocity limit
             const int f = j / 3, jj = j % 3;
             const FK& k = (f == 0) ? fk0 : ((f == 1) ? fk1 : fk2);
             const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
             const int c0 = (jj == 0) ? 0 : ((jj == 1) ? 1 : 2);
             const int c1 = (jj == 0) ? 1 : ((jj == 1) ? 3 : 4);
             const int c2 = (jj == 0) ? 2 : ((jj == 1) ? 4 : 5);
-            float v0 = vq[j] - k.Minv[dg] * lim_lam[j];
+            float v0 = FMA(-k.Minv[dg], lim_lam[j], vq[j]);
             float tgt = f_clamp(v0, vlo[j], vhi[j]);
             float lam_new = (tgt - v0) * lim_dinv[j];
             float dl = lam_new - lim_lam[j];
             lim_lam[j] = lam_new;
-            vq[3 * f + 0] = vq[3 * f + 0] + k.Minv[c0] * dl;
-            vq[3 * f + 1] = vq[3 * f + 1] + k.Minv[c1] * dl;
-            vq[3 * f + 2] = vq[3 * f + 2] + k.Minv[c2] * dl;
+            vq[3 * f + 0] = FMA(k.Minv[c0], dl, vq[3 * f + 0]);
+            vq[3 * f + 1] = FMA(k.Minv[c1], dl, vq[3 * f + 1]);
+            vq[3 * f + 2] = FMA(k.Minv[c2], dl, vq[3 * f + 2]);
         }
     }
     // ---- fingertip wrench sensor ----
     if (WRENCH) {
-        float inv_h = 1.0f / h;
         add_wrench<true>(fc0, lds, lane, FC_BASE(0), inv_h, &e.ft[0]);
         add_wrench<false>(tf0, lds, lane, TF_BASE(0), inv_h, &e.ft[0]);
         add_wrench<true>(fc1, lds, lane, FC_BASE(1), inv_h, &e.ft[6]);
@@ -960,12 +975,12 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         e.qd[j] = vq[j];
-        e.q[j] = f_clamp(e.q[j] + h * vq[j], m.q_lo[j % 3], m.q_hi[j % 3]);
+        e.q[j] = f_clamp(FMA(h, vq[j], e.q[j]), m.q_lo[j % 3], m.q_hi[j % 3]);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         e.cv[i] = v[i]; e.cw[i] = w[i];
-        e.cp[i] = e.cp[i] + h * v[i];
+        e.cp[i] = FMA(h, v[i], e.cp[i]);
     }
     quat_integrate(e.cq, e.cw, h);
 }

@@ -39,6 +39,8 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* deterministic elementary functions (coefficients: Cephes single-precision minimax polynomials)    */
 /* ------------------------------------------------------------------------------------------------ */
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
 static inline float f_min(float a, float b) { return (a < b) ? a : b; }
 static inline float f_max(float a, float b) { return (a > b) ? a : b; }
 static inline float f_clamp(float x, float lo, float hi) { return f_max(f_min(x, hi), lo); }
@@ -430,38 +432,38 @@ static inline void rot_link(const FK* k, int link, const float u[3], float o[3])
     float wx = u[0], wy = u[1], wz = u[2];
     if (link >= 2) {
         float ca = (link == 2) ? k->c2 : k->c23, sa = (link == 2) ? k->s2 : k->s23;
-        float ty = ca * u[1] - sa * u[2];
-        float tz = sa * u[1] + ca * u[2];
+        float ty = FMA(ca, u[1], -(sa * u[2]));
+        float tz = FMA(sa, u[1], ca * u[2]);
         wy = ty; wz = tz;
     }
-    o[0] = k->c1 * wx + k->s1 * wz;
+    o[0] = FMA(k->c1, wx, k->s1 * wz);
     o[1] = wy;
-    o[2] = k->c1 * wz - k->s1 * wx;
+    o[2] = FMA(k->c1, wz, -(k->s1 * wx));
 }
 /* base frame -> link k frame */
 static inline void rot_link_T(const FK* k, int link, const float v[3], float o[3]) {
-    float wx = k->c1 * v[0] - k->s1 * v[2];
+    float wx = FMA(k->c1, v[0], -(k->s1 * v[2]));
     float wy = v[1];
-    float wz = k->s1 * v[0] + k->c1 * v[2];
+    float wz = FMA(k->s1, v[0], k->c1 * v[2]);
     if (link >= 2) {
         float ca = (link == 2) ? k->c2 : k->c23, sa = (link == 2) ? k->s2 : k->s23;
-        float ty = ca * wy + sa * wz;
-        float tz = ca * wz - sa * wy;
+        float ty = FMA(ca, wy, sa * wz);
+        float tz = FMA(ca, wz, -(sa * wy));
         wy = ty; wz = tz;
     }
     o[0] = wx; o[1] = wy; o[2] = wz;
 }
 static inline void cross3(const float a[3], const float b[3], float o[3]) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
+    o[0] = FMA(a[1], b[2], -(a[2] * b[1]));
+    o[1] = FMA(a[2], b[0], -(a[0] * b[2]));
+    o[2] = FMA(a[0], b[1], -(a[1] * b[0]));
 }
-static inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline float dot3(const float a[3], const float b[3]) { return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0])); }
 /* symmetric inertia (xx yy zz xy xz yz) times vector */
 static inline void sym_mul(const float I[6], const float v[3], float o[3]) {
-    o[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
-    o[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
-    o[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+    o[0] = FMA(I[4], v[2], FMA(I[3], v[1], I[0] * v[0]));
+    o[1] = FMA(I[5], v[2], FMA(I[1], v[1], I[3] * v[0]));
+    o[2] = FMA(I[2], v[2], FMA(I[5], v[1], I[4] * v[0]));
 }
 
 static void fk_setup(const TfModel* m, const float q[3], FK* k) {
@@ -582,9 +584,9 @@ static void inv3sym(const float M[6], float Mi[6]) {
     Mi[5] = (M[0] * M[3] - M[1] * M[1]) * rd;
 }
 static inline void sym3_mul(const float S[6], const float v[3], float o[3]) { /* S = 00 01 02 11 12 22 */
-    o[0] = S[0] * v[0] + S[1] * v[1] + S[2] * v[2];
-    o[1] = S[1] * v[0] + S[3] * v[1] + S[4] * v[2];
-    o[2] = S[2] * v[0] + S[4] * v[1] + S[5] * v[2];
+    o[0] = FMA(S[2], v[2], FMA(S[1], v[1], S[0] * v[0]));
+    o[1] = FMA(S[4], v[2], FMA(S[3], v[1], S[1] * v[0]));
+    o[2] = FMA(S[5], v[2], FMA(S[4], v[1], S[2] * v[0]));
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -604,58 +606,67 @@ typedef struct {
     float Jf[3][3];    /* row d: J^T dir_d (joint space) */
     float Wf[3][3];    /* Minv Jf */
     float dir[3][3];   /* world directions n, t1, t2 (cube side)            */
-    float rxd[3][3];   /* r_c x dir_d                                       */
+    float rc[3];       /* contact point on the cube relative to its centre  */
     float Dinv[3];
     float bias;
-    float mu;
     float arm[3];      /* world contact point - tip-link origin (for the wrench sensor) */
     float lam[3];
 } FingerContact;
 
+/* one cube corner against the floor or the wall.  Rows are always evaluated: an inactive contact has
+ * Dinv = 0 and bias = 0, so its impulses stay exactly zero (the kernel does the same, branch-free). */
 typedef struct {
     int active;
     float r[3];
-    float dir[3][3];
-    float rxd[3][3];
+    float n[2];        /* wall: horizontal inward normal */
     float Dinv[3];
     float bias;
-    float mu;
     float lam[3];
 } CubeContact;
 
 static void base_to_world(const TfModel* m, int f, const float b[3], float w[3]) {
     float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
-    w[0] = c * b[0] - s * b[1];
-    w[1] = s * b[0] + c * b[1];
+    w[0] = FMA(c, b[0], -(s * b[1]));
+    w[1] = FMA(s, b[0], c * b[1]);
     w[2] = b[2] + m->base_height;
 }
 static void dir_world_to_base(const TfModel* m, int f, const float w[3], float b[3]) {
     float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
-    b[0] = c * w[0] + s * w[1];
-    b[1] = c * w[1] - s * w[0];
+    b[0] = FMA(c, w[0], s * w[1]);
+    b[1] = FMA(c, w[1], -(s * w[0]));
     b[2] = w[2];
 }
 static void dir_base_to_world(const TfModel* m, int f, const float b[3], float w[3]) {
     float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
-    w[0] = c * b[0] - s * b[1];
-    w[1] = s * b[0] + c * b[1];
+    w[0] = FMA(c, b[0], -(s * b[1]));
+    w[1] = FMA(s, b[0], c * b[1]);
     w[2] = b[2];
+}
+/* o = R v and o = R^T v for a row-major 3x3 */
+static inline void mat3_mul(const float R[9], const float v[3], float o[3]) {
+    o[0] = FMA(R[2], v[2], FMA(R[1], v[1], R[0] * v[0]));
+    o[1] = FMA(R[5], v[2], FMA(R[4], v[1], R[3] * v[0]));
+    o[2] = FMA(R[8], v[2], FMA(R[7], v[1], R[6] * v[0]));
+}
+static inline void mat3T_mul(const float R[9], const float v[3], float o[3]) {
+    o[0] = FMA(R[6], v[2], FMA(R[3], v[1], R[0] * v[0]));
+    o[1] = FMA(R[7], v[2], FMA(R[4], v[1], R[1] * v[0]));
+    o[2] = FMA(R[8], v[2], FMA(R[5], v[1], R[2] * v[0]));
 }
 
 static void tangent_basis(const float n[3], float t1[3], float t2[3]) {
     if (f_abs(n[2]) < 0.9f) {
-        float inv = 1.0f / sqrtf(n[0] * n[0] + n[1] * n[1]);
+        float inv = 1.0f / sqrtf(FMA(n[0], n[0], n[1] * n[1]));
         t1[0] = -n[1] * inv; t1[1] = n[0] * inv; t1[2] = 0.0f;
     } else {
-        float inv = 1.0f / sqrtf(n[1] * n[1] + n[2] * n[2]);
+        float inv = 1.0f / sqrtf(FMA(n[1], n[1], n[2] * n[2]));
         t1[0] = 0.0f; t1[1] = -n[2] * inv; t1[2] = n[1] * inv;
     }
     cross3(n, t1, t2);
 }
 
 /* normal-row bias from gap and approach speed (DESIGN.md "contact rows") */
-static float contact_bias(const TfModel* m, float gap, float vn0, float h, float restitution) {
-    float inv_h = 1.0f / h;
+static float contact_bias(const TfModel* m, float gap, float vn0, float inv_h, float restitution) {
     float b;
     if (gap >= 0.0f) b = gap * inv_h;
     else b = f_max(m->erp * gap * inv_h, -m->max_depenetration_velocity);
@@ -665,7 +676,7 @@ static float contact_bias(const TfModel* m, float gap, float vn0, float h, float
 
 /* Rows of one finger contact once point P (base frame), world normal n and cube arm r_c are known. */
 static void finger_rows(const TfModel* m, int f, const FK* k, const float Pb[3], const float n_w[3],
-                        const float rc[3], int with_cube, FingerContact* c) {
+                        const float rc[3], int with_cube, float inv_m, float inv_I, FingerContact* c) {
     float t1[3], t2[3];
     tangent_basis(n_w, t1, t2);
     const float* dw[3] = {n_w, t1, t2};
@@ -679,38 +690,107 @@ static void finger_rows(const TfModel* m, int f, const FK* k, const float Pb[3],
         sym3_mul(k->Minv, c->Jf[d], c->Wf[d]);
         float D = dot3(c->Jf[d], c->Wf[d]);
         if (with_cube) {
-            cross3(rc, dw[d], c->rxd[d]);
-            D = D + 1.0f / m->cube_mass + dot3(c->rxd[d], c->rxd[d]) / m->cube_inertia;
-        } else {
-            c->rxd[d][0] = 0.0f; c->rxd[d][1] = 0.0f; c->rxd[d][2] = 0.0f;
+            float rxd[3];
+            cross3(rc, dw[d], rxd);
+            D = FMA(dot3(rxd, rxd), inv_I, D + inv_m);
         }
         c->Dinv[d] = 1.0f / D;
     }
+    c->rc[0] = rc[0]; c->rc[1] = rc[1]; c->rc[2] = rc[2];
 }
 
-static void cube_corner(const float R[9], float hc, int k, float sk, int idx, float y[3], float r[3]) {
+static void cube_corner(const float R[9], float hc, int k, float sk, int idx, float r[3]) {
     int a = (k + 1) % 3, b = (k + 2) % 3;
+    float y[3];
     if (a > b) { int t = a; a = b; b = t; }
     y[k] = sk * hc;
     y[a] = (idx & 1) ? hc : -hc;
     y[b] = (idx & 2) ? hc : -hc;
-    r[0] = R[0] * y[0] + R[1] * y[1] + R[2] * y[2];
-    r[1] = R[3] * y[0] + R[4] * y[1] + R[5] * y[2];
-    r[2] = R[6] * y[0] + R[7] * y[1] + R[8] * y[2];
+    mat3_mul(R, y, r);
 }
 
-static void cube_rows(const TfModel* m, CubeContact* c) {
-    for (int d = 0; d < 3; ++d) {
-        cross3(c->r, c->dir[d], c->rxd[d]);
-        float D = 1.0f / m->cube_mass + dot3(c->rxd[d], c->rxd[d]) / m->cube_inertia;
-        c->Dinv[d] = 1.0f / D;
-    }
+/* ---- PGS row kernels (identical arithmetic in the HIP file) ---- */
+static inline float solve_normal(float* lam, float Dinv, float vrel, float bias) {
+    float ln = f_max(FMA(-Dinv, vrel + bias, *lam), 0.0f);
+    float dl = ln - *lam;
+    *lam = ln;
+    return dl;
+}
+static inline float solve_tangent(float* lam, float Dinv, float vrel, float lim) {
+    float ln = f_clamp(FMA(-Dinv, vrel, *lam), -lim, lim);
+    float dl = ln - *lam;
+    *lam = ln;
+    return dl;
+}
+/* axis-aligned rows of a cube corner with arm r: direction +z / +x / +y */
+static inline void cube_row_z(CubeContact* c, int slot, int is_normal, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    const float* r = c->r;
+    float vrel = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
+    float dl = is_normal ? solve_normal(&c->lam[slot], c->Dinv[slot], vrel, c->bias)
+                         : solve_tangent(&c->lam[slot], c->Dinv[slot], vrel, mu * c->lam[0]);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[2] = v[2] + s;
+    w[0] = FMA(r[1], q, w[0]);
+    w[1] = FMA(-r[0], q, w[1]);
+}
+static inline void cube_row_x(CubeContact* c, int slot, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    const float* r = c->r;
+    float vrel = FMA(r[2], w[1], FMA(-r[1], w[2], v[0]));
+    float dl = solve_tangent(&c->lam[slot], c->Dinv[slot], vrel, mu * c->lam[0]);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = v[0] + s;
+    w[1] = FMA(r[2], q, w[1]);
+    w[2] = FMA(-r[1], q, w[2]);
+}
+static inline void cube_row_y(CubeContact* c, int slot, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    const float* r = c->r;
+    float vrel = FMA(-r[2], w[0], FMA(r[0], w[2], v[1]));
+    float dl = solve_tangent(&c->lam[slot], c->Dinv[slot], vrel, mu * c->lam[0]);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[1] = v[1] + s;
+    w[0] = FMA(-r[2], q, w[0]);
+    w[2] = FMA(r[0], q, w[2]);
+}
+/* wall rows: inward horizontal normal n = (n0, n1, 0) and tangent t = (-n1, n0, 0) */
+static inline void wall_arm_n(const CubeContact* c, float a[3]) {
+    const float* r = c->r;
+    a[0] = -(r[2] * c->n[1]);
+    a[1] = r[2] * c->n[0];
+    a[2] = FMA(r[0], c->n[1], -(r[1] * c->n[0]));
+}
+static inline void wall_arm_t(const CubeContact* c, float b[3]) {
+    const float* r = c->r;
+    b[0] = -(r[2] * c->n[0]);
+    b[1] = -(r[2] * c->n[1]);
+    b[2] = FMA(r[0], c->n[0], r[1] * c->n[1]);
+}
+static inline void wall_row_n(CubeContact* c, float inv_m, float inv_I, float v[3], float w[3]) {
+    float a[3];
+    wall_arm_n(c, a);
+    float vrel = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c->n[1], v[1], c->n[0] * v[0]))));
+    float dl = solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = FMA(c->n[0], s, v[0]);
+    v[1] = FMA(c->n[1], s, v[1]);
+    w[0] = FMA(a[0], q, w[0]); w[1] = FMA(a[1], q, w[1]); w[2] = FMA(a[2], q, w[2]);
+}
+static inline void wall_row_t(CubeContact* c, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
+    float b[3];
+    wall_arm_t(c, b);
+    float vrel = FMA(b[2], w[2], FMA(b[1], w[1], FMA(b[0], w[0], FMA(c->n[0], v[1], -(c->n[1] * v[0])))));
+    float dl = solve_tangent(&c->lam[1], c->Dinv[1], vrel, mu * c->lam[0]);
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = FMA(-c->n[1], s, v[0]);
+    v[1] = FMA(c->n[0], s, v[1]);
+    w[0] = FMA(b[0], q, w[0]); w[1] = FMA(b[1], q, w[1]); w[2] = FMA(b[2], q, w[2]);
 }
 
 /* One solver substep of length h for one env. */
 static void substep(const struct TfHandle_* H, Env* e, float h) {
     const TfConfig* cfg = &H->cfg;
     const TfModel* m = &cfg->model;
+    const float inv_h = 1.0f / h;
+    const float inv_m = 1.0f / m->cube_mass, inv_I = 1.0f / m->cube_inertia;
     FK fk[3];
     float vq[9];                 /* joint velocities being solved */
     float v[3], w[3];            /* cube velocities being solved  */
@@ -723,12 +803,12 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int j = 0; j < 3; ++j) rhs[j] = e->tau[3 * f + j] - bias[j];
         sym3_mul(fk[f].Minv, rhs, acc);
         float damp = 1.0f - h * m->link_angular_damping;
-        for (int j = 0; j < 3; ++j) vq[3 * f + j] = (e->qd[3 * f + j] + h * acc[j]) * damp;
+        for (int j = 0; j < 3; ++j) vq[3 * f + j] = FMA(h, acc[j], e->qd[3 * f + j]) * damp;
     }
     {
         float dl = 1.0f - h * m->cube_linear_damping, da = 1.0f - h * m->cube_angular_damping;
         for (int i = 0; i < 3; ++i) {
-            v[i] = (e->cv[i] + h * cfg->gravity[i]) * dl;
+            v[i] = FMA(h, cfg->gravity[i], e->cv[i]) * dl;
             w[i] = e->cw[i] * da;
         }
     }
@@ -738,10 +818,9 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     const float hc = m->cube_half;
     FingerContact fc[3], tf_[3];
     CubeContact cf[4], cwl[4];
-    float tip_origin_w[3][3];
     for (int f = 0; f < 3; ++f) {
         const FK* k = &fk[f];
-        float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3];
+        float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3], Tw[3];
         rot_link(k, 3, m->cap_a, t);
         Ab[0] = k->p3[0] + t[0]; Ab[1] = k->p3[1] + t[1]; Ab[2] = k->p3[2] + t[2];
         rot_link(k, 3, m->cap_b, t);
@@ -750,26 +829,24 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         To[0] = k->p3[0] + t[0]; To[1] = k->p3[1] + t[1]; To[2] = k->p3[2] + t[2];
         base_to_world(m, f, Ab, Aw);
         base_to_world(m, f, Bb, Bw);
-        base_to_world(m, f, To, tip_origin_w[f]);
+        base_to_world(m, f, To, Tw);
         /* --- capsule (distal link) vs cube: closest points by alternating projection, cube frame --- */
         FingerContact* c = &fc[f];
         memset(c, 0, sizeof(*c));
         float da[3] = {Aw[0] - e->cp[0], Aw[1] - e->cp[1], Aw[2] - e->cp[2]};
         float db[3] = {Bw[0] - e->cp[0], Bw[1] - e->cp[1], Bw[2] - e->cp[2]};
         float a[3], b[3];
-        for (int i = 0; i < 3; ++i) {                       /* R^T d */
-            a[i] = R[i] * da[0] + R[3 + i] * da[1] + R[6 + i] * da[2];
-            b[i] = R[i] * db[0] + R[3 + i] * db[1] + R[6 + i] * db[2];
-        }
+        mat3T_mul(R, da, a);
+        mat3T_mul(R, db, b);
         float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
         float inv_dd = 1.0f / dot3(d, d);
         float s = 1.0f, x[3], y[3];
         for (int it = 0; it < 4; ++it) {
-            for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+            for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
             float ya[3] = {y[0] - a[0], y[1] - a[1], y[2] - a[2]};
             s = f_clamp(dot3(ya, d) * inv_dd, 0.0f, 1.0f);
         }
-        for (int i = 0; i < 3; ++i) { x[i] = a[i] + s * d[i]; y[i] = f_clamp(x[i], -hc, hc); }
+        for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
         float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
         float dist2 = dot3(ev, ev);
         float nc[3], gap;
@@ -794,23 +871,22 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         }
         if (gap < m->contact_margin) {
             float n_w[3], rc[3], xw[3];
-            for (int i = 0; i < 3; ++i) {
-                n_w[i] = R[3 * i] * nc[0] + R[3 * i + 1] * nc[1] + R[3 * i + 2] * nc[2];
-                rc[i] = R[3 * i] * y[0] + R[3 * i + 1] * y[1] + R[3 * i + 2] * y[2];
-                xw[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
-            }
-            /* finger-side contact point (world, relative to the cube centre): axis point minus r n */
-            float Pw[3] = {e->cp[0] + xw[0] - m->cap_radius * n_w[0], e->cp[1] + xw[1] - m->cap_radius * n_w[1],
-                           e->cp[2] + xw[2] - m->cap_radius * n_w[2]};
+            mat3_mul(R, nc, n_w);
+            mat3_mul(R, y, rc);
+            mat3_mul(R, x, xw);
+            /* finger-side contact point (world): axis point minus r n */
+            float Pw[3] = {FMA(-m->cap_radius, n_w[0], e->cp[0] + xw[0]), FMA(-m->cap_radius, n_w[1], e->cp[1] + xw[1]),
+                           FMA(-m->cap_radius, n_w[2], e->cp[2] + xw[2])};
             float Pr[3] = {Pw[0], Pw[1], Pw[2] - m->base_height};
             float Pb[3];
             dir_world_to_base(m, f, Pr, Pb);
             c->active = 1;
-            c->mu = m->mu_finger_cube;
-            finger_rows(m, f, k, Pb, n_w, rc, 1, c);
-            for (int i = 0; i < 3; ++i) c->arm[i] = Pw[i] - tip_origin_w[f][i];
-            float vn0 = dot3(c->Jf[0], &vq[3 * f]) - (dot3(c->dir[0], v) + dot3(c->rxd[0], w));
-            c->bias = contact_bias(m, gap, vn0, h, m->restitution_finger);
+            finger_rows(m, f, k, Pb, n_w, rc, 1, inv_m, inv_I, c);
+            for (int i = 0; i < 3; ++i) c->arm[i] = Pw[i] - Tw[i];
+            float rxn[3];
+            cross3(rc, c->dir[0], rxn);
+            float vn0 = dot3(c->Jf[0], &vq[3 * f]) - (dot3(c->dir[0], v) + dot3(rxn, w));
+            c->bias = contact_bias(m, gap, vn0, inv_h, m->restitution_finger);
         }
         /* --- tip sphere vs floor --- */
         FingerContact* g = &tf_[f];
@@ -821,11 +897,10 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             float Pb[3] = {Bb[0], Bb[1], Bb[2] - m->cap_radius};
             float Pw[3] = {Bw[0], Bw[1], Bw[2] - m->cap_radius};
             g->active = 1;
-            g->mu = m->mu_tip_floor;
-            finger_rows(m, f, k, Pb, n_w, zero, 0, g);
-            for (int i = 0; i < 3; ++i) g->arm[i] = Pw[i] - tip_origin_w[f][i];
+            finger_rows(m, f, k, Pb, n_w, zero, 0, inv_m, inv_I, g);
+            for (int i = 0; i < 3; ++i) g->arm[i] = Pw[i] - Tw[i];
             float vn0 = dot3(g->Jf[0], &vq[3 * f]);
-            g->bias = contact_bias(m, gapf, vn0, h, m->restitution_finger);
+            g->bias = contact_bias(m, gapf, vn0, inv_h, m->restitution_finger);
         }
     }
     /* --- cube vs floor: the four corners of the face that points down most --- */
@@ -838,27 +913,27 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int i = 0; i < 4; ++i) {
             CubeContact* c = &cf[i];
             memset(c, 0, sizeof(*c));
-            float y[3];
-            cube_corner(R, hc, k, sk, i, y, c->r);
+            cube_corner(R, hc, k, sk, i, c->r);
             float gap = e->cp[2] + c->r[2];
             if (gap < m->contact_margin) {
+                const float* r = c->r;
                 c->active = 1;
-                c->mu = m->mu_cube_floor;
-                c->dir[0][2] = 1.0f; c->dir[1][0] = 1.0f; c->dir[2][1] = 1.0f;
-                cube_rows(m, c);
-                float vn0 = dot3(c->dir[0], v) + dot3(c->rxd[0], w);
-                c->bias = contact_bias(m, gap, vn0, h, 0.0f);
+                c->Dinv[0] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);   /* +z */
+                c->Dinv[1] = 1.0f / FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m);   /* +x */
+                c->Dinv[2] = 1.0f / FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m);   /* +y */
+                float vn0 = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
+                c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
         }
     }
     /* --- cube vs boundary wall: the four corners of the face that points outward most --- */
     {
-        float rho_c = sqrtf(e->cp[0] * e->cp[0] + e->cp[1] * e->cp[1]);
+        float rho_c = sqrtf(FMA(e->cp[0], e->cp[0], e->cp[1] * e->cp[1]));
         int any = rho_c > 1e-6f;
         float dx = 0.0f, dy = 0.0f;
         if (any) { float inv = 1.0f / rho_c; dx = e->cp[0] * inv; dy = e->cp[1] * inv; }
         float pr[3];
-        for (int i = 0; i < 3; ++i) pr[i] = R[i] * dx + R[3 + i] * dy;
+        for (int i = 0; i < 3; ++i) pr[i] = FMA(R[i], dx, R[3 + i] * dy);
         int k = 0;
         float best = f_abs(pr[0]);
         if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
@@ -867,124 +942,110 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int i = 0; i < 4; ++i) {
             CubeContact* c = &cwl[i];
             memset(c, 0, sizeof(*c));
-            float y[3];
-            cube_corner(R, hc, k, sk, i, y, c->r);
+            cube_corner(R, hc, k, sk, i, c->r);
             float px = e->cp[0] + c->r[0], py = e->cp[1] + c->r[1];
-            float rho = sqrtf(px * px + py * py);
+            float rho = sqrtf(FMA(px, px, py * py));
             float gap = m->wall_radius - rho;
             if (any && gap < m->contact_margin && rho > 1e-6f) {
                 float inv = 1.0f / rho;
+                const float* r = c->r;
                 c->active = 1;
-                c->mu = m->mu_cube_wall;
-                c->dir[0][0] = -px * inv; c->dir[0][1] = -py * inv;
-                c->dir[1][0] = py * inv;  c->dir[1][1] = -px * inv;
-                c->dir[2][2] = 1.0f;
-                cube_rows(m, c);
-                float vn0 = dot3(c->dir[0], v) + dot3(c->rxd[0], w);
-                c->bias = contact_bias(m, gap, vn0, h, 0.0f);
+                c->n[0] = -px * inv; c->n[1] = -py * inv;
+                float a[3], b[3];
+                wall_arm_n(c, a);
+                wall_arm_t(c, b);
+                c->Dinv[0] = 1.0f / FMA(dot3(a, a), inv_I, inv_m);
+                c->Dinv[1] = 1.0f / FMA(dot3(b, b), inv_I, inv_m);
+                c->Dinv[2] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);
+                float vn0 = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c->n[1], v[1], c->n[0] * v[0]))));
+                c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
         }
     }
     /* --- joint limit / velocity limit rows --- */
     float vlo[9], vhi[9], lim_dinv[9], lim_lam[9];
-    {
-        float inv_h = 1.0f / h;
-        for (int j = 0; j < 9; ++j) {
-            int f = j / 3, jj = j % 3;
-            static const int diag[3] = {0, 3, 5};
-            vlo[j] = f_clamp((m->q_lo[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
-            vhi[j] = f_clamp((m->q_hi[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
-            lim_dinv[j] = 1.0f / fk[f].Minv[diag[jj]];
-            lim_lam[j] = 0.0f;
-        }
+    for (int j = 0; j < 9; ++j) {
+        int f = j / 3, jj = j % 3;
+        static const int diag[3] = {0, 3, 5};
+        vlo[j] = f_clamp((m->q_lo[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
+        vhi[j] = f_clamp((m->q_hi[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
+        lim_dinv[j] = 1.0f / fk[f].Minv[diag[jj]];
+        lim_lam[j] = 0.0f;
     }
     /* ---- projected Gauss-Seidel ---- */
-    const float inv_m = 1.0f / m->cube_mass, inv_I = 1.0f / m->cube_inertia;
     for (int it = 0; it < cfg->solver_iterations; ++it) {
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int f = 0; f < 3; ++f) {
-                FingerContact* c = (pass == 0) ? &fc[f] : &tf_[f];
-                if (!c->active) continue;
-                float* vf = &vq[3 * f];
-                for (int d = 0; d < 3; ++d) {
-                    float vrel = dot3(c->Jf[d], vf);
-                    if (pass == 0) vrel = vrel - (dot3(c->dir[d], v) + dot3(c->rxd[d], w));
-                    float lam_new;
-                    if (d == 0) lam_new = f_max(c->lam[0] - c->Dinv[0] * (vrel + c->bias), 0.0f);
-                    else {
-                        float lim = c->mu * c->lam[0];
-                        lam_new = f_clamp(c->lam[d] - c->Dinv[d] * vrel, -lim, lim);
-                    }
-                    float dl = lam_new - c->lam[d];
-                    c->lam[d] = lam_new;
-                    vf[0] = vf[0] + c->Wf[d][0] * dl; vf[1] = vf[1] + c->Wf[d][1] * dl; vf[2] = vf[2] + c->Wf[d][2] * dl;
-                    if (pass == 0) {
-                        float s = dl * inv_m, q = dl * inv_I;
-                        v[0] = v[0] - c->dir[d][0] * s; v[1] = v[1] - c->dir[d][1] * s; v[2] = v[2] - c->dir[d][2] * s;
-                        w[0] = w[0] - c->rxd[d][0] * q; w[1] = w[1] - c->rxd[d][1] * q; w[2] = w[2] - c->rxd[d][2] * q;
-                    }
-                }
+        for (int f = 0; f < 3; ++f) {             /* finger - cube */
+            FingerContact* c = &fc[f];
+            if (!c->active) continue;
+            float* vf = &vq[3 * f];
+            for (int d = 0; d < 3; ++d) {
+                float rxd[3];
+                cross3(c->rc, c->dir[d], rxd);
+                float vrel = dot3(c->Jf[d], vf) - (dot3(c->dir[d], v) + dot3(rxd, w));
+                float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
+                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, m->mu_finger_cube * c->lam[0]);
+                for (int j = 0; j < 3; ++j) vf[j] = FMA(c->Wf[d][j], dl, vf[j]);
+                float sc = dl * inv_m, q = dl * inv_I;
+                for (int j = 0; j < 3; ++j) { v[j] = FMA(-c->dir[d][j], sc, v[j]); w[j] = FMA(-rxd[j], q, w[j]); }
             }
         }
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int i = 0; i < 4; ++i) {
-                CubeContact* c = (pass == 0) ? &cf[i] : &cwl[i];
-                if (!c->active) continue;
-                for (int d = 0; d < 3; ++d) {
-                    float vrel = dot3(c->dir[d], v) + dot3(c->rxd[d], w);
-                    float lam_new;
-                    if (d == 0) lam_new = f_max(c->lam[0] - c->Dinv[0] * (vrel + c->bias), 0.0f);
-                    else {
-                        float lim = c->mu * c->lam[0];
-                        lam_new = f_clamp(c->lam[d] - c->Dinv[d] * vrel, -lim, lim);
-                    }
-                    float dl = lam_new - c->lam[d];
-                    c->lam[d] = lam_new;
-                    float s = dl * inv_m, q = dl * inv_I;
-                    v[0] = v[0] + c->dir[d][0] * s; v[1] = v[1] + c->dir[d][1] * s; v[2] = v[2] + c->dir[d][2] * s;
-                    w[0] = w[0] + c->rxd[d][0] * q; w[1] = w[1] + c->rxd[d][1] * q; w[2] = w[2] + c->rxd[d][2] * q;
-                }
+        for (int f = 0; f < 3; ++f) {             /* fingertip - floor */
+            FingerContact* c = &tf_[f];
+            if (!c->active) continue;
+            float* vf = &vq[3 * f];
+            for (int d = 0; d < 3; ++d) {
+                float vrel = dot3(c->Jf[d], vf);
+                float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
+                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, m->mu_tip_floor * c->lam[0]);
+                for (int j = 0; j < 3; ++j) vf[j] = FMA(c->Wf[d][j], dl, vf[j]);
             }
         }
-        for (int j = 0; j < 9; ++j) {
+        for (int i = 0; i < 4; ++i) {             /* cube - floor: rows +z (normal), +x, +y */
+            cube_row_z(&cf[i], 0, 1, m->mu_cube_floor, inv_m, inv_I, v, w);
+            cube_row_x(&cf[i], 1, m->mu_cube_floor, inv_m, inv_I, v, w);
+            cube_row_y(&cf[i], 2, m->mu_cube_floor, inv_m, inv_I, v, w);
+        }
+        for (int i = 0; i < 4; ++i) {             /* cube - wall: rows n (normal), t, +z */
+            wall_row_n(&cwl[i], inv_m, inv_I, v, w);
+            wall_row_t(&cwl[i], m->mu_cube_wall, inv_m, inv_I, v, w);
+            cube_row_z(&cwl[i], 2, 0, m->mu_cube_wall, inv_m, inv_I, v, w);
+        }
+        for (int j = 0; j < 9; ++j) {             /* joint limits + velocity limit */
             int f = j / 3, jj = j % 3;
             static const int col[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
             static const int diag[3] = {0, 3, 5};
             const float* Mi = fk[f].Minv;
-            float v0 = vq[j] - Mi[diag[jj]] * lim_lam[j];
+            float v0 = FMA(-Mi[diag[jj]], lim_lam[j], vq[j]);
             float tgt = f_clamp(v0, vlo[j], vhi[j]);
             float lam_new = (tgt - v0) * lim_dinv[j];
             float dl = lam_new - lim_lam[j];
             lim_lam[j] = lam_new;
-            vq[3 * f + 0] = vq[3 * f + 0] + Mi[col[jj][0]] * dl;
-            vq[3 * f + 1] = vq[3 * f + 1] + Mi[col[jj][1]] * dl;
-            vq[3 * f + 2] = vq[3 * f + 2] + Mi[col[jj][2]] * dl;
+            vq[3 * f + 0] = FMA(Mi[col[jj][0]], dl, vq[3 * f + 0]);
+            vq[3 * f + 1] = FMA(Mi[col[jj][1]], dl, vq[3 * f + 1]);
+            vq[3 * f + 2] = FMA(Mi[col[jj][2]], dl, vq[3 * f + 2]);
         }
     }
     /* ---- fingertip wrench sensor: contact impulses / h, world frame, about the tip-link origin ---- */
-    {
-        float inv_h = 1.0f / h;
-        for (int f = 0; f < 3; ++f) {
-            for (int pass = 0; pass < 2; ++pass) {
-                const FingerContact* c = (pass == 0) ? &fc[f] : &tf_[f];
-                if (!c->active) continue;
-                float F[3];
-                for (int i = 0; i < 3; ++i)
-                    F[i] = (c->dir[0][i] * c->lam[0] + c->dir[1][i] * c->lam[1] + c->dir[2][i] * c->lam[2]) * inv_h;
-                float T[3];
-                cross3(c->arm, F, T);
-                for (int i = 0; i < 3; ++i) { e->ft[6 * f + i] += F[i]; e->ft[6 * f + 3 + i] += T[i]; }
-            }
+    for (int f = 0; f < 3; ++f) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const FingerContact* c = (pass == 0) ? &fc[f] : &tf_[f];
+            if (!c->active) continue;
+            float F[3];
+            for (int i = 0; i < 3; ++i)
+                F[i] = FMA(c->dir[2][i], c->lam[2], FMA(c->dir[1][i], c->lam[1], c->dir[0][i] * c->lam[0])) * inv_h;
+            float T[3];
+            cross3(c->arm, F, T);
+            for (int i = 0; i < 3; ++i) { e->ft[6 * f + i] += F[i]; e->ft[6 * f + 3 + i] += T[i]; }
         }
     }
     /* ---- integrate ---- */
     for (int j = 0; j < 9; ++j) {
         e->qd[j] = vq[j];
-        e->q[j] = f_clamp(e->q[j] + h * vq[j], m->q_lo[j % 3], m->q_hi[j % 3]);
+        e->q[j] = f_clamp(FMA(h, vq[j], e->q[j]), m->q_lo[j % 3], m->q_hi[j % 3]);
     }
     for (int i = 0; i < 3; ++i) {
         e->cv[i] = v[i]; e->cw[i] = w[i];
-        e->cp[i] = e->cp[i] + h * v[i];
+        e->cp[i] = FMA(h, v[i], e->cp[i]);
     }
     quat_integrate(e->cq, e->cw, h);
     if (cfg->goal_rotation_activate) quat_integrate(e->gq, e->gw, h);
