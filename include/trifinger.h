@@ -92,7 +92,9 @@ enum {
     TF_S_PREV_OBJ_Q = 62,/*  4 object orientation of history[1]                                   */
     TF_S_FT = 66,        /* 18 fingertip contact wrench (world frame force 3 + torque 3 per finger about
                               the tip-link origin, mean over the substeps of the step); split path only */
-    TF_STATE_ROWS = 84
+    TF_S_DR = 84,        /*  4 per-env domain-randomisation scale factors drawn at reset (1.0 when DR is off):
+                              cube mass, cube size, contact friction, motor torque                  */
+    TF_STATE_ROWS = 88
 };
 
 #define TF_OBS_DIM_BASE 32    /* 9 + 9 + 7 + 7; the action slot (9 or 18) follows  trifinger_env.py:280-286 */
@@ -183,6 +185,13 @@ typedef struct TfConfig {
     int32_t substeps;             /* solver substeps per simulate()                                  */
     int32_t solver_iterations;    /* num_position_iterations                                         */
     float gravity[3];
+    /* Domain randomisation (build-defined: the reference has none, leibnizgym/dr/__init__.py is empty; the intent
+     * list is the comment block at trifinger_env.py:385-393).  Scale factors ~ U[lo, hi], drawn per env at reset. */
+    int32_t dr_enable;
+    float dr_cube_mass[2];
+    float dr_cube_size[2];
+    float dr_friction[2];
+    float dr_motor[2];
     TfModel model;
 } TfConfig;
 

@@ -14,7 +14,7 @@ import os
 TF_API_VERSION = 1
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
-TF_STATE_ROWS = 84
+TF_STATE_ROWS = 88
 
 # status codes (include/trifinger.h: TfStatus)
 TF_OK = 0
@@ -41,7 +41,7 @@ REWARD_TERM_ORDER = (
 # rows of the SoA state matrix (include/trifinger.h)
 S_Q, S_QD, S_CUBE_P, S_CUBE_Q, S_CUBE_V, S_CUBE_W = 0, 9, 18, 21, 25, 28
 S_GOAL_P, S_GOAL_Q, S_GOAL_W, S_TIP_P, S_TAU = 31, 34, 38, 41, 50
-S_PREV_OBJ_P, S_PREV_OBJ_Q, S_FT = 59, 62, 66
+S_PREV_OBJ_P, S_PREV_OBJ_Q, S_FT, S_DR = 59, 62, 66, 84
 
 INFO_POS_COUNT, INFO_ORI_COUNT, INFO_SUCCESS_MEAN, INFO_NUM_RESETS, INFO_NUM_NONFINITE = 6, 7, 8, 9, 10
 
@@ -90,6 +90,9 @@ class TfConfig(C.Structure):
         ("position_tolerance", C.c_float), ("orientation_tolerance", C.c_float),
         ("dt", C.c_float), ("substeps", C.c_int32), ("solver_iterations", C.c_int32),
         ("gravity", C.c_float * 3),
+        ("dr_enable", C.c_int32),
+        ("dr_cube_mass", C.c_float * 2), ("dr_cube_size", C.c_float * 2),
+        ("dr_friction", C.c_float * 2), ("dr_motor", C.c_float * 2),
         ("model", TfModel),
     ]
 

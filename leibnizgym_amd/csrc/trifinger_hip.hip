@@ -68,6 +68,8 @@ struct DevParams {
     int32_t task_difficulty, episode_length;
     int32_t robot_reset_type, object_reset_type, goal_rotation_activate;
     float dof_pos_stddev, dof_vel_stddev, goal_rate;
+    int32_t dr_enable;
+    float dr_cube_mass[2], dr_cube_size[2], dr_friction[2], dr_motor[2];
     int32_t rew_active[6];
     int32_t success_activate;
     float success_bonus, pos_tol, ori_tol;
@@ -194,7 +196,7 @@ DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
-enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4 };
+enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 };
 DEV void rng4(const DevParams& P, uint32_t gid, uint32_t count, uint32_t tag, float u[4]) {
     uint32_t r[4];
     philox4x32_10(gid, count, tag, 0u, P.seed_lo, P.seed_hi, r);
@@ -473,6 +475,7 @@ struct Env {
     float gp[3], gq[4], gw[3];
     float tau[9];
     float ft[18];
+    float dr[4];     // domain-randomisation scale factors: cube mass, cube size, friction, motor torque
 };
 
 // LDS layout, floats per lane: finger-cube contact f at FC_BASE(f): Jf[3][3] Wf[3][3] dir[3][3] rc[3] (30);
@@ -646,10 +649,9 @@ DEV void cube_contact_zero(CubeContactRegs& c) {
 // ---- contact generation for finger F (capsule vs cube, tip vs floor) ----
 template <int F>
 DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const float R[9], const float* vq,
-                         const float v[3], const float w[3], float inv_h, float inv_m, float inv_I, float* lds,
+                         const float v[3], const float w[3], float hc, float inv_h, float inv_m, float inv_I, float* lds,
                          int lane, FingerContactRegs& c, FingerContactRegs& g) {
     const TfModel& m = P.m;
-    const float hc = m.cube_half;
     float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3], Tw[3];
     rot_link<3>(k, m.cap_a, t);
     Ab[0] = k.p3[0] + t[0]; Ab[1] = k.p3[1] + t[1]; Ab[2] = k.p3[2] + t[2];
@@ -739,7 +741,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
 
 // PGS rows of the finger-cube contact of finger F (reads J/W/dir/rc from LDS)
 template <int F>
-DEV void solve_finger_cube(const TfModel& m, FingerContactRegs& c, const float* lds, int lane, float* vq, float v[3],
+DEV void solve_finger_cube(float mu, FingerContactRegs& c, const float* lds, int lane, float* vq, float v[3],
                            float w[3], float inv_m, float inv_I) {
     if (!c.active) return;
     float* vf = &vq[3 * F];
@@ -756,7 +758,7 @@ DEV void solve_finger_cube(const TfModel& m, FingerContactRegs& c, const float* 
         cross3(rc, dir, rxd);
         float vrel = dot3(Jf, vf) - (dot3(dir, v) + dot3(rxd, w));
         float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
-                            : solve_tangent(c.lam[d], c.Dinv[d], vrel, m.mu_finger_cube * c.lam[0]);
+                            : solve_tangent(c.lam[d], c.Dinv[d], vrel, mu * c.lam[0]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) vf[j] = FMA(Wf[j], dl, vf[j]);
         float sc = dl * inv_m, q = dl * inv_I;
@@ -765,7 +767,7 @@ DEV void solve_finger_cube(const TfModel& m, FingerContactRegs& c, const float* 
     }
 }
 template <int F>
-DEV void solve_tip_floor(const TfModel& m, FingerContactRegs& c, const float* lds, int lane, float* vq) {
+DEV void solve_tip_floor(float mu, FingerContactRegs& c, const float* lds, int lane, float* vq) {
     if (!c.active) return;
     float* vf = &vq[3 * F];
 #pragma unroll
@@ -778,7 +780,7 @@ DEV void solve_tip_floor(const TfModel& m, FingerContactRegs& c, const float* ld
         }
         float vrel = dot3(Jf, vf);
         float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
-                            : solve_tangent(c.lam[d], c.Dinv[d], vrel, m.mu_tip_floor * c.lam[0]);
+                            : solve_tangent(c.lam[d], c.Dinv[d], vrel, mu * c.lam[0]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) vf[j] = FMA(Wf[j], dl, vf[j]);
     }
@@ -813,7 +815,12 @@ template <bool WRENCH>
 DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     const TfModel& m = P.m;
     const float inv_h = 1.0f / h;
-    const float inv_m = 1.0f / m.cube_mass, inv_I = 1.0f / m.cube_inertia;
+    // per-env cube and friction parameters: nominal values times the domain-randomisation factors (1.0 when off)
+    const float cube_mass = m.cube_mass * e.dr[0];
+    const float cube_inertia = m.cube_inertia * e.dr[0] * e.dr[1] * e.dr[1];
+    const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
+    const float mu_fc = m.mu_finger_cube * e.dr[2], mu_tf = m.mu_tip_floor * e.dr[2];
+    const float mu_cf = m.mu_cube_floor * e.dr[2], mu_cw = m.mu_cube_wall * e.dr[2];
     FK fk0, fk1, fk2;
     float vq[9];
     float v[3], w[3];
@@ -844,11 +851,11 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     // ---- contact generation ----
     float R[9];
     quat_to_rot(e.cq, R);
-    const float hc = m.cube_half;
+    const float hc = m.cube_half * e.dr[1];
     FingerContactRegs fc0, fc1, fc2, tf0, tf1, tf2;
-    finger_contacts<0>(P, e, fk0, R, vq, v, w, inv_h, inv_m, inv_I, lds, lane, fc0, tf0);
-    finger_contacts<1>(P, e, fk1, R, vq, v, w, inv_h, inv_m, inv_I, lds, lane, fc1, tf1);
-    finger_contacts<2>(P, e, fk2, R, vq, v, w, inv_h, inv_m, inv_I, lds, lane, fc2, tf2);
+    finger_contacts<0>(P, e, fk0, R, vq, v, w, hc, inv_h, inv_m, inv_I, lds, lane, fc0, tf0);
+    finger_contacts<1>(P, e, fk1, R, vq, v, w, hc, inv_h, inv_m, inv_I, lds, lane, fc1, tf1);
+    finger_contacts<2>(P, e, fk2, R, vq, v, w, hc, inv_h, inv_m, inv_I, lds, lane, fc2, tf2);
     CubeContactRegs cf[4], cwl[4];
     {   // cube vs floor: corners of the face that points down most
         int k = 0;
@@ -925,23 +932,23 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     __syncthreads();   // LDS rows written above are read below (same lane; keeps the phases ordered)
     // ---- projected Gauss-Seidel ----
     for (int it = 0; it < P.iters; ++it) {
-        solve_finger_cube<0>(m, fc0, lds, lane, vq, v, w, inv_m, inv_I);
-        solve_finger_cube<1>(m, fc1, lds, lane, vq, v, w, inv_m, inv_I);
-        solve_finger_cube<2>(m, fc2, lds, lane, vq, v, w, inv_m, inv_I);
-        solve_tip_floor<0>(m, tf0, lds, lane, vq);
-        solve_tip_floor<1>(m, tf1, lds, lane, vq);
-        solve_tip_floor<2>(m, tf2, lds, lane, vq);
+        solve_finger_cube<0>(mu_fc, fc0, lds, lane, vq, v, w, inv_m, inv_I);
+        solve_finger_cube<1>(mu_fc, fc1, lds, lane, vq, v, w, inv_m, inv_I);
+        solve_finger_cube<2>(mu_fc, fc2, lds, lane, vq, v, w, inv_m, inv_I);
+        solve_tip_floor<0>(mu_tf, tf0, lds, lane, vq);
+        solve_tip_floor<1>(mu_tf, tf1, lds, lane, vq);
+        solve_tip_floor<2>(mu_tf, tf2, lds, lane, vq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {       // cube - floor: rows +z (normal), +x, +y
-            cube_row_z<0, true>(cf[i], m.mu_cube_floor, inv_m, inv_I, v, w);
-            cube_row_x<1>(cf[i], m.mu_cube_floor, inv_m, inv_I, v, w);
-            cube_row_y<2>(cf[i], m.mu_cube_floor, inv_m, inv_I, v, w);
+            cube_row_z<0, true>(cf[i], mu_cf, inv_m, inv_I, v, w);
+            cube_row_x<1>(cf[i], mu_cf, inv_m, inv_I, v, w);
+            cube_row_y<2>(cf[i], mu_cf, inv_m, inv_I, v, w);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {       // cube - wall: rows n (normal), t, +z
             wall_row_n(cwl[i], inv_m, inv_I, v, w);
-            wall_row_t(cwl[i], m.mu_cube_wall, inv_m, inv_I, v, w);
-            cube_row_z<2, false>(cwl[i], m.mu_cube_wall, inv_m, inv_I, v, w);
+            wall_row_t(cwl[i], mu_cw, inv_m, inv_I, v, w);
+            cube_row_z<2, false>(cwl[i], mu_cw, inv_m, inv_I, v, w);
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {       // joint limits + velocity limit
@@ -1012,6 +1019,8 @@ DEV void store_goal(const DevParams& P, int i, const Env& e, bool pred) {
     for (int j = 0; j < 4; ++j) ST(TF_S_GOAL_Q + j) = e.gq[j];
 }
 DEV void load_dyn(const DevParams& P, int i, Env& e) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e.dr[j] = ST(TF_S_DR + j);
 #pragma unroll
     for (int j = 0; j < 9; ++j) { e.q[j] = ST(TF_S_Q + j); e.qd[j] = ST(TF_S_QD + j); }
 #pragma unroll
@@ -1125,6 +1134,14 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
     uint32_t count = P.reset_count[i];
     if (rflag) {
         did_reset = true;
+        if (P.dr_enable) {      // build-defined domain randomisation: scale = lo + (hi - lo) u
+            float u[4];
+            rng4(P, gid, count, RNG_DR, u);
+            e.dr[0] = FMA(P.dr_cube_mass[1] - P.dr_cube_mass[0], u[0], P.dr_cube_mass[0]);
+            e.dr[1] = FMA(P.dr_cube_size[1] - P.dr_cube_size[0], u[1], P.dr_cube_size[0]);
+            e.dr[2] = FMA(P.dr_friction[1] - P.dr_friction[0], u[2], P.dr_friction[0]);
+            e.dr[3] = FMA(P.dr_motor[1] - P.dr_motor[0], u[3], P.dr_motor[0]);
+        }
         if (P.robot_reset_type == TF_RESET_DEFAULT) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) { e.q[j] = m.q_default[j % 3]; e.qd[j] = 0.0f; }
@@ -1139,7 +1156,7 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
             }
         }
         if (P.object_reset_type == TF_RESET_DEFAULT) {
-            e.cp[0] = 0.0f; e.cp[1] = 0.0f; e.cp[2] = CUBE_MIN_HEIGHT;
+            e.cp[0] = 0.0f; e.cp[1] = 0.0f; e.cp[2] = CUBE_MIN_HEIGHT * e.dr[1];
             e.cq[0] = 0.0f; e.cq[1] = 0.0f; e.cq[2] = 0.0f; e.cq[3] = 1.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) { e.cv[k] = 0.0f; e.cw[k] = 0.0f; }
@@ -1147,7 +1164,7 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
             float u[4];
             rng4(P, gid, count, RNG_OBJECT, u);
             sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, e.cp[0], e.cp[1]);
-            e.cp[2] = 0.065f / 2.0f;
+            e.cp[2] = (0.065f / 2.0f) * e.dr[1];
             sample_yaw_quat(u[2], e.cq);
 #pragma unroll
             for (int k = 0; k < 3; ++k) { e.cv[k] = 0.0f; e.cw[k] = 0.0f; }
@@ -1163,6 +1180,10 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
         if (rflag) { P.reset_buf[i] = 0; P.steps[i] = 0; P.successes[i] = 0; }
         if (gflag) P.goal_reset_buf[i] = 0;
         if (rflag || gflag) P.reset_count[i] = count;
+        if (rflag && P.dr_enable) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ST(TF_S_DR + j) = e.dr[j];
+        }
     }
     goal_changed = rflag || gflag;
     return did_reset;
@@ -1170,7 +1191,8 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
 
 // trifinger_env.py:442-494
 template <int A>
-DEV void compute_torque(const DevParams& P, const float* act, const float q[9], const float qd[9], float tau[9]) {
+DEV void compute_torque(const DevParams& P, const float* act, const float q[9], const float qd[9], float motor_scale,
+                        float tau[9]) {
     float at[A];
 #pragma unroll
     for (int j = 0; j < A; ++j) {
@@ -1192,7 +1214,7 @@ DEV void compute_torque(const DevParams& P, const float* act, const float q[9], 
             t = t - P.tables[TAB_KS + j] * qd[j];
             t = f_max(f_min(t, 0.36f), -0.36f);
         }
-        tau[j] = t;
+        tau[j] = t * motor_scale;     // domain randomisation of the motor strength (1.0 when off)
     }
 }
 
@@ -1496,7 +1518,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         __syncthreads();
         store_tile(P.action_buf, lds, wave_first, n_valid, A, lane);
         __syncthreads();
-        compute_torque<A>(P, act, e.q, e.qd, e.tau);
+        compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
         store_prev_obj(P, i, e, valid);                         // history[1] of the object (trifinger_env.py:975)
     }
     // ---- phase B: physics ----
@@ -1582,7 +1604,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_pre_step(const DevParams* __restric
     float act[A];
 #pragma unroll
     for (int j = 0; j < A; ++j) act[j] = P.action_buf[(size_t)i * A + j];
-    compute_torque<A>(P, act, e.q, e.qd, e.tau);
+    compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
 #pragma unroll
     for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
     store_dyn(P, i, e, valid);
@@ -1887,6 +1909,8 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     P.task_difficulty = cfg->task_difficulty; P.episode_length = cfg->episode_length;
     P.robot_reset_type = cfg->robot_reset_type; P.object_reset_type = cfg->object_reset_type;
     P.goal_rotation_activate = cfg->goal_rotation_activate;
+    P.dr_enable = cfg->dr_enable;
+    for (int i = 0; i < 2; ++i) { P.dr_cube_mass[i] = cfg->dr_cube_mass[i]; P.dr_cube_size[i] = cfg->dr_cube_size[i]; P.dr_friction[i] = cfg->dr_friction[i]; P.dr_motor[i] = cfg->dr_motor[i]; }
     P.dof_pos_stddev = cfg->dof_pos_stddev; P.dof_vel_stddev = cfg->dof_vel_stddev; P.goal_rate = cfg->goal_rotation_rate_magnitude;
     for (int t = 0; t < 6; ++t) P.rew_active[t] = cfg->reward[t].activate;
     P.success_activate = cfg->success_activate; P.success_bonus = cfg->success_bonus;

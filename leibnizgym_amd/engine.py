@@ -58,7 +58,8 @@ def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, co
                 enable_ft_sensors=False, task_difficulty=1, episode_length=750, control_decimation=1,
                 robot_reset="default", dof_pos_stddev=0.4, dof_vel_stddev=0.2, object_reset="random",
                 goal_rotation=False, goal_rotation_rate=0.5, reward_terms=None, success=None,
-                dt=0.02, substeps=2, solver_iterations=8, gravity=(0.0, 0.0, -9.81), model=None):
+                dt=0.02, substeps=2, solver_iterations=8, gravity=(0.0, 0.0, -9.81), model=None,
+                domain_randomization=None):
     """Build a TfConfig.  String options are validated here with the reference's ValueErrors."""
     if command_mode not in capi.COMMAND_MODES:
         raise ValueError(f"Invalid command mode. Input: {command_mode} not in ['torque', 'position'].")
@@ -102,6 +103,16 @@ def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, co
     cfg.solver_iterations = int(solver_iterations)
     for i in range(3):
         cfg.gravity[i] = float(gravity[i])
+    dr = {"activate": False, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "friction": (0.7, 1.3),
+          "motor_torque": (0.9, 1.1)}
+    dr.update(domain_randomization or {})
+    cfg.dr_enable = int(bool(dr["activate"]))
+    for name, field in (("cube_mass", cfg.dr_cube_mass), ("cube_size", cfg.dr_cube_size),
+                        ("friction", cfg.dr_friction), ("motor_torque", cfg.dr_motor)):
+        lo, hi = dr[name]
+        if not (0.0 < float(lo) <= float(hi)):
+            raise ValueError(f"domain_randomization.{name}: need 0 < lo <= hi, got {(lo, hi)}")
+        field[0], field[1] = float(lo), float(hi)
     cfg.model = model if model is not None else lib.default_model()
     return cfg
 
@@ -150,6 +161,7 @@ class TrifingerEngine:
         self.state[capi.S_CUBE_Q + 3] = 1.0     # identity quaternions (xyzw)
         self.state[capi.S_GOAL_Q + 3] = 1.0
         self.state[capi.S_PREV_OBJ_Q + 3] = 1.0
+        self.state[capi.S_DR:capi.S_DR + 4] = 1.0    # domain-randomisation scale factors
         self.action_buf = torch.zeros((n, self.action_dim), **f32)
         self.obs = torch.zeros((n, self.obs_dim), **f32)
         self.states = torch.zeros((n, self.states_dim), **f32)

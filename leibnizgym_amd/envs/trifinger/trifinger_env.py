@@ -46,6 +46,12 @@ TRIFINGER_DEFAULT_CONFIG_DICT = {
     "termination_conditions": {
         "success": {"activate": True, "bonus": 5000.0, "position_tolerance": 0.01, "orientation_tolerance": 0.2},
     },
+    # Build-defined (the reference ships no domain randomisation: leibnizgym/dr/__init__.py is empty, the hook is
+    # commented out at utils/config_utils.py:143-151).  Per-env scale factors ~ U[lo, hi] drawn at every reset.
+    "domain_randomization": {
+        "activate": False,
+        "cube_mass": [0.7, 1.3], "cube_size": [0.9, 1.1], "friction": [0.7, 1.3], "motor_torque": [0.9, 1.1],
+    },
 }
 
 
@@ -146,7 +152,7 @@ class TrifingerEnv(IsaacEnvBase):
             # with gymapi's default of 2.  "native.substeps" overrides it explicitly.
             substeps=int(native.get("substeps", 2)),
             solver_iterations=int(c["sim"]["physx"]["num_position_iterations"]),
-            gravity=c["sim"]["gravity"])
+            gravity=c["sim"]["gravity"], domain_randomization=c.get("domain_randomization"))
         return TrifingerEngine(cfg, device=self.device, lib=lib)
 
     def _configure_mdp_spaces(self):

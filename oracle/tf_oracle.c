@@ -144,7 +144,7 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 static inline float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; } /* [0,1) 24 bit */
 
 /* RNG stream tags (counter word 2) */
-enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4 };
+enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 };
 
 static void rng4(uint64_t seed, uint32_t env_gid, uint32_t count, uint32_t tag, float u[4]) {
     uint32_t r[4];
@@ -598,6 +598,7 @@ typedef struct {
     float gp[3], gq[4], gw[3];
     float tau[9];
     float ft[18];      /* accumulated fingertip wrench (world), summed over substeps */
+    float dr[4];       /* domain-randomisation scale factors: cube mass, cube size, friction, motor torque */
 } Env;
 
 /* one contact between finger f and something: three rows (normal + two tangents) */
@@ -790,7 +791,12 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     const TfConfig* cfg = &H->cfg;
     const TfModel* m = &cfg->model;
     const float inv_h = 1.0f / h;
-    const float inv_m = 1.0f / m->cube_mass, inv_I = 1.0f / m->cube_inertia;
+    /* per-env cube and friction parameters: nominal values times the domain-randomisation factors (1.0 when off) */
+    const float cube_mass = m->cube_mass * e->dr[0];
+    const float cube_inertia = m->cube_inertia * e->dr[0] * e->dr[1] * e->dr[1];
+    const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
+    const float mu_fc = m->mu_finger_cube * e->dr[2], mu_tf = m->mu_tip_floor * e->dr[2];
+    const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2];
     FK fk[3];
     float vq[9];                 /* joint velocities being solved */
     float v[3], w[3];            /* cube velocities being solved  */
@@ -815,7 +821,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     /* ---- contact generation (positions at the start of the substep) ---- */
     float R[9];
     quat_to_rot(e->cq, R);
-    const float hc = m->cube_half;
+    const float hc = m->cube_half * e->dr[1];
     FingerContact fc[3], tf_[3];
     CubeContact cf[4], cwl[4];
     for (int f = 0; f < 3; ++f) {
@@ -983,7 +989,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 cross3(c->rc, c->dir[d], rxd);
                 float vrel = dot3(c->Jf[d], vf) - (dot3(c->dir[d], v) + dot3(rxd, w));
                 float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
-                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, m->mu_finger_cube * c->lam[0]);
+                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, mu_fc * c->lam[0]);
                 for (int j = 0; j < 3; ++j) vf[j] = FMA(c->Wf[d][j], dl, vf[j]);
                 float sc = dl * inv_m, q = dl * inv_I;
                 for (int j = 0; j < 3; ++j) { v[j] = FMA(-c->dir[d][j], sc, v[j]); w[j] = FMA(-rxd[j], q, w[j]); }
@@ -996,19 +1002,19 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             for (int d = 0; d < 3; ++d) {
                 float vrel = dot3(c->Jf[d], vf);
                 float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
-                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, m->mu_tip_floor * c->lam[0]);
+                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, mu_tf * c->lam[0]);
                 for (int j = 0; j < 3; ++j) vf[j] = FMA(c->Wf[d][j], dl, vf[j]);
             }
         }
         for (int i = 0; i < 4; ++i) {             /* cube - floor: rows +z (normal), +x, +y */
-            cube_row_z(&cf[i], 0, 1, m->mu_cube_floor, inv_m, inv_I, v, w);
-            cube_row_x(&cf[i], 1, m->mu_cube_floor, inv_m, inv_I, v, w);
-            cube_row_y(&cf[i], 2, m->mu_cube_floor, inv_m, inv_I, v, w);
+            cube_row_z(&cf[i], 0, 1, mu_cf, inv_m, inv_I, v, w);
+            cube_row_x(&cf[i], 1, mu_cf, inv_m, inv_I, v, w);
+            cube_row_y(&cf[i], 2, mu_cf, inv_m, inv_I, v, w);
         }
         for (int i = 0; i < 4; ++i) {             /* cube - wall: rows n (normal), t, +z */
             wall_row_n(&cwl[i], inv_m, inv_I, v, w);
-            wall_row_t(&cwl[i], m->mu_cube_wall, inv_m, inv_I, v, w);
-            cube_row_z(&cwl[i], 2, 0, m->mu_cube_wall, inv_m, inv_I, v, w);
+            wall_row_t(&cwl[i], mu_cw, inv_m, inv_I, v, w);
+            cube_row_z(&cwl[i], 2, 0, mu_cw, inv_m, inv_I, v, w);
         }
         for (int j = 0; j < 9; ++j) {             /* joint limits + velocity limit */
             int f = j / 3, jj = j % 3;
@@ -1064,6 +1070,7 @@ static void env_load(const struct TfHandle_* h, int i, Env* e) {
     }
     for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
     for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
+    for (int j = 0; j < 4; ++j) e->dr[j] = ST(h, TF_S_DR + j, i);
 }
 static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_ft) {
     for (int j = 0; j < 9; ++j) { ST(h, TF_S_Q + j, i) = e->q[j]; ST(h, TF_S_QD + j, i) = e->qd[j]; ST(h, TF_S_TAU + j, i) = e->tau[j]; }
@@ -1073,6 +1080,7 @@ static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_
     }
     for (int j = 0; j < 4; ++j) { ST(h, TF_S_CUBE_Q + j, i) = e->cq[j]; ST(h, TF_S_GOAL_Q + j, i) = e->gq[j]; }
     if (store_ft) for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
+    for (int j = 0; j < 4; ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1153,6 +1161,14 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
         h->buf.reset_buf[i] = 0;
         h->buf.steps[i] = 0;
         h->buf.successes[i] = 0;
+        if (c->dr_enable) {     /* build-defined domain randomisation: scale = lo + (hi - lo) u */
+            float u[4];
+            rng4(c->seed, gid, count, RNG_DR, u);
+            e->dr[0] = FMA(c->dr_cube_mass[1] - c->dr_cube_mass[0], u[0], c->dr_cube_mass[0]);
+            e->dr[1] = FMA(c->dr_cube_size[1] - c->dr_cube_size[0], u[1], c->dr_cube_size[0]);
+            e->dr[2] = FMA(c->dr_friction[1] - c->dr_friction[0], u[2], c->dr_friction[0]);
+            e->dr[3] = FMA(c->dr_motor[1] - c->dr_motor[0], u[3], c->dr_motor[0]);
+        }
         if (c->robot_reset_type == TF_RESET_DEFAULT) {
             for (int j = 0; j < 9; ++j) { e->q[j] = m->q_default[j % 3]; e->qd[j] = 0.0f; }
         } else if (c->robot_reset_type == TF_RESET_RANDOM) {   /* trifinger_env.py:1125-1141 */
@@ -1164,14 +1180,14 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
             }
         }
         if (c->object_reset_type == TF_RESET_DEFAULT) {
-            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = CUBE_MIN_HEIGHT;
+            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = CUBE_MIN_HEIGHT * e->dr[1];
             e->cq[0] = 0.0f; e->cq[1] = 0.0f; e->cq[2] = 0.0f; e->cq[3] = 1.0f;
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
         } else if (c->object_reset_type == TF_RESET_RANDOM) {  /* trifinger_env.py:1169-1173 */
             float u[4];
             rng4(c->seed, gid, count, RNG_OBJECT, u);
             sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, &e->cp[0], &e->cp[1]);
-            e->cp[2] = 0.065f / 2.0f;
+            e->cp[2] = (0.065f / 2.0f) * e->dr[1];
             sample_yaw_quat(u[2], e->cq);
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
         }
@@ -1189,7 +1205,7 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
 
 /* trifinger_env.py:442-494 */
 static void compute_torque(const struct TfHandle_* h, const float* act, const float q[9], const float qd[9],
-                           float tau[9]) {
+                           float motor_scale, float tau[9]) {
     const TfConfig* c = &h->cfg;
     int A = h->action_dim;
     float at[18];
@@ -1209,7 +1225,7 @@ static void compute_torque(const struct TfHandle_* h, const float* act, const fl
             t = t - h->ks[j] * qd[j];
             t = f_max(f_min(t, 0.36f), -0.36f);
         }
-        tau[j] = t;
+        tau[j] = t * motor_scale;     /* domain randomisation of the motor strength (1.0 when off) */
     }
 }
 
@@ -1449,7 +1465,7 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
                 for (int j = 0; j < A; ++j) abuf[j] = 0.0f;                  /* trifinger_env.py:387 */
                 local.resets += 1.0;
             }
-            compute_torque(h, abuf, e.q, e.qd, e.tau);
+            compute_torque(h, abuf, e.q, e.qd, e.dr[3], e.tau);
             float prev_obj[7] = {e.cp[0], e.cp[1], e.cp[2], e.cq[0], e.cq[1], e.cq[2], e.cq[3]};
             for (int j = 0; j < 3; ++j) ST(h, TF_S_PREV_OBJ_P + j, i) = e.cp[j];   /* history[1] of the object */
             for (int j = 0; j < 4; ++j) ST(h, TF_S_PREV_OBJ_Q + j, i) = e.cq[j];
@@ -1512,7 +1528,7 @@ int tf_pre_step(tf_handle h, void* stream) {
     for (int i = 0; i < h->cfg.num_envs; ++i) {
         Env e;
         env_load(h, i, &e);
-        compute_torque(h, &h->buf.action_buf[(size_t)i * (size_t)A], e.q, e.qd, e.tau);
+        compute_torque(h, &h->buf.action_buf[(size_t)i * (size_t)A], e.q, e.qd, e.dr[3], e.tau);
         for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
         env_store(h, i, &e, 1);
         for (int j = 0; j < 3; ++j) ST(h, TF_S_PREV_OBJ_P + j, i) = e.cp[j];

@@ -36,6 +36,14 @@ CONFIGS = {
     "envdefault_position": dict(command_mode="position", task_difficulty=1, asymmetric_obs=True,
                                 success={"activate": True, "bonus": 5000.0, "position_tolerance": 0.05,
                                          "orientation_tolerance": 0.2}),
+    # BASELINE config 4 shape: difficulty 4 + (build-defined) domain randomisation
+    "d4_domain_randomization": dict(command_mode="torque", task_difficulty=4, asymmetric_obs=True,
+                                    reward_terms=D4_REWARDS,
+                                    domain_randomization={"activate": True, "cube_mass": (0.5, 1.5),
+                                                          "cube_size": (0.85, 1.1), "friction": (0.5, 1.4),
+                                                          "motor_torque": (0.8, 1.2)},
+                                    success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.02,
+                                             "orientation_tolerance": 0.25}),
     # everything else: impedance actions (A=18), random robot reset, moving goal, difficulty 3, decimation 2
     "impedance_random_moving": dict(command_mode="position_impedance", task_difficulty=3, asymmetric_obs=True,
                                     robot_reset="random", goal_rotation=True, control_decimation=2,
