@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""End-to-end PPO on the native TriFinger env (BASELINE config 5: difficulty 4, 8192 envs per GPU).
+
+    python scripts/train_ppo.py gym=trifinger_difficulty_4 args.num_envs=8192 [epochs=20]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ppo.py ...
+
+One process per GPU; envs are sharded (no data-path collective), gradients are averaged with one fused RCCL
+all-reduce per minibatch.  Uses RL-Games' hyper-parameters of resources/config/rlg/asymm.yaml (leibnizgym_amd/ppo.py)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from leibnizgym_amd.config import compose  # noqa: E402
+from leibnizgym_amd.envs import TrifingerEnv  # noqa: E402
+from leibnizgym_amd.ppo import PPOConfig, PPOTrainer  # noqa: E402
+from leibnizgym_amd.utils.rlg_train import RlGamesGpuEnvAdapter  # noqa: E402
+from leibnizgym_amd.wrappers import VecTaskPython  # noqa: E402
+
+
+def main(argv):
+    epochs = 20
+    rest = []
+    for a in argv:
+        if a.startswith("epochs="):
+            epochs = int(a.split("=", 1)[1])
+        else:
+            rest.append(a)
+    cfg = compose(rest)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    n = cfg["gym"]["num_instances"]                 # envs per GPU
+    env = TrifingerEnv(config=cfg["gym"], device=dev, verbose=False, env_id_offset=rank * n,
+                       global_num_instances=world * n)
+    adapter = RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device=dev))
+    tr = PPOTrainer(adapter, env.get_obs_dim(), env.get_state_dim(), env.get_action_dim(),
+                    PPOConfig(seed=cfg["args"]["seed"]), device=dev)
+    t0 = time.perf_counter()
+
+    def log(st):
+        if rank == 0:
+            dt = time.perf_counter() - t0
+            print(f"epoch {st['epoch']:4d} frames {st['frames'] * world:10d} reward/step {st['mean_reward']:9.3f} "
+                  f"kl {st['kl']:.4f} lr {st['lr']:.2e} loss {st['loss']:.4f}  {st['frames'] * world / dt:.3e} frames/s",
+                  flush=True)
+    tr.train(epochs, log)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,79 @@
+"""The in-repo PPO (BASELINE config 5 glue) on the CPU with the oracle env injected: shapes, finite
+losses, parameters move, GAE against a hand computation, and 2-rank gradient averaging (gloo)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from leibnizgym_amd.config import gym_config
+from leibnizgym_amd.envs import TrifingerEnv
+from leibnizgym_amd.ppo import ActorCritic, PPOConfig, PPOTrainer
+from leibnizgym_amd.utils.rlg_train import RlGamesGpuEnvAdapter
+from leibnizgym_amd.wrappers import VecTaskPython
+
+
+def make(oracle, n=32, **kw):
+    cfg = gym_config("trifinger_difficulty_4")
+    cfg.update(num_instances=n, seed=1, physics_engine="physx", asymmetric_obs=True, episode_length=20)
+    env = TrifingerEnv(config=cfg, device="cpu", verbose=False, lib=oracle, **kw)
+    return env, RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device="cpu"))
+
+
+def test_network_shapes_match_asymm_yaml():
+    net = ActorCritic(41, 113, 9, [400, 200, 100])
+    actor = sum(p.numel() for p in net.actor.parameters()) + net.log_std.numel()
+    critic = sum(p.numel() for p in net.critic.parameters())
+    assert actor == 41 * 400 + 400 + 400 * 200 + 200 + 200 * 100 + 100 + 100 * 9 + 9 + 9      # ~118 k
+    assert critic == 113 * 400 + 400 + 400 * 200 + 200 + 200 * 100 + 100 + 100 + 1            # ~146 k
+
+
+def test_two_epochs_run_and_learn_something(oracle):
+    env, ad = make(oracle)
+    tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2), device="cpu")
+    before = [p.detach().clone() for p in tr.net.parameters()]
+    stats = tr.train(2)
+    assert len(stats) == 2 and all(torch.isfinite(torch.tensor([s["loss"], s["kl"]])).all() for s in stats)
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.net.parameters()))
+    assert tr.frames == 2 * 8 * 32 and stats[-1]["c_loss"] >= 0
+
+
+def test_gae_matches_hand_computation(oracle):
+    env, ad = make(oracle, n=4)
+    c = PPOConfig(horizon=3, minibatches=1, mini_epochs=1)
+    tr = PPOTrainer(ad, 41, 113, 9, c, device="cpu")
+    buf = tr.rollout()
+    r, v, d = buf["rew"], buf["val"], buf["done"]
+    adv = torch.zeros(3, 4)
+    last = torch.zeros(4)
+    for t in (2, 1, 0):
+        nd = 1 - d[t]
+        delta = r[t] + c.gamma * v[t + 1] * nd - v[t]
+        last = delta + c.gamma * c.tau * nd * last
+        adv[t] = last
+    assert torch.allclose(buf["adv"], adv) and torch.allclose(buf["ret"], adv + v[:3])
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_util import load_oracle
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    env, ad = make(load_oracle(), n=16, env_id_offset=rank * 16, global_num_instances=32)
+    tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=4, minibatches=2, mini_epochs=1, seed=5), device="cpu")
+    tr.train(1)
+    torch.save([p.detach().clone() for p in tr.net.parameters()], os.path.join(out, f"w{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_stay_in_sync(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0, w1 = (torch.load(os.path.join(tmp_path, f"w{r}.pt")) for r in range(2))
+    # different env shards and different sampled actions, one averaged gradient: identical weights afterwards
+    assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(w0, w1))
