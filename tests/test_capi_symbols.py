@@ -92,3 +92,32 @@ def test_product_package_never_imports_the_oracle():
                     code = line.split("#")[0].split("//")[0]
                     assert "oracle_util" not in code and "tf_oracle" not in code and "libtrifinger_oracle" not in code, \
                         (f, line)
+
+
+def test_create_rejects_bad_configs(oracle):
+    """Empty / invalid inputs at the C boundary: status codes, not crashes."""
+    import ctypes as C
+    from leibnizgym_amd.engine import make_config
+    for lib in (oracle, hip_lib()):
+        h = C.c_void_p()
+        cfg = make_config(lib, 4)
+        cfg.num_envs = 0                                   # empty batch
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
+        cfg = make_config(lib, 4); cfg.command_mode = 9
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_COMMAND_MODE
+        cfg = make_config(lib, 4); cfg.task_difficulty = 0
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_DIFFICULTY
+        cfg = make_config(lib, 4); cfg.robot_reset_type = 5
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_ROBOT_RESET
+        cfg = make_config(lib, 4); cfg.object_reset_type = -1
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_OBJECT_RESET
+        cfg = make_config(lib, 4); cfg.finger_reach_norm_p = 1
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_UNSUPPORTED
+        cfg = make_config(lib, 4); cfg.api_version = 99
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
+        assert lib.tf_step(None, None, None) == capi.TF_ERR_INVALID_ARG
+    # unbound handle on the oracle (no device needed)
+    h = C.c_void_p()
+    assert oracle.tf_create(C.byref(make_config(oracle, 4)), C.byref(h)) == 0
+    assert oracle.tf_step(h, C.c_void_p(1), None) == capi.TF_ERR_NOT_BOUND
+    oracle.tf_destroy(h)
