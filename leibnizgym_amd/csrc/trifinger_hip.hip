@@ -39,6 +39,16 @@
 // ------------------------------------------------------------------------------------------------------
 // device-side parameter block (kernel argument, lives in SGPRs / scalar cache)
 // ------------------------------------------------------------------------------------------------------
+// table rows
+#define TAB_OFF 0
+#define TAB_INV (MAX_STATES)
+#define TAB_ACT_LO (2 * MAX_STATES)
+#define TAB_ACT_HI (2 * MAX_STATES + 18)
+#define TAB_KP (2 * MAX_STATES + 36)
+#define TAB_KD (2 * MAX_STATES + 45)
+#define TAB_KS (2 * MAX_STATES + 54)
+#define TAB_FLOATS (2 * MAX_STATES + 63)
+
 struct RewardCoef {
     float c_reach, c_move_pen, dt, c_dist, rot_num, rot_scale, w_rot, rot_delta_sched, w_rot_delta, w_move;
 };
@@ -58,7 +68,6 @@ struct DevParams {
     uint32_t* reset_count;
     float* info;
     float* scratch;
-    const float* tables;      // [4][MAX_STATES]: obs/states offset, obs/states 1/range ; then act_lo/hi, kp kd ks
     // sizes
     int32_t N, A, OD, SD;
     int32_t env_id_offset;
@@ -78,6 +87,9 @@ struct DevParams {
     float dt, hsub;
     float grav[3];
     TfModel m;
+    // obs/states offset and 1/range tables, action limits, PD gains (index = TAB_*).  Embedded so that every access
+    // is a scalar load at a constant offset of the parameter block (a pointer member would be fetched per lane).
+    float tables[TAB_FLOATS];
 };
 
 // what changes every launch travels by value; everything else is read through a pointer to constant
@@ -88,20 +100,17 @@ struct StepArgs {
     int32_t nsim;
 };
 
-// table rows
-#define TAB_OFF 0
-#define TAB_INV (MAX_STATES)
-#define TAB_ACT_LO (2 * MAX_STATES)
-#define TAB_ACT_HI (2 * MAX_STATES + 18)
-#define TAB_KP (2 * MAX_STATES + 36)
-#define TAB_KD (2 * MAX_STATES + 45)
-#define TAB_KS (2 * MAX_STATES + 54)
-#define TAB_FLOATS (2 * MAX_STATES + 63)
 
 // ------------------------------------------------------------------------------------------------------
 // deterministic elementary functions (Cephes single-precision polynomials; identical to the oracle's)
 // ------------------------------------------------------------------------------------------------------
 #define DEV __device__ __forceinline__
+
+// Every workgroup of the env kernels is ONE wavefront.  LDS operations of a wave are executed in order by the LDS
+// unit, so lane-to-lane hand-offs through LDS (tile transposes, contact rows) need no s_barrier and no counter
+// drain - only the compiler must keep the program order.  A wavefront-scope fence does exactly that and emits no
+// instruction; __syncthreads() would add `s_waitcnt vmcnt(0)` (waits for every outstanding global store) each time.
+#define WAVE_LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
@@ -929,7 +938,7 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
         lim_dinv[j] = 1.0f / k.Minv[dg];
         lim_lam[j] = 0.0f;
     }
-    __syncthreads();   // LDS rows written above are read below (same lane; keeps the phases ordered)
+    WAVE_LDS_ORDER();   // LDS rows written above are read below (same lane; keeps the phases ordered)
     // ---- projected Gauss-Seidel ----
     for (int it = 0; it < P.iters; ++it) {
         solve_finger_cube<0>(mu_fc, fc0, lds, lane, vq, v, w, inv_m, inv_I);
@@ -977,7 +986,7 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
         add_wrench<true>(fc2, lds, lane, FC_BASE(2), inv_h, &e.ft[12]);
         add_wrench<false>(tf2, lds, lane, TF_BASE(2), inv_h, &e.ft[12]);
     }
-    __syncthreads();
+    WAVE_LDS_ORDER();
     // ---- integrate ----
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -1334,11 +1343,11 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     _Pragma("unroll") for (int j = 0; j < 3; ++j) EMIT(W, 25 + j, e.gp[j])             \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) EMIT(W, 28 + j, e.gq[j])             \
     _Pragma("unroll") for (int j = 0; j < A; ++j) EMIT(W, 32 + j, opaque(act[j]))
-    __syncthreads();
+    WAVE_LDS_ORDER();
     EMIT_COMMON(OD)
-    __syncthreads();
+    WAVE_LDS_ORDER();
     store_tile(P.obs, lds, wave_first, n_valid, OD, lane);
-    __syncthreads();
+    WAVE_LDS_ORDER();
     if (P.asymmetric_obs) {
         EMIT_COMMON(SD)
 #pragma unroll
@@ -1364,9 +1373,9 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
         wrench_local<2>(P, e, inv_n, wl);
 #pragma unroll
         for (int j = 0; j < 6; ++j) EMIT(SD, OD + 66 + j, wl[j])
-        __syncthreads();
+        WAVE_LDS_ORDER();
         store_tile(P.states, lds, wave_first, n_valid, SD, lane);
-        __syncthreads();
+        WAVE_LDS_ORDER();
     }
 #undef EMIT_COMMON
 #undef EMIT
@@ -1493,11 +1502,11 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
             const float* src = action + (size_t)wave_first * (size_t)A;
             const int total = n_valid * A;
             for (int idx = lane; idx < total; idx += WAVE) lds[idx] = src[idx];
-            __syncthreads();
+            WAVE_LDS_ORDER();
             const int row = valid ? lane : (n_valid - 1);
 #pragma unroll
             for (int j = 0; j < A; ++j) act[j] = lds[row * A + j];
-            __syncthreads();
+            WAVE_LDS_ORDER();
         } else {
 #pragma unroll
             for (int j = 0; j < A; ++j) act[j] = 0.0f;
@@ -1515,9 +1524,9 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         // _action_buf (what the observation reports as the last command): transposed back through LDS
 #pragma unroll
         for (int j = 0; j < A; ++j) lds[lane * A + j] = act[j];
-        __syncthreads();
+        WAVE_LDS_ORDER();
         store_tile(P.action_buf, lds, wave_first, n_valid, A, lane);
-        __syncthreads();
+        WAVE_LDS_ORDER();
         compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
         store_prev_obj(P, i, e, valid);                         // history[1] of the object (trifinger_env.py:975)
     }
@@ -1527,7 +1536,10 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
     const int nsub = sa.nsim * P.substeps;
     for (int s = 0; s < nsub; ++s) substep<ASYM>(P, e, P.hsub, lds, lane);
     // ---- phase C: observations, rewards, termination, counters ----
-    __syncthreads();
+    // rows written in phase A (action_buf tile, goal, previous object pose) are re-read below, possibly by other
+    // lanes of this wave: make sure those stores have completed (they were issued ~100 us ago: no stall)
+    __builtin_amdgcn_s_waitcnt(0);
+    WAVE_LDS_ORDER();
     {
         LaneStats st;
         stats_zero(st);
@@ -1589,7 +1601,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_apply_resets(const DevParams* __res
     for (int j = 0; j < A; ++j) act[j] = did ? 0.0f : P.action_buf[(size_t)row * A + j];
 #pragma unroll
     for (int j = 0; j < A; ++j) lds[lane * A + j] = act[j];
-    __syncthreads();
+    WAVE_LDS_ORDER();
     store_tile(P.action_buf, lds, wave_first, n_valid, A, lane);
     load_split_extras(P, i, e);
     store_dyn(P, i, e, valid);
@@ -1730,7 +1742,6 @@ struct TfHandle_ {
     int bound;
     int64_t frame_count;
     int action_dim;
-    float* d_tables;
     // optional kernel timing (bench.py): event pairs around the fused step kernel
     hipEvent_t* ev;          // [2 * ev_cap]
     int ev_cap, ev_used;
@@ -1892,15 +1903,10 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     h->cfg = *cfg;
     if (h->cfg.global_num_envs <= 0) h->cfg.global_num_envs = cfg->num_envs;
     h->action_dim = tf_action_dim(cfg->command_mode);
-    float tab[TAB_FLOATS];
     int od = 0, sd = 0;
-    build_tables(&h->cfg, h->action_dim, tab, &od, &sd);
-    hipError_t e = hipMalloc((void**)&h->d_tables, sizeof(tab));
-    if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(tables)"); }
-    e = hipMemcpy(h->d_tables, tab, sizeof(tab), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(h->d_tables); delete h; return hip_fail(e, "hipMemcpy(tables)"); }
     DevParams& P = h->dp;
-    P.tables = h->d_tables;
+    build_tables(&h->cfg, h->action_dim, P.tables, &od, &sd);
+    hipError_t e;
     P.N = cfg->num_envs; P.A = h->action_dim; P.OD = od; P.SD = sd;
     P.env_id_offset = cfg->env_id_offset;
     P.seed_lo = (uint32_t)cfg->seed; P.seed_hi = (uint32_t)(cfg->seed >> 32);
@@ -1920,16 +1926,15 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     for (int i = 0; i < 3; ++i) P.grav[i] = cfg->gravity[i];
     P.m = cfg->model;
     e = hipMalloc((void**)&h->d_params, sizeof(DevParams));
-    if (e != hipSuccess) { (void)hipFree(h->d_tables); delete h; return hip_fail(e, "hipMalloc(params)"); }
+    if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(params)"); }
     e = hipMemcpy(h->d_params, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(h->d_tables); (void)hipFree(h->d_params); delete h; return hip_fail(e, "hipMemcpy(params)"); }
+    if (e != hipSuccess) { (void)hipFree(h->d_params); delete h; return hip_fail(e, "hipMemcpy(params)"); }
     *out = h;
     return TF_OK;
 }
 
 int tf_destroy(tf_handle h) {
     if (!h) return TF_OK;
-    if (h->d_tables) (void)hipFree(h->d_tables);
     if (h->d_params) (void)hipFree(h->d_params);
     free_events(h);
     delete h;
