@@ -748,23 +748,41 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
     }
 }
 
-// PGS rows of the finger-cube contact of finger F (reads J/W/dir/rc from LDS)
+// Finger contact rows staged in LDS are fetched one contact AHEAD of their use (software pipeline): with a single
+// wave per SIMD nothing else hides the ~100+ cycle LDS round trip.
+struct FcRows { float Jf[9], Wf[9], dir[9], rc[3]; };
+struct TfRows { float Jf[9], Wf[9]; };
+template <int F> DEV void load_fc_rows(const float* lds, int lane, FcRows& r) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        r.Jf[j] = LDS_AT(FC_BASE(F) + j);
+        r.Wf[j] = LDS_AT(FC_BASE(F) + 9 + j);
+        r.dir[j] = LDS_AT(FC_BASE(F) + 18 + j);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.rc[j] = LDS_AT(FC_BASE(F) + 27 + j);
+}
+template <int F> DEV void load_tf_rows(const float* lds, int lane, TfRows& r) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        r.Jf[j] = LDS_AT(TF_BASE(F) + j);
+        r.Wf[j] = LDS_AT(TF_BASE(F) + 9 + j);
+    }
+}
+
+// PGS rows of the finger-cube contact of finger F
 template <int F>
-DEV void solve_finger_cube(float mu, FingerContactRegs& c, const float* lds, int lane, float* vq, float v[3],
-                           float w[3], float inv_m, float inv_I) {
+DEV void solve_finger_cube(float mu, FingerContactRegs& c, const FcRows& r, float* vq, float v[3], float w[3],
+                           float inv_m, float inv_I) {
     if (!c.active) return;
     float* vf = &vq[3 * F];
-    float rc[3] = {LDS_AT(FC_BASE(F) + 27), LDS_AT(FC_BASE(F) + 28), LDS_AT(FC_BASE(F) + 29)};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float Jf[3], Wf[3], dir[3], rxd[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Jf[j] = LDS_AT(FC_BASE(F) + d * 3 + j);
-            Wf[j] = LDS_AT(FC_BASE(F) + 9 + d * 3 + j);
-            dir[j] = LDS_AT(FC_BASE(F) + 18 + d * 3 + j);
-        }
-        cross3(rc, dir, rxd);
+        const float* Jf = &r.Jf[3 * d];
+        const float* Wf = &r.Wf[3 * d];
+        const float* dir = &r.dir[3 * d];
+        float rxd[3];
+        cross3(r.rc, dir, rxd);
         float vrel = dot3(Jf, vf) - (dot3(dir, v) + dot3(rxd, w));
         float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
                             : solve_tangent(c.lam[d], c.Dinv[d], vrel, mu * c.lam[0]);
@@ -776,17 +794,13 @@ DEV void solve_finger_cube(float mu, FingerContactRegs& c, const float* lds, int
     }
 }
 template <int F>
-DEV void solve_tip_floor(float mu, FingerContactRegs& c, const float* lds, int lane, float* vq) {
+DEV void solve_tip_floor(float mu, FingerContactRegs& c, const TfRows& r, float* vq) {
     if (!c.active) return;
     float* vf = &vq[3 * F];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float Jf[3], Wf[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            Jf[j] = LDS_AT(TF_BASE(F) + d * 3 + j);
-            Wf[j] = LDS_AT(TF_BASE(F) + 9 + d * 3 + j);
-        }
+        const float* Jf = &r.Jf[3 * d];
+        const float* Wf = &r.Wf[3 * d];
         float vrel = dot3(Jf, vf);
         float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
                             : solve_tangent(c.lam[d], c.Dinv[d], vrel, mu * c.lam[0]);
@@ -940,13 +954,22 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     }
     WAVE_LDS_ORDER();   // LDS rows written above are read below (same lane; keeps the phases ordered)
     // ---- projected Gauss-Seidel ----
+    FcRows ra, rb;
+    TfRows ta, tb;
+    load_fc_rows<0>(lds, lane, ra);
     for (int it = 0; it < P.iters; ++it) {
-        solve_finger_cube<0>(mu_fc, fc0, lds, lane, vq, v, w, inv_m, inv_I);
-        solve_finger_cube<1>(mu_fc, fc1, lds, lane, vq, v, w, inv_m, inv_I);
-        solve_finger_cube<2>(mu_fc, fc2, lds, lane, vq, v, w, inv_m, inv_I);
-        solve_tip_floor<0>(mu_tf, tf0, lds, lane, vq);
-        solve_tip_floor<1>(mu_tf, tf1, lds, lane, vq);
-        solve_tip_floor<2>(mu_tf, tf2, lds, lane, vq);
+        load_fc_rows<1>(lds, lane, rb);
+        solve_finger_cube<0>(mu_fc, fc0, ra, vq, v, w, inv_m, inv_I);
+        load_fc_rows<2>(lds, lane, ra);
+        solve_finger_cube<1>(mu_fc, fc1, rb, vq, v, w, inv_m, inv_I);
+        load_tf_rows<0>(lds, lane, ta);
+        solve_finger_cube<2>(mu_fc, fc2, ra, vq, v, w, inv_m, inv_I);
+        load_tf_rows<1>(lds, lane, tb);
+        solve_tip_floor<0>(mu_tf, tf0, ta, vq);
+        load_tf_rows<2>(lds, lane, ta);
+        solve_tip_floor<1>(mu_tf, tf1, tb, vq);
+        load_fc_rows<0>(lds, lane, ra);          // for the next sweep; hidden behind the register-only rows below
+        solve_tip_floor<2>(mu_tf, tf2, ta, vq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {       // cube - floor: rows +z (normal), +x, +y
             cube_row_z<0, true>(cf[i], mu_cf, inv_m, inv_I, v, w);
