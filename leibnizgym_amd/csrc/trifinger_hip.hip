@@ -487,15 +487,18 @@ struct Env {
     float dr[4];     // domain-randomisation scale factors: cube mass, cube size, friction, motor torque
 };
 
-// LDS layout, floats per lane: finger-cube contact f at FC_BASE(f): Jf[3][3] Wf[3][3] dir[3][3] rc[3] (30);
-// tip-floor contact f at TF_BASE(f): Jf[3][3] Wf[3][3] (18).  Stored [slot][lane].
-#define FC_BASE(f) ((f) * 30)
-#define TF_BASE(f) (90 + (f) * 18)
-#define LDS_SLOTS 144
-#define LDS_FLOATS (LDS_SLOTS * WAVE)
+// LDS is used for the row-major API tiles only ([64][W] transposes); W <= MAX_STATES.
+#define LDS_FLOATS (WAVE * MAX_STATES)
 
-struct FingerContactRegs {   // the small per-contact scalars stay in VGPRs
+// One finger contact (capsule-cube or tip-floor): three rows (normal + two tangents).  The Jacobian rows J, M^-1 J^T,
+// the world directions and the cube arm are loop-invariant over the solver sweeps and live in the register file
+// (the allocator parks the cold part in AGPRs: v_accvgpr_read, no wait counters) - measured faster than re-reading
+// them from LDS every sweep with only one wave per SIMD to hide the LDS round trip.
+struct FingerContactRegs {
     bool active;
+    float Jf[9], Wf[9];      // row d at [3d .. 3d+2]
+    float dir[9];            // world n, t1, t2 (capsule-cube contact only)
+    float rc[3];             // cube arm (capsule-cube contact only)
     float Dinv[3];
     float bias;
     float arm[3];
@@ -511,13 +514,10 @@ struct CubeContactRegs {
     float lam[3];
 };
 
-#define LDS_AT(slot) lds[(slot) * WAVE + lane]
-
-// rows of one finger contact: point Pb (base frame), world normal, cube arm rc.  Writes J / W / dir / rc to LDS.
+// rows of one finger contact: point Pb (base frame), world normal, cube arm rc
 template <int F, bool WITH_CUBE>
 DEV void finger_rows(const TfModel& m, const FK& k, const float Pb[3], const float n_w[3], const float rc[3],
-                     float inv_m, float inv_I, float* lds, int lane, int base, FingerContactRegs& c, float Jn[3],
-                     float dirn[3]) {
+                     float inv_m, float inv_I, FingerContactRegs& c) {
     float t1[3], t2[3];
     tangent_basis(n_w, t1, t2);
     float L1[3], L2[3], L3[3];
@@ -525,30 +525,22 @@ DEV void finger_rows(const TfModel& m, const FK& k, const float Pb[3], const flo
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float* dw = (d == 0) ? n_w : ((d == 1) ? t1 : t2);
-        float db[3], Jf[3], Wf[3];
+        float db[3];
+        float* Jf = &c.Jf[3 * d];
+        float* Wf = &c.Wf[3 * d];
         dir_world_to_base<F>(m, dw, db);
         Jf[0] = dot3(L1, db); Jf[1] = dot3(L2, db); Jf[2] = dot3(L3, db);
         sym3_mul(k.Minv, Jf, Wf);
         float D = dot3(Jf, Wf);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            LDS_AT(base + d * 3 + j) = Jf[j];
-            LDS_AT(base + 9 + d * 3 + j) = Wf[j];
-        }
         if (WITH_CUBE) {
             float rxd[3];
             cross3(rc, dw, rxd);
             D = FMA(dot3(rxd, rxd), inv_I, D + inv_m);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) LDS_AT(base + 18 + d * 3 + j) = dw[j];
+            c.dir[3 * d] = dw[0]; c.dir[3 * d + 1] = dw[1]; c.dir[3 * d + 2] = dw[2];
         }
-        if (d == 0) { Jn[0] = Jf[0]; Jn[1] = Jf[1]; Jn[2] = Jf[2]; dirn[0] = dw[0]; dirn[1] = dw[1]; dirn[2] = dw[2]; }
         c.Dinv[d] = 1.0f / D;
     }
-    if (WITH_CUBE) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) LDS_AT(base + 27 + j) = rc[j];
-    }
+    if (WITH_CUBE) { c.rc[0] = rc[0]; c.rc[1] = rc[1]; c.rc[2] = rc[2]; }
 }
 
 DEV void cube_corner(const float R[9], float hc, int k, float sk, int idx, float r[3]) {
@@ -644,6 +636,9 @@ DEV void wall_row_t(CubeContactRegs& c, float mu, float inv_m, float inv_I, floa
 
 DEV void finger_contact_zero(FingerContactRegs& c) {
     c.active = false;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { c.Jf[j] = 0.0f; c.Wf[j] = 0.0f; c.dir[j] = 0.0f; }
+    c.rc[0] = 0.0f; c.rc[1] = 0.0f; c.rc[2] = 0.0f;
     c.lam[0] = 0.0f; c.lam[1] = 0.0f; c.lam[2] = 0.0f;
     c.bias = 0.0f;
     c.Dinv[0] = 0.0f; c.Dinv[1] = 0.0f; c.Dinv[2] = 0.0f;
@@ -658,8 +653,8 @@ DEV void cube_contact_zero(CubeContactRegs& c) {
 // ---- contact generation for finger F (capsule vs cube, tip vs floor) ----
 template <int F>
 DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const float R[9], const float* vq,
-                         const float v[3], const float w[3], float hc, float inv_h, float inv_m, float inv_I, float* lds,
-                         int lane, FingerContactRegs& c, FingerContactRegs& g) {
+                         const float v[3], const float w[3], float hc, float inv_h, float inv_m, float inv_I,
+                         FingerContactRegs& c, FingerContactRegs& g) {
     const TfModel& m = P.m;
     float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3], Tw[3];
     rot_link<3>(k, m.cap_a, t);
@@ -722,13 +717,12 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
         float Pb[3];
         dir_world_to_base<F>(m, Pr, Pb);
         c.active = true;
-        float Jn[3], dirn[3];
-        finger_rows<F, true>(m, k, Pb, n_w, rc, inv_m, inv_I, lds, lane, FC_BASE(F), c, Jn, dirn);
+        finger_rows<F, true>(m, k, Pb, n_w, rc, inv_m, inv_I, c);
 #pragma unroll
         for (int i = 0; i < 3; ++i) c.arm[i] = Pw[i] - Tw[i];
         float rxn[3];
-        cross3(rc, dirn, rxn);
-        float vn0 = dot3(Jn, &vq[3 * F]) - (dot3(dirn, v) + dot3(rxn, w));
+        cross3(rc, &c.dir[0], rxn);
+        float vn0 = dot3(&c.Jf[0], &vq[3 * F]) - (dot3(&c.dir[0], v) + dot3(rxn, w));
         c.bias = contact_bias(m, gap, vn0, inv_h, m.restitution_finger);
     }
     // tip sphere vs floor
@@ -739,50 +733,26 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
         float Pb[3] = {Bb[0], Bb[1], Bb[2] - m.cap_radius};
         float Pw[3] = {Bw[0], Bw[1], Bw[2] - m.cap_radius};
         g.active = true;
-        float Jn[3], dirn[3];
-        finger_rows<F, false>(m, k, Pb, n_w, zero, inv_m, inv_I, lds, lane, TF_BASE(F), g, Jn, dirn);
+        finger_rows<F, false>(m, k, Pb, n_w, zero, inv_m, inv_I, g);
 #pragma unroll
         for (int i = 0; i < 3; ++i) g.arm[i] = Pw[i] - Tw[i];
-        float vn0 = dot3(Jn, &vq[3 * F]);
+        float vn0 = dot3(&g.Jf[0], &vq[3 * F]);
         g.bias = contact_bias(m, gapf, vn0, inv_h, m.restitution_finger);
-    }
-}
-
-// Finger contact rows staged in LDS are fetched one contact AHEAD of their use (software pipeline): with a single
-// wave per SIMD nothing else hides the ~100+ cycle LDS round trip.
-struct FcRows { float Jf[9], Wf[9], dir[9], rc[3]; };
-struct TfRows { float Jf[9], Wf[9]; };
-template <int F> DEV void load_fc_rows(const float* lds, int lane, FcRows& r) {
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        r.Jf[j] = LDS_AT(FC_BASE(F) + j);
-        r.Wf[j] = LDS_AT(FC_BASE(F) + 9 + j);
-        r.dir[j] = LDS_AT(FC_BASE(F) + 18 + j);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r.rc[j] = LDS_AT(FC_BASE(F) + 27 + j);
-}
-template <int F> DEV void load_tf_rows(const float* lds, int lane, TfRows& r) {
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        r.Jf[j] = LDS_AT(TF_BASE(F) + j);
-        r.Wf[j] = LDS_AT(TF_BASE(F) + 9 + j);
     }
 }
 
 // PGS rows of the finger-cube contact of finger F
 template <int F>
-DEV void solve_finger_cube(float mu, FingerContactRegs& c, const FcRows& r, float* vq, float v[3], float w[3],
-                           float inv_m, float inv_I) {
+DEV void solve_finger_cube(float mu, FingerContactRegs& c, float* vq, float v[3], float w[3], float inv_m, float inv_I) {
     if (!c.active) return;
     float* vf = &vq[3 * F];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const float* Jf = &r.Jf[3 * d];
-        const float* Wf = &r.Wf[3 * d];
-        const float* dir = &r.dir[3 * d];
+        const float* Jf = &c.Jf[3 * d];
+        const float* Wf = &c.Wf[3 * d];
+        const float* dir = &c.dir[3 * d];
         float rxd[3];
-        cross3(r.rc, dir, rxd);
+        cross3(c.rc, dir, rxd);
         float vrel = dot3(Jf, vf) - (dot3(dir, v) + dot3(rxd, w));
         float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
                             : solve_tangent(c.lam[d], c.Dinv[d], vrel, mu * c.lam[0]);
@@ -794,13 +764,13 @@ DEV void solve_finger_cube(float mu, FingerContactRegs& c, const FcRows& r, floa
     }
 }
 template <int F>
-DEV void solve_tip_floor(float mu, FingerContactRegs& c, const TfRows& r, float* vq) {
+DEV void solve_tip_floor(float mu, FingerContactRegs& c, float* vq) {
     if (!c.active) return;
     float* vf = &vq[3 * F];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const float* Jf = &r.Jf[3 * d];
-        const float* Wf = &r.Wf[3 * d];
+        const float* Jf = &c.Jf[3 * d];
+        const float* Wf = &c.Wf[3 * d];
         float vrel = dot3(Jf, vf);
         float dl = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
                             : solve_tangent(c.lam[d], c.Dinv[d], vrel, mu * c.lam[0]);
@@ -811,13 +781,13 @@ DEV void solve_tip_floor(float mu, FingerContactRegs& c, const TfRows& r, float*
 
 // wrench of one finger contact, world frame, about the tip-link origin
 template <bool WITH_CUBE>
-DEV void add_wrench(const FingerContactRegs& c, const float* lds, int lane, int base, float inv_h, float* ft) {
+DEV void add_wrench(const FingerContactRegs& c, float inv_h, float* ft) {
     if (!c.active) return;
     float F[3];
     if (WITH_CUBE) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            F[i] = FMA(LDS_AT(base + 24 + i), c.lam[2], FMA(LDS_AT(base + 21 + i), c.lam[1], LDS_AT(base + 18 + i) * c.lam[0])) * inv_h;
+            F[i] = FMA(c.dir[6 + i], c.lam[2], FMA(c.dir[3 + i], c.lam[1], c.dir[i] * c.lam[0])) * inv_h;
     } else {
         // floor contact directions are constants: n = +z, t1 = -y, t2 = +x (tangent_basis of +z)
         const float n_w[3] = {0.0f, 0.0f, 1.0f};
@@ -835,7 +805,7 @@ DEV void add_wrench(const FingerContactRegs& c, const float* lds, int lane, int 
 // One solver substep of length h for the env held by this lane.  WRENCH: accumulate the fingertip contact
 // wrench (only the asymmetric `states` vector consumes it).
 template <bool WRENCH>
-DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
+DEV void substep(const DevParams& P, Env& e, float h) {
     const TfModel& m = P.m;
     const float inv_h = 1.0f / h;
     // per-env cube and friction parameters: nominal values times the domain-randomisation factors (1.0 when off)
@@ -876,9 +846,9 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     quat_to_rot(e.cq, R);
     const float hc = m.cube_half * e.dr[1];
     FingerContactRegs fc0, fc1, fc2, tf0, tf1, tf2;
-    finger_contacts<0>(P, e, fk0, R, vq, v, w, hc, inv_h, inv_m, inv_I, lds, lane, fc0, tf0);
-    finger_contacts<1>(P, e, fk1, R, vq, v, w, hc, inv_h, inv_m, inv_I, lds, lane, fc1, tf1);
-    finger_contacts<2>(P, e, fk2, R, vq, v, w, hc, inv_h, inv_m, inv_I, lds, lane, fc2, tf2);
+    finger_contacts<0>(P, e, fk0, R, vq, v, w, hc, inv_h, inv_m, inv_I, fc0, tf0);
+    finger_contacts<1>(P, e, fk1, R, vq, v, w, hc, inv_h, inv_m, inv_I, fc1, tf1);
+    finger_contacts<2>(P, e, fk2, R, vq, v, w, hc, inv_h, inv_m, inv_I, fc2, tf2);
     CubeContactRegs cf[4], cwl[4];
     {   // cube vs floor: corners of the face that points down most
         int k = 0;
@@ -952,24 +922,14 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
         lim_dinv[j] = 1.0f / k.Minv[dg];
         lim_lam[j] = 0.0f;
     }
-    WAVE_LDS_ORDER();   // LDS rows written above are read below (same lane; keeps the phases ordered)
     // ---- projected Gauss-Seidel ----
-    FcRows ra, rb;
-    TfRows ta, tb;
-    load_fc_rows<0>(lds, lane, ra);
     for (int it = 0; it < P.iters; ++it) {
-        load_fc_rows<1>(lds, lane, rb);
-        solve_finger_cube<0>(mu_fc, fc0, ra, vq, v, w, inv_m, inv_I);
-        load_fc_rows<2>(lds, lane, ra);
-        solve_finger_cube<1>(mu_fc, fc1, rb, vq, v, w, inv_m, inv_I);
-        load_tf_rows<0>(lds, lane, ta);
-        solve_finger_cube<2>(mu_fc, fc2, ra, vq, v, w, inv_m, inv_I);
-        load_tf_rows<1>(lds, lane, tb);
-        solve_tip_floor<0>(mu_tf, tf0, ta, vq);
-        load_tf_rows<2>(lds, lane, ta);
-        solve_tip_floor<1>(mu_tf, tf1, tb, vq);
-        load_fc_rows<0>(lds, lane, ra);          // for the next sweep; hidden behind the register-only rows below
-        solve_tip_floor<2>(mu_tf, tf2, ta, vq);
+        solve_finger_cube<0>(mu_fc, fc0, vq, v, w, inv_m, inv_I);
+        solve_finger_cube<1>(mu_fc, fc1, vq, v, w, inv_m, inv_I);
+        solve_finger_cube<2>(mu_fc, fc2, vq, v, w, inv_m, inv_I);
+        solve_tip_floor<0>(mu_tf, tf0, vq);
+        solve_tip_floor<1>(mu_tf, tf1, vq);
+        solve_tip_floor<2>(mu_tf, tf2, vq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {       // cube - floor: rows +z (normal), +x, +y
             cube_row_z<0, true>(cf[i], mu_cf, inv_m, inv_I, v, w);
@@ -1002,14 +962,13 @@ DEV void substep(const DevParams& P, Env& e, float h, float* lds, int lane) {
     }
     // ---- fingertip wrench sensor ----
     if (WRENCH) {
-        add_wrench<true>(fc0, lds, lane, FC_BASE(0), inv_h, &e.ft[0]);
-        add_wrench<false>(tf0, lds, lane, TF_BASE(0), inv_h, &e.ft[0]);
-        add_wrench<true>(fc1, lds, lane, FC_BASE(1), inv_h, &e.ft[6]);
-        add_wrench<false>(tf1, lds, lane, TF_BASE(1), inv_h, &e.ft[6]);
-        add_wrench<true>(fc2, lds, lane, FC_BASE(2), inv_h, &e.ft[12]);
-        add_wrench<false>(tf2, lds, lane, TF_BASE(2), inv_h, &e.ft[12]);
+        add_wrench<true>(fc0, inv_h, &e.ft[0]);
+        add_wrench<false>(tf0, inv_h, &e.ft[0]);
+        add_wrench<true>(fc1, inv_h, &e.ft[6]);
+        add_wrench<false>(tf1, inv_h, &e.ft[6]);
+        add_wrench<true>(fc2, inv_h, &e.ft[12]);
+        add_wrench<false>(tf2, inv_h, &e.ft[12]);
     }
-    WAVE_LDS_ORDER();
     // ---- integrate ----
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -1557,7 +1516,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
     const int nsub = sa.nsim * P.substeps;
-    for (int s = 0; s < nsub; ++s) substep<ASYM>(P, e, P.hsub, lds, lane);
+    for (int s = 0; s < nsub; ++s) substep<ASYM>(P, e, P.hsub);
     // ---- phase C: observations, rewards, termination, counters ----
     // rows written in phase A (action_buf tile, goal, previous object pose) are re-read below, possibly by other
     // lanes of this wave: make sure those stores have completed (they were issued ~100 us ago: no stall)
@@ -1648,12 +1607,11 @@ __global__ void __launch_bounds__(WAVE, 1) k_pre_step(const DevParams* __restric
 }
 
 __global__ void __launch_bounds__(WAVE, 1) k_simulate(const DevParams* __restrict__ Pp) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     LANE_SETUP
     Env e;
     load_dyn(P, i, e);
     load_split_extras(P, i, e);
-    for (int s = 0; s < P.substeps; ++s) substep<true>(P, e, P.hsub, lds, lane);
+    for (int s = 0; s < P.substeps; ++s) substep<true>(P, e, P.hsub);
     store_dyn(P, i, e, valid);
     store_ft(P, i, e, valid);
     if (P.goal_rotation_activate) {
