@@ -1115,8 +1115,18 @@ DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, Env& e) {
     for (int i = 0; i < 4; ++i) e.gq[i] = quat[i];
 }
 
+// per-env values read once at the top of the step and carried in registers to the bookkeeping at its end
+// (so that nothing at the end of the kernel waits for a global-memory round trip)
+struct Carried {
+    float tip_prev[9];       // history[0] fingertip positions of the previous frame
+    bool successes;          // _successes after the reset logic
+    bool goal_reset;         // _goal_reset_buf after the reset logic
+    bool reset;              // _reset_buf after the reset logic
+    int steps;               // _steps_count_buf after the reset logic
+};
+
 // masked _reset_impl then _goal_reset_impl (env_base.py:370-379; trifinger_env.py:373-440)
-DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_all, bool& goal_changed) {
+DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_all, bool& goal_changed, Carried& cy) {
     const TfModel& m = P.m;
     uint32_t gid = (uint32_t)(P.env_id_offset + i);
     bool did_reset = false;
@@ -1177,6 +1187,10 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
         }
     }
     goal_changed = rflag || gflag;
+    cy.reset = false;                                   // cleared by the reset, or it was not set
+    cy.goal_reset = force_all ? (P.goal_reset_buf[i] != 0) : false;   // reset() leaves _goal_reset_buf alone
+    cy.successes = rflag ? false : (P.successes[i] != 0);
+    cy.steps = rflag ? 0 : P.steps[i];
     return did_reset;
 }
 
@@ -1266,6 +1280,7 @@ DEV void store_tile(float* __restrict__ dst, const float* lds, int wave_first_en
 
 struct LaneStats { float rew[6]; float pos_cnt, ori_cnt, succ, resets, nonfinite; };
 
+
 DEV float wave_sum(float x) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x = x + __shfl_xor(x, off, WAVE);
@@ -1276,7 +1291,8 @@ DEV float wave_sum(float x) {
 // trifinger_env.py:500-559 + 959-1099 for the env of this lane.  prev_obj = history[1] pose (7).
 template <int A>
 DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool valid, int wave_first, int n_valid, Env& e,
-                       const float* act, const float prev_obj[7], bool with_reward, float* lds, int lane, LaneStats& st) {
+                       const float* act, const float prev_obj[7], bool with_reward, float* lds, int lane, LaneStats& st,
+                       Carried& cy) {
     const TfModel& m = P.m;
     constexpr int OD = TF_OBS_DIM_BASE + A;
     constexpr int SD = OD + TF_STATES_EXTRA;
@@ -1305,6 +1321,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
             tip_state<1>(m, &e.q[3], &e.qd[3], tips1);
             tip_state<2>(m, &e.q[6], &e.qd[6], tips2);
             if (valid) P.reset_buf[i] = 1;
+            cy.reset = true;
             st.nonfinite += valid ? 1.0f : 0.0f;
         }
     }
@@ -1362,9 +1379,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
 #undef EMIT_COMMON
 #undef EMIT
     // ---- history: previous fingertip positions are whatever the last filled frame left ----
-    float tip_prev[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) tip_prev[j] = ST(TF_S_TIP_P + j);
+    const float* tip_prev = cy.tip_prev;
     if (valid) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { ST(TF_S_TIP_P + j) = tips0[j]; ST(TF_S_TIP_P + 3 + j) = tips1[j]; ST(TF_S_TIP_P + 6 + j) = tips2[j]; }
@@ -1410,14 +1425,16 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     if (P.task_difficulty < 4) done = pos_ok;
     else if (P.task_difficulty == 4) done = pos_ok && ori_ok;
     else done = ori_ok;
-    bool succ = P.successes[i] != 0;
+    bool succ = cy.successes;
     if (P.success_activate) {
         if (done) total = total + P.success_bonus;
         if (valid) P.goal_reset_buf[i] = (uint8_t)done;
+        cy.goal_reset = done;
         succ = succ || done;
     } else {
-        succ = (P.goal_reset_buf[i] != 0) && succ;
+        succ = cy.goal_reset && succ;
     }
+    cy.successes = succ;
     if (valid) {
         P.successes[i] = (uint8_t)succ;
         P.reward[i] = total;
@@ -1425,13 +1442,21 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     st.succ += (valid && succ) ? 1.0f : 0.0f;
 }
 
-DEV void finish_env(const DevParams& P, int i, bool valid) {     // env_base.py:391-399
+DEV void finish_env(const DevParams& P, int i, bool valid, const Carried& cy) {     // env_base.py:391-399
     if (!valid) return;
-    int s = P.steps[i] + 1;
+    int s = cy.steps + 1;
     P.steps[i] = s;
-    uint8_t rb = P.reset_buf[i];
-    if (P.episode_length > 0 && s >= P.episode_length) { rb = 1; P.reset_buf[i] = 1; }
-    P.dones[i] = (uint8_t)(rb && P.goal_reset_buf[i]);
+    bool rb = cy.reset;
+    if (P.episode_length > 0 && s >= P.episode_length) { rb = true; P.reset_buf[i] = 1; }
+    P.dones[i] = (uint8_t)(rb && cy.goal_reset);
+}
+DEV void load_carried(const DevParams& P, int i, Carried& cy) {        // split path: everything comes from memory
+#pragma unroll
+    for (int j = 0; j < 9; ++j) cy.tip_prev[j] = ST(TF_S_TIP_P + j);
+    cy.successes = P.successes[i] != 0;
+    cy.goal_reset = P.goal_reset_buf[i] != 0;
+    cy.reset = P.reset_buf[i] != 0;
+    cy.steps = P.steps[i];
 }
 
 DEV void stats_zero(LaneStats& st) {
@@ -1475,10 +1500,11 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     LANE_SETUP
     Env e;
+    Carried cy;
     float n_resets = 0.0f;
+    float act[A], prev_obj[7];
     // ---- phase A: action tile, masked resets, torque law ----
     {
-        float act[A];
         if (!IS_RESET) {
             // action tile [n_valid][A] is contiguous: coalesced dword loads into LDS, each lane picks its row
             const float* src = action + (size_t)wave_first * (size_t)A;
@@ -1495,8 +1521,10 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         }
         load_dyn(P, i, e);
         load_goal(P, i, e);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) cy.tip_prev[j] = ST(TF_S_TIP_P + j);
         bool goal_changed;
-        bool did_reset = apply_resets(P, i, valid, e, IS_RESET, goal_changed);
+        bool did_reset = apply_resets(P, i, valid, e, IS_RESET, goal_changed, cy);
         store_goal(P, i, e, valid && goal_changed);
         if (did_reset) {
 #pragma unroll
@@ -1511,32 +1539,62 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         WAVE_LDS_ORDER();
         compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
         store_prev_obj(P, i, e, valid);                         // history[1] of the object (trifinger_env.py:975)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) prev_obj[j] = e.cp[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) prev_obj[3 + j] = e.cq[j];
+    }
+    // Values that are cold while the contact solve runs (last action, goal, previous object pose and fingertips)
+    // are parked in this wave's LDS tile buffer as [slot][lane] (idle between the two transposes) instead of
+    // occupying 35+ registers through the substeps or being re-fetched from HBM at the end.
+#define PARK(slot, val) lds[(slot) * WAVE + lane] = (val)
+#define UNPARK(slot) lds[(slot) * WAVE + lane]
+    {
+        int sl = 0;
+#pragma unroll
+        for (int j = 0; j < A; ++j) PARK(sl++, act[j]);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) PARK(sl++, prev_obj[j]);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) PARK(sl++, cy.tip_prev[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { PARK(sl++, e.gp[j]); PARK(sl++, e.gw[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) PARK(sl++, e.gq[j]);
     }
     // ---- phase B: physics ----
 #pragma unroll
     for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
     const int nsub = sa.nsim * P.substeps;
     for (int s = 0; s < nsub; ++s) substep<ASYM>(P, e, P.hsub);
-    // ---- phase C: observations, rewards, termination, counters ----
-    // rows written in phase A (action_buf tile, goal, previous object pose) are re-read below, possibly by other
-    // lanes of this wave: make sure those stores have completed (they were issued ~100 us ago: no stall)
-    __builtin_amdgcn_s_waitcnt(0);
+    // ---- phase C: observations, rewards, termination, counters.  Its inputs come back from the LDS parking slots
+    // (no global load sits between the last solver sweep and the output stores) ----
+    WAVE_LDS_ORDER();
+    {
+        int sl = 0;
+#pragma unroll
+        for (int j = 0; j < A; ++j) act[j] = UNPARK(sl++);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) prev_obj[j] = UNPARK(sl++);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) cy.tip_prev[j] = UNPARK(sl++);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { e.gp[j] = UNPARK(sl++); e.gw[j] = UNPARK(sl++); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e.gq[j] = UNPARK(sl++);
+    }
+#undef PARK
+#undef UNPARK
     WAVE_LDS_ORDER();
     {
         LaneStats st;
         stats_zero(st);
         st.resets = n_resets;
-        float act[A], prev_obj[7];
-        const int row = valid ? i : (P.N - 1);
-#pragma unroll
-        for (int j = 0; j < A; ++j) act[j] = P.action_buf[(size_t)row * A + j];
-        load_prev_obj(P, i, prev_obj);
-        load_goal(P, i, e);
         goal_advance(P, e, nsub, P.hsub);
-        post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st);
+        post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st, cy);
         store_dyn(P, i, e, valid);
         if (P.goal_rotation_activate) store_goal(P, i, e, valid);
-        if (!IS_RESET) finish_env(P, i, valid);
+        if (!IS_RESET) finish_env(P, i, valid, cy);
         stats_publish(P, st, lane);
     }
 }
@@ -1576,7 +1634,8 @@ __global__ void __launch_bounds__(WAVE, 1) k_apply_resets(const DevParams* __res
     load_dyn(P, i, e);
     load_goal(P, i, e);
     bool goal_changed;
-    bool did = apply_resets(P, i, valid, e, false, goal_changed);
+    Carried cy;
+    bool did = apply_resets(P, i, valid, e, false, goal_changed, cy);
     float act[A];
     const int row = valid ? i : (P.N - 1);
 #pragma unroll
@@ -1636,7 +1695,9 @@ __global__ void __launch_bounds__(WAVE, 1) k_post_step(const DevParams* __restri
     for (int j = 0; j < A; ++j) act[j] = P.action_buf[(size_t)i * A + j];
     float prev_obj[7];
     load_prev_obj(P, i, prev_obj);
-    post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, true, lds, lane, st);
+    Carried cy;
+    load_carried(P, i, cy);
+    post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, true, lds, lane, st, cy);
     store_dyn(P, i, e, valid);
     store_ft(P, i, e, valid);
     stats_publish(P, st, lane);
@@ -1644,7 +1705,9 @@ __global__ void __launch_bounds__(WAVE, 1) k_post_step(const DevParams* __restri
 
 __global__ void __launch_bounds__(WAVE, 1) k_finish(const DevParams* __restrict__ Pp) {
     LANE_SETUP
-    finish_env(P, i, valid);
+    Carried cy;
+    load_carried(P, i, cy);
+    finish_env(P, i, valid, cy);
 }
 
 // ---- leaf kernels for the golden tests ----
