@@ -114,9 +114,11 @@ struct StepArgs {
 
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
-DEV float f_min(float a, float b) { return (a < b) ? a : b; }
-DEV float f_max(float a, float b) { return (a > b) ? a : b; }
-DEV float f_clamp(float x, float lo, float hi) { return f_max(f_min(x, hi), lo); }
+// one instruction each: v_min_f32 / v_max_f32 / v_med3_f32.  On non-NaN inputs they implement a total order with
+// -0 < +0; the oracle's f_min / f_max / f_clamp restate exactly that (bitwise OR / AND of equal operands).
+DEV float f_min(float a, float b) { return __builtin_fminf(a, b); }
+DEV float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
+DEV float f_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 DEV float f_abs(float a) { return (a < 0.0f) ? -a : a; }
 
 DEV void tf_sincos(float x, float& s_out, float& c_out) {

@@ -41,9 +41,20 @@
 /* ------------------------------------------------------------------------------------------------ */
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
-static inline float f_min(float a, float b) { return (a < b) ? a : b; }
-static inline float f_max(float a, float b) { return (a > b) ? a : b; }
-static inline float f_clamp(float x, float lo, float hi) { return f_max(f_min(x, hi), lo); }
+/* min / max / clamp with the semantics of the GPU's v_min_f32 / v_max_f32 / v_med3_f32 on non-NaN inputs:
+ * a total order in which -0 < +0.  They differ from (a < b) ? a : b only when both operands are zeros of
+ * opposite sign: min returns -0 (bitwise OR), max returns +0 (bitwise AND). */
+static inline uint32_t f2u_(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f_(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float f_min(float a, float b) {
+    float m = (a < b) ? a : b;
+    return (a == b) ? u2f_(f2u_(a) | f2u_(b)) : m;
+}
+static inline float f_max(float a, float b) {
+    float m = (a > b) ? a : b;
+    return (a == b) ? u2f_(f2u_(a) & f2u_(b)) : m;
+}
+static inline float f_clamp(float x, float lo, float hi) { return f_min(f_max(x, lo), hi); }   /* median for lo <= hi */
 static inline float f_abs(float a) { return (a < 0.0f) ? -a : a; }
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
