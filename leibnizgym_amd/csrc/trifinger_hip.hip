@@ -119,7 +119,7 @@ struct StepArgs {
 DEV float f_min(float a, float b) { return __builtin_fminf(a, b); }
 DEV float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
 DEV float f_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-DEV float f_abs(float a) { return (a < 0.0f) ? -a : a; }
+DEV float f_abs(float a) { return __builtin_fabsf(a); }
 
 DEV void tf_sincos(float x, float& s_out, float& c_out) {
     float k = __builtin_rintf(x * 0.63661977236758134f);
@@ -1230,9 +1230,7 @@ DEV float norm3d(const float a[3], const float b[3]) {
     return f_sqrt(dx * dx + dy * dy + dz * dz);
 }
 
-template <int F> DEV void tip_state(const TfModel& m, const float q[3], const float qd[3], float out[13]) {
-    FK k;
-    fk_setup(m, q, k);
+template <int F> DEV void tip_state(const TfModel& m, const FK& k, const float q[3], const float qd[3], float out[13]) {
     float t[3], To[3];
     rot_link<3>(k, m.tip_origin, t);
     To[0] = k.p3[0] + t[0]; To[1] = k.p3[1] + t[1]; To[2] = k.p3[2] + t[2];
@@ -1254,9 +1252,7 @@ template <int F> DEV void tip_state(const TfModel& m, const float q[3], const fl
     dir_base_to_world<F>(m, wb, &out[10]);
 }
 
-template <int F> DEV void wrench_local(const DevParams& P, const Env& e, float inv_n, float out[6]) {
-    FK kk;
-    fk_setup(P.m, &e.q[3 * F], kk);
+template <int F> DEV void wrench_local(const DevParams& P, const FK& kk, const Env& e, float inv_n, float out[6]) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         float wv[3] = {e.ft[6 * F + 3 * half] * inv_n, e.ft[6 * F + 3 * half + 1] * inv_n, e.ft[6 * F + 3 * half + 2] * inv_n};
@@ -1299,9 +1295,13 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     constexpr int OD = TF_OBS_DIM_BASE + A;
     constexpr int SD = OD + TF_STATES_EXTRA;
     float tips0[13], tips1[13], tips2[13];
-    tip_state<0>(m, &e.q[0], &e.qd[0], tips0);
-    tip_state<1>(m, &e.q[3], &e.qd[3], tips1);
-    tip_state<2>(m, &e.q[6], &e.qd[6], tips2);
+    FK pk0, pk1, pk2;       // forward kinematics of the final pose: shared by the fingertip states and the wrench frames
+    fk_setup(m, &e.q[0], pk0);
+    fk_setup(m, &e.q[3], pk1);
+    fk_setup(m, &e.q[6], pk2);
+    tip_state<0>(m, pk0, &e.q[0], &e.qd[0], tips0);
+    tip_state<1>(m, pk1, &e.q[3], &e.qd[3], tips1);
+    tip_state<2>(m, pk2, &e.q[6], &e.qd[6], tips2);
     {   // NaN guard: a non-finite env is flagged for reset and parked at the default pose
         float acc = 0.0f;
 #pragma unroll
@@ -1319,9 +1319,12 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
             for (int k = 0; k < 3; ++k) { e.cv[k] = 0.0f; e.cw[k] = 0.0f; }
 #pragma unroll
             for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
-            tip_state<0>(m, &e.q[0], &e.qd[0], tips0);
-            tip_state<1>(m, &e.q[3], &e.qd[3], tips1);
-            tip_state<2>(m, &e.q[6], &e.qd[6], tips2);
+            fk_setup(m, &e.q[0], pk0);
+            fk_setup(m, &e.q[3], pk1);
+            fk_setup(m, &e.q[6], pk2);
+            tip_state<0>(m, pk0, &e.q[0], &e.qd[0], tips0);
+            tip_state<1>(m, pk1, &e.q[3], &e.qd[3], tips1);
+            tip_state<2>(m, pk2, &e.q[6], &e.qd[6], tips2);
             if (valid) P.reset_buf[i] = 1;
             cy.reset = true;
             st.nonfinite += valid ? 1.0f : 0.0f;
@@ -1365,13 +1368,13 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
         for (int j = 0; j < 9; ++j) EMIT(SD, OD + 45 + j, (P.enable_ft ? e.tau[j] : 0.0f))
         float inv_n = 1.0f / (float)(P.substeps * P.control_decimation);
         float wl[6];
-        wrench_local<0>(P, e, inv_n, wl);
+        wrench_local<0>(P, pk0, e, inv_n, wl);
 #pragma unroll
         for (int j = 0; j < 6; ++j) EMIT(SD, OD + 54 + j, wl[j])
-        wrench_local<1>(P, e, inv_n, wl);
+        wrench_local<1>(P, pk1, e, inv_n, wl);
 #pragma unroll
         for (int j = 0; j < 6; ++j) EMIT(SD, OD + 60 + j, wl[j])
-        wrench_local<2>(P, e, inv_n, wl);
+        wrench_local<2>(P, pk2, e, inv_n, wl);
 #pragma unroll
         for (int j = 0; j < 6; ++j) EMIT(SD, OD + 66 + j, wl[j])
         WAVE_LDS_ORDER();

@@ -55,7 +55,7 @@ static inline float f_max(float a, float b) {
     return (a == b) ? u2f_(f2u_(a) & f2u_(b)) : m;
 }
 static inline float f_clamp(float x, float lo, float hi) { return f_min(f_max(x, lo), hi); }   /* median for lo <= hi */
-static inline float f_abs(float a) { return (a < 0.0f) ? -a : a; }
+static inline float f_abs(float a) { return u2f_(f2u_(a) & 0x7fffffffu); }   /* |a|: clears the sign bit (also of -0) */
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
