@@ -35,6 +35,9 @@ from leibnizgym_amd.engine import TrifingerEngine, make_config  # noqa: E402
 from leibnizgym_amd import _capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# HBM bytes per k_step launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, raw
+# counter expressions; profiles/r1_d_pmc.txt).  Only valid for the exact workload it was measured on.
+PMC_TRAFFIC = {(65536, True): (9080.895 + 56768.000) * 1024.0}
 FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
@@ -60,31 +63,42 @@ def workload_kwargs(asym):
 
 
 def cpu_baseline(asym, budget_s=12.0):
-    """Time the CPU oracle (same algorithm, scalar C, OpenMP over envs) on a bounded sample of the workload."""
+    """Time the CPU oracle (same algorithm, scalar C, OpenMP over envs) on a bounded sample of the workload,
+    on one thread and on every host core."""
+    import ctypes
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s"], stdout=subprocess.DEVNULL)
     so = os.path.join(REPO, "oracle", "_build", "libtrifinger_oracle_omp.so")
     lib = _capi.TfLib(so)
+    lib.dll.tfo_omp_threads.argtypes = [ctypes.c_int]
+    lib.dll.tfo_omp_threads.restype = ctypes.c_int
     cores = os.cpu_count() or 1
-    torch.set_num_threads(1)
-    n = 8192
-    eng = TrifingerEngine(make_config(lib, n, seed=7, **workload_kwargs(asym)), device="cpu", lib=lib)
-    eng.reset()
+    n = 65536                     # the headline batch
     acts = [(torch.rand(n, 9) * 2 - 1).contiguous() for _ in range(4)]
-    eng.step(acts[0])                                   # warm-up
-    t0 = time.perf_counter()
-    eng.step(acts[1])
-    one = time.perf_counter() - t0
-    steps = max(3, min(400, int(budget_s / max(one, 1e-6))))
-    t0 = time.perf_counter()
-    for k in range(steps):
-        eng.step(acts[k % 4])
-    el = time.perf_counter() - t0
-    eng.close()
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} steps of the same workload, OpenMP static schedule over envs "
-                      f"({cores} threads), {el:.1f} s; reference IsaacGym CPU pipeline not available, "
-                      f"baseline is this repo's CPU oracle (oracle/tf_oracle.c)"}
+
+    def run(threads, budget):
+        used = lib.dll.tfo_omp_threads(threads)
+        eng = TrifingerEngine(make_config(lib, n, seed=7, **workload_kwargs(asym)), device="cpu", lib=lib)
+        eng.reset()
+        eng.step(acts[0])                                   # warm-up
+        t0 = time.perf_counter()
+        eng.step(acts[1])
+        one = time.perf_counter() - t0
+        steps = max(1, min(1000, int(budget / max(one, 1e-6))))
+        t0 = time.perf_counter()
+        for k in range(steps):
+            eng.step(acts[k % 4])
+        el = time.perf_counter() - t0
+        eng.close()
+        return used, steps, el, n * steps / el
+
+    _, s1, e1, v1 = run(1, budget_s * 0.4)
+    used, sa, ea, va = run(cores, budget_s * 0.6)
+    return {"value": va, "unit": "env-steps/s", "cores": used, "kind": "port",
+            "single_thread_value": v1,
+            "sample": f"{n} envs x {sa} steps of the same workload on {used} OpenMP threads (static schedule over envs, "
+                      f"{ea:.1f} s) and x {s1} steps on 1 thread ({e1:.1f} s); reference IsaacGym CPU pipeline not "
+                      f"available, baseline is this repo's CPU oracle (oracle/tf_oracle.c)"}
 
 
 def main():
@@ -177,7 +191,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": PMC_TRAFFIC.get((n, asym)),
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_d_pmc.txt" if (n, asym) in PMC_TRAFFIC else None,
             "kernel": "k_step<9,false>",
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,

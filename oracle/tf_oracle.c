@@ -1645,6 +1645,17 @@ int tf_test_finger_dynamics(tf_handle h, const float* q, const float* qd, float*
     return TF_OK;
 }
 
+/* thread control for the OpenMP build (bench.py's cpu_baseline): set the team size, return what will be used */
+int tfo_omp_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* extra oracle-only leaf functions used by tests/test_oracle_math.py */
 void tfo_sincos(const float* x, float* s, float* c, int32_t n) { for (int i = 0; i < n; ++i) tf_sincos(x[i], &s[i], &c[i]); }
 void tfo_exp(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = tf_exp(x[i]); }

@@ -1,0 +1,31 @@
+"""Soak run on the GPU box: many steps at the headline size, invariants checked every 1000 steps."""
+import sys, os, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+import bench
+from leibnizgym_amd.engine import TrifingerEngine, make_config
+from leibnizgym_amd import _capi as capi
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+lib = capi.load_hip_library()
+kw = bench.workload_kwargs(True)
+kw.update(domain_randomization={"activate": True}, episode_length=300)
+eng = TrifingerEngine(make_config(lib, n, seed=11, **kw), device="cuda:0", lib=lib)
+g = torch.Generator(device="cuda:0").manual_seed(3)
+ring = [(torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1) for _ in range(32)]
+eng.reset()
+nonfinite = torch.zeros((), device="cuda:0"); resets = torch.zeros((), device="cuda:0")
+t0 = time.perf_counter()
+for k in range(steps):
+    eng.step(ring[k % 32])
+    nonfinite += eng.info[capi.INFO_NUM_NONFINITE]; resets += eng.info[capi.INFO_NUM_RESETS]
+    if k % 1000 == 999:
+        st = eng.state
+        ok = bool(torch.isfinite(st).all()) and bool(torch.isfinite(eng.obs).all()) and bool(torch.isfinite(eng.states).all())
+        zmin = float(st[capi.S_CUBE_P + 2].min()); rmax = float(torch.hypot(st[capi.S_CUBE_P], st[capi.S_CUBE_P + 1]).max())
+        print(f"step {k+1}: finite={ok} cube z min {zmin:.4f} r max {rmax:.4f} |qd| max {float(st[9:18].abs().max()):.2f} "
+              f"nonfinite so far {float(nonfinite):.0f} resets {float(resets):.0f} mean reward {float(eng.reward.mean()):.3f}", flush=True)
+        assert ok and rmax < 0.25
+torch.cuda.synchronize()
+print(f"{n} envs x {steps} steps in {time.perf_counter()-t0:.1f} s; non-finite envs caught: {float(nonfinite):.0f}")
