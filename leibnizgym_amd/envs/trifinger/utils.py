@@ -1,38 +1,37 @@
-"""Dimensions of the TriFinger platform and of the manipulated cuboid.
+"""Sizes of the TriFinger platform and of the manipulated cuboid.
 
-Counterpart of reference leibnizgym/envs/trifinger/utils.py; the numbers are pinned against the
-reference by tests/golden/constants.npz (CuboidalObject(0.065): radius_3d 0.05629165,
-max_com_distance_to_center 0.13870835, min_height 0.0325, max_height 0.1)."""
+Numbers are pinned against the reference by tests/golden/constants.npz (generated from
+leibnizgym/envs/trifinger/utils.py of the reference): for the 65 mm cube radius_3d = 0.05629165,
+max_com_distance_to_center = 0.13870835, min_height = 0.0325, max_height = 0.1; arena radius 0.195 m."""
 import enum
 import math
-from typing import Tuple, Union
+from typing import Sequence, Tuple, Union
+
+ARENA_RADIUS = 0.195          # metres: the cube's centre is sampled so that its bounding sphere stays inside
 
 
 class TrifingerDimensions(enum.Enum):
-    # the reference writes `PoseDim = 7,` (a tuple, utils.py:26); nothing reads it - kept as an int here
-    PoseDim = 7
+    """Vector sizes used by the observation / state / action specs (members compare by value, so several names
+    share one value exactly as in the reference enum)."""
+    StateDim = 13             # pose (7) + twist (6)
+    PoseDim = 7               # the reference's `PoseDim = 7,` is a 1-tuple by accident; nothing reads it
     VelocityDim = 6
-    StateDim = 13
     WrenchDim = 6
     NumFingers = 3
     JointPositionDim = 9
     JointVelocityDim = 9
     JointTorqueDim = 9
-    GeneralizedCoordinatesDim = JointPositionDim
-    GeneralizedVelocityDim = JointVelocityDim
+    GeneralizedCoordinatesDim = 9
+    GeneralizedVelocityDim = 9
     ObjectPoseDim = 7
     ObjectVelocityDim = 6
 
 
-# radius of the arena in which the cube may be placed
-ARENA_RADIUS = 0.195
-
-
 class CuboidalObject:
-    """Sizes derived from the cuboid's edge lengths; used for sampling poses inside the arena."""
-    max_height = 0.1
+    """Derived sizes of a cuboid with edge lengths `size` (a float means a cube)."""
+    max_height = 0.1          # highest goal position of the object's centre
 
-    def __init__(self, size: Union[float, Tuple[float, float, float]]):
+    def __init__(self, size: Union[float, Sequence[float]]):
         self.size = size
 
     @property
@@ -40,8 +39,9 @@ class CuboidalObject:
         return self._size
 
     @size.setter
-    def size(self, size: Union[float, Tuple[float, float, float]]):
-        self._size = (size, size, size) if isinstance(size, float) else tuple(size)
-        self.radius_3d = max(self._size) * math.sqrt(3) / 2
-        self.max_com_distance_to_center = ARENA_RADIUS - self.radius_3d
-        self.min_height = self._size[2] / 2
+    def size(self, value: Union[float, Sequence[float]]):
+        edges = (value,) * 3 if isinstance(value, (int, float)) else tuple(value)
+        self._size = edges
+        self.radius_3d = 0.5 * math.sqrt(3.0) * max(edges)               # bounding-sphere radius of the largest edge
+        self.max_com_distance_to_center = ARENA_RADIUS - self.radius_3d   # sampling radius on the table
+        self.min_height = 0.5 * edges[2]                                  # resting on the table

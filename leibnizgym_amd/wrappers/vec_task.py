@@ -1,8 +1,12 @@
-"""Vectorised-task wrappers for RL training (counterpart of reference leibnizgym/wrappers/vec_task.py).
+"""RL-facing wrapper of a task: action / observation clipping, device hand-over, gym-style spaces.
 
-`VecTaskPython.step` is: clamp actions to +-clip_actions -> task.step -> clamp obs to +-clip_obs -> move to
-the RL device (vec_task.py:157-170); `get_state` clamps the states the same way (:146-147)."""
-from typing import Tuple
+API counterpart of the reference's `VecTask` / `VecTaskPython` (leibnizgym/wrappers/vec_task.py:26-170): same
+constructor, same properties (`num_envs`, `num_obs`, `num_states`, `num_actions`, `observation_space`, `state_space`,
+`action_space`), same call contract.  Per control step the wrapper adds exactly three element-wise operations around
+the native step: actions are limited to +-clip_actions before the task sees them, observations (and the privileged
+states returned by `get_state`) to +-clip_obs afterwards, and results are moved to the learner's device.
+"""
+from typing import Dict, Tuple
 
 import numpy as np
 import torch
@@ -11,62 +15,46 @@ from ..envs.env_base import IsaacEnvBase
 from ..utils.spaces import Box
 
 
-class VecTask:
-    def __init__(self, task: IsaacEnvBase, rl_device: str, clip_obs: float = 5.0, clip_actions: float = 1.0):
-        assert isinstance(task, IsaacEnvBase)
-        self._task = task
-        self._clip_obs = float(clip_obs)
-        self._clip_actions = float(clip_actions)
-        self._rl_device = rl_device
-        self._obs_space = Box(np.full(self.num_obs, -self._clip_obs), np.full(self.num_obs, self._clip_obs))
-        self._state_space = Box(np.full(self.num_states, -self._clip_obs), np.full(self.num_states, self._clip_obs))
-        self._act_space = Box(np.full(self.num_actions, -self._clip_actions),
-                              np.full(self.num_actions, self._clip_actions))
+def _symmetric_box(dim: int, bound: float) -> Box:
+    edge = np.full(dim, bound)
+    return Box(-edge, edge)
 
-    def __str__(self) -> str:
-        return (f"Vectorized Environment around task: {type(self._task).__name__} \n"
-                f"\t Number of instances   : {self.num_envs} \n"
-                f"\t Number of observations: {self.num_obs} \n"
-                f"\t Number of states      : {self.num_states} \n"
-                f"\t Number of actions     : {self.num_actions} \n"
-                f"\t Observation clipping  : {self._clip_obs} \n"
-                f"\t Actions clipping      : {self._clip_actions} \n")
+
+class VecTask:
+    """Holds the task, the clipping bounds and the three spaces; `reset`/`step` are provided by subclasses."""
+
+    def __init__(self, task: IsaacEnvBase, rl_device: str, clip_obs: float = 5.0, clip_actions: float = 1.0):
+        assert isinstance(task, IsaacEnvBase), "VecTask wraps environments derived from IsaacEnvBase"
+        self._task, self._rl_device = task, rl_device
+        self._clip_obs, self._clip_actions = float(clip_obs), float(clip_actions)
+        dims = {"obs": task.get_obs_dim(), "state": task.get_state_dim(), "act": task.get_action_dim()}
+        self._dims: Dict[str, int] = dims
+        self._obs_space = _symmetric_box(dims["obs"], self._clip_obs)
+        self._state_space = _symmetric_box(dims["state"], self._clip_obs)
+        self._act_space = _symmetric_box(dims["act"], self._clip_actions)
+
+    # sizes ------------------------------------------------------------------------------------------
+    num_envs = property(lambda self: self._task.get_num_instances())
+    num_obs = property(lambda self: self._dims["obs"])
+    num_states = property(lambda self: self._dims["state"])
+    num_actions = property(lambda self: self._dims["act"])
+    # spaces -----------------------------------------------------------------------------------------
+    observation_space = property(lambda self: self._obs_space)
+    state_space = property(lambda self: self._state_space)
+    action_space = property(lambda self: self._act_space)
 
     def get_number_of_agents(self) -> int:
-        if hasattr(self._task, 'get_number_of_agents'):
-            return self._task.get_number_of_agents()
-        return 1
-
-    @property
-    def num_envs(self) -> int:
-        return self._task.get_num_instances()
-
-    @property
-    def num_states(self) -> int:
-        return self._task.get_state_dim()
-
-    @property
-    def num_obs(self) -> int:
-        return self._task.get_obs_dim()
-
-    @property
-    def num_actions(self) -> int:
-        return self._task.get_action_dim()
-
-    @property
-    def observation_space(self):
-        return self._obs_space
-
-    @property
-    def state_space(self):
-        return self._state_space
-
-    @property
-    def action_space(self):
-        return self._act_space
+        return getattr(self._task, "get_number_of_agents", lambda: 1)()
 
     def dump_config(self, filename: str):
         self._task.dump_config(filename)
+
+    def __str__(self) -> str:
+        rows = (("Number of instances", self.num_envs), ("Number of observations", self.num_obs),
+                ("Number of states", self.num_states), ("Number of actions", self.num_actions),
+                ("Observation clipping", self._clip_obs), ("Actions clipping", self._clip_actions))
+        body = "".join(f"\t {k:<22}: {v} \n" for k, v in rows)
+        return f"Vectorized Environment around task: {type(self._task).__name__} \n{body}"
 
     def reset(self) -> torch.Tensor:
         raise NotImplementedError
@@ -76,19 +64,20 @@ class VecTask:
 
 
 class VecTaskPython(VecTask):
+    """Wrapper for tasks whose buffers are torch tensors (all of them, here)."""
+
+    def _limit_obs(self, x: torch.Tensor) -> torch.Tensor:
+        return x.clamp(-self._clip_obs, self._clip_obs).to(self._rl_device)
+
     def get_state(self) -> torch.Tensor:
-        return torch.clamp(self._task.states_buf, -self._clip_obs, self._clip_obs).to(self._rl_device)
+        return self._limit_obs(self._task.states_buf)
 
     def reset(self) -> torch.Tensor:
-        obs = self._task.reset()
-        return torch.clamp(obs, -self._clip_obs, self._clip_obs).to(self._rl_device)
+        return self._limit_obs(self._task.reset())
 
     def step(self, actions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, dict]:
-        if self._task.visualize:
-            self._task.render()
-        actions_tensor = torch.clamp(actions, -self._clip_actions, self._clip_actions)
-        obs, rew, is_done, info = self._task.step(actions_tensor)
-        obs = torch.clamp(obs, -self._clip_obs, self._clip_obs).to(self._rl_device)
-        rew = rew.to(self._rl_device)
-        is_done = is_done.to(self._rl_device)
-        return obs, rew, is_done, info
+        task = self._task
+        if task.visualize:
+            task.render()
+        obs, reward, done, info = task.step(actions.clamp(-self._clip_actions, self._clip_actions))
+        return self._limit_obs(obs), reward.to(self._rl_device), done.to(self._rl_device), info
