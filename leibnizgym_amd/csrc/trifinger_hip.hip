@@ -1339,13 +1339,28 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
         float x_ = (val);                                                               \
         lds[lane * (W) + (col)] = nrm ? (2.0f * (x_ - off[col])) * inv[col] : x_;       \
     }
+    // Every slot but the action one has limits that are constants of the MDP (reference trifinger_env.py:153-213):
+    // with the loops unrolled, offset and 1/range fold into instruction literals - same fp32 values as the host-built
+    // table ((lo+hi)*0.5f and 1.0f/(hi-lo)), no scalar loads.  The action slot depends on the configuration and
+    // keeps reading the table.
+#define EMITC(W, col, val, lo_, hi_)                                                    \
+    {                                                                                   \
+        float x_ = (val);                                                               \
+        const float o_ = ((lo_) + (hi_)) * 0.5f, i_ = 1.0f / ((hi_) - (lo_));           \
+        lds[lane * (W) + (col)] = nrm ? (2.0f * (x_ - o_)) * i_ : x_;                   \
+    }
+#define QLO(j) (((j) % 3 == 0) ? -0.33f : (((j) % 3 == 1) ? 0.0f : -2.7f))
+#define QHI(j) (((j) % 3 == 0) ? 1.0f : (((j) % 3 == 1) ? 1.57f : 0.0f))
+#define PLO(j) (((j) == 2) ? 0.0f : -0.3f)
+#define TLO(j) (((j) < 2) ? -0.4f : (((j) == 2) ? 0.0f : (((j) < 7) ? -1.0f : -0.2f)))
+#define THI(j) (((j) < 2) ? 0.4f : (((j) == 2) ? 0.5f : (((j) < 7) ? 1.0f : 0.2f)))
 #define EMIT_COMMON(W)                                                                  \
-    _Pragma("unroll") for (int j = 0; j < 9; ++j) EMIT(W, j, e.q[j])                   \
-    _Pragma("unroll") for (int j = 0; j < 9; ++j) EMIT(W, 9 + j, e.qd[j])              \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) EMIT(W, 18 + j, e.cp[j])             \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) EMIT(W, 21 + j, e.cq[j])             \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) EMIT(W, 25 + j, e.gp[j])             \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) EMIT(W, 28 + j, e.gq[j])             \
+    _Pragma("unroll") for (int j = 0; j < 9; ++j) EMITC(W, j, e.q[j], QLO(j), QHI(j))   \
+    _Pragma("unroll") for (int j = 0; j < 9; ++j) EMITC(W, 9 + j, e.qd[j], -10.0f, 10.0f) \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) EMITC(W, 18 + j, e.cp[j], PLO(j), 0.3f) \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) EMITC(W, 21 + j, e.cq[j], -1.0f, 1.0f) \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) EMITC(W, 25 + j, e.gp[j], PLO(j), 0.3f) \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) EMITC(W, 28 + j, e.gq[j], -1.0f, 1.0f) \
     _Pragma("unroll") for (int j = 0; j < A; ++j) EMIT(W, 32 + j, opaque(act[j]))
     WAVE_LDS_ORDER();
     EMIT_COMMON(OD)
@@ -1355,34 +1370,40 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     if (P.asymmetric_obs) {
         EMIT_COMMON(SD)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) EMIT(SD, OD + j, e.cv[j])
+        for (int j = 0; j < 3; ++j) EMITC(SD, OD + j, e.cv[j], -0.5f, 0.5f)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) EMIT(SD, OD + 3 + j, e.cw[j])
+        for (int j = 0; j < 3; ++j) EMITC(SD, OD + 3 + j, e.cw[j], -0.5f, 0.5f)
 #pragma unroll
-        for (int j = 0; j < 13; ++j) EMIT(SD, OD + 6 + j, tips0[j])
+        for (int j = 0; j < 13; ++j) EMITC(SD, OD + 6 + j, tips0[j], TLO(j), THI(j))
 #pragma unroll
-        for (int j = 0; j < 13; ++j) EMIT(SD, OD + 19 + j, tips1[j])
+        for (int j = 0; j < 13; ++j) EMITC(SD, OD + 19 + j, tips1[j], TLO(j), THI(j))
 #pragma unroll
-        for (int j = 0; j < 13; ++j) EMIT(SD, OD + 32 + j, tips2[j])
+        for (int j = 0; j < 13; ++j) EMITC(SD, OD + 32 + j, tips2[j], TLO(j), THI(j))
 #pragma unroll
-        for (int j = 0; j < 9; ++j) EMIT(SD, OD + 45 + j, (P.enable_ft ? e.tau[j] : 0.0f))
+        for (int j = 0; j < 9; ++j) EMITC(SD, OD + 45 + j, (P.enable_ft ? e.tau[j] : 0.0f), -0.36f, 0.36f)
         float inv_n = 1.0f / (float)(P.substeps * P.control_decimation);
         float wl[6];
         wrench_local<0>(P, pk0, e, inv_n, wl);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) EMIT(SD, OD + 54 + j, wl[j])
+        for (int j = 0; j < 6; ++j) EMITC(SD, OD + 54 + j, wl[j], -1.0f, 1.0f)
         wrench_local<1>(P, pk1, e, inv_n, wl);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) EMIT(SD, OD + 60 + j, wl[j])
+        for (int j = 0; j < 6; ++j) EMITC(SD, OD + 60 + j, wl[j], -1.0f, 1.0f)
         wrench_local<2>(P, pk2, e, inv_n, wl);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) EMIT(SD, OD + 66 + j, wl[j])
+        for (int j = 0; j < 6; ++j) EMITC(SD, OD + 66 + j, wl[j], -1.0f, 1.0f)
         WAVE_LDS_ORDER();
         store_tile(P.states, lds, wave_first, n_valid, SD, lane);
         WAVE_LDS_ORDER();
     }
 #undef EMIT_COMMON
 #undef EMIT
+#undef EMITC
+#undef QLO
+#undef QHI
+#undef PLO
+#undef TLO
+#undef THI
     // ---- history: previous fingertip positions are whatever the last filled frame left ----
     const float* tip_prev = cy.tip_prev;
     if (valid) {
@@ -1498,6 +1519,15 @@ DEV void stats_publish(const DevParams& P, const LaneStats& st, int lane) {
     const int n_valid = (P.N - wave_first < WAVE) ? (P.N - wave_first) : WAVE; \
     (void)n_valid; (void)i; (void)valid;
 
+// Developer instrumentation (make TIMING=1 -> libtrifinger_hip_timing.so, used by tools/phase_timing.py only):
+// lane 0 of every wave stamps s_memtime at the phase boundaries into scratch[wave*16 + 11..15].
+#ifdef TF_PHASE_TIMING
+#define PHASE_STAMP(k) do { if (lane == 0) { unsigned long long t_ = __builtin_readcyclecounter(); \
+    reinterpret_cast<unsigned int*>(P.scratch)[(size_t)blockIdx.x * 16 + 11 + (k)] = (unsigned int)t_; } } while (0)
+#else
+#define PHASE_STAMP(k) do { } while (0)
+#endif
+
 // fused control step (IS_RESET=false) or IsaacEnvBase.reset (IS_RESET=true)
 template <int A, bool IS_RESET, bool ASYM>
 __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ Pp, const StepArgs sa,
@@ -1508,6 +1538,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
     Carried cy;
     float n_resets = 0.0f;
     float act[A], prev_obj[7];
+    PHASE_STAMP(0);
     // ---- phase A: action tile, masked resets, torque law ----
     {
         if (!IS_RESET) {
@@ -1571,7 +1602,9 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
     const int nsub = sa.nsim * P.substeps;
+    PHASE_STAMP(1);
     for (int s = 0; s < nsub; ++s) substep<ASYM>(P, e, P.hsub);
+    PHASE_STAMP(2);
     // ---- phase C: observations, rewards, termination, counters.  Its inputs come back from the LDS parking slots
     // (no global load sits between the last solver sweep and the output stores) ----
     WAVE_LDS_ORDER();
@@ -1601,6 +1634,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         if (P.goal_rotation_activate) store_goal(P, i, e, valid);
         if (!IS_RESET) finish_env(P, i, valid, cy);
         stats_publish(P, st, lane);
+        PHASE_STAMP(3);
     }
 }
 
