@@ -36,8 +36,8 @@ from leibnizgym_amd import _capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per k_step launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, raw
-# counter expressions; profiles/r1_d_pmc.txt).  Only valid for the exact workload it was measured on.
-PMC_TRAFFIC = {(65536, True): (9080.895 + 56768.000) * 1024.0}
+# counter expressions; profiles/r1_f_pmc.txt).  Only valid for the exact workload it was measured on.
+PMC_TRAFFIC = {(65536, True): (9061.500 + 56768.000) * 1024.0}
 FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
@@ -208,7 +208,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": PMC_TRAFFIC.get((n, asym)),
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_d_pmc.txt" if (n, asym) in PMC_TRAFFIC else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_f_pmc.txt" if (n, asym) in PMC_TRAFFIC else None,
             "kernel": "k_step<9,false>",
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
