@@ -129,6 +129,17 @@ _STATUS_TO_EXC = {
 }
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 def check(lib, status, what):
     if status == capi.TF_OK:
         return
@@ -174,8 +185,12 @@ class TrifingerEngine:
         self.reset_count = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.info = torch.zeros((capi.TF_NUM_INFO,), **f32)
         self.scratch = torch.zeros((int(lib.tf_scratch_floats(n)),), **f32)
+        self._is_cuda = dev.type == "cuda"
+        if self._is_cuda:
+            self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         self._handle = C.c_void_p()
-        check(lib, lib.tf_create(C.byref(cfg), C.byref(self._handle)), "tf_create")
+        with self._on_device():          # the library allocates its parameter block on the CURRENT HIP device
+            check(lib, lib.tf_create(C.byref(cfg), C.byref(self._handle)), "tf_create")
         b = capi.TfBuffers()
         b.state = self.state.data_ptr()
         b.action_buf = self.action_buf.data_ptr()
@@ -191,12 +206,16 @@ class TrifingerEngine:
         b.info = self.info.data_ptr()
         b.scratch = self.scratch.data_ptr()
         self._bufs = b
-        check(lib, lib.tf_bind(self._handle, C.byref(b)), "tf_bind")
-        self._is_cuda = dev.type == "cuda"
-        if self._is_cuda:
-            self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        with self._on_device():
+            check(lib, lib.tf_bind(self._handle, C.byref(b)), "tf_bind")
 
     # -- plumbing ---------------------------------------------------------------------------
+    def _on_device(self):
+        """Context that makes the engine's GPU the current HIP device (kernels are launched on the current device)."""
+        if self._is_cuda and torch.cuda.current_device() != self._dev_index:
+            return torch.cuda.device(self._dev_index)
+        return _NULL_CTX
+
     def _stream(self):
         if self._is_cuda:
             return C.c_void_p(torch.cuda.current_stream(self._dev_index).cuda_stream)
@@ -228,10 +247,17 @@ class TrifingerEngine:
     # -- hot path ---------------------------------------------------------------------------
     def step(self, action):
         """One fused control step.  `action`: contiguous float32 [N, A] tensor on the engine's device."""
-        check(self.lib, self.lib.tf_step(self._handle, C.c_void_p(action.data_ptr()), self._stream()), "tf_step")
+        if self._is_cuda and torch.cuda.current_device() != self._dev_index:
+            with torch.cuda.device(self._dev_index):
+                rc = self.lib.tf_step(self._handle, C.c_void_p(action.data_ptr()), self._stream())
+        else:
+            rc = self.lib.tf_step(self._handle, C.c_void_p(action.data_ptr()), self._stream())
+        if rc:
+            check(self.lib, rc, "tf_step")
 
     def reset(self):
-        check(self.lib, self.lib.tf_reset(self._handle, self._stream()), "tf_reset")
+        with self._on_device():
+            check(self.lib, self.lib.tf_reset(self._handle, self._stream()), "tf_reset")
 
     def enable_kernel_timing(self, max_launches):
         check(self.lib, self.lib.tf_enable_kernel_timing(self._handle, int(max_launches)), "tf_enable_kernel_timing")
