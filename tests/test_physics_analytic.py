@@ -138,6 +138,24 @@ def test_coriolis_bias_is_power_free(oracle):
         assert abs(lhs - rhs) < 2e-3 * max(1.0, abs(rhs)) + 2e-4, (lhs, rhs)
 
 
+def test_bias_forces_match_the_lagrangian(oracle):
+    """Full check of the velocity-dependent forces: h(q, qd) = Mdot qd - 1/2 d(qd^T M qd)/dq + dV/dq, with every
+    derivative taken numerically on the independent fp64 model (pins all Coriolis / centrifugal terms, not only their
+    projection on qd)."""
+    rng = np.random.default_rng(7)
+    q = rng.uniform([-0.3, 0.1, -2.5], [0.9, 1.4, -0.2], (12, 3))
+    qd = rng.uniform(-4, 4, (12, 3))
+    _, _, b = call_dynamics(oracle, "cpu", q, qd)
+    eps = 1e-5
+    for i in range(12):
+        dM = [(kinetic_matrix(q[i] + eps * e) - kinetic_matrix(q[i] - eps * e)) / (2 * eps) for e in np.eye(3)]
+        Mdot = sum(dM[k] * qd[i][k] for k in range(3))
+        dT = np.array([0.5 * qd[i] @ dM[k] @ qd[i] for k in range(3)])
+        dV = np.array([(potential(q[i] + eps * e) - potential(q[i] - eps * e)) / (2 * eps) for e in np.eye(3)])
+        h = Mdot @ qd[i] - dT + dV
+        np.testing.assert_allclose(b[i], h, atol=3e-4, rtol=2e-3)
+
+
 # ---- whole-env known answers ---------------------------------------------------------------------------
 def engine(lib, n=1, model_edit=None, **kw):
     m = lib.default_model()
