@@ -53,21 +53,31 @@ struct RewardCoef {
     float c_reach, c_move_pen, dt, c_dist, rot_num, rot_scale, w_rot, rot_delta_sched, w_rot_delta, w_move;
 };
 
+// Buffer pointers that are read out of the parameter block carry the global address space in their type: a plain
+// pointer loaded from memory is "generic" to the compiler, which then emits flat_load/flat_store - those count
+// against lgkmcnt as well as vmcnt, so every LDS read or scalar load that follows a store would wait for HBM.
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef GLOBAL_AS float gfloat;
+typedef GLOBAL_AS uint8_t gu8;
+typedef GLOBAL_AS int32_t gi32;
+typedef GLOBAL_AS uint32_t gu32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct DevParams {
     // buffers
-    float* state;
-    float* action_buf;
-    float* obs;
-    float* states;
-    float* reward;
-    uint8_t* reset_buf;
-    uint8_t* goal_reset_buf;
-    uint8_t* successes;
-    uint8_t* dones;
-    int32_t* steps;
-    uint32_t* reset_count;
-    float* info;
-    float* scratch;
+    gfloat* state;
+    gfloat* action_buf;
+    gfloat* obs;
+    gfloat* states;
+    gfloat* reward;
+    gu8* reset_buf;
+    gu8* goal_reset_buf;
+    gu8* successes;
+    gu8* dones;
+    gi32* steps;
+    gu32* reset_count;
+    gfloat* info;
+    gfloat* scratch;
     // sizes
     int32_t N, A, OD, SD;
     int32_t env_id_offset;
@@ -111,6 +121,21 @@ struct StepArgs {
 // drain - only the compiler must keep the program order.  A wavefront-scope fence does exactly that and emits no
 // instruction; __syncthreads() would add `s_waitcnt vmcnt(0)` (waits for every outstanding global store) each time.
 #define WAVE_LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+// Developer instrumentation (libtrifinger_hip_timing.so, used by tools/phase_timing.py only): lane 0 of every wave
+// appends s_memtime stamps to scratch[wave*SCR_STRIDE + 16 ...]; the stamp counter lives in LDS.
+#ifdef TF_PHASE_TIMING
+#define SCR_STRIDE 80
+__shared__ unsigned int g_stamp_ctr;
+#define PHASE_STAMP_RESET() do { if (threadIdx.x == 0) g_stamp_ctr = 0; } while (0)
+#define PHASE_STAMP() do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_readcyclecounter(); \
+    unsigned int n_ = g_stamp_ctr; g_stamp_ctr = n_ + 1; if (n_ < SCR_STRIDE - 16) \
+    ((gu32*)P.scratch)[(size_t)blockIdx.x * SCR_STRIDE + 16 + n_] = (unsigned int)t_; } } while (0)
+#else
+#define SCR_STRIDE 16
+#define PHASE_STAMP_RESET() do { } while (0)
+#define PHASE_STAMP() do { } while (0)
+#endif
 
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
@@ -843,6 +868,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             w[i] = e.cw[i] * da;
         }
     }
+    PHASE_STAMP();
     // ---- contact generation ----
     float R[9];
     quat_to_rot(e.cq, R);
@@ -851,6 +877,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
     finger_contacts<0>(P, e, fk0, R, vq, v, w, hc, inv_h, inv_m, inv_I, fc0, tf0);
     finger_contacts<1>(P, e, fk1, R, vq, v, w, hc, inv_h, inv_m, inv_I, fc1, tf1);
     finger_contacts<2>(P, e, fk2, R, vq, v, w, hc, inv_h, inv_m, inv_I, fc2, tf2);
+    PHASE_STAMP();
     CubeContactRegs cf[4], cwl[4];
     {   // cube vs floor: corners of the face that points down most
         int k = 0;
@@ -875,6 +902,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             }
         }
     }
+    PHASE_STAMP();
     {   // cube vs boundary wall: corners of the face that points outward most
         float rho_c = f_sqrt(FMA(e.cp[0], e.cp[0], e.cp[1] * e.cp[1]));
         bool any = rho_c > 1e-6f;
@@ -912,6 +940,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             }
         }
     }
+    PHASE_STAMP();
     // ---- joint / velocity limit rows ----
     float vlo[9], vhi[9], lim_dinv[9], lim_lam[9];
 #pragma unroll
@@ -924,6 +953,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
         lim_dinv[j] = 1.0f / k.Minv[dg];
         lim_lam[j] = 0.0f;
     }
+    PHASE_STAMP();
     // ---- projected Gauss-Seidel ----
     for (int it = 0; it < P.iters; ++it) {
         solve_finger_cube<0>(mu_fc, fc0, vq, v, w, inv_m, inv_I);
@@ -962,6 +992,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             vq[3 * f + 2] = FMA(k.Minv[c2], dl, vq[3 * f + 2]);
         }
     }
+    PHASE_STAMP();
     // ---- fingertip wrench sensor ----
     if (WRENCH) {
         add_wrench<true>(fc0, inv_h, &e.ft[0]);
@@ -983,6 +1014,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
         e.cp[i] = FMA(h, v[i], e.cp[i]);
     }
     quat_integrate(e.cq, e.cw, h);
+    PHASE_STAMP();
 }
 
 // the moving goal (goal_movement.rotation) is a free body nothing interacts with: its orientation is
@@ -996,63 +1028,68 @@ DEV void goal_advance(const DevParams& P, Env& e, int nsub, float h) {
 // ------------------------------------------------------------------------------------------------------
 // SoA <-> registers
 // ------------------------------------------------------------------------------------------------------
-#define ST(row) P.state[(size_t)(row) * (size_t)P.N + (size_t)i]
+// The state block float[88][N] is addressed through a raw buffer resource: wave-uniform row offset in an SGPR (soffset),
+// 32-bit lane offset in one VGPR - buffer_load/store_dword ... offen, no per-lane 64-bit address arithmetic at all.
+// (tf_create limits N so that 88*N*4 fits the 32-bit offsets.)
+#define ST_RSRC() __builtin_amdgcn_make_buffer_rsrc((void*)P.state, 0, TF_STATE_ROWS * P.N * 4, 0x00020000)
+#define LDST(row) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ST_RSRC(), (unsigned)i * 4u, (row) * P.N * 4, 0))
+#define STST(row, val) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), ST_RSRC(), (unsigned)i * 4u, (row) * P.N * 4, 0)
 
 DEV void load_goal(const DevParams& P, int i, Env& e) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { e.gp[j] = ST(TF_S_GOAL_P + j); e.gw[j] = ST(TF_S_GOAL_W + j); }
+    for (int j = 0; j < 3; ++j) { e.gp[j] = LDST(TF_S_GOAL_P + j); e.gw[j] = LDST(TF_S_GOAL_W + j); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) e.gq[j] = ST(TF_S_GOAL_Q + j);
+    for (int j = 0; j < 4; ++j) e.gq[j] = LDST(TF_S_GOAL_Q + j);
 }
 DEV void store_goal(const DevParams& P, int i, const Env& e, bool pred) {
     if (!pred) return;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { ST(TF_S_GOAL_P + j) = e.gp[j]; ST(TF_S_GOAL_W + j) = e.gw[j]; }
+    for (int j = 0; j < 3; ++j) { STST(TF_S_GOAL_P + j, e.gp[j]); STST(TF_S_GOAL_W + j, e.gw[j]); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ST(TF_S_GOAL_Q + j) = e.gq[j];
+    for (int j = 0; j < 4; ++j) STST(TF_S_GOAL_Q + j, e.gq[j]);
 }
 DEV void load_dyn(const DevParams& P, int i, Env& e) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) e.dr[j] = ST(TF_S_DR + j);
+    for (int j = 0; j < 4; ++j) e.dr[j] = LDST(TF_S_DR + j);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) { e.q[j] = ST(TF_S_Q + j); e.qd[j] = ST(TF_S_QD + j); }
+    for (int j = 0; j < 9; ++j) { e.q[j] = LDST(TF_S_Q + j); e.qd[j] = LDST(TF_S_QD + j); }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { e.cp[j] = ST(TF_S_CUBE_P + j); e.cv[j] = ST(TF_S_CUBE_V + j); e.cw[j] = ST(TF_S_CUBE_W + j); }
+    for (int j = 0; j < 3; ++j) { e.cp[j] = LDST(TF_S_CUBE_P + j); e.cv[j] = LDST(TF_S_CUBE_V + j); e.cw[j] = LDST(TF_S_CUBE_W + j); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) e.cq[j] = ST(TF_S_CUBE_Q + j);
+    for (int j = 0; j < 4; ++j) e.cq[j] = LDST(TF_S_CUBE_Q + j);
 }
 DEV void store_dyn(const DevParams& P, int i, const Env& e, bool valid) {
     if (!valid) return;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) { ST(TF_S_Q + j) = e.q[j]; ST(TF_S_QD + j) = e.qd[j]; ST(TF_S_TAU + j) = e.tau[j]; }
+    for (int j = 0; j < 9; ++j) { STST(TF_S_Q + j, e.q[j]); STST(TF_S_QD + j, e.qd[j]); STST(TF_S_TAU + j, e.tau[j]); }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { ST(TF_S_CUBE_P + j) = e.cp[j]; ST(TF_S_CUBE_V + j) = e.cv[j]; ST(TF_S_CUBE_W + j) = e.cw[j]; }
+    for (int j = 0; j < 3; ++j) { STST(TF_S_CUBE_P + j, e.cp[j]); STST(TF_S_CUBE_V + j, e.cv[j]); STST(TF_S_CUBE_W + j, e.cw[j]); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ST(TF_S_CUBE_Q + j) = e.cq[j];
+    for (int j = 0; j < 4; ++j) STST(TF_S_CUBE_Q + j, e.cq[j]);
 }
 DEV void load_split_extras(const DevParams& P, int i, Env& e) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) e.tau[j] = ST(TF_S_TAU + j);
+    for (int j = 0; j < 9; ++j) e.tau[j] = LDST(TF_S_TAU + j);
 #pragma unroll
-    for (int j = 0; j < 18; ++j) e.ft[j] = ST(TF_S_FT + j);
+    for (int j = 0; j < 18; ++j) e.ft[j] = LDST(TF_S_FT + j);
 }
 DEV void store_ft(const DevParams& P, int i, const Env& e, bool valid) {
     if (!valid) return;
 #pragma unroll
-    for (int j = 0; j < 18; ++j) ST(TF_S_FT + j) = e.ft[j];
+    for (int j = 0; j < 18; ++j) STST(TF_S_FT + j, e.ft[j]);
 }
 DEV void store_prev_obj(const DevParams& P, int i, const Env& e, bool valid) {
     if (!valid) return;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) ST(TF_S_PREV_OBJ_P + j) = e.cp[j];
+    for (int j = 0; j < 3; ++j) STST(TF_S_PREV_OBJ_P + j, e.cp[j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ST(TF_S_PREV_OBJ_Q + j) = e.cq[j];
+    for (int j = 0; j < 4; ++j) STST(TF_S_PREV_OBJ_Q + j, e.cq[j]);
 }
 DEV void load_prev_obj(const DevParams& P, int i, float prev_obj[7]) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) prev_obj[j] = ST(TF_S_PREV_OBJ_P + j);
+    for (int j = 0; j < 3; ++j) prev_obj[j] = LDST(TF_S_PREV_OBJ_P + j);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) prev_obj[3 + j] = ST(TF_S_PREV_OBJ_Q + j);
+    for (int j = 0; j < 4; ++j) prev_obj[3 + j] = LDST(TF_S_PREV_OBJ_Q + j);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1127,14 +1164,29 @@ struct Carried {
     int steps;               // _steps_count_buf after the reset logic
 };
 
+// flag and counter buffers of one env, fetched together with the state rows (one memory round trip for everything)
+struct EnvFlags {
+    uint8_t reset, goal_reset, successes;
+    int steps;
+    uint32_t count;
+};
+DEV void load_flags(const DevParams& P, int i, EnvFlags& fl) {
+    fl.reset = P.reset_buf[(unsigned)i];
+    fl.goal_reset = P.goal_reset_buf[(unsigned)i];
+    fl.successes = P.successes[(unsigned)i];
+    fl.steps = P.steps[(unsigned)i];
+    fl.count = P.reset_count[(unsigned)i];
+}
+
 // masked _reset_impl then _goal_reset_impl (env_base.py:370-379; trifinger_env.py:373-440)
-DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_all, bool& goal_changed, Carried& cy) {
+DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_all, bool& goal_changed, Carried& cy,
+                      const EnvFlags& fl) {
     const TfModel& m = P.m;
     uint32_t gid = (uint32_t)(P.env_id_offset + i);
     bool did_reset = false;
-    bool rflag = force_all || (P.reset_buf[i] != 0);
-    bool gflag = !force_all && (P.goal_reset_buf[i] != 0);
-    uint32_t count = P.reset_count[i];
+    bool rflag = force_all || (fl.reset != 0);
+    bool gflag = !force_all && (fl.goal_reset != 0);
+    uint32_t count = fl.count;
     if (rflag) {
         did_reset = true;
         if (P.dr_enable) {      // build-defined domain randomisation: scale = lo + (hi - lo) u
@@ -1180,19 +1232,19 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
         count = count + 1u;
     }
     if (valid) {
-        if (rflag) { P.reset_buf[i] = 0; P.steps[i] = 0; P.successes[i] = 0; }
-        if (gflag) P.goal_reset_buf[i] = 0;
-        if (rflag || gflag) P.reset_count[i] = count;
+        if (rflag) { P.reset_buf[(unsigned)i] = 0; P.steps[(unsigned)i] = 0; P.successes[(unsigned)i] = 0; }
+        if (gflag) P.goal_reset_buf[(unsigned)i] = 0;
+        if (rflag || gflag) P.reset_count[(unsigned)i] = count;
         if (rflag && P.dr_enable) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ST(TF_S_DR + j) = e.dr[j];
+            for (int j = 0; j < 4; ++j) STST(TF_S_DR + j, e.dr[j]);
         }
     }
     goal_changed = rflag || gflag;
     cy.reset = false;                                   // cleared by the reset, or it was not set
-    cy.goal_reset = force_all ? (P.goal_reset_buf[i] != 0) : false;   // reset() leaves _goal_reset_buf alone
-    cy.successes = rflag ? false : (P.successes[i] != 0);
-    cy.steps = rflag ? 0 : P.steps[i];
+    cy.goal_reset = force_all ? (fl.goal_reset != 0) : false;   // reset() leaves _goal_reset_buf alone
+    cy.successes = rflag ? false : (fl.successes != 0);
+    cy.steps = rflag ? 0 : fl.steps;
     return did_reset;
 }
 
@@ -1264,24 +1316,45 @@ template <int F> DEV void wrench_local(const DevParams& P, const FK& kk, const E
     }
 }
 
-// cooperative, coalesced store of a [64][W] tile staged in LDS as lds[lane * W + j]
-DEV void store_tile(float* __restrict__ dst, const float* lds, int wave_first_env, int n_valid, int W, int lane) {
-    const int total = n_valid * W;                       // floats in this wave's tile
-    float* base = dst + (size_t)wave_first_env * (size_t)W;   // 64*W*4-byte multiple: 16-B aligned
-    const int total4 = total >> 2;
-    for (int idx = lane; idx < total4; idx += WAVE) {
-        float4 vv = *reinterpret_cast<const float4*>(&lds[idx * 4]);
-        *reinterpret_cast<float4*>(&base[idx * 4]) = vv;
+// cooperative, coalesced store of a [64][W] tile staged in LDS as lds[lane * W + j]: ceil(16 W / 64) predicated
+// dwordx4 stores per lane, fully unrolled (every LDS read can be issued before the first store); a ragged last wave
+// (n_valid < 64) finishes its < 4 trailing floats with dword stores.
+template <int W>
+DEV void store_tile(gfloat* __restrict__ dst, const float* lds, int wave_first_env, int n_valid, int lane) {
+    const unsigned total = (unsigned)(n_valid * W);              // floats in this wave's tile
+    gfloat* base = dst + (size_t)wave_first_env * (size_t)W;     // 64*W*4-byte multiple: 16-B aligned
+    const unsigned total4 = total >> 2;
+    constexpr int ITER = (16 * W + WAVE - 1) / WAVE;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const unsigned idx = (unsigned)lane + (unsigned)(WAVE * k);
+        if (idx < total4) {
+            f32x4 vv = *reinterpret_cast<const f32x4*>(&lds[idx * 4u]);
+            *(GLOBAL_AS f32x4*)(&base[idx * 4u]) = vv;
+        }
     }
-    for (int idx = (total4 << 2) + lane; idx < total; idx += WAVE) base[idx] = lds[idx];
+    const unsigned tail = (total4 << 2) + (unsigned)lane;
+    if (tail < total) base[tail] = lds[tail];
 }
 
 struct LaneStats { float rew[6]; float pos_cnt, ori_cnt, succ, resets, nonfinite; };
 
 
-DEV float wave_sum(float x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = x + __shfl_xor(x, off, WAVE);
+// Sum over the 64 lanes, valid in lane 63.  DPP only (operand swizzles of v_add_f32, no LDS round trips like
+// ds_bpermute): xor-1 / xor-2 inside the quads, rotate by 4 and 8 inside the 16-lane rows, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Fixed order, so the statistics stay deterministic.
+template <int CTRL, int ROW_MASK>
+DEV float dpp_add(float x) {
+    int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false);
+    return x + __builtin_bit_cast(float, moved);
+}
+DEV float wave_sum_lane63(float x) {
+    x = dpp_add<0xB1, 0xF>(x);      // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E, 0xF>(x);      // quad_perm [2,3,0,1]
+    x = dpp_add<0x124, 0xF>(x);     // row_ror:4
+    x = dpp_add<0x128, 0xF>(x);     // row_ror:8
+    x = dpp_add<0x142, 0xA>(x);     // row_bcast:15 -> rows 1, 3
+    x = dpp_add<0x143, 0xC>(x);     // row_bcast:31 -> rows 2, 3
     return x;
 }
 
@@ -1325,11 +1398,12 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
             tip_state<0>(m, pk0, &e.q[0], &e.qd[0], tips0);
             tip_state<1>(m, pk1, &e.q[3], &e.qd[3], tips1);
             tip_state<2>(m, pk2, &e.q[6], &e.qd[6], tips2);
-            if (valid) P.reset_buf[i] = 1;
+            if (valid) P.reset_buf[(unsigned)i] = 1;
             cy.reset = true;
             st.nonfinite += valid ? 1.0f : 0.0f;
         }
     }
+    PHASE_STAMP();
     // ---- observations: stage [lane][OD] in LDS, then one coalesced tile store ----
     const float* off = P.tables + TAB_OFF;
     const float* inv = P.tables + TAB_INV;
@@ -1365,8 +1439,9 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     WAVE_LDS_ORDER();
     EMIT_COMMON(OD)
     WAVE_LDS_ORDER();
-    store_tile(P.obs, lds, wave_first, n_valid, OD, lane);
+    store_tile<OD>(P.obs, lds, wave_first, n_valid, lane);
     WAVE_LDS_ORDER();
+    PHASE_STAMP();
     if (P.asymmetric_obs) {
         EMIT_COMMON(SD)
 #pragma unroll
@@ -1393,7 +1468,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
 #pragma unroll
         for (int j = 0; j < 6; ++j) EMITC(SD, OD + 66 + j, wl[j], -1.0f, 1.0f)
         WAVE_LDS_ORDER();
-        store_tile(P.states, lds, wave_first, n_valid, SD, lane);
+        store_tile<SD>(P.states, lds, wave_first, n_valid, lane);
         WAVE_LDS_ORDER();
     }
 #undef EMIT_COMMON
@@ -1404,11 +1479,12 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
 #undef PLO
 #undef TLO
 #undef THI
+    PHASE_STAMP();
     // ---- history: previous fingertip positions are whatever the last filled frame left ----
     const float* tip_prev = cy.tip_prev;
     if (valid) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { ST(TF_S_TIP_P + j) = tips0[j]; ST(TF_S_TIP_P + 3 + j) = tips1[j]; ST(TF_S_TIP_P + 6 + j) = tips2[j]; }
+        for (int j = 0; j < 3; ++j) { STST(TF_S_TIP_P + j, tips0[j]); STST(TF_S_TIP_P + 3 + j, tips1[j]); STST(TF_S_TIP_P + 6 + j, tips2[j]); }
     }
     if (!with_reward) return;
     // ---- rewards (reference rewards.py; order of trifinger_env.py:513-550) ----
@@ -1454,7 +1530,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     bool succ = cy.successes;
     if (P.success_activate) {
         if (done) total = total + P.success_bonus;
-        if (valid) P.goal_reset_buf[i] = (uint8_t)done;
+        if (valid) P.goal_reset_buf[(unsigned)i] = (uint8_t)done;
         cy.goal_reset = done;
         succ = succ || done;
     } else {
@@ -1462,8 +1538,8 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     }
     cy.successes = succ;
     if (valid) {
-        P.successes[i] = (uint8_t)succ;
-        P.reward[i] = total;
+        P.successes[(unsigned)i] = (uint8_t)succ;
+        P.reward[(unsigned)i] = total;
     }
     st.succ += (valid && succ) ? 1.0f : 0.0f;
 }
@@ -1471,18 +1547,18 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
 DEV void finish_env(const DevParams& P, int i, bool valid, const Carried& cy) {     // env_base.py:391-399
     if (!valid) return;
     int s = cy.steps + 1;
-    P.steps[i] = s;
+    P.steps[(unsigned)i] = s;
     bool rb = cy.reset;
-    if (P.episode_length > 0 && s >= P.episode_length) { rb = true; P.reset_buf[i] = 1; }
-    P.dones[i] = (uint8_t)(rb && cy.goal_reset);
+    if (P.episode_length > 0 && s >= P.episode_length) { rb = true; P.reset_buf[(unsigned)i] = 1; }
+    P.dones[(unsigned)i] = (uint8_t)(rb && cy.goal_reset);
 }
 DEV void load_carried(const DevParams& P, int i, Carried& cy) {        // split path: everything comes from memory
 #pragma unroll
-    for (int j = 0; j < 9; ++j) cy.tip_prev[j] = ST(TF_S_TIP_P + j);
-    cy.successes = P.successes[i] != 0;
-    cy.goal_reset = P.goal_reset_buf[i] != 0;
-    cy.reset = P.reset_buf[i] != 0;
-    cy.steps = P.steps[i];
+    for (int j = 0; j < 9; ++j) cy.tip_prev[j] = LDST(TF_S_TIP_P + j);
+    cy.successes = P.successes[(unsigned)i] != 0;
+    cy.goal_reset = P.goal_reset_buf[(unsigned)i] != 0;
+    cy.reset = P.reset_buf[(unsigned)i] != 0;
+    cy.steps = P.steps[(unsigned)i];
 }
 
 DEV void stats_zero(LaneStats& st) {
@@ -1491,15 +1567,15 @@ DEV void stats_zero(LaneStats& st) {
     st.pos_cnt = 0.0f; st.ori_cnt = 0.0f; st.succ = 0.0f; st.resets = 0.0f; st.nonfinite = 0.0f;
 }
 DEV void stats_publish(const DevParams& P, const LaneStats& st, int lane) {
-    float* out = P.scratch + (size_t)blockIdx.x * 16;
+    gfloat* out = P.scratch + (size_t)blockIdx.x * SCR_STRIDE;
     float vals[11];
 #pragma unroll
     for (int t = 0; t < 6; ++t) vals[t] = st.rew[t];
     vals[6] = st.pos_cnt; vals[7] = st.ori_cnt; vals[8] = st.succ; vals[9] = st.resets; vals[10] = st.nonfinite;
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-        float s = wave_sum(vals[k]);
-        if (lane == 0) out[k] = s;
+        float s = wave_sum_lane63(vals[k]);
+        if (lane == WAVE - 1) out[k] = s;
     }
 }
 
@@ -1519,15 +1595,6 @@ DEV void stats_publish(const DevParams& P, const LaneStats& st, int lane) {
     const int n_valid = (P.N - wave_first < WAVE) ? (P.N - wave_first) : WAVE; \
     (void)n_valid; (void)i; (void)valid;
 
-// Developer instrumentation (make TIMING=1 -> libtrifinger_hip_timing.so, used by tools/phase_timing.py only):
-// lane 0 of every wave stamps s_memtime at the phase boundaries into scratch[wave*16 + 11..15].
-#ifdef TF_PHASE_TIMING
-#define PHASE_STAMP(k) do { if (lane == 0) { unsigned long long t_ = __builtin_readcyclecounter(); \
-    reinterpret_cast<unsigned int*>(P.scratch)[(size_t)blockIdx.x * 16 + 11 + (k)] = (unsigned int)t_; } } while (0)
-#else
-#define PHASE_STAMP(k) do { } while (0)
-#endif
-
 // fused control step (IS_RESET=false) or IsaacEnvBase.reset (IS_RESET=true)
 template <int A, bool IS_RESET, bool ASYM>
 __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ Pp, const StepArgs sa,
@@ -1538,14 +1605,34 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
     Carried cy;
     float n_resets = 0.0f;
     float act[A], prev_obj[7];
-    PHASE_STAMP(0);
+    PHASE_STAMP_RESET();
+    PHASE_STAMP();
     // ---- phase A: action tile, masked resets, torque law ----
     {
+        // every global load of the step is issued here, back to back (one exposed memory latency, not four): the action
+        // tile [n_valid][A] (contiguous: coalesced dword loads, index clamped instead of branching), the state rows,
+        // the flag / counter buffers
+        float tile[A];
+        EnvFlags fl;
         if (!IS_RESET) {
-            // action tile [n_valid][A] is contiguous: coalesced dword loads into LDS, each lane picks its row
             const float* src = action + (size_t)wave_first * (size_t)A;
-            const int total = n_valid * A;
-            for (int idx = lane; idx < total; idx += WAVE) lds[idx] = src[idx];
+            const unsigned last = (unsigned)(n_valid * A) - 1u;
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                const unsigned idx = (unsigned)lane + (unsigned)(WAVE * k);
+                tile[k] = src[idx < last ? idx : last];
+            }
+        }
+        load_dyn(P, i, e);
+        load_goal(P, i, e);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) cy.tip_prev[j] = LDST(TF_S_TIP_P + j);
+        load_flags(P, i, fl);
+        PHASE_STAMP();
+        if (!IS_RESET) {
+            // the tile goes through LDS so that each lane can pick up its row
+#pragma unroll
+            for (int k = 0; k < A; ++k) lds[lane + WAVE * k] = tile[k];
             WAVE_LDS_ORDER();
             const int row = valid ? lane : (n_valid - 1);
 #pragma unroll
@@ -1555,12 +1642,10 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
 #pragma unroll
             for (int j = 0; j < A; ++j) act[j] = 0.0f;
         }
-        load_dyn(P, i, e);
-        load_goal(P, i, e);
-#pragma unroll
-        for (int j = 0; j < 9; ++j) cy.tip_prev[j] = ST(TF_S_TIP_P + j);
+        PHASE_STAMP();
         bool goal_changed;
-        bool did_reset = apply_resets(P, i, valid, e, IS_RESET, goal_changed, cy);
+        bool did_reset = apply_resets(P, i, valid, e, IS_RESET, goal_changed, cy, fl);
+        PHASE_STAMP();
         store_goal(P, i, e, valid && goal_changed);
         if (did_reset) {
 #pragma unroll
@@ -1571,7 +1656,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
 #pragma unroll
         for (int j = 0; j < A; ++j) lds[lane * A + j] = act[j];
         WAVE_LDS_ORDER();
-        store_tile(P.action_buf, lds, wave_first, n_valid, A, lane);
+        store_tile<A>(P.action_buf, lds, wave_first, n_valid, lane);
         WAVE_LDS_ORDER();
         compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
         store_prev_obj(P, i, e, valid);                         // history[1] of the object (trifinger_env.py:975)
@@ -1602,9 +1687,9 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
     const int nsub = sa.nsim * P.substeps;
-    PHASE_STAMP(1);
+    PHASE_STAMP();
     for (int s = 0; s < nsub; ++s) substep<ASYM>(P, e, P.hsub);
-    PHASE_STAMP(2);
+    PHASE_STAMP();
     // ---- phase C: observations, rewards, termination, counters.  Its inputs come back from the LDS parking slots
     // (no global load sits between the last solver sweep and the output stores) ----
     WAVE_LDS_ORDER();
@@ -1630,11 +1715,13 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         st.resets = n_resets;
         goal_advance(P, e, nsub, P.hsub);
         post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st, cy);
+        PHASE_STAMP();
         store_dyn(P, i, e, valid);
         if (P.goal_rotation_activate) store_goal(P, i, e, valid);
         if (!IS_RESET) finish_env(P, i, valid, cy);
+        PHASE_STAMP();
         stats_publish(P, st, lane);
-        PHASE_STAMP(3);
+        PHASE_STAMP();
     }
 }
 
@@ -1645,7 +1732,7 @@ __global__ void __launch_bounds__(256) k_reduce_stats(const DevParams* __restric
     const int t = threadIdx.x;
     const int k = blockIdx.x;
     float s = 0.0f;
-    for (int w = t; w < n_waves; w += 256) s = s + P.scratch[(size_t)w * 16 + k];
+    for (int w = t; w < n_waves; w += 256) s = s + P.scratch[(size_t)w * SCR_STRIDE + k];
     red[t] = s;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
@@ -1674,7 +1761,9 @@ __global__ void __launch_bounds__(WAVE, 1) k_apply_resets(const DevParams* __res
     load_goal(P, i, e);
     bool goal_changed;
     Carried cy;
-    bool did = apply_resets(P, i, valid, e, false, goal_changed, cy);
+    EnvFlags fl;
+    load_flags(P, i, fl);
+    bool did = apply_resets(P, i, valid, e, false, goal_changed, cy, fl);
     float act[A];
     const int row = valid ? i : (P.N - 1);
 #pragma unroll
@@ -1682,7 +1771,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_apply_resets(const DevParams* __res
 #pragma unroll
     for (int j = 0; j < A; ++j) lds[lane * A + j] = act[j];
     WAVE_LDS_ORDER();
-    store_tile(P.action_buf, lds, wave_first, n_valid, A, lane);
+    store_tile<A>(P.action_buf, lds, wave_first, n_valid, lane);
     load_split_extras(P, i, e);
     store_dyn(P, i, e, valid);
     store_goal(P, i, e, valid);
@@ -1848,7 +1937,7 @@ extern "C" {
 int tf_api_version(void) { return TF_API_VERSION; }
 const char* tf_backend_name(void) { return "hip-gfx950"; }
 const char* tf_last_error_string(void) { return g_err; }
-int64_t tf_scratch_floats(int32_t num_envs) { return (int64_t)((num_envs + WAVE - 1) / WAVE) * 16; }
+int64_t tf_scratch_floats(int32_t num_envs) { return (int64_t)((num_envs + WAVE - 1) / WAVE) * SCR_STRIDE; }
 
 int tf_action_dim(int32_t mode) {
     if (mode == TF_CMD_TORQUE || mode == TF_CMD_POSITION) return 9;
@@ -2031,9 +2120,11 @@ int tf_bind(tf_handle h, const TfBuffers* b) {
         return TF_ERR_INVALID_ARG;
     if (h->cfg.asymmetric_obs && !b->states) return TF_ERR_INVALID_ARG;
     DevParams& P = h->dp;
-    P.state = b->state; P.action_buf = b->action_buf; P.obs = b->obs; P.states = b->states; P.reward = b->reward;
-    P.reset_buf = b->reset_buf; P.goal_reset_buf = b->goal_reset_buf; P.successes = b->successes; P.dones = b->dones;
-    P.steps = b->steps; P.reset_count = b->reset_count; P.info = b->info; P.scratch = b->scratch;
+    P.state = (gfloat*)b->state; P.action_buf = (gfloat*)b->action_buf; P.obs = (gfloat*)b->obs;
+    P.states = (gfloat*)b->states; P.reward = (gfloat*)b->reward;
+    P.reset_buf = (gu8*)b->reset_buf; P.goal_reset_buf = (gu8*)b->goal_reset_buf; P.successes = (gu8*)b->successes;
+    P.dones = (gu8*)b->dones; P.steps = (gi32*)b->steps; P.reset_count = (gu32*)b->reset_count;
+    P.info = (gfloat*)b->info; P.scratch = (gfloat*)b->scratch;
     HIP_TRY(hipMemcpy(h->d_params, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice));
     h->bound = 1;
     return TF_OK;

@@ -1,5 +1,5 @@
 """Developer tool (GPU box): per-phase cycle counts of k_step from s_memtime stamps (build: make -C leibnizgym_amd/csrc
-libtrifinger_hip_timing.so).  Phases: A = loads/resets/torque, B = physics substeps, C = outputs/rewards/stats."""
+libtrifinger_hip_timing.so; lane 0 of every wave appends a stamp at each PHASE_STAMP site)."""
 import sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -7,8 +7,17 @@ import numpy as np, torch
 import bench
 from leibnizgym_amd.engine import TrifingerEngine, make_config
 from leibnizgym_amd import _capi
+
+SUB = ["free motion (FK, dynamics, M^-1)", "finger contacts + rows", "cube-floor corners", "cube-wall corners",
+       "limit rows", "PGS sweeps", "wrench + integrate"]
+LABELS = (["action tile", "state loads", "apply_resets", "action_buf store, torque, park"]
+          + [f"sub0: {x}" for x in SUB] + [f"sub1: {x}" for x in SUB]
+          + ["(stamp 2)", "unpark, tip FK, NaN guard", "obs emit + store", "states emit + store",
+             "tip history, rewards, termination", "state stores, finish", "stats butterflies"])
+
 lib = _capi.TfLib(os.path.join(REPO, "leibnizgym_amd", "csrc", "libtrifinger_hip_timing.so"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+stride = int(lib.tf_scratch_floats(64))
 for asym in (True, False):
     eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym)), device="cuda:0", lib=lib)
     g = torch.Generator(device="cuda:0").manual_seed(1)
@@ -19,12 +28,12 @@ for asym in (True, False):
         eng.step(ring[k % 8])
         if k >= 10:
             torch.cuda.synchronize()
-            st = eng.scratch.view(torch.int32).view(-1, 16)[:, 11:15].cpu().numpy().astype(np.int64) & 0xffffffff
-            d = np.diff(st, axis=1) & 0xffffffff
-            acc.append(d)
-    d = np.stack(acc).astype(np.float64)           # [steps, waves, 3]
+            st = eng.scratch.view(torch.int32).view(-1, stride)[:, 16:16 + len(LABELS) + 1].cpu().numpy().astype(np.int64) & 0xffffffff
+            acc.append(np.diff(st, axis=1) & 0xffffffff)
+    d = np.stack(acc).astype(np.float64)           # [steps, waves, phases]
     med = np.median(d, axis=(0, 1))
-    print(f"asym={asym} N={n}: median cycles per wave  A {med[0]:.0f}  B {med[1]:.0f}  C {med[2]:.0f}  (100 MHz s_memtime ticks x?) "
-          f"ratio A:B:C = {med[0]/med.sum():.2f}:{med[1]/med.sum():.2f}:{med[2]/med.sum():.2f}; start skew over waves "
-          f"{np.ptp(st[:, 0] & 0xffffffff):.0f}")
+    tot = med.sum()
+    print(f"asym={asym} N={n}: median s_memtime ticks per wave, total {tot:.0f}")
+    for lab, m in zip(LABELS, med):
+        print(f"  {lab:40s} {m:9.0f}  {100 * m / tot:5.1f} %")
     eng.close()
