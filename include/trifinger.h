@@ -96,6 +96,9 @@ enum {
                               cube mass, cube size, contact friction, motor torque                  */
     TF_STATE_ROWS = 88
 };
+/* Largest num_envs of one handle: the kernels address state[TF_STATE_ROWS][num_envs] with 32-bit byte offsets
+ * (88 * 4 Mi * 4 B = 1.4 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
+#define TF_MAX_ENVS 4194304
 
 #define TF_OBS_DIM_BASE 32    /* 9 + 9 + 7 + 7; the action slot (9 or 18) follows  trifinger_env.py:280-286 */
 #define TF_STATES_EXTRA 72    /* 6 + 39 + 9 + 18                                   trifinger_env.py:296-300 */

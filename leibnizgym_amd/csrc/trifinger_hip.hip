@@ -26,6 +26,7 @@
 //
 // Physics is this build's own spec (the reference's lives in closed-source PhysX): DESIGN.md "Physics spec".
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -61,7 +62,7 @@ typedef GLOBAL_AS float gfloat;
 typedef GLOBAL_AS uint8_t gu8;
 typedef GLOBAL_AS int32_t gi32;
 typedef GLOBAL_AS uint32_t gu32;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct DevParams {
     // buffers
@@ -1252,29 +1253,42 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
 template <int A>
 DEV void compute_torque(const DevParams& P, const float* act, const float q[9], const float qd[9], float motor_scale,
                         float tau[9]) {
+    // the mode switches are wave-uniform: they are taken once around the joint loops (not once per joint), so that the
+    // scalar table loads of a loop sit in one block and are fetched as one batch
     float at[A];
+    if (P.normalize_action) {
 #pragma unroll
-    for (int j = 0; j < A; ++j) {
-        if (P.normalize_action) {
+        for (int j = 0; j < A; ++j) {
             float lo = P.tables[TAB_ACT_LO + j], hi = P.tables[TAB_ACT_HI + j];
             float off = (lo + hi) * 0.5f;
             at[j] = act[j] * (hi - lo) * 0.5f + off;
-        } else at[j] = act[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A; ++j) at[j] = act[j];
+    }
+    float t[9];
+    if (P.command_mode == TF_CMD_TORQUE) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) t[j] = at[j];
+    } else if (P.command_mode == TF_CMD_POSITION) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { t[j] = P.tables[TAB_KP + j] * (at[j] - q[j]); t[j] = t[j] - P.tables[TAB_KD + j] * qd[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { t[j] = at[(A == 18) ? 9 + j : j] * (at[j] - q[j]); t[j] = t[j] - P.tables[TAB_KD + j] * qd[j]; }
     }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        float t;
-        float kd = P.tables[TAB_KD + j];
-        if (P.command_mode == TF_CMD_TORQUE) t = at[j];
-        else if (P.command_mode == TF_CMD_POSITION) { t = P.tables[TAB_KP + j] * (at[j] - q[j]); t = t - kd * qd[j]; }
-        else { t = at[(A == 18) ? 9 + j : j] * (at[j] - q[j]); t = t - kd * qd[j]; }
-        t = f_max(f_min(t, 0.36f), -0.36f);
-        if (P.apply_safety_damping) {
-            t = t - P.tables[TAB_KS + j] * qd[j];
-            t = f_max(f_min(t, 0.36f), -0.36f);
+    for (int j = 0; j < 9; ++j) t[j] = f_max(f_min(t[j], 0.36f), -0.36f);
+    if (P.apply_safety_damping) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            t[j] = t[j] - P.tables[TAB_KS + j] * qd[j];
+            t[j] = f_max(f_min(t[j], 0.36f), -0.36f);
         }
-        tau[j] = t * motor_scale;     // domain randomisation of the motor strength (1.0 when off)
     }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) tau[j] = t[j] * motor_scale;     // domain randomisation of the motor strength (1.0 when off)
 }
 
 DEV float norm3d(const float a[3], const float b[3]) {
@@ -1316,22 +1330,24 @@ template <int F> DEV void wrench_local(const DevParams& P, const FK& kk, const E
     }
 }
 
-// cooperative, coalesced store of a [64][W] tile staged in LDS as lds[lane * W + j]: ceil(16 W / 64) predicated
-// dwordx4 stores per lane, fully unrolled (every LDS read can be issued before the first store); a ragged last wave
-// (n_valid < 64) finishes its < 4 trailing floats with dword stores.
+// cooperative, coalesced store of a [64][W] tile staged in LDS as lds[lane * W + j]: ceil(16 W / 64) dwordx4 stores per
+// lane, fully unrolled and branch-free - the tile is a raw buffer of total4*16 bytes, so the hardware range check drops
+// the lanes past its end and all LDS reads (index clamped) can be in flight before the first store.  A ragged last
+// wave (n_valid < 64) finishes its < 4 trailing floats with dword stores.
 template <int W>
 DEV void store_tile(gfloat* __restrict__ dst, const float* lds, int wave_first_env, int n_valid, int lane) {
     const unsigned total = (unsigned)(n_valid * W);              // floats in this wave's tile
     gfloat* base = dst + (size_t)wave_first_env * (size_t)W;     // 64*W*4-byte multiple: 16-B aligned
     const unsigned total4 = total >> 2;
+    const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(total4 * 16u), 0x00020000);
     constexpr int ITER = (16 * W + WAVE - 1) / WAVE;
+    const unsigned last4 = total4 - 1u;
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
         const unsigned idx = (unsigned)lane + (unsigned)(WAVE * k);
-        if (idx < total4) {
-            f32x4 vv = *reinterpret_cast<const f32x4*>(&lds[idx * 4u]);
-            *(GLOBAL_AS f32x4*)(&base[idx * 4u]) = vv;
-        }
+        const unsigned src = (idx < last4) ? idx : last4;
+        u32x4 vv = *reinterpret_cast<const u32x4*>(&lds[src * 4u]);
+        __builtin_amdgcn_raw_buffer_store_b128(vv, tile, idx * 16u, 0, 0);
     }
     const unsigned tail = (total4 << 2) + (unsigned)lane;
     if (tail < total) base[tail] = lds[tail];
@@ -1407,7 +1423,6 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     // ---- observations: stage [lane][OD] in LDS, then one coalesced tile store ----
     const float* off = P.tables + TAB_OFF;
     const float* inv = P.tables + TAB_INV;
-    const bool nrm = P.normalize_obs != 0;
 #define EMIT(W, col, val)                                                               \
     {                                                                                   \
         float x_ = (val);                                                               \
@@ -1435,7 +1450,11 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     _Pragma("unroll") for (int j = 0; j < 4; ++j) EMITC(W, 21 + j, e.cq[j], -1.0f, 1.0f) \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) EMITC(W, 25 + j, e.gp[j], PLO(j), 0.3f) \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) EMITC(W, 28 + j, e.gq[j], -1.0f, 1.0f) \
-    _Pragma("unroll") for (int j = 0; j < A; ++j) EMIT(W, 32 + j, opaque(act[j]))
+    _Pragma("unroll") for (int j = 0; j < A; ++j) EMIT(W, 32 + j, act[j])
+    // normalize_obs is wave-uniform: decided once around the whole emission (compile-time inside), so that the table
+    // loads of the action slots sit in one block and nothing branches per element
+    auto emit_tiles = [&](auto nrm_tag) {
+    constexpr bool nrm = decltype(nrm_tag)::value;
     WAVE_LDS_ORDER();
     EMIT_COMMON(OD)
     WAVE_LDS_ORDER();
@@ -1471,6 +1490,8 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
         store_tile<SD>(P.states, lds, wave_first, n_valid, lane);
         WAVE_LDS_ORDER();
     }
+    };
+    if (P.normalize_obs != 0) emit_tiles(std::true_type{}); else emit_tiles(std::false_type{});
 #undef EMIT_COMMON
 #undef EMIT
 #undef EMITC
@@ -1696,7 +1717,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
     {
         int sl = 0;
 #pragma unroll
-        for (int j = 0; j < A; ++j) act[j] = UNPARK(sl++);
+        for (int j = 0; j < A; ++j) act[j] = opaque(UNPARK(sl++));   // opaque: see DESIGN.md section 3, item 2
 #pragma unroll
         for (int j = 0; j < 7; ++j) prev_obj[j] = UNPARK(sl++);
 #pragma unroll
@@ -2062,6 +2083,7 @@ static void build_tables(const TfConfig* c, int A, float* tab, int* obs_dim, int
 int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (!cfg || !out) return TF_ERR_INVALID_ARG;
     if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
+    if (cfg->num_envs > TF_MAX_ENVS) return TF_ERR_INVALID_ARG;     // 32-bit buffer offsets into state[88][N]
     if (tf_action_dim(cfg->command_mode) < 0) return TF_ERR_COMMAND_MODE;
     if (cfg->robot_reset_type < 0 || cfg->robot_reset_type > 2) return TF_ERR_ROBOT_RESET;
     if (cfg->object_reset_type < 0 || cfg->object_reset_type > 2) return TF_ERR_OBJECT_RESET;

@@ -389,6 +389,7 @@ static void build_tables(struct TfHandle_* h) {
 int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (!cfg || !out) return TF_ERR_INVALID_ARG;
     if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
+    if (cfg->num_envs > TF_MAX_ENVS) return TF_ERR_INVALID_ARG;
     if (tf_action_dim(cfg->command_mode) < 0) return TF_ERR_COMMAND_MODE;
     if (cfg->robot_reset_type < 0 || cfg->robot_reset_type > 2) return TF_ERR_ROBOT_RESET;
     if (cfg->object_reset_type < 0 || cfg->object_reset_type > 2) return TF_ERR_OBJECT_RESET;

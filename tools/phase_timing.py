@@ -10,7 +10,7 @@ from leibnizgym_amd import _capi
 
 SUB = ["free motion (FK, dynamics, M^-1)", "finger contacts + rows", "cube-floor corners", "cube-wall corners",
        "limit rows", "PGS sweeps", "wrench + integrate"]
-LABELS = (["action tile", "state loads", "apply_resets", "action_buf store, torque, park"]
+LABELS = (["issue all loads", "wait for loads, action via LDS", "apply_resets", "action_buf store, torque, park"]
           + [f"sub0: {x}" for x in SUB] + [f"sub1: {x}" for x in SUB]
           + ["(stamp 2)", "unpark, tip FK, NaN guard", "obs emit + store", "states emit + store",
              "tip history, rewards, termination", "state stores, finish", "stats butterflies"])
