@@ -150,13 +150,14 @@ DEV float f_abs(float a) { return __builtin_fabsf(a); }
 DEV void tf_sincos(float x, float& s_out, float& c_out) {
     float k = __builtin_rintf(x * 0.63661977236758134f);
     int n = (int)k;
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188216e-8f;
+    float r = FMA(-k, 1.5703125f, x);
+    r = FMA(-k, 4.837512969970703125e-4f, r);
+    r = FMA(-k, 7.54978995489188216e-8f, r);
     float z = r * r;
-    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
-               - 0.5f * z + 1.0f;
+    float ps = FMA(FMA(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    ps = FMA(ps * z, r, r);
+    float pc = FMA(FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    pc = FMA(pc * z, z, FMA(-0.5f, z, 1.0f));
     int q = n & 3;
     float s = (q & 1) ? pc : ps;
     float c = (q & 1) ? ps : pc;
@@ -168,12 +169,12 @@ DEV float tf_exp(float x) {
     x = f_clamp(x, -87.0f, 88.0f);
     float k = __builtin_rintf(x * 1.44269504088896341f);
     int n = (int)k;
-    float r = x - k * 0.693359375f;
-    r = r - k * -2.12194440e-4f;
+    float r = FMA(-k, 0.693359375f, x);
+    r = FMA(k, 2.12194440e-4f, r);
     float z = r * r;
-    float p = ((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r
-               + 1.6666665459e-1f) * r + 5.0000001201e-1f;
-    float e = p * z + r + 1.0f;
+    float p = FMA(FMA(FMA(FMA(FMA(1.9875691500e-4f, r, 1.3981999507e-3f), r, 8.3334519073e-3f), r, 4.1665795894e-2f), r,
+                      1.6666665459e-1f), r, 5.0000001201e-1f);
+    float e = FMA(p, z, r) + 1.0f;
     return e * __uint_as_float((uint32_t)(n + 127) << 23);
 }
 
@@ -183,8 +184,9 @@ DEV float tf_asin(float x) {
     bool big = a > 0.5f;
     float z = big ? 0.5f * (1.0f - a) : a * a;
     float y = big ? __builtin_sqrtf(z) : a;
-    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
-               + 1.6666752422e-1f) * z * y + y;
+    float p = FMA(FMA(FMA(FMA(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z,
+                  1.6666752422e-1f);
+    p = FMA(p * z, y, y);
     if (big) p = 1.5707963267948966f - (p + p);
     return (x < 0.0f) ? -p : p;
 }
@@ -200,14 +202,15 @@ DEV float tf_log(float x) {
         m = m - 1.0f;
     }
     float z = m * m;
-    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
-                   + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
-               + 3.3333331174e-1f) * m * z;
+    float y = FMA(FMA(FMA(FMA(FMA(FMA(FMA(FMA(7.0376836292e-2f, m, -1.1514610310e-1f), m, 1.1676998740e-1f), m,
+                  -1.2420140846e-1f), m, 1.4249322787e-1f), m, -1.6668057665e-1f), m, 2.0000714765e-1f), m,
+                  -2.4999993993e-1f), m, 3.3333331174e-1f);
+    y = (y * m) * z;
     float fe = (float)e;
-    y = y + fe * -2.12194440e-4f;
-    y = y - 0.5f * z;
+    y = FMA(fe, -2.12194440e-4f, y);
+    y = FMA(-0.5f, z, y);
     float r = m + y;
-    r = r + fe * 0.693359375f;
+    r = FMA(fe, 0.693359375f, r);
     return r;
 }
 
@@ -295,21 +298,18 @@ DEV float lgsk(float x, float scale) {      // reference rewards.py:20-34
 }
 DEV void quat_to_rot(const float q[4], float R[9]) {
     float x = q[0], y = q[1], z = q[2], w = q[3];
-    float xx = x * x, yy = y * y, zz = z * z;
-    float xy = x * y, xz = x * z, yz = y * z;
-    float wx = w * x, wy = w * y, wz = w * z;
-    R[0] = 1.0f - 2.0f * (yy + zz); R[1] = 2.0f * (xy - wz);        R[2] = 2.0f * (xz + wy);
-    R[3] = 2.0f * (xy + wz);        R[4] = 1.0f - 2.0f * (xx + zz); R[5] = 2.0f * (yz - wx);
-    R[6] = 2.0f * (xz - wy);        R[7] = 2.0f * (yz + wx);        R[8] = 1.0f - 2.0f * (xx + yy);
+    R[0] = FMA(-2.0f, FMA(y, y, z * z), 1.0f); R[1] = 2.0f * FMA(x, y, -(w * z));   R[2] = 2.0f * FMA(x, z, w * y);
+    R[3] = 2.0f * FMA(x, y, w * z);            R[4] = FMA(-2.0f, FMA(x, x, z * z), 1.0f); R[5] = 2.0f * FMA(y, z, -(w * x));
+    R[6] = 2.0f * FMA(x, z, -(w * y));         R[7] = 2.0f * FMA(y, z, w * x);      R[8] = FMA(-2.0f, FMA(x, x, y * y), 1.0f);
 }
 DEV void quat_integrate(float q[4], const float w[3], float h) {
     float hx = 0.5f * h * w[0], hy = 0.5f * h * w[1], hz = 0.5f * h * w[2];
     float x = q[0], y = q[1], z = q[2], s = q[3];
-    float nx = x + (hx * s + hy * z - hz * y);
-    float ny = y + (hy * s + hz * x - hx * z);
-    float nz = z + (hz * s + hx * y - hy * x);
-    float ns = s - (hx * x + hy * y + hz * z);
-    float inv = 1.0f / f_sqrt(nx * nx + ny * ny + nz * nz + ns * ns);
+    float nx = x + FMA(hx, s, FMA(hy, z, -(hz * y)));
+    float ny = y + FMA(hy, s, FMA(hz, x, -(hx * z)));
+    float nz = z + FMA(hz, s, FMA(hx, y, -(hy * x)));
+    float ns = s - FMA(hx, x, FMA(hy, y, hz * z));
+    float inv = 1.0f / f_sqrt(FMA(nx, nx, FMA(ny, ny, FMA(nz, nz, ns * ns))));
     q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
 }
 
@@ -367,90 +367,123 @@ DEV void levers(const FK& k, const float P[3], float L1[3], float L2[3], float L
     cross3(k.ax, r3, L3);
 }
 
+// Joint-space mass matrix M (00 01 02 11 12 22) and bias h = C(q,qd) qd + g(q); grav = gravity vector (base frame).
+// Evaluated in the coordinates of link 1 ("frame A": the base frame turned by joint 1 about y).  There joint 1 is the
+// y axis, joints 2 and 3 are the x axis, links 2 and 3 turn about x by q2 and q2+q3, and every vector of the recursive
+// Newton-Euler pass has structural zeros: w_k = (a_k, w, 0) with a_2 = qd2, a_3 = qd2 + qd3 and dw_k = (0, 0, -w a_k),
+// hence  dw x r + w x (w x r) = (w (2 a r_y - w r_x), -a^2 r_y, -(a^2 + w^2) r_z).  Only the components that reach
+// the three joint torques (n1_y, n2_x, n3_x) are formed.  tests/test_physics_analytic.py checks M against the fp64
+// kinetic energy and h against the Lagrangian derivatives of an independent model.
 DEV void finger_dynamics(const TfModel& m, const FK& k, const float qd[3], const float grav[3], float M[6], float bias[3]) {
-    float c1[3], c2[3], c3[3], t[3];
-    rot_link<1>(k, m.link_com[0], c1);
-    rot_link<2>(k, m.link_com[1], t);
-    c2[0] = k.p2[0] + t[0]; c2[1] = k.p2[1] + t[1]; c2[2] = k.p2[2] + t[2];
-    rot_link<3>(k, m.link_com[2], t);
-    c3[0] = k.p3[0] + t[0]; c3[1] = k.p3[1] + t[1]; c3[2] = k.p3[2] + t[2];
-    float a1L[3], a2L[3], a3L[3], b1L[3], b2L[3], b3L[3], e1L[3], e2L[3], e3L[3];
-    levers(k, c1, a1L, a2L, a3L);
-    levers(k, c2, b1L, b2L, b3L);
-    levers(k, c3, e1L, e2L, e3L);
-    float m1 = m.link_mass[0], m2 = m.link_mass[1], m3 = m.link_mass[2];
+    const float m1 = m.link_mass[0], m2 = m.link_mass[1], m3 = m.link_mass[2];
     const float* I1 = m.link_inertia[0];
     const float* I2 = m.link_inertia[1];
     const float* I3 = m.link_inertia[2];
-    float u2I = k.c2 * k.c2 * I2[1] - 2.0f * k.c2 * k.s2 * I2[5] + k.s2 * k.s2 * I2[2];
-    float u3I = k.c23 * k.c23 * I3[1] - 2.0f * k.c23 * k.s23 * I3[5] + k.s23 * k.s23 * I3[2];
-    float u2x = k.c2 * I2[3] - k.s2 * I2[4];
-    float u3x = k.c23 * I3[3] - k.s23 * I3[4];
-    M[0] = m1 * dot3(a1L, a1L) + m2 * dot3(b1L, b1L) + m3 * dot3(e1L, e1L) + I1[1] + u2I + u3I;
-    M[1] = m2 * dot3(b1L, b2L) + m3 * dot3(e1L, e2L) + u2x + u3x;
-    M[2] = m3 * dot3(e1L, e3L) + u3x;
-    M[3] = m2 * dot3(b2L, b2L) + m3 * dot3(e2L, e2L) + I2[0] + I3[0];
-    M[4] = m3 * dot3(e2L, e3L) + I3[0];
-    M[5] = m3 * dot3(e3L, e3L) + I3[0];
-    float w1[3] = {0.0f, qd[0], 0.0f};
-    float w2[3] = {w1[0] + k.ax[0] * qd[1], w1[1] + k.ax[1] * qd[1], w1[2] + k.ax[2] * qd[1]};
-    float w3[3] = {w2[0] + k.ax[0] * qd[2], w2[1] + k.ax[1] * qd[2], w2[2] + k.ax[2] * qd[2]};
-    float axq2[3] = {k.ax[0] * qd[1], k.ax[1] * qd[1], k.ax[2] * qd[1]};
-    float axq3[3] = {k.ax[0] * qd[2], k.ax[1] * qd[2], k.ax[2] * qd[2]};
-    float dw2[3], dw3[3];
-    cross3(w1, axq2, dw2);
-    cross3(w2, axq3, t);
-    dw3[0] = dw2[0] + t[0]; dw3[1] = dw2[1] + t[1]; dw3[2] = dw2[2] + t[2];
-    float a0[3] = {-grav[0], -grav[1], -grav[2]};
-    float u[3], v[3], ap2[3], ap3[3];
-    cross3(w1, k.p2, u); cross3(w1, u, v);
-    ap2[0] = a0[0] + v[0]; ap2[1] = a0[1] + v[1]; ap2[2] = a0[2] + v[2];
-    float d23[3] = {k.p3[0] - k.p2[0], k.p3[1] - k.p2[1], k.p3[2] - k.p2[2]};
-    cross3(dw2, d23, t); cross3(w2, d23, u); cross3(w2, u, v);
-    ap3[0] = ap2[0] + t[0] + v[0]; ap3[1] = ap2[1] + t[1] + v[1]; ap3[2] = ap2[2] + t[2] + v[2];
-    float F1[3], F2[3], F3[3], N1[3], N2[3], N3[3];
-    cross3(w1, c1, u); cross3(w1, u, v);
-    F1[0] = m1 * (a0[0] + v[0]); F1[1] = m1 * (a0[1] + v[1]); F1[2] = m1 * (a0[2] + v[2]);
-    float r2c[3] = {c2[0] - k.p2[0], c2[1] - k.p2[1], c2[2] - k.p2[2]};
-    cross3(dw2, r2c, t); cross3(w2, r2c, u); cross3(w2, u, v);
-    F2[0] = m2 * (ap2[0] + t[0] + v[0]); F2[1] = m2 * (ap2[1] + t[1] + v[1]); F2[2] = m2 * (ap2[2] + t[2] + v[2]);
-    float r3c[3] = {c3[0] - k.p3[0], c3[1] - k.p3[1], c3[2] - k.p3[2]};
-    cross3(dw3, r3c, t); cross3(w3, r3c, u); cross3(w3, u, v);
-    F3[0] = m3 * (ap3[0] + t[0] + v[0]); F3[1] = m3 * (ap3[1] + t[1] + v[1]); F3[2] = m3 * (ap3[2] + t[2] + v[2]);
-    float wl[3], Iw[3], Iww[3], dl[3], Id[3], Idw[3];
-    rot_link_T<1>(k, w1, wl); sym_mul(I1, wl, Iw); rot_link<1>(k, Iw, Iww);
-    cross3(w1, Iww, N1);
-    rot_link_T<2>(k, w2, wl); sym_mul(I2, wl, Iw); rot_link<2>(k, Iw, Iww);
-    rot_link_T<2>(k, dw2, dl); sym_mul(I2, dl, Id); rot_link<2>(k, Id, Idw);
-    cross3(w2, Iww, t);
-    N2[0] = Idw[0] + t[0]; N2[1] = Idw[1] + t[1]; N2[2] = Idw[2] + t[2];
-    rot_link_T<3>(k, w3, wl); sym_mul(I3, wl, Iw); rot_link<3>(k, Iw, Iww);
-    rot_link_T<3>(k, dw3, dl); sym_mul(I3, dl, Id); rot_link<3>(k, Id, Idw);
-    cross3(w3, Iww, t);
-    N3[0] = Idw[0] + t[0]; N3[1] = Idw[1] + t[1]; N3[2] = Idw[2] + t[2];
-    float n3[3], n2[3], n1[3], f2[3];
-    cross3(r3c, F3, t);
-    n3[0] = N3[0] + t[0]; n3[1] = N3[1] + t[1]; n3[2] = N3[2] + t[2];
-    f2[0] = F2[0] + F3[0]; f2[1] = F2[1] + F3[1]; f2[2] = F2[2] + F3[2];
-    cross3(r2c, F2, t); cross3(d23, F3, u);
-    n2[0] = N2[0] + t[0] + n3[0] + u[0]; n2[1] = N2[1] + t[1] + n3[1] + u[1]; n2[2] = N2[2] + t[2] + n3[2] + u[2];
-    cross3(c1, F1, t); cross3(k.p2, f2, u);
-    n1[0] = N1[0] + t[0] + n2[0] + u[0]; n1[1] = N1[1] + t[1] + n2[1] + u[1]; n1[2] = N1[2] + t[2] + n2[2] + u[2];
-    bias[0] = n1[1];
-    bias[1] = dot3(k.ax, n2);
-    bias[2] = dot3(k.ax, n3);
+    const float* p2 = m.j2_origin;               /* joint-2 origin and link-1 COM are constants of frame A */
+    const float* c1 = m.link_com[0];
+    /* frame-A geometry: Rx(a) v = (v_x, c v_y - s v_z, s v_y + c v_z) */
+    float d23[3], b[3], e3[3], e2[3];
+    d23[0] = m.j3_origin[0];                     /* joint 2 -> joint 3 */
+    d23[1] = FMA(k.c2, m.j3_origin[1], -(k.s2 * m.j3_origin[2]));
+    d23[2] = FMA(k.s2, m.j3_origin[1], k.c2 * m.j3_origin[2]);
+    b[0] = m.link_com[1][0];                     /* joint 2 -> COM 2 */
+    b[1] = FMA(k.c2, m.link_com[1][1], -(k.s2 * m.link_com[1][2]));
+    b[2] = FMA(k.s2, m.link_com[1][1], k.c2 * m.link_com[1][2]);
+    e3[0] = m.link_com[2][0];                    /* joint 3 -> COM 3 */
+    e3[1] = FMA(k.c23, m.link_com[2][1], -(k.s23 * m.link_com[2][2]));
+    e3[2] = FMA(k.s23, m.link_com[2][1], k.c23 * m.link_com[2][2]);
+    e2[0] = d23[0] + e3[0]; e2[1] = d23[1] + e3[1]; e2[2] = d23[2] + e3[2];     /* joint 2 -> COM 3 */
+    const float c2x = p2[0] + b[0], c2z = p2[2] + b[2];                           /* COM 2 (x, z) */
+    const float c3x = p2[0] + e2[0], c3z = p2[2] + e2[2];                         /* COM 3 (x, z) */
+    /* ---- mass matrix: linear part from the COM lever arms L1 = y x P = (P_z, 0, -P_x), L2/L3 = x x r = (0, -r_z, r_y);
+     * angular part from the joint axes seen in the link frames, y -> (0, c, -s), x -> x ---- */
+    const float u2I = FMA(k.s2 * k.s2, I2[2], FMA(k.c2 * k.c2, I2[1], ((-2.0f * k.c2) * k.s2) * I2[5]));
+    const float u3I = FMA(k.s23 * k.s23, I3[2], FMA(k.c23 * k.c23, I3[1], ((-2.0f * k.c23) * k.s23) * I3[5]));
+    const float u2x = FMA(k.c2, I2[3], -(k.s2 * I2[4]));
+    const float u3x = FMA(k.c23, I3[3], -(k.s23 * I3[4]));
+    M[0] = FMA(m3, FMA(c3x, c3x, c3z * c3z), FMA(m2, FMA(c2x, c2x, c2z * c2z), m1 * FMA(c1[0], c1[0], c1[2] * c1[2])))
+           + ((I1[1] + u2I) + u3I);
+    M[1] = (u2x + u3x) - FMA(m3 * c3x, e2[1], (m2 * c2x) * b[1]);
+    M[2] = FMA(-(m3 * c3x), e3[1], u3x);
+    M[3] = FMA(m3, FMA(e2[1], e2[1], e2[2] * e2[2]), FMA(m2, FMA(b[1], b[1], b[2] * b[2]), I2[0] + I3[0]));
+    M[4] = FMA(m3, FMA(e2[1], e3[1], e2[2] * e3[2]), I3[0]);
+    M[5] = FMA(m3, FMA(e3[1], e3[1], e3[2] * e3[2]), I3[0]);
+    /* ---- recursive Newton-Euler with zero joint acceleration, base acceleration = -gravity (in frame A) ---- */
+    const float w = qd[0], a2 = qd[1], a3 = qd[1] + qd[2];
+    const float ww = w * w;
+    float a0[3];
+    a0[0] = FMA(k.s1, grav[2], -(k.c1 * grav[0]));
+    a0[1] = -grav[1];
+    a0[2] = -FMA(k.s1, grav[0], k.c1 * grav[2]);
+    /* link 1 (a = 0): COM force (x, z only: F1_y never reaches a joint torque), acceleration of joint 2 */
+    const float F1x = m1 * FMA(-ww, c1[0], a0[0]);
+    const float F1z = m1 * FMA(-ww, c1[2], a0[2]);
+    float A2[3] = {FMA(-ww, p2[0], a0[0]), a0[1], FMA(-ww, p2[2], a0[2])};
+    /* link 2: offset(r) = (w (2 a r_y - w r_x), -a^2 r_y, -(a^2 + w^2) r_z) */
+    const float aa2 = a2 * a2, sw2 = aa2 + ww, ta2 = a2 + a2;
+    float A3[3], F2[3], F3[3];
+    A3[0] = FMA(w, FMA(ta2, d23[1], -(w * d23[0])), A2[0]);
+    A3[1] = FMA(-aa2, d23[1], A2[1]);
+    A3[2] = FMA(-sw2, d23[2], A2[2]);
+    F2[0] = m2 * FMA(w, FMA(ta2, b[1], -(w * b[0])), A2[0]);
+    F2[1] = m2 * FMA(-aa2, b[1], A2[1]);
+    F2[2] = m2 * FMA(-sw2, b[2], A2[2]);
+    /* link 3 */
+    const float aa3 = a3 * a3, sw3 = aa3 + ww, ta3 = a3 + a3;
+    F3[0] = m3 * FMA(w, FMA(ta3, e3[1], -(w * e3[0])), A3[0]);
+    F3[1] = m3 * FMA(-aa3, e3[1], A3[1]);
+    F3[2] = m3 * FMA(-sw3, e3[2], A3[2]);
+    /* inertial moments N = I dw + w x I w in the link frames (w_l = (a, c w, -s w), dw_l = (0, s d, c d), d = -w a),
+     * turned back to frame A; only x and y are needed */
+    float N2x, N2y, N3x, N3y;
+    {
+        const float d = -(w * a2);
+        float wl[3] = {a2, k.c2 * w, -(k.s2 * w)}, dl1 = k.s2 * d, dl2 = k.c2 * d;
+        float Iw[3], Id[3], t[3];
+        sym_mul(I2, wl, Iw);
+        Id[0] = FMA(I2[4], dl2, I2[3] * dl1);
+        Id[1] = FMA(I2[5], dl2, I2[1] * dl1);
+        Id[2] = FMA(I2[2], dl2, I2[5] * dl1);
+        cross3(wl, Iw, t);
+        const float n0 = Id[0] + t[0], n1 = Id[1] + t[1], n2 = Id[2] + t[2];
+        N2x = n0;
+        N2y = FMA(k.c2, n1, -(k.s2 * n2));
+    }
+    {
+        const float d = -(w * a3);
+        float wl[3] = {a3, k.c23 * w, -(k.s23 * w)}, dl1 = k.s23 * d, dl2 = k.c23 * d;
+        float Iw[3], Id[3], t[3];
+        sym_mul(I3, wl, Iw);
+        Id[0] = FMA(I3[4], dl2, I3[3] * dl1);
+        Id[1] = FMA(I3[5], dl2, I3[1] * dl1);
+        Id[2] = FMA(I3[2], dl2, I3[5] * dl1);
+        cross3(wl, Iw, t);
+        const float n0 = Id[0] + t[0], n1 = Id[1] + t[1], n2 = Id[2] + t[2];
+        N3x = n0;
+        N3y = FMA(k.c23, n1, -(k.s23 * n2));
+    }
+    /* backward pass, moments about the joint origins: x and y components only */
+    const float n3x = N3x + FMA(e3[1], F3[2], -(e3[2] * F3[1]));
+    const float n3y = N3y + FMA(e3[2], F3[0], -(e3[0] * F3[2]));
+    const float n2x = ((N2x + FMA(b[1], F2[2], -(b[2] * F2[1]))) + n3x) + FMA(d23[1], F3[2], -(d23[2] * F3[1]));
+    const float n2y = ((N2y + FMA(b[2], F2[0], -(b[0] * F2[2]))) + n3y) + FMA(d23[2], F3[0], -(d23[0] * F3[2]));
+    const float f2x = F2[0] + F3[0], f2z = F2[2] + F3[2];
+    const float n1y = (FMA(c1[2], F1x, -(c1[0] * F1z)) + n2y) + FMA(p2[2], f2x, -(p2[0] * f2z));
+    bias[0] = n1y;
+    bias[1] = n2x;
+    bias[2] = n3x;
 }
 
 DEV void inv3sym(const float M[6], float Mi[6]) {
-    float A = M[3] * M[5] - M[4] * M[4];
-    float B = M[2] * M[4] - M[1] * M[5];
-    float C = M[1] * M[4] - M[2] * M[3];
-    float det = M[0] * A + M[1] * B + M[2] * C;
+    float A = FMA(M[3], M[5], -(M[4] * M[4]));
+    float B = FMA(M[2], M[4], -(M[1] * M[5]));
+    float C = FMA(M[1], M[4], -(M[2] * M[3]));
+    float det = FMA(M[2], C, FMA(M[1], B, M[0] * A));
     float rd = 1.0f / det;
     Mi[0] = A * rd; Mi[1] = B * rd; Mi[2] = C * rd;
-    Mi[3] = (M[0] * M[5] - M[2] * M[2]) * rd;
-    Mi[4] = (M[1] * M[2] - M[0] * M[4]) * rd;
-    Mi[5] = (M[0] * M[3] - M[1] * M[1]) * rd;
+    Mi[3] = FMA(M[0], M[5], -(M[2] * M[2])) * rd;
+    Mi[4] = FMA(M[1], M[2], -(M[0] * M[4])) * rd;
+    Mi[5] = FMA(M[0], M[3], -(M[1] * M[1])) * rd;
 }
 
 template <int F> DEV void base_to_world(const TfModel& m, const float b[3], float w[3]) {
