@@ -191,6 +191,28 @@ DEV float tf_asin(float x) {
     return (x < 0.0f) ? -p : p;
 }
 
+// Deterministic reciprocal / reciprocal square root for positive normal x, used for the physics-internal scalings
+// (1/D of the contact rows, unit normals, 1/det ...): integer seed + 3 Newton steps in FMA arithmetic, ~1 ulp (rcp) and
+// ~2 ulp (rsqrt).  Integer and fused multiply-add operations only, so both sides of the parity tests agree bit for
+// bit, and the GPU issues neither the quarter-rate v_rcp/v_sqrt nor the IEEE division / square-root fix-up sequences
+// (11 and 19 issue slots against 7 and 12).  Quantities that the reference defines (rewards, sampling) keep IEEE
+// division and square root.
+DEV float f_rcp(float x) {
+    float r = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    return r;
+}
+DEV float f_rsqrt(float x) {
+    float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
+    const float h = 0.5f * x;
+    y = y * FMA(-h, y * y, 1.5f);
+    y = y * FMA(-h, y * y, 1.5f);
+    y = y * FMA(-h, y * y, 1.5f);
+    return y;
+}
+
 DEV float tf_log(float x) {
     uint32_t u = __float_as_uint(x);
     int e = (int)((u >> 23) & 0xff) - 126;
@@ -309,7 +331,7 @@ DEV void quat_integrate(float q[4], const float w[3], float h) {
     float ny = y + FMA(hy, s, FMA(hz, x, -(hx * z)));
     float nz = z + FMA(hz, s, FMA(hx, y, -(hy * x)));
     float ns = s - FMA(hx, x, FMA(hy, y, hz * z));
-    float inv = 1.0f / f_sqrt(FMA(nx, nx, FMA(ny, ny, FMA(nz, nz, ns * ns))));
+    float inv = f_rsqrt(FMA(nx, nx, FMA(ny, ny, FMA(nz, nz, ns * ns))));
     q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
 }
 
@@ -479,7 +501,7 @@ DEV void inv3sym(const float M[6], float Mi[6]) {
     float B = FMA(M[2], M[4], -(M[1] * M[5]));
     float C = FMA(M[1], M[4], -(M[2] * M[3]));
     float det = FMA(M[2], C, FMA(M[1], B, M[0] * A));
-    float rd = 1.0f / det;
+    float rd = f_rcp(det);
     Mi[0] = A * rd; Mi[1] = B * rd; Mi[2] = C * rd;
     Mi[3] = FMA(M[0], M[5], -(M[2] * M[2])) * rd;
     Mi[4] = FMA(M[1], M[2], -(M[0] * M[4])) * rd;
@@ -519,10 +541,10 @@ DEV void mat3T_mul(const float R[9], const float v[3], float o[3]) {
 
 DEV void tangent_basis(const float n[3], float t1[3], float t2[3]) {
     if (f_abs(n[2]) < 0.9f) {
-        float inv = 1.0f / f_sqrt(FMA(n[0], n[0], n[1] * n[1]));
+        float inv = f_rsqrt(FMA(n[0], n[0], n[1] * n[1]));
         t1[0] = -n[1] * inv; t1[1] = n[0] * inv; t1[2] = 0.0f;
     } else {
-        float inv = 1.0f / f_sqrt(FMA(n[1], n[1], n[2] * n[2]));
+        float inv = f_rsqrt(FMA(n[1], n[1], n[2] * n[2]));
         t1[0] = 0.0f; t1[1] = -n[2] * inv; t1[2] = n[1] * inv;
     }
     cross3(n, t1, t2);
@@ -599,7 +621,7 @@ DEV void finger_rows(const TfModel& m, const FK& k, const float Pb[3], const flo
             D = FMA(dot3(rxd, rxd), inv_I, D + inv_m);
             c.dir[3 * d] = dw[0]; c.dir[3 * d + 1] = dw[1]; c.dir[3 * d + 2] = dw[2];
         }
-        c.Dinv[d] = 1.0f / D;
+        c.Dinv[d] = f_rcp(D);
     }
     if (WITH_CUBE) { c.rc[0] = rc[0]; c.rc[1] = rc[1]; c.rc[2] = rc[2]; }
 }
@@ -735,7 +757,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
     mat3T_mul(R, da, a);
     mat3T_mul(R, db, b);
     float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-    float inv_dd = 1.0f / dot3(d, d);
+    float inv_dd = f_rcp(dot3(d, d));
     float s = 1.0f, x[3], y[3];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -750,8 +772,8 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
     float dist2 = dot3(ev, ev);
     float nc[3], gap;
     if (dist2 > 1e-12f) {
-        float dist = f_sqrt(dist2);
-        float inv = 1.0f / dist;
+        float inv = f_rsqrt(dist2);
+        float dist = dist2 * inv;
         nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
         gap = dist - m.cap_radius;
     } else {
@@ -928,9 +950,9 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             float gap = e.cp[2] + c.r[2];
             if (gap < m.contact_margin) {
                 const float* r = c.r;
-                c.Dinv[0] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);
-                c.Dinv[1] = 1.0f / FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m);
-                c.Dinv[2] = 1.0f / FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m);
+                c.Dinv[0] = f_rcp(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                c.Dinv[1] = f_rcp(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
+                c.Dinv[2] = f_rcp(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
                 float vn0 = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
                 c.bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
@@ -938,10 +960,12 @@ DEV void substep(const DevParams& P, Env& e, float h) {
     }
     PHASE_STAMP();
     {   // cube vs boundary wall: corners of the face that points outward most
-        float rho_c = f_sqrt(FMA(e.cp[0], e.cp[0], e.cp[1] * e.cp[1]));
+        float rc2 = FMA(e.cp[0], e.cp[0], e.cp[1] * e.cp[1]);
+        float irc = f_rsqrt(f_max(rc2, 1e-24f));
+        float rho_c = rc2 * irc;
         bool any = rho_c > 1e-6f;
         float dx = 0.0f, dy = 0.0f;
-        if (any) { float inv = 1.0f / rho_c; dx = e.cp[0] * inv; dy = e.cp[1] * inv; }
+        if (any) { dx = e.cp[0] * irc; dy = e.cp[1] * irc; }
         float pr[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) pr[i] = FMA(R[i], dx, R[3 + i] * dy);
@@ -957,18 +981,19 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             cube_contact_zero(c);
             cube_corner(R, hc, k, sk, i, c.r);
             float px = e.cp[0] + c.r[0], py = e.cp[1] + c.r[1];
-            float rho = f_sqrt(FMA(px, px, py * py));
+            float rho2 = FMA(px, px, py * py);
+            float inv = f_rsqrt(f_max(rho2, 1e-24f));
+            float rho = rho2 * inv;
             float gap = m.wall_radius - rho;
             if (any && gap < m.contact_margin && rho > 1e-6f) {
-                float inv = 1.0f / rho;
                 const float* r = c.r;
                 c.n[0] = -px * inv; c.n[1] = -py * inv;
                 float a[3], b[3];
                 wall_arm_n(c, a);
                 wall_arm_t(c, b);
-                c.Dinv[0] = 1.0f / FMA(dot3(a, a), inv_I, inv_m);
-                c.Dinv[1] = 1.0f / FMA(dot3(b, b), inv_I, inv_m);
-                c.Dinv[2] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);
+                c.Dinv[0] = f_rcp(FMA(dot3(a, a), inv_I, inv_m));
+                c.Dinv[1] = f_rcp(FMA(dot3(b, b), inv_I, inv_m));
+                c.Dinv[2] = f_rcp(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                 float vn0 = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c.n[1], v[1], c.n[0] * v[0]))));
                 c.bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
@@ -984,7 +1009,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
         const FK& k = (f == 0) ? fk0 : ((f == 1) ? fk1 : fk2);
         vlo[j] = f_clamp((m.q_lo[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
         vhi[j] = f_clamp((m.q_hi[jj] - e.q[j]) * inv_h, -m.qd_max, m.qd_max);
-        lim_dinv[j] = 1.0f / k.Minv[dg];
+        lim_dinv[j] = f_rcp(k.Minv[dg]);
         lim_lam[j] = 0.0f;
     }
     PHASE_STAMP();

@@ -112,6 +112,28 @@ static float tf_asin(float x) {
     return (x < 0.0f) ? -p : p;
 }
 
+/* Deterministic reciprocal / reciprocal square root for positive normal x, used for the physics-internal scalings
+ * (1/D of the contact rows, unit normals, 1/det ...): integer seed + 3 Newton steps in FMA arithmetic, ~1 ulp (rcp) and
+ * ~2 ulp (rsqrt).  Integer and fused multiply-add operations only, so both sides of the parity tests agree bit for
+ * bit, and the GPU issues neither the quarter-rate v_rcp/v_sqrt nor the IEEE division / square-root fix-up sequences
+ * (11 and 19 issue slots against 7 and 12).  Quantities that the reference defines (rewards, sampling) keep IEEE
+ * division and square root. */
+static inline float f_rcp(float x) {
+    float r = u2f(0x7EF311C7u - f2u(x));
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    return r;
+}
+static inline float f_rsqrt(float x) {
+    float y = u2f(0x5F375A86u - (f2u(x) >> 1));
+    const float h = 0.5f * x;
+    y = y * FMA(-h, y * y, 1.5f);
+    y = y * FMA(-h, y * y, 1.5f);
+    y = y * FMA(-h, y * y, 1.5f);
+    return y;
+}
+
 static float tf_log(float x) {
     /* x > 0, normal.  Cephes logf. */
     uint32_t u = f2u(x);
@@ -223,7 +245,7 @@ static void quat_integrate(float q[4], const float w[3], float h) {
     float ny = y + FMA(hy, s, FMA(hz, x, -(hx * z)));
     float nz = z + FMA(hz, s, FMA(hx, y, -(hy * x)));
     float ns = s - FMA(hx, x, FMA(hy, y, hz * z));
-    float inv = 1.0f / sqrtf(FMA(nx, nx, FMA(ny, ny, FMA(nz, nz, ns * ns))));
+    float inv = f_rsqrt(FMA(nx, nx, FMA(ny, ny, FMA(nz, nz, ns * ns))));
     q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
 }
 
@@ -611,7 +633,7 @@ static void inv3sym(const float M[6], float Mi[6]) {
     float B = FMA(M[2], M[4], -(M[1] * M[5]));
     float C = FMA(M[1], M[4], -(M[2] * M[3]));
     float det = FMA(M[2], C, FMA(M[1], B, M[0] * A));
-    float rd = 1.0f / det;
+    float rd = f_rcp(det);
     Mi[0] = A * rd; Mi[1] = B * rd; Mi[2] = C * rd;
     Mi[3] = FMA(M[0], M[5], -(M[2] * M[2])) * rd;
     Mi[4] = FMA(M[1], M[2], -(M[0] * M[4])) * rd;
@@ -691,10 +713,10 @@ static inline void mat3T_mul(const float R[9], const float v[3], float o[3]) {
 
 static void tangent_basis(const float n[3], float t1[3], float t2[3]) {
     if (f_abs(n[2]) < 0.9f) {
-        float inv = 1.0f / sqrtf(FMA(n[0], n[0], n[1] * n[1]));
+        float inv = f_rsqrt(FMA(n[0], n[0], n[1] * n[1]));
         t1[0] = -n[1] * inv; t1[1] = n[0] * inv; t1[2] = 0.0f;
     } else {
-        float inv = 1.0f / sqrtf(FMA(n[1], n[1], n[2] * n[2]));
+        float inv = f_rsqrt(FMA(n[1], n[1], n[2] * n[2]));
         t1[0] = 0.0f; t1[1] = -n[2] * inv; t1[2] = n[1] * inv;
     }
     cross3(n, t1, t2);
@@ -729,7 +751,7 @@ static void finger_rows(const TfModel* m, int f, const FK* k, const float Pb[3],
             cross3(rc, dw[d], rxd);
             D = FMA(dot3(rxd, rxd), inv_I, D + inv_m);
         }
-        c->Dinv[d] = 1.0f / D;
+        c->Dinv[d] = f_rcp(D);
     }
     c->rc[0] = rc[0]; c->rc[1] = rc[1]; c->rc[2] = rc[2];
 }
@@ -879,7 +901,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         mat3T_mul(R, da, a);
         mat3T_mul(R, db, b);
         float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-        float inv_dd = 1.0f / dot3(d, d);
+        float inv_dd = f_rcp(dot3(d, d));
         float s = 1.0f, x[3], y[3];
         for (int it = 0; it < 4; ++it) {
             for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
@@ -891,8 +913,8 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         float dist2 = dot3(ev, ev);
         float nc[3], gap;
         if (dist2 > 1e-12f) {
-            float dist = sqrtf(dist2);
-            float inv = 1.0f / dist;
+            float inv = f_rsqrt(dist2);
+            float dist = dist2 * inv;
             nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
             gap = dist - m->cap_radius;
         } else {
@@ -958,9 +980,9 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             if (gap < m->contact_margin) {
                 const float* r = c->r;
                 c->active = 1;
-                c->Dinv[0] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);   /* +z */
-                c->Dinv[1] = 1.0f / FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m);   /* +x */
-                c->Dinv[2] = 1.0f / FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m);   /* +y */
+                c->Dinv[0] = f_rcp(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));   /* +z */
+                c->Dinv[1] = f_rcp(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));   /* +x */
+                c->Dinv[2] = f_rcp(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));   /* +y */
                 float vn0 = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
                 c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
@@ -968,10 +990,12 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     }
     /* --- cube vs boundary wall: the four corners of the face that points outward most --- */
     {
-        float rho_c = sqrtf(FMA(e->cp[0], e->cp[0], e->cp[1] * e->cp[1]));
+        float rc2 = FMA(e->cp[0], e->cp[0], e->cp[1] * e->cp[1]);
+        float irc = f_rsqrt(f_max(rc2, 1e-24f));
+        float rho_c = rc2 * irc;
         int any = rho_c > 1e-6f;
         float dx = 0.0f, dy = 0.0f;
-        if (any) { float inv = 1.0f / rho_c; dx = e->cp[0] * inv; dy = e->cp[1] * inv; }
+        if (any) { dx = e->cp[0] * irc; dy = e->cp[1] * irc; }
         float pr[3];
         for (int i = 0; i < 3; ++i) pr[i] = FMA(R[i], dx, R[3 + i] * dy);
         int k = 0;
@@ -984,19 +1008,20 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             memset(c, 0, sizeof(*c));
             cube_corner(R, hc, k, sk, i, c->r);
             float px = e->cp[0] + c->r[0], py = e->cp[1] + c->r[1];
-            float rho = sqrtf(FMA(px, px, py * py));
+            float rho2 = FMA(px, px, py * py);
+            float inv = f_rsqrt(f_max(rho2, 1e-24f));
+            float rho = rho2 * inv;
             float gap = m->wall_radius - rho;
             if (any && gap < m->contact_margin && rho > 1e-6f) {
-                float inv = 1.0f / rho;
                 const float* r = c->r;
                 c->active = 1;
                 c->n[0] = -px * inv; c->n[1] = -py * inv;
                 float a[3], b[3];
                 wall_arm_n(c, a);
                 wall_arm_t(c, b);
-                c->Dinv[0] = 1.0f / FMA(dot3(a, a), inv_I, inv_m);
-                c->Dinv[1] = 1.0f / FMA(dot3(b, b), inv_I, inv_m);
-                c->Dinv[2] = 1.0f / FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m);
+                c->Dinv[0] = f_rcp(FMA(dot3(a, a), inv_I, inv_m));
+                c->Dinv[1] = f_rcp(FMA(dot3(b, b), inv_I, inv_m));
+                c->Dinv[2] = f_rcp(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                 float vn0 = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c->n[1], v[1], c->n[0] * v[0]))));
                 c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
@@ -1009,7 +1034,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         static const int diag[3] = {0, 3, 5};
         vlo[j] = f_clamp((m->q_lo[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
         vhi[j] = f_clamp((m->q_hi[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
-        lim_dinv[j] = 1.0f / fk[f].Minv[diag[jj]];
+        lim_dinv[j] = f_rcp(fk[f].Minv[diag[jj]]);
         lim_lam[j] = 0.0f;
     }
     /* ---- projected Gauss-Seidel ---- */
@@ -1684,6 +1709,8 @@ void tfo_sincos(const float* x, float* s, float* c, int32_t n) { for (int i = 0;
 void tfo_exp(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = tf_exp(x[i]); }
 void tfo_asin(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = tf_asin(x[i]); }
 void tfo_log(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = tf_log(x[i]); }
+void tfo_rcp(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = f_rcp(x[i]); }
+void tfo_rsqrt(const float* x, float* y, int32_t n) { for (int i = 0; i < n; ++i) y[i] = f_rsqrt(x[i]); }
 void tfo_philox_raw(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }

@@ -27,6 +27,18 @@ def test_elementary_functions(oracle):
     assert (np.abs(y - ref) < 2e-7 * np.maximum(1.0, np.abs(ref))).all()
 
 
+def test_newton_reciprocal_and_rsqrt(oracle):
+    """The integer-seeded Newton reciprocal / reciprocal square root of the physics-internal scalings: ~1 ulp / ~2 ulp
+    over the whole range they are used on (1e-12 ... 1e12)."""
+    d = oracle.dll
+    x = np.exp(np.linspace(np.log(1e-12), np.log(1e12), 400001)).astype(np.float32)
+    y = np.empty_like(x)
+    d.tfo_rcp(fptr(x), fptr(y), len(x))
+    assert np.abs(y.astype(np.float64) * x.astype(np.float64) - 1).max() < 1.2e-7
+    d.tfo_rsqrt(fptr(x), fptr(y), len(x))
+    assert np.abs(y.astype(np.float64) * np.sqrt(x.astype(np.float64)) - 1).max() < 2.5e-7
+
+
 def test_philox_known_answers(oracle):
     def ph(ctr, key):
         c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
