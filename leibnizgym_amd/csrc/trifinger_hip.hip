@@ -771,7 +771,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
     float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
     float dist2 = dot3(ev, ev);
     float nc[3], gap;
-    if (dist2 > 1e-12f) {
+    if (__builtin_expect(dist2 > 1e-12f, 1)) {
         float inv = f_rsqrt(dist2);
         float dist = dist2 * inv;
         nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
@@ -789,7 +789,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
         y[0] = (bi == 0) ? sg * hc : y[0]; y[1] = (bi == 1) ? sg * hc : y[1]; y[2] = (bi == 2) ? sg * hc : y[2];
         gap = best - m.cap_radius;
     }
-    if (gap < m.contact_margin) {
+    if (__builtin_expect(gap < m.contact_margin, 1)) {
         float n_w[3], rc[3], xw[3];
         mat3_mul(R, nc, n_w);
         mat3_mul(R, y, rc);
@@ -811,7 +811,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
     // tip sphere vs floor
     finger_contact_zero(g);
     float gapf = Bw[2] - m.cap_radius;
-    if (gapf < m.contact_margin) {
+    if (__builtin_expect(gapf < m.contact_margin, 1)) {
         float n_w[3] = {0.0f, 0.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
         float Pb[3] = {Bb[0], Bb[1], Bb[2] - m.cap_radius};
         float Pw[3] = {Bw[0], Bw[1], Bw[2] - m.cap_radius};
@@ -827,7 +827,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
 // PGS rows of the finger-cube contact of finger F
 template <int F>
 DEV void solve_finger_cube(float mu, FingerContactRegs& c, float* vq, float v[3], float w[3], float inv_m, float inv_I) {
-    if (!c.active) return;
+    if (__builtin_expect(!c.active, 0)) return;      // likely path falls through: no taken branch, no fetch bubble
     float* vf = &vq[3 * F];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -848,7 +848,7 @@ DEV void solve_finger_cube(float mu, FingerContactRegs& c, float* vq, float v[3]
 }
 template <int F>
 DEV void solve_tip_floor(float mu, FingerContactRegs& c, float* vq) {
-    if (!c.active) return;
+    if (__builtin_expect(!c.active, 0)) return;      // likely path falls through: no taken branch, no fetch bubble
     float* vf = &vq[3 * F];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -865,7 +865,7 @@ DEV void solve_tip_floor(float mu, FingerContactRegs& c, float* vq) {
 // wrench of one finger contact, world frame, about the tip-link origin
 template <bool WITH_CUBE>
 DEV void add_wrench(const FingerContactRegs& c, float inv_h, float* ft) {
-    if (!c.active) return;
+    if (__builtin_expect(!c.active, 0)) return;      // likely path falls through: no taken branch, no fetch bubble
     float F[3];
     if (WITH_CUBE) {
 #pragma unroll
@@ -948,7 +948,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             cube_contact_zero(c);
             cube_corner(R, hc, k, sk, i, c.r);
             float gap = e.cp[2] + c.r[2];
-            if (gap < m.contact_margin) {
+            if (__builtin_expect(gap < m.contact_margin, 1)) {
                 const float* r = c.r;
                 c.Dinv[0] = f_rcp(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                 c.Dinv[1] = f_rcp(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
@@ -985,7 +985,7 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             float inv = f_rsqrt(f_max(rho2, 1e-24f));
             float rho = rho2 * inv;
             float gap = m.wall_radius - rho;
-            if (any && gap < m.contact_margin && rho > 1e-6f) {
+            if (__builtin_expect(any && gap < m.contact_margin && rho > 1e-6f, 1)) {
                 const float* r = c.r;
                 c.n[0] = -px * inv; c.n[1] = -py * inv;
                 float a[3], b[3];

@@ -21,11 +21,38 @@ for n, line in enumerate(open(SRC), 1):
     m = re.match(r"\s*(?:template\s*<[^>]*>\s*)?(?:DEV|__global__)\s+[\w:<>\s\*&]*?\b(\w+)\s*\(", line)
     if m and not line.lstrip().startswith("//"):
         starts.append(n); names.append(m.group(1))
+src_lines = open(SRC).read().split("\n")
+def block_range(marker):
+    """(first, last) source line of the brace block opened on the line containing `marker`"""
+    for n, line in enumerate(src_lines, 1):
+        if marker in line:
+            depth = 0
+            for mline in range(n, len(src_lines) + 1):
+                depth += src_lines[mline - 1].count("{") - src_lines[mline - 1].count("}")
+                if depth == 0 and mline > n or (depth == 0 and "{" in src_lines[mline - 1] and "}" in src_lines[mline - 1]):
+                    return n, mline
+    return 0, -1
+PGS = block_range("for (int it = 0; it < P.iters; ++it) {")
+NANG = block_range("if (!(acc == 0.0f)) {")
+RESET = block_range("    if (rflag) {")
+GOALR = block_range("    if (gflag) {")
+def weight(lines, chain):
+    """estimated executions per control step of an instruction with this inline chain (headline workload: 2 substeps,
+    8 sweeps, resets in ~8 % of the waves)"""
+    for ln, f in zip(lines, chain):
+        if f == "substep":
+            return 16.0 if PGS[0] <= ln <= PGS[1] else 2.0
+        if f == "post_step_env" and NANG[0] <= ln <= NANG[1]:
+            return 0.0
+        if f == "apply_resets" and (RESET[0] <= ln <= RESET[1] or GOALR[0] <= ln <= GOALR[1]):
+            return 0.08
+    return 1.0
 def func_of(line):
     i = bisect.bisect_right(starts, line) - 1
     return names[i] if i >= 0 else "?"
 inside, cur, chain = False, None, ()
 per_func, per_line, per_top = collections.Counter(), collections.Counter(), collections.Counter()
+dyn_func, dyn_top, dyn_total, lines = collections.Counter(), collections.Counter(), 0.0, []
 TOP = {"substep", "post_step_env", "k_step", "apply_resets"}
 total = 0
 for l in asm:
@@ -59,9 +86,19 @@ for l in asm:
             top = f + " > " + (chain[idx - 1] if idx > 0 else "(own code)")
             break
     per_top[top] += 1
+    wgt = weight(lines, chain)
+    dyn_total += wgt
+    dyn_func[func_of(cur) if cur else "?"] += wgt
+    dyn_top[top] += wgt
 print(f"{K}: {total} instructions (static)")
 for f, c in per_func.most_common(40):
     print(f"  {f:28s} {c:6d}  {100.0 * c / total:5.1f} %")
+print(f"estimated dynamic instructions per control step: {dyn_total:.0f}")
+for f, c in dyn_top.most_common(30):
+    print(f"  {f:50s} {c:8.0f}  {100.0 * c / dyn_total:5.1f} %")
+print("dynamic, by innermost function:")
+for f, c in dyn_func.most_common(30):
+    print(f"  {f:50s} {c:8.0f}  {100.0 * c / dyn_total:5.1f} %")
 print("by call site under the top-level bodies:")
 for f, c in per_top.most_common(40):
     print(f"  {f:50s} {c:6d}  {100.0 * c / total:5.1f} %")
