@@ -36,8 +36,8 @@ from leibnizgym_amd import _capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per k_step launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, raw
-# counter expressions; profiles/r1_f_pmc.txt).  Only valid for the exact workload it was measured on.
-PMC_TRAFFIC = {(65536, True): (9061.500 + 56768.000) * 1024.0}
+# counter expressions; profiles/r1_g_pmc.txt).  Only valid for the exact workload it was measured on.
+PMC_TRAFFIC = {(65536, True): (8961.000 + 56768.000) * 1024.0}
 FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--symmetric", action="store_true", help="asymmetric_obs=False (obs only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-stride", type=int, default=8,
+                    help="bracket every S-th k_step launch of the timed region with a HIP event pair (an event pair "
+                         "costs ~3 us of stream time, so timing every launch would slow the region it measures); 0: none")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,7 +161,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.enable_kernel_timing(min(args.steps, 8192))
+    eng.enable_kernel_timing(8192 if args.time_stride > 0 else 0, max(1, args.time_stride))
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -208,10 +211,12 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": PMC_TRAFFIC.get((n, asym)),
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_f_pmc.txt" if (n, asym) in PMC_TRAFFIC else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_g_pmc.txt" if (n, asym) in PMC_TRAFFIC else None,
             "kernel": "k_step<9,false>",
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
+            "kernel_timing": f"HIP event pair on the launch stream around every {max(1, args.time_stride)}-th k_step launch "
+                             f"of the timed region",
             "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP[asym],
             "note": "north star asks for the HBM fraction; the kernel is FP32-issue/latency bound "
                     "(<=9x9 per-env algebra, no MFMA): see fp32_frac_est",

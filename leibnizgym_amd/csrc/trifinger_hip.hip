@@ -1996,6 +1996,7 @@ struct TfHandle_ {
     // optional kernel timing (bench.py): event pairs around the fused step kernel
     hipEvent_t* ev;          // [2 * ev_cap]
     int ev_cap, ev_used;
+    int ev_stride, ev_phase; // every ev_stride-th launch is bracketed
 };
 
 static thread_local char g_err[512] = "";
@@ -2153,6 +2154,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     TfHandle_* h = new TfHandle_();
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
+    h->ev_stride = 1;
     if (h->cfg.global_num_envs <= 0) h->cfg.global_num_envs = cfg->num_envs;
     h->action_dim = tf_action_dim(cfg->command_mode);
     int od = 0, sd = 0;
@@ -2270,7 +2272,8 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     h->sa.nsim = nsim;
     reward_coefs(h);
     dim3 grid(n_waves(h)), block(WAVE);
-    const bool timed = !is_reset && h->ev && h->ev_used < h->ev_cap;
+    bool timed = !is_reset && h->ev && h->ev_used < h->ev_cap;
+    if (timed) { timed = (h->ev_phase == 0); h->ev_phase = (h->ev_phase + 1) % h->ev_stride; }
     if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], s));
     const bool asym = h->cfg.asymmetric_obs != 0;
 #define LAUNCH_STEP(AA, RR, SS) hipLaunchKernelGGL((k_step<AA, RR, SS>), grid, block, 0, s, h->d_params, h->sa, action)
@@ -2306,7 +2309,7 @@ static void free_events(TfHandle_* h) {
         for (int i = 0; i < 2 * h->ev_cap; ++i) (void)hipEventDestroy(h->ev[i]);
         delete[] h->ev;
     }
-    h->ev = nullptr; h->ev_cap = 0; h->ev_used = 0;
+    h->ev = nullptr; h->ev_cap = 0; h->ev_used = 0; h->ev_phase = 0;
 }
 int tf_enable_kernel_timing(tf_handle h, int32_t max_launches) {
     if (!h) return TF_ERR_INVALID_ARG;
@@ -2315,6 +2318,11 @@ int tf_enable_kernel_timing(tf_handle h, int32_t max_launches) {
     h->ev = new hipEvent_t[2 * (size_t)max_launches];
     for (int i = 0; i < 2 * max_launches; ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
     h->ev_cap = max_launches;
+    return TF_OK;
+}
+int tf_set_kernel_timing_stride(tf_handle h, int32_t stride) {
+    if (!h || stride <= 0) return TF_ERR_INVALID_ARG;
+    h->ev_stride = stride; h->ev_phase = 0;
     return TF_OK;
 }
 int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {

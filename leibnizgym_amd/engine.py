@@ -259,8 +259,9 @@ class TrifingerEngine:
         with self._on_device():
             check(self.lib, self.lib.tf_reset(self._handle, self._stream()), "tf_reset")
 
-    def enable_kernel_timing(self, max_launches):
+    def enable_kernel_timing(self, max_launches, stride=1):
         check(self.lib, self.lib.tf_enable_kernel_timing(self._handle, int(max_launches)), "tf_enable_kernel_timing")
+        check(self.lib, self.lib.tf_set_kernel_timing_stride(self._handle, int(stride)), "tf_set_kernel_timing_stride")
 
     def kernel_time_ms(self):
         """(summed duration of the timed fused-step kernels in ms, number of launches); synchronises."""

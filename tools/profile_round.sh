@@ -1,0 +1,26 @@
+#!/bin/bash
+# Developer tool (GPU box): everything a round's profiles/ entry needs, in one gpurun call.
+#   tools/profile_round.sh <tag>   ->  gpurun_out/<tag>_{bench.json,bench_symmetric.json,kernel_trace_stats.txt,pmc.txt}
+# Tracing and counters are separate rocprofv3 runs; the profiled program is python3 itself (no launcher hop).
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+T=${1:-rX}
+O=gpurun_out
+mkdir -p $O
+python3 bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
+python3 bench.py --symmetric --no-cpu-baseline > $O/${T}_bench_symmetric.json 2>> $O/${T}_bench.err
+CMD="python3 bench.py --steps 500 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $O/prof_$T/trace -o r -- $CMD > /dev/null 2>&1
+{ echo "# command: rocprofv3 --kernel-trace --stats -- $CMD   (MI355X, 65536 envs, asymmetric obs)"
+  python3 tools/rocprof_summary.py trace $(find $O/prof_$T/trace -name "*.db" | head -1); } > $O/${T}_kernel_trace_stats.txt
+CMD="python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline"
+: > $O/${T}_pmc.txt
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+  d=$O/prof_$T/pmc
+  rm -rf $d
+  rocprofv3 --pmc $C -d $d -o r -- $CMD > /dev/null 2>&1
+  { echo "# command: rocprofv3 --pmc $C -- $CMD"
+    python3 tools/rocprof_summary.py pmc $(find $d -name "*.db" | head -1) "k_step"; echo; } >> $O/${T}_pmc.txt
+done
+echo "# units: FETCH_SIZE / WRITE_SIZE in KiB per dispatch (raw rocprofv3 expressions); SQ cycle counters in quad-cycles summed over waves" >> $O/${T}_pmc.txt
+rm -rf $O/prof_$T
+cat $O/${T}_bench.json $O/${T}_kernel_trace_stats.txt
