@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TF_API_VERSION 1
+#define TF_API_VERSION 2
 
 typedef enum TfStatus {
     TF_OK = 0,
@@ -92,12 +92,14 @@ enum {
     TF_S_PREV_OBJ_Q = 62,/*  4 object orientation of history[1]                                   */
     TF_S_FT = 66,        /* 18 fingertip contact wrench (world frame force 3 + torque 3 per finger about
                               the tip-link origin, mean over the substeps of the step); split path only */
-    TF_S_DR = 84,        /*  4 per-env domain-randomisation scale factors drawn at reset (1.0 when DR is off):
-                              cube mass, cube size, contact friction, motor torque                  */
-    TF_STATE_ROWS = 88
+    TF_S_DR = 84,        /*  6 per-env domain-randomisation scale factors drawn at reset (1.0 when DR is off):
+                              cube mass, cube size, contact friction, motor torque, finger link mass,
+                              finger contact restitution                                           */
+    TF_STATE_ROWS = 90
 };
+#define TF_NUM_DR 6
 /* Largest num_envs of one handle: the kernels address state[TF_STATE_ROWS][num_envs] with 32-bit byte offsets
- * (88 * 4 Mi * 4 B = 1.4 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
+ * (90 * 4 Mi * 4 B = 1.5 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
 #define TF_MAX_ENVS 4194304
 
 #define TF_OBS_DIM_BASE 32    /* 9 + 9 + 7 + 7; the action slot (9 or 18) follows  trifinger_env.py:280-286 */
@@ -195,6 +197,13 @@ typedef struct TfConfig {
     float dr_cube_size[2];
     float dr_friction[2];
     float dr_motor[2];
+    float dr_link_mass[2];        /* one factor for the three moving links of every finger (mass and inertia)      */
+    float dr_restitution[2];      /* factor on the finger contact restitution                                      */
+    /* Observation noise (the reference leaves a TODO at trifinger_env.py:979): with dr_enable and dr_obs_noise > 0
+     * every step adds dr_obs_noise * U(-1, 1) to the emitted (already scaled) joint positions, joint velocities and
+     * object pose of `obs` (slots 0..24); goal, last action and the privileged `states` vector stay exact.  Draws are
+     * Philox outputs keyed by (seed, global env id, frame count): reproducible and invariant to the sharding. */
+    float dr_obs_noise;
     TfModel model;
 } TfConfig;
 

@@ -11,10 +11,11 @@ same binding at the CPU oracle; nothing in this package ever does.
 import ctypes as C
 import os
 
-TF_API_VERSION = 1
+TF_API_VERSION = 2
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
-TF_STATE_ROWS = 88
+TF_STATE_ROWS = 90
+TF_NUM_DR = 6
 
 # status codes (include/trifinger.h: TfStatus)
 TF_OK = 0
@@ -93,6 +94,7 @@ class TfConfig(C.Structure):
         ("dr_enable", C.c_int32),
         ("dr_cube_mass", C.c_float * 2), ("dr_cube_size", C.c_float * 2),
         ("dr_friction", C.c_float * 2), ("dr_motor", C.c_float * 2),
+        ("dr_link_mass", C.c_float * 2), ("dr_restitution", C.c_float * 2), ("dr_obs_noise", C.c_float),
         ("model", TfModel),
     ]
 

@@ -89,7 +89,8 @@ struct DevParams {
     int32_t robot_reset_type, object_reset_type, goal_rotation_activate;
     float dof_pos_stddev, dof_vel_stddev, goal_rate;
     int32_t dr_enable;
-    float dr_cube_mass[2], dr_cube_size[2], dr_friction[2], dr_motor[2];
+    float dr_cube_mass[2], dr_cube_size[2], dr_friction[2], dr_motor[2], dr_link_mass[2], dr_restitution[2];
+    float dr_obs_noise;      // half-width of the observation noise; 0 when off (or when dr_enable is 0)
     int32_t rew_active[6];
     int32_t success_activate;
     float success_bonus, pos_tol, ori_tol;
@@ -109,6 +110,7 @@ struct DevParams {
 struct StepArgs {
     RewardCoef rc;
     int32_t nsim;
+    uint32_t frame;          // frame count after this launch (counter of the observation-noise draws)
 };
 
 
@@ -258,7 +260,8 @@ DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
-enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 };
+enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 /* and 10 */,
+       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */ };
 DEV void rng4(const DevParams& P, uint32_t gid, uint32_t count, uint32_t tag, float u[4]) {
     uint32_t r[4];
     philox4x32_10(gid, count, tag, 0u, P.seed_lo, P.seed_hi, r);
@@ -567,7 +570,7 @@ struct Env {
     float gp[3], gq[4], gw[3];
     float tau[9];
     float ft[18];
-    float dr[4];     // domain-randomisation scale factors: cube mass, cube size, friction, motor torque
+    float dr[TF_NUM_DR];   // domain-randomisation scale factors: cube mass, cube size, friction, motor torque, link mass, restitution
 };
 
 // LDS is used for the row-major API tiles only ([64][W] transposes); W <= MAX_STATES.
@@ -806,7 +809,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
         float rxn[3];
         cross3(rc, &c.dir[0], rxn);
         float vn0 = dot3(&c.Jf[0], &vq[3 * F]) - (dot3(&c.dir[0], v) + dot3(rxn, w));
-        c.bias = contact_bias(m, gap, vn0, inv_h, m.restitution_finger);
+        c.bias = contact_bias(m, gap, vn0, inv_h, m.restitution_finger * e.dr[5]);
     }
     // tip sphere vs floor
     finger_contact_zero(g);
@@ -820,7 +823,7 @@ DEV void finger_contacts(const DevParams& P, const Env& e, const FK& k, const fl
 #pragma unroll
         for (int i = 0; i < 3; ++i) g.arm[i] = Pw[i] - Tw[i];
         float vn0 = dot3(&g.Jf[0], &vq[3 * F]);
-        g.bias = contact_bias(m, gapf, vn0, inv_h, m.restitution_finger);
+        g.bias = contact_bias(m, gapf, vn0, inv_h, m.restitution_finger * e.dr[5]);
     }
 }
 
@@ -908,6 +911,8 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             float M[6], bias[3], rhs[3], acc[3];                                                 \
             fk_setup(m, &e.q[3 * F], fk);                                                        \
             finger_dynamics(m, fk, &e.qd[3 * F], P.grav, M, bias);                               \
+            for (int j = 0; j < 6; ++j) M[j] = M[j] * e.dr[4];    /* link-mass factor (1.0 when off) */ \
+            for (int j = 0; j < 3; ++j) bias[j] = bias[j] * e.dr[4];                             \
             inv3sym(M, fk.Minv);                                                                 \
             for (int j = 0; j < 3; ++j) rhs[j] = e.tau[3 * F + j] - bias[j];                     \
             sym3_mul(fk.Minv, rhs, acc);                                                         \
@@ -1109,7 +1114,7 @@ DEV void store_goal(const DevParams& P, int i, const Env& e, bool pred) {
 }
 DEV void load_dyn(const DevParams& P, int i, Env& e) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) e.dr[j] = LDST(TF_S_DR + j);
+    for (int j = 0; j < TF_NUM_DR; ++j) e.dr[j] = LDST(TF_S_DR + j);
 #pragma unroll
     for (int j = 0; j < 9; ++j) { e.q[j] = LDST(TF_S_Q + j); e.qd[j] = LDST(TF_S_QD + j); }
 #pragma unroll
@@ -1255,6 +1260,9 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
             e.dr[1] = FMA(P.dr_cube_size[1] - P.dr_cube_size[0], u[1], P.dr_cube_size[0]);
             e.dr[2] = FMA(P.dr_friction[1] - P.dr_friction[0], u[2], P.dr_friction[0]);
             e.dr[3] = FMA(P.dr_motor[1] - P.dr_motor[0], u[3], P.dr_motor[0]);
+            rng4(P, gid, count, RNG_DR + 1u, u);
+            e.dr[4] = FMA(P.dr_link_mass[1] - P.dr_link_mass[0], u[0], P.dr_link_mass[0]);
+            e.dr[5] = FMA(P.dr_restitution[1] - P.dr_restitution[0], u[1], P.dr_restitution[0]);
         }
         if (P.robot_reset_type == TF_RESET_DEFAULT) {
 #pragma unroll
@@ -1296,7 +1304,7 @@ DEV bool apply_resets(const DevParams& P, int i, bool valid, Env& e, bool force_
         if (rflag || gflag) P.reset_count[(unsigned)i] = count;
         if (rflag && P.dr_enable) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) STST(TF_S_DR + j, e.dr[j]);
+            for (int j = 0; j < TF_NUM_DR; ++j) STST(TF_S_DR + j, e.dr[j]);
         }
     }
     goal_changed = rflag || gflag;
@@ -1435,7 +1443,7 @@ DEV float wave_sum_lane63(float x) {
 
 // trifinger_env.py:500-559 + 959-1099 for the env of this lane.  prev_obj = history[1] pose (7).
 template <int A>
-DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool valid, int wave_first, int n_valid, Env& e,
+DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame, int i, bool valid, int wave_first, int n_valid, Env& e,
                        const float* act, const float prev_obj[7], bool with_reward, float* lds, int lane, LaneStats& st,
                        Carried& cy) {
     const TfModel& m = P.m;
@@ -1515,6 +1523,14 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, int i, bool val
     constexpr bool nrm = decltype(nrm_tag)::value;
     WAVE_LDS_ORDER();
     EMIT_COMMON(OD)
+    if (P.dr_obs_noise > 0.0f) {        // wave-uniform; observation noise on q, qd and the object pose (build-defined DR)
+        const uint32_t gid = (uint32_t)(P.env_id_offset + i);
+        float nz[28];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) rng4(P, gid, frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+#pragma unroll
+        for (int j = 0; j < 25; ++j) lds[lane * OD + j] = FMA(P.dr_obs_noise, 2.0f * nz[j] - 1.0f, lds[lane * OD + j]);
+    }
     WAVE_LDS_ORDER();
     store_tile<OD>(P.obs, lds, wave_first, n_valid, lane);
     WAVE_LDS_ORDER();
@@ -1793,7 +1809,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         stats_zero(st);
         st.resets = n_resets;
         goal_advance(P, e, nsub, P.hsub);
-        post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st, cy);
+        post_step_env<A>(P, sa.rc, sa.frame, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st, cy);
         PHASE_STAMP();
         store_dyn(P, i, e, valid);
         if (P.goal_rotation_activate) store_goal(P, i, e, valid);
@@ -1904,7 +1920,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_post_step(const DevParams* __restri
     load_prev_obj(P, i, prev_obj);
     Carried cy;
     load_carried(P, i, cy);
-    post_step_env<A>(P, sa.rc, i, valid, wave_first, n_valid, e, act, prev_obj, true, lds, lane, st, cy);
+    post_step_env<A>(P, sa.rc, sa.frame, i, valid, wave_first, n_valid, e, act, prev_obj, true, lds, lane, st, cy);
     store_dyn(P, i, e, valid);
     store_ft(P, i, e, valid);
     stats_publish(P, st, lane);
@@ -2170,7 +2186,11 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     P.robot_reset_type = cfg->robot_reset_type; P.object_reset_type = cfg->object_reset_type;
     P.goal_rotation_activate = cfg->goal_rotation_activate;
     P.dr_enable = cfg->dr_enable;
-    for (int i = 0; i < 2; ++i) { P.dr_cube_mass[i] = cfg->dr_cube_mass[i]; P.dr_cube_size[i] = cfg->dr_cube_size[i]; P.dr_friction[i] = cfg->dr_friction[i]; P.dr_motor[i] = cfg->dr_motor[i]; }
+    for (int i = 0; i < 2; ++i) {
+        P.dr_cube_mass[i] = cfg->dr_cube_mass[i]; P.dr_cube_size[i] = cfg->dr_cube_size[i]; P.dr_friction[i] = cfg->dr_friction[i];
+        P.dr_motor[i] = cfg->dr_motor[i]; P.dr_link_mass[i] = cfg->dr_link_mass[i]; P.dr_restitution[i] = cfg->dr_restitution[i];
+    }
+    P.dr_obs_noise = (cfg->dr_enable && cfg->dr_obs_noise > 0.0f) ? cfg->dr_obs_noise : 0.0f;
     P.dof_pos_stddev = cfg->dof_pos_stddev; P.dof_vel_stddev = cfg->dof_vel_stddev; P.goal_rate = cfg->goal_rotation_rate_magnitude;
     for (int t = 0; t < 6; ++t) P.rew_active[t] = cfg->reward[t].activate;
     P.success_activate = cfg->success_activate; P.success_bonus = cfg->success_bonus;
@@ -2270,6 +2290,7 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     const int nsim = is_reset ? 1 : h->cfg.control_decimation;
     h->frame_count += nsim;
     h->sa.nsim = nsim;
+    h->sa.frame = (uint32_t)h->frame_count;
     reward_coefs(h);
     dim3 grid(n_waves(h)), block(WAVE);
     bool timed = !is_reset && h->ev && h->ev_used < h->ev_cap;
@@ -2365,6 +2386,7 @@ int tf_simulate(tf_handle h, void* stream) {
 int tf_post_step(tf_handle h, void* stream) {
     CHECK_HANDLE(h)
     reward_coefs(h);
+    h->sa.frame = (uint32_t)h->frame_count;
     dim3 grid(n_waves(h)), block(WAVE);
     if (h->action_dim == 9) hipLaunchKernelGGL(k_post_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
     else hipLaunchKernelGGL(k_post_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);

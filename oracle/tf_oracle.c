@@ -180,7 +180,8 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 static inline float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; } /* [0,1) 24 bit */
 
 /* RNG stream tags (counter word 2) */
-enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 };
+enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 /* and 10 */,
+       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */ };
 
 static void rng4(uint64_t seed, uint32_t env_gid, uint32_t count, uint32_t tag, float u[4]) {
     uint32_t r[4];
@@ -654,7 +655,7 @@ typedef struct {
     float gp[3], gq[4], gw[3];
     float tau[9];
     float ft[18];      /* accumulated fingertip wrench (world), summed over substeps */
-    float dr[4];       /* domain-randomisation scale factors: cube mass, cube size, friction, motor torque */
+    float dr[TF_NUM_DR]; /* domain-randomisation scale factors: cube mass, cube size, friction, motor torque, link mass, restitution */
 } Env;
 
 /* one contact between finger f and something: three rows (normal + two tangents) */
@@ -853,6 +854,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
     const float mu_fc = m->mu_finger_cube * e->dr[2], mu_tf = m->mu_tip_floor * e->dr[2];
     const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2];
+    const float rest_f = m->restitution_finger * e->dr[5];
     FK fk[3];
     float vq[9];                 /* joint velocities being solved */
     float v[3], w[3];            /* cube velocities being solved  */
@@ -861,6 +863,8 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         float M[6], bias[3], rhs[3], acc[3];
         fk_setup(m, &e->q[3 * f], &fk[f]);
         finger_dynamics(m, &fk[f], &e->qd[3 * f], cfg->gravity, M, bias);
+        for (int j = 0; j < 6; ++j) M[j] = M[j] * e->dr[4];       /* link-mass factor: masses and inertias scale together */
+        for (int j = 0; j < 3; ++j) bias[j] = bias[j] * e->dr[4];
         inv3sym(M, fk[f].Minv);
         for (int j = 0; j < 3; ++j) rhs[j] = e->tau[3 * f + j] - bias[j];
         sym3_mul(fk[f].Minv, rhs, acc);
@@ -948,7 +952,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             float rxn[3];
             cross3(rc, c->dir[0], rxn);
             float vn0 = dot3(c->Jf[0], &vq[3 * f]) - (dot3(c->dir[0], v) + dot3(rxn, w));
-            c->bias = contact_bias(m, gap, vn0, inv_h, m->restitution_finger);
+            c->bias = contact_bias(m, gap, vn0, inv_h, rest_f);
         }
         /* --- tip sphere vs floor --- */
         FingerContact* g = &tf_[f];
@@ -962,7 +966,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             finger_rows(m, f, k, Pb, n_w, zero, 0, inv_m, inv_I, g);
             for (int i = 0; i < 3; ++i) g->arm[i] = Pw[i] - Tw[i];
             float vn0 = dot3(g->Jf[0], &vq[3 * f]);
-            g->bias = contact_bias(m, gapf, vn0, inv_h, m->restitution_finger);
+            g->bias = contact_bias(m, gapf, vn0, inv_h, rest_f);
         }
     }
     /* --- cube vs floor: the four corners of the face that points down most --- */
@@ -1129,7 +1133,7 @@ static void env_load(const struct TfHandle_* h, int i, Env* e) {
     }
     for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
     for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
-    for (int j = 0; j < 4; ++j) e->dr[j] = ST(h, TF_S_DR + j, i);
+    for (int j = 0; j < TF_NUM_DR; ++j) e->dr[j] = ST(h, TF_S_DR + j, i);
 }
 static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_ft) {
     for (int j = 0; j < 9; ++j) { ST(h, TF_S_Q + j, i) = e->q[j]; ST(h, TF_S_QD + j, i) = e->qd[j]; ST(h, TF_S_TAU + j, i) = e->tau[j]; }
@@ -1139,7 +1143,7 @@ static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_
     }
     for (int j = 0; j < 4; ++j) { ST(h, TF_S_CUBE_Q + j, i) = e->cq[j]; ST(h, TF_S_GOAL_Q + j, i) = e->gq[j]; }
     if (store_ft) for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
-    for (int j = 0; j < 4; ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
+    for (int j = 0; j < TF_NUM_DR; ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1227,6 +1231,9 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
             e->dr[1] = FMA(c->dr_cube_size[1] - c->dr_cube_size[0], u[1], c->dr_cube_size[0]);
             e->dr[2] = FMA(c->dr_friction[1] - c->dr_friction[0], u[2], c->dr_friction[0]);
             e->dr[3] = FMA(c->dr_motor[1] - c->dr_motor[0], u[3], c->dr_motor[0]);
+            rng4(c->seed, gid, count, RNG_DR + 1u, u);
+            e->dr[4] = FMA(c->dr_link_mass[1] - c->dr_link_mass[0], u[0], c->dr_link_mass[0]);
+            e->dr[5] = FMA(c->dr_restitution[1] - c->dr_restitution[0], u[1], c->dr_restitution[0]);
         }
         if (c->robot_reset_type == TF_RESET_DEFAULT) {
             for (int j = 0; j < 9; ++j) { e->q[j] = m->q_default[j % 3]; e->qd[j] = 0.0f; }
@@ -1393,6 +1400,12 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
     for (int j = 0; j < A; ++j) raw[k++] = act[j];
     float* obs = &h->buf.obs[(size_t)i * (size_t)OD];
     for (int j = 0; j < OD; ++j) obs[j] = c->normalize_obs ? (2.0f * (raw[j] - h->obs_off[j])) * h->obs_inv[j] : raw[j];
+    if (c->dr_enable && c->dr_obs_noise > 0.0f) {      /* observation noise on q, qd, object pose (slots 0..24) */
+        uint32_t gid = (uint32_t)(c->env_id_offset + i);
+        float nz[28];
+        for (int b = 0; b < 7; ++b) rng4(c->seed, gid, (uint32_t)h->frame_count, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+        for (int j = 0; j < 25; ++j) obs[j] = FMA(c->dr_obs_noise, 2.0f * nz[j] - 1.0f, obs[j]);
+    }
     if (c->asymmetric_obs) {
         for (int j = 0; j < 3; ++j) raw[k++] = e->cv[j];
         for (int j = 0; j < 3; ++j) raw[k++] = e->cw[j];
