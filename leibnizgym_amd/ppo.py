@@ -7,6 +7,9 @@ lr 3e-4 adaptive on a KL threshold of 0.008, e_clip 0.2, critic_coef 4, reward s
 bounds loss 1e-4, normalised advantages.
 
 This is host-side training glue, NOT part of the measured hot path: networks are plain `torch.nn` (rocBLAS GEMMs).
+The update is launch-bound (two tiny MLPs, ~150 launches per minibatch, 128 minibatches per iteration), so on the GPU
+one minibatch step is captured once into two HIP graphs (gather + forward + backward + gradient flattening | clip +
+fused Adam) and replayed; the gradient all-reduce sits between the two replays, outside the capture.
 Data parallelism: every rank owns an env shard (leibnizgym_amd.sharding) and its own rollout; gradients are averaged
 with ONE all-reduce of a flat buffer per minibatch (`torch.distributed`, backend nccl = RCCL over xGMI on the GPU
 box, gloo in the CPU tests) - ~1 MB, latency-bound, so a single fused collective is the right shape.
@@ -38,6 +41,7 @@ class PPOConfig:
     entropy_coef: float = 0.0
     normalize_advantage: bool = True
     seed: int = 7
+    use_graphs: bool = True           # capture the minibatch step into HIP graphs when the trainer runs on a GPU
 
 
 def mlp(inp, units, out):
@@ -78,8 +82,14 @@ class PPOTrainer:
         self.net = ActorCritic(obs_dim, state_dim, act_dim, self.cfg.units).to(self.device)
         # fused multi-tensor Adam on the GPU: the update is launch-bound (tiny MLPs), one kernel instead of ~60
         fused = self.device.type == "cuda"
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=self.cfg.lr, eps=1e-8, **({"fused": True} if fused else {}))
+        self.graphs = fused and self.cfg.use_graphs
+        if self.graphs:                        # capturable: the step counter and the learning rate live on the device
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=torch.tensor(self.cfg.lr, device=self.device), eps=1e-8,
+                                        fused=True, capturable=True)
+        else:
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=self.cfg.lr, eps=1e-8, **({"fused": True} if fused else {}))
         self.lr = self.cfg.lr
+        self._g = None                         # captured minibatch step (built on the first update)
         self.dist_on = False
         try:
             import torch.distributed as dist
@@ -138,69 +148,150 @@ class PPOTrainer:
         self.frames += T * n
         return buf
 
-    def _allreduce_grads(self):
-        if not self.dist_on:
-            return
-        grads = [p.grad for p in self.net.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+    # ---- one minibatch step, split at the gradient exchange ----
+    def _mb_backward(self, d, idx, acc):
+        """gather the minibatch, forward, losses, backward; returns nothing - gradients sit in p.grad, the running
+        sums of the logged quantities in `acc` (device tensors, no host sync)"""
+        c = self.cfg
+        obs = d["obs"][idx]
+        mu, ls = self.net.dist(obs)
+        nlp = neglogp(d["act"][idx], mu, ls)
+        ratio = (d["old_nlp"][idx] - nlp).exp()
+        a = d["adv"][idx]
+        a_loss = torch.max(-a * ratio, -a * ratio.clamp(1 - c.e_clip, 1 + c.e_clip)).mean()
+        v = self.net.value(obs, d["states"][idx] if d["states"] is not None else None)
+        c_loss = (v - d["ret"][idx]).pow(2).mean()
+        b_loss = ((mu - 1.1).clamp(min=0).pow(2) + (-1.1 - mu).clamp(min=0).pow(2)).sum(-1).mean()
+        ent = (ls + 0.5 + 0.5 * math.log(2 * math.pi)).sum(-1).mean()
+        loss = a_loss + 0.5 * c.critic_coef * c_loss - c.entropy_coef * ent + c.bounds_loss_coef * b_loss
+        for p in self.net.parameters():
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():      # KL between the old and new diagonal Gaussians (same sigma)
+            kl = (0.5 * ((mu - d["old_mu"][idx]) / ls.exp()).pow(2)).sum(-1).mean()
+            acc["kl"] += kl
+            acc["loss"] += loss.detach(); acc["a_loss"] += a_loss.detach(); acc["c_loss"] += c_loss.detach()
+
+    def _mb_apply(self):
+        nn.utils.clip_grad_norm_(self.net.parameters(), self.cfg.grad_norm, foreach=True)
+        self.opt.step()
+
+    def _flatten_grads(self, out=None):
+        grads = [p.grad for p in self.net.parameters()]
+        return torch.cat([g.reshape(-1) for g in grads], out=out)
+
+    def _unflatten_grads(self, flat):
+        off = 0
+        for p in self.net.parameters():
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            off += p.numel()
+
+    def _exchange(self, flat):
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         flat /= self.dist.get_world_size(self.group)
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+
+    def _capture(self, d, mb, acc):
+        """Capture the minibatch step once: graph A = gather + forward + backward (+ flat gradient buffer when the ranks
+        exchange gradients), graph B = (unflatten +) clip + Adam.  Static inputs: the flat rollout buffers `d`, the index
+        tensor, the statistics accumulators."""
+        dev = self.device
+        idx = torch.zeros(mb, dtype=torch.long, device=dev)
+        nflat = sum(p.numel() for p in self.net.parameters())
+        flat = torch.zeros(nflat, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        state = {k: v.detach().clone() for k, v in self.net.state_dict().items()}
+        with torch.cuda.stream(side):          # warm-up off the capture (allocator, lazy optimizer state), then undone
+            for _ in range(3):
+                self._mb_backward(d, idx, acc)
+                if self.dist_on:
+                    self._flatten_grads(out=flat)
+                    self._unflatten_grads(flat)
+                self._mb_apply()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.net.load_state_dict(state)
+        for st in self.opt.state.values():     # the warm-up steps must not count: moments and step counter back to zero
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        for v in acc.values():
+            v.zero_()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._mb_backward(d, idx, acc)
+            if self.dist_on:
+                self._flatten_grads(out=flat)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            if self.dist_on:
+                self._unflatten_grads(flat)
+            self._mb_apply()
+        # the two captures above executed nothing; parameters and accumulators are untouched
+        self._g = dict(a=ga, b=gb, idx=idx, flat=flat, d=d, acc=acc, mb=mb)
 
     def update(self, buf):
         c = self.cfg
         T, n = buf["nlp"].shape
         flat = lambda x: x.reshape(T * n, *x.shape[2:]) if x is not None else None  # noqa: E731
-        obs, states, act = flat(buf["obs"]), flat(buf["states"]), flat(buf["act"])
-        old_nlp, ret, adv, old_mu = flat(buf["nlp"]), flat(buf["ret"]), flat(buf["adv"]), flat(buf["mu"])
+        adv = flat(buf["adv"])
         if c.normalize_advantage:
             adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        src = dict(obs=flat(buf["obs"]), states=flat(buf["states"]), act=flat(buf["act"]), old_nlp=flat(buf["nlp"]),
+                   ret=flat(buf["ret"]), adv=adv, old_mu=flat(buf["mu"]))
         total = T * n
         mb = max(1, total // c.minibatches)
-        zero = torch.zeros((), device=obs.device)
-        acc = {"loss": zero.clone(), "a_loss": zero.clone(), "c_loss": zero.clone()}     # device-side, no per-minibatch sync
+        dev = src["obs"].device
+        if self.graphs:
+            if self._g is None or self._g["mb"] != mb or self._g["d"]["obs"].shape != src["obs"].shape:
+                d = {k: (v.clone() if v is not None else None) for k, v in src.items()}
+                acc = {k: torch.zeros((), device=dev) for k in ("kl", "loss", "a_loss", "c_loss")}
+                self._capture(d, mb, acc)
+            d, acc = self._g["d"], self._g["acc"]
+            for k, v in src.items():           # the graphs read the rollout from fixed addresses
+                if v is not None:
+                    d[k].copy_(v)
+        else:
+            d = src
+            acc = {k: torch.zeros((), device=dev) for k in ("kl", "loss", "a_loss", "c_loss")}
+        for v in acc.values():
+            v.zero_()
         stats = {"kl": 0.0}
         count = 0
         for _ in range(c.mini_epochs):
-            perm = torch.randperm(total, device=obs.device)
-            kls = []
+            perm = torch.randperm(total, device=dev)
+            acc["kl"].zero_()
+            nmb = 0
             for s in range(0, total - mb + 1, mb):
-                idx = perm[s:s + mb]
-                mu, ls = self.net.dist(obs[idx])
-                nlp = neglogp(act[idx], mu, ls)
-                ratio = (old_nlp[idx] - nlp).exp()
-                a = adv[idx]
-                a_loss = torch.max(-a * ratio, -a * ratio.clamp(1 - c.e_clip, 1 + c.e_clip)).mean()
-                v = self.net.value(obs[idx], states[idx] if states is not None else None)
-                c_loss = (v - ret[idx]).pow(2).mean()
-                b_loss = ((mu - 1.1).clamp(min=0).pow(2) + (-1.1 - mu).clamp(min=0).pow(2)).sum(-1).mean()
-                ent = (ls + 0.5 + 0.5 * math.log(2 * math.pi)).sum(-1).mean()
-                loss = a_loss + 0.5 * c.critic_coef * c_loss - c.entropy_coef * ent + c.bounds_loss_coef * b_loss
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
-                self._allreduce_grads()
-                nn.utils.clip_grad_norm_(self.net.parameters(), c.grad_norm, foreach=True)
-                self.opt.step()
-                with torch.no_grad():      # KL between the old and new diagonal Gaussians (same sigma)
-                    kl = (0.5 * ((mu - old_mu[idx]) / ls.exp()).pow(2)).sum(-1).mean()
-                kls.append(kl)
-                acc["loss"] += loss.detach(); acc["a_loss"] += a_loss.detach(); acc["c_loss"] += c_loss.detach()
-                count += 1
-            kl = torch.stack(kls).mean()
+                if self.graphs:
+                    g = self._g
+                    g["idx"].copy_(perm[s:s + mb])
+                    g["a"].replay()
+                    if self.dist_on:
+                        self._exchange(g["flat"])
+                    g["b"].replay()
+                else:
+                    self._mb_backward(d, perm[s:s + mb], acc)
+                    if self.dist_on:
+                        fl = self._flatten_grads()
+                        self._exchange(fl)
+                        self._unflatten_grads(fl)
+                    self._mb_apply()
+                nmb += 1
+            count += nmb
+            kl = acc["kl"] / max(nmb, 1)
             if self.dist_on:
                 self.dist.all_reduce(kl, op=self.dist.ReduceOp.SUM, group=self.group)
                 kl /= self.dist.get_world_size(self.group)
-            kl = float(kl)
+            kl = float(kl)                     # the one host sync per mini-epoch (adaptive learning rate)
             stats["kl"] = kl
             if kl > 2.0 * c.kl_threshold:      # rl_games AdaptiveScheduler
                 self.lr = max(self.lr / 1.5, 1e-6)
             elif kl < 0.5 * c.kl_threshold:
                 self.lr = min(self.lr * 1.5, 1e-2)
             for g in self.opt.param_groups:
-                g["lr"] = self.lr
+                if torch.is_tensor(g["lr"]):
+                    g["lr"].fill_(self.lr)
+                else:
+                    g["lr"] = self.lr
         for k in ("loss", "a_loss", "c_loss"):
             stats[k] = float(acc[k]) / max(count, 1)
         stats["lr"] = self.lr

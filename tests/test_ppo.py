@@ -3,6 +3,7 @@ losses, parameters move, GAE against a hand computation, and 2-rank gradient ave
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -77,3 +78,31 @@ def test_data_parallel_ranks_stay_in_sync(tmp_path):
     w0, w1 = (torch.load(os.path.join(tmp_path, f"w{r}.pt")) for r in range(2))
     # different env shards and different sampled actions, one averaged gradient: identical weights afterwards
     assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(w0, w1))
+
+
+@pytest.mark.gpu
+def test_graph_captured_update_matches_eager(hip):
+    """The HIP-graph minibatch step (one-rank form and the split form used around the gradient all-reduce) takes the
+    same optimisation steps as the eager code."""
+    def run(use_graphs, split):
+        cfg = gym_config("trifinger_difficulty_4")
+        cfg.update(num_instances=256, seed=1, physics_engine="physx", asymmetric_obs=True, episode_length=20)
+        env = TrifingerEnv(config=cfg, device="cuda:0", verbose=False)
+        ad = RlGamesGpuEnvAdapter("rlgpu", 256, env=VecTaskPython(env, rl_device="cuda:0"))
+        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2, use_graphs=use_graphs),
+                        device="cuda:0")
+        if split:                                     # one rank: the average of one gradient is itself
+            from types import SimpleNamespace
+            tr.dist_on = True
+            tr.dist = SimpleNamespace(all_reduce=lambda *a, **k: None, get_world_size=lambda g=None: 1,
+                                      ReduceOp=SimpleNamespace(SUM=None))
+        torch.manual_seed(11)
+        stats = tr.train(2)
+        return [p.detach().clone() for p in tr.net.parameters()], stats
+    eager, s0 = run(False, False)
+    graph, s1 = run(True, False)
+    split, s2 = run(True, True)
+    for a, b, c in zip(eager, graph, split):
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-4) and torch.allclose(a, c, atol=2e-5, rtol=1e-4)
+    assert abs(s0[-1]["loss"] - s1[-1]["loss"]) < 1e-3 * max(1.0, abs(s0[-1]["loss"]))
+    assert abs(s0[-1]["kl"] - s2[-1]["kl"]) < 1e-4
