@@ -1492,7 +1492,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
 #define EMIT(W, col, val)                                                               \
     {                                                                                   \
         float x_ = (val);                                                               \
-        lds[lane * (W) + (col)] = nrm ? (2.0f * (x_ - off[col])) * inv[col] : x_;       \
+        lds[lane * (W) + (col)] = nrm ? FMA(x_, 2.0f * inv[col], -(2.0f * off[col]) * inv[col]) : x_; \
     }
     // Every slot but the action one has limits that are constants of the MDP (reference trifinger_env.py:153-213):
     // with the loops unrolled, offset and 1/range fold into instruction literals - same fp32 values as the host-built
@@ -1502,7 +1502,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
     {                                                                                   \
         float x_ = (val);                                                               \
         const float o_ = ((lo_) + (hi_)) * 0.5f, i_ = 1.0f / ((hi_) - (lo_));           \
-        lds[lane * (W) + (col)] = nrm ? (2.0f * (x_ - o_)) * i_ : x_;                   \
+        lds[lane * (W) + (col)] = nrm ? FMA(x_, 2.0f * i_, -(2.0f * o_) * i_) : x_;     \
     }
 #define QLO(j) (((j) % 3 == 0) ? -0.33f : (((j) % 3 == 1) ? 0.0f : -2.7f))
 #define QHI(j) (((j) % 3 == 0) ? 1.0f : (((j) % 3 == 1) ? 1.57f : 0.0f))

@@ -1363,6 +1363,13 @@ static void tip_state(const TfModel* m, int f, const float q[3], const float qd[
 typedef struct { double rew[6]; double pos_cnt, ori_cnt, succ, resets, nonfinite; } Stats;
 
 /* trifinger_env.py:500-559 + 959-1099 for one env.  prev_obj = history[1] pose (7).  */
+/* scale_transform (torch_utils.py:18-36: 2 (x - offset) / (upper - lower)) as ONE fused multiply-add with the two
+ * constants of the slot, k1 = 2 / range and k0 = -(2 offset) / range, each rounded to fp32 once: x k1 + k0.  Differs
+ * from the reference's three roundings by at most a few ulp of the scaled value (< 1e-6; the golden fixtures pin it). */
+static inline float scale_slot(float x, float off, float inv) {
+    const float k1 = 2.0f * inv, k0 = -(2.0f * off) * inv;
+    return FMA(x, k1, k0);
+}
 static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float prev_obj[7], const RewardCoef* rc,
                           int with_reward, Stats* st) {
     const TfConfig* c = &h->cfg;
@@ -1399,7 +1406,7 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
     const float* act = &h->buf.action_buf[(size_t)i * (size_t)A];
     for (int j = 0; j < A; ++j) raw[k++] = act[j];
     float* obs = &h->buf.obs[(size_t)i * (size_t)OD];
-    for (int j = 0; j < OD; ++j) obs[j] = c->normalize_obs ? (2.0f * (raw[j] - h->obs_off[j])) * h->obs_inv[j] : raw[j];
+    for (int j = 0; j < OD; ++j) obs[j] = c->normalize_obs ? scale_slot(raw[j], h->obs_off[j], h->obs_inv[j]) : raw[j];
     if (c->dr_enable && c->dr_obs_noise > 0.0f) {      /* observation noise on q, qd, object pose (slots 0..24) */
         uint32_t gid = (uint32_t)(c->env_id_offset + i);
         float nz[28];
@@ -1428,7 +1435,7 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
             }
         }
         float* sts = &h->buf.states[(size_t)i * (size_t)SD];
-        for (int j = 0; j < SD; ++j) sts[j] = c->normalize_obs ? (2.0f * (raw[j] - h->st_off[j])) * h->st_inv[j] : raw[j];
+        for (int j = 0; j < SD; ++j) sts[j] = c->normalize_obs ? scale_slot(raw[j], h->st_off[j], h->st_inv[j]) : raw[j];
     }
     /* history bookkeeping: previous fingertip positions are whatever the last filled frame left */
     float tip_prev[9];
