@@ -204,6 +204,11 @@ typedef struct TfConfig {
      * object pose of `obs` (slots 0..24); goal, last action and the privileged `states` vector stay exact.  Draws are
      * Philox outputs keyed by (seed, global env id, frame count): reproducible and invariant to the sharding. */
     float dr_obs_noise;
+    /* Action repeat (late or dropped command packets): with dr_enable and dr_action_repeat > 0 every env ignores the new
+     * action with this probability and re-applies the torque it applied in the previous step (state rows TF_S_TAU; a
+     * reset clears them).  `_action_buf` / the obs action slot still report the commanded action.  One Philox draw per
+     * env and step, keyed by the frame count at the start of the step. */
+    float dr_action_repeat;
     TfModel model;
 } TfConfig;
 

@@ -94,7 +94,7 @@ class TfConfig(C.Structure):
         ("dr_enable", C.c_int32),
         ("dr_cube_mass", C.c_float * 2), ("dr_cube_size", C.c_float * 2),
         ("dr_friction", C.c_float * 2), ("dr_motor", C.c_float * 2),
-        ("dr_link_mass", C.c_float * 2), ("dr_restitution", C.c_float * 2), ("dr_obs_noise", C.c_float),
+        ("dr_link_mass", C.c_float * 2), ("dr_restitution", C.c_float * 2), ("dr_obs_noise", C.c_float), ("dr_action_repeat", C.c_float),
         ("model", TfModel),
     ]
 

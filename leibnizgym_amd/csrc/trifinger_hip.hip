@@ -91,6 +91,7 @@ struct DevParams {
     int32_t dr_enable;
     float dr_cube_mass[2], dr_cube_size[2], dr_friction[2], dr_motor[2], dr_link_mass[2], dr_restitution[2];
     float dr_obs_noise;      // half-width of the observation noise; 0 when off (or when dr_enable is 0)
+    float dr_action_repeat;  // probability of re-applying the previous step's torque; 0 when off
     int32_t rew_active[6];
     int32_t success_activate;
     float success_bonus, pos_tol, ori_tol;
@@ -111,6 +112,7 @@ struct StepArgs {
     RewardCoef rc;
     int32_t nsim;
     uint32_t frame;          // frame count after this launch (counter of the observation-noise draws)
+    uint32_t frame0;         // frame count at the start of the control step (counter of the action-repeat draw)
 };
 
 
@@ -261,7 +263,7 @@ DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 }
 DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
 enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 /* and 10 */,
-       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */ };
+       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */, RNG_ACT_REPEAT = 24 /* counter = frame count */ };
 DEV void rng4(const DevParams& P, uint32_t gid, uint32_t count, uint32_t tag, float u[4]) {
     uint32_t r[4];
     philox4x32_10(gid, count, tag, 0u, P.seed_lo, P.seed_hi, r);
@@ -1357,6 +1359,23 @@ DEV void compute_torque(const DevParams& P, const float* act, const float q[9], 
     for (int j = 0; j < 9; ++j) tau[j] = t[j] * motor_scale;     // domain randomisation of the motor strength (1.0 when off)
 }
 
+// build-defined action repeat: keep the previous step's applied torque (state rows TF_S_TAU, cleared by a reset) with
+// probability dr_action_repeat.  The switch is wave-uniform: nothing is loaded or drawn when it is off.
+template <int A>
+DEV void torque_with_repeat(const DevParams& P, int i, uint32_t frame0, bool was_reset, const float* act, Env& e) {
+    compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
+    if (P.dr_action_repeat > 0.0f) {
+        float u[4];
+        rng4(P, (uint32_t)(P.env_id_offset + i), frame0, RNG_ACT_REPEAT, u);
+        const bool keep = u[0] < P.dr_action_repeat;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float prev = was_reset ? 0.0f : LDST(TF_S_TAU + j);
+            e.tau[j] = keep ? prev : e.tau[j];
+        }
+    }
+}
+
 DEV float norm3d(const float a[3], const float b[3]) {
     float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     return f_sqrt(dx * dx + dy * dy + dz * dz);
@@ -1753,7 +1772,8 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         WAVE_LDS_ORDER();
         store_tile<A>(P.action_buf, lds, wave_first, n_valid, lane);
         WAVE_LDS_ORDER();
-        compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
+        if (IS_RESET) compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
+        else torque_with_repeat<A>(P, i, sa.frame0, did_reset, act, e);
         store_prev_obj(P, i, e, valid);                         // history[1] of the object (trifinger_env.py:975)
 #pragma unroll
         for (int j = 0; j < 3; ++j) prev_obj[j] = e.cp[j];
@@ -1868,19 +1888,23 @@ __global__ void __launch_bounds__(WAVE, 1) k_apply_resets(const DevParams* __res
     WAVE_LDS_ORDER();
     store_tile<A>(P.action_buf, lds, wave_first, n_valid, lane);
     load_split_extras(P, i, e);
+    if (did) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e.tau[j] = 0.0f;            // a reset clears the stored torque
+    }
     store_dyn(P, i, e, valid);
     store_goal(P, i, e, valid);
 }
 
 template <int A>
-__global__ void __launch_bounds__(WAVE, 1) k_pre_step(const DevParams* __restrict__ Pp) {
+__global__ void __launch_bounds__(WAVE, 1) k_pre_step(const DevParams* __restrict__ Pp, uint32_t frame0) {
     LANE_SETUP
     Env e;
     load_dyn(P, i, e);
     float act[A];
 #pragma unroll
     for (int j = 0; j < A; ++j) act[j] = P.action_buf[(size_t)i * A + j];
-    compute_torque<A>(P, act, e.q, e.qd, e.dr[3], e.tau);
+    torque_with_repeat<A>(P, i, frame0, false, act, e);
 #pragma unroll
     for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
     store_dyn(P, i, e, valid);
@@ -2191,6 +2215,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
         P.dr_motor[i] = cfg->dr_motor[i]; P.dr_link_mass[i] = cfg->dr_link_mass[i]; P.dr_restitution[i] = cfg->dr_restitution[i];
     }
     P.dr_obs_noise = (cfg->dr_enable && cfg->dr_obs_noise > 0.0f) ? cfg->dr_obs_noise : 0.0f;
+    P.dr_action_repeat = (cfg->dr_enable && cfg->dr_action_repeat > 0.0f) ? cfg->dr_action_repeat : 0.0f;
     P.dof_pos_stddev = cfg->dof_pos_stddev; P.dof_vel_stddev = cfg->dof_vel_stddev; P.goal_rate = cfg->goal_rotation_rate_magnitude;
     for (int t = 0; t < 6; ++t) P.rew_active[t] = cfg->reward[t].activate;
     P.success_activate = cfg->success_activate; P.success_bonus = cfg->success_bonus;
@@ -2291,6 +2316,7 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     h->frame_count += nsim;
     h->sa.nsim = nsim;
     h->sa.frame = (uint32_t)h->frame_count;
+    h->sa.frame0 = (uint32_t)(h->frame_count - nsim);
     reward_coefs(h);
     dim3 grid(n_waves(h)), block(WAVE);
     bool timed = !is_reset && h->ev && h->ev_used < h->ev_cap;
@@ -2371,8 +2397,9 @@ int tf_apply_resets(tf_handle h, void* stream) {
 int tf_pre_step(tf_handle h, void* stream) {
     CHECK_HANDLE(h)
     dim3 grid(n_waves(h)), block(WAVE);
-    if (h->action_dim == 9) hipLaunchKernelGGL(k_pre_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params);
-    else hipLaunchKernelGGL(k_pre_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params);
+    const uint32_t frame0 = (uint32_t)h->frame_count;
+    if (h->action_dim == 9) hipLaunchKernelGGL(k_pre_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params, frame0);
+    else hipLaunchKernelGGL(k_pre_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params, frame0);
     LAUNCH_CHECK("k_pre_step");
     return TF_OK;
 }

@@ -104,12 +104,15 @@ def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, co
     for i in range(3):
         cfg.gravity[i] = float(gravity[i])
     dr = {"activate": False, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "friction": (0.7, 1.3),
-          "motor_torque": (0.9, 1.1), "link_mass": (0.9, 1.1), "restitution": (0.5, 1.5), "obs_noise": 0.0}
+          "motor_torque": (0.9, 1.1), "link_mass": (0.9, 1.1), "restitution": (0.5, 1.5), "obs_noise": 0.0, "action_repeat_prob": 0.0}
     dr.update(domain_randomization or {})
     cfg.dr_enable = int(bool(dr["activate"]))
     if not (float(dr["obs_noise"]) >= 0.0):
         raise ValueError(f"domain_randomization.obs_noise: need a half-width >= 0, got {dr['obs_noise']}")
     cfg.dr_obs_noise = float(dr["obs_noise"])
+    if not (0.0 <= float(dr["action_repeat_prob"]) <= 1.0):
+        raise ValueError(f"domain_randomization.action_repeat_prob: need a probability, got {dr['action_repeat_prob']}")
+    cfg.dr_action_repeat = float(dr["action_repeat_prob"])
     for name, field in (("cube_mass", cfg.dr_cube_mass), ("cube_size", cfg.dr_cube_size),
                         ("friction", cfg.dr_friction), ("motor_torque", cfg.dr_motor),
                         ("link_mass", cfg.dr_link_mass), ("restitution", cfg.dr_restitution)):

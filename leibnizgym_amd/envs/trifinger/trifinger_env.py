@@ -51,7 +51,7 @@ TRIFINGER_DEFAULT_CONFIG_DICT = {
     "domain_randomization": {
         "activate": False,
         "cube_mass": [0.7, 1.3], "cube_size": [0.9, 1.1], "friction": [0.7, 1.3], "motor_torque": [0.9, 1.1],
-        "link_mass": [0.9, 1.1], "restitution": [0.5, 1.5], "obs_noise": 0.0,
+        "link_mass": [0.9, 1.1], "restitution": [0.5, 1.5], "obs_noise": 0.0, "action_repeat_prob": 0.0,
     },
 }
 

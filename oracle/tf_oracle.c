@@ -181,7 +181,7 @@ static inline float u01(uint32_t x) { return (float)(x >> 8) * 5.960464477539062
 
 /* RNG stream tags (counter word 2) */
 enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 /* and 10 */,
-       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */ };
+       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */, RNG_ACT_REPEAT = 24 /* counter = frame count */ };
 
 static void rng4(uint64_t seed, uint32_t env_gid, uint32_t count, uint32_t tag, float u[4]) {
     uint32_t r[4];
@@ -1224,6 +1224,7 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
         h->buf.reset_buf[i] = 0;
         h->buf.steps[i] = 0;
         h->buf.successes[i] = 0;
+        for (int j = 0; j < 9; ++j) e->tau[j] = 0.0f;      /* the stored torque (what an action repeat re-applies) */
         if (c->dr_enable) {     /* build-defined domain randomisation: scale = lo + (hi - lo) u */
             float u[4];
             rng4(c->seed, gid, count, RNG_DR, u);
@@ -1267,6 +1268,21 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
         h->buf.reset_count[i] = count + 1u;
     }
     return did_reset;
+}
+
+static void compute_torque(const struct TfHandle_* h, const float* act, const float q[9], const float qd[9],
+                           float motor_scale, float tau[9]);
+/* build-defined action repeat: keep the torque of the previous step with probability dr_action_repeat */
+static void torque_with_repeat(const struct TfHandle_* h, int i, int64_t frame0, const float* act, Env* e) {
+    const TfConfig* c = &h->cfg;
+    float prev[9];
+    for (int j = 0; j < 9; ++j) prev[j] = e->tau[j];
+    compute_torque(h, act, e->q, e->qd, e->dr[3], e->tau);
+    if (c->dr_enable && c->dr_action_repeat > 0.0f) {
+        float u[4];
+        rng4(c->seed, (uint32_t)(c->env_id_offset + i), (uint32_t)frame0, RNG_ACT_REPEAT, u);
+        if (u[0] < c->dr_action_repeat) for (int j = 0; j < 9; ++j) e->tau[j] = prev[j];
+    }
 }
 
 /* trifinger_env.py:442-494 */
@@ -1544,7 +1560,8 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
                 for (int j = 0; j < A; ++j) abuf[j] = 0.0f;                  /* trifinger_env.py:387 */
                 local.resets += 1.0;
             }
-            compute_torque(h, abuf, e.q, e.qd, e.dr[3], e.tau);
+            if (is_reset) compute_torque(h, abuf, e.q, e.qd, e.dr[3], e.tau);
+            else torque_with_repeat(h, i, h->frame_count - nsim, abuf, &e);
             float prev_obj[7] = {e.cp[0], e.cp[1], e.cp[2], e.cq[0], e.cq[1], e.cq[2], e.cq[3]};
             for (int j = 0; j < 3; ++j) ST(h, TF_S_PREV_OBJ_P + j, i) = e.cp[j];   /* history[1] of the object */
             for (int j = 0; j < 4; ++j) ST(h, TF_S_PREV_OBJ_Q + j, i) = e.cq[j];
@@ -1611,7 +1628,7 @@ int tf_pre_step(tf_handle h, void* stream) {
     for (int i = 0; i < h->cfg.num_envs; ++i) {
         Env e;
         env_load(h, i, &e);
-        compute_torque(h, &h->buf.action_buf[(size_t)i * (size_t)A], e.q, e.qd, e.dr[3], e.tau);
+        torque_with_repeat(h, i, h->frame_count, &h->buf.action_buf[(size_t)i * (size_t)A], &e);
         for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
         env_store(h, i, &e, 1);
         for (int j = 0; j < 3; ++j) ST(h, TF_S_PREV_OBJ_P + j, i) = e.cp[j];

@@ -42,7 +42,8 @@ CONFIGS = {
                                     domain_randomization={"activate": True, "cube_mass": (0.5, 1.5),
                                                           "cube_size": (0.85, 1.1), "friction": (0.5, 1.4),
                                                           "motor_torque": (0.8, 1.2), "link_mass": (0.8, 1.25),
-                                                          "restitution": (0.25, 2.0), "obs_noise": 0.02},
+                                                          "restitution": (0.25, 2.0), "obs_noise": 0.02,
+                                                          "action_repeat_prob": 0.2},
                                     success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.02,
                                              "orientation_tolerance": 0.25}),
     # everything else: impedance actions (A=18), random robot reset, moving goal, difficulty 3, decimation 2

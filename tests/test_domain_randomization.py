@@ -156,3 +156,39 @@ def test_observation_noise(oracle):
         assert torch.equal(shard.obs, noisy.obs[2048:3072])
     for e in (clean, noisy, shard):
         e.close()
+
+
+def test_action_repeat(oracle):
+    """With probability p an env re-applies the torque of its previous step; the command the obs reports is unaffected;
+    a reset clears the stored torque; the draw is the same whatever the shard layout."""
+    n, p = 8192, 0.3
+    base = dict(seed=9, command_mode="torque", normalize_action=False, apply_safety_damping=False,
+                success={"activate": False}, episode_length=0)
+    mk = lambda lib_n, **kw: TrifingerEngine(make_config(oracle, lib_n, domain_randomization=dict(   # noqa: E731
+        activate=True, action_repeat_prob=p, **NEUTRAL), **base, **kw), device="cpu", lib=oracle)
+    eng, shard = mk(n), mk(1024, env_id_offset=4096, global_num_envs=n)
+    eng.reset(), shard.reset()
+    prev = eng.tau.clone()
+    assert torch.all(prev == 0)
+    fracs = []
+    for t in range(6):
+        act = torch.full((n, 9), 0.05 * (t + 1))
+        eng.step(act), shard.step(act[4096:5120])
+        tau = eng.tau
+        kept = torch.all(tau == prev, dim=0)
+        new = torch.all(tau == act.T, dim=0)
+        assert torch.all(kept | new)
+        fracs.append(float(kept.float().mean()))
+        assert torch.equal(eng.action_buf, act)            # the commanded action is what the observation reports
+        assert torch.equal(shard.tau, tau[:, 4096:5120])
+        prev = tau.clone()
+    assert all(abs(f - p) < 0.02 for f in fracs), fracs
+    eng.close(), shard.close()
+    # p = 1 and a time-out reset: the stored torque is cleared, so the env keeps applying zero
+    e1 = TrifingerEngine(make_config(oracle, 64, domain_randomization=dict(activate=True, action_repeat_prob=1.0, **NEUTRAL),
+                                     **dict(base, episode_length=3)), device="cpu", lib=oracle)
+    e1.reset()
+    for t in range(8):
+        e1.step(torch.full((64, 9), 0.1))
+        assert torch.all(e1.tau == 0)
+    e1.close()

@@ -27,11 +27,13 @@ def test_ragged_sizes(hip, oracle, n):
         pu.assert_bit_equal(a, b, f"N={n} step {t}")
 
 
-def test_split_path_equals_fused(hip):
-    """tf_apply_resets/pre_step/simulate/post_step/finish_step == tf_step on the GPU."""
+@pytest.mark.parametrize("cfg_name", ["envdefault_position", "d4_domain_randomization"])
+def test_split_path_equals_fused(hip, cfg_name):
+    """tf_apply_resets/pre_step/simulate/post_step/finish_step == tf_step on the GPU (also with every
+    domain-randomisation feature on: the frame-keyed draws must agree between the two paths)."""
     from leibnizgym_amd.engine import TrifingerEngine, make_config
     n = 777
-    kw = dict(pu.CONFIGS["envdefault_position"])
+    kw = dict(pu.CONFIGS[cfg_name])
     engs = [TrifingerEngine(make_config(hip, n, seed=5, episode_length=30, **kw), device=DEV, lib=hip)
             for _ in range(2)]
     for e in engs:
