@@ -1840,22 +1840,27 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
     }
 }
 
-// fold the per-wave partials into info[] (deterministic order): one block per statistic
-__global__ void __launch_bounds__(256) k_reduce_stats(const DevParams* __restrict__ Pp, int n_waves) {
+// fold the per-wave partials into info[] (deterministic order): one wave per statistic - every lane sums its strided
+// share in index order (the loads are independent: one memory round trip), then the DPP tree; no LDS, no barrier
+__global__ void __launch_bounds__(WAVE) k_reduce_stats(const DevParams* __restrict__ Pp, int n_waves) {
     const DevParams& P = *Pp;
-    __shared__ float red[256];
     const int t = threadIdx.x;
     const int k = blockIdx.x;
     float s = 0.0f;
-    for (int w = t; w < n_waves; w += 256) s = s + P.scratch[(size_t)w * SCR_STRIDE + k];
-    red[t] = s;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (t < off) red[t] = red[t] + red[t + off];
-        __syncthreads();
+    for (int base = 0; base < n_waves; base += 16 * WAVE) {      // 16 loads in flight per lane: one round trip per 1024 waves
+        float v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int w = base + t + WAVE * m;
+            const int wc = (w < n_waves) ? w : (n_waves - 1);
+            const float x = P.scratch[(size_t)wc * SCR_STRIDE + k];
+            v[m] = (w < n_waves) ? x : 0.0f;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) s = s + v[m];
     }
-    if (t == 0) {
-        float total = red[0];
+    const float total = wave_sum_lane63(s);
+    if (t == WAVE - 1) {
         float n = (float)P.N;
         float out;
         if (k < 6 || k == 8) out = total / n;
@@ -2334,7 +2339,7 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
 #undef LAUNCH_STEP
     LAUNCH_CHECK("k_step");
     if (timed) { HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], s)); h->ev_used += 1; }
-    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(256), 0, s, h->d_params, n_waves(h));
+    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(WAVE), 0, s, h->d_params, n_waves(h));
     LAUNCH_CHECK("k_reduce_stats");
     return TF_OK;
 }
@@ -2418,7 +2423,7 @@ int tf_post_step(tf_handle h, void* stream) {
     if (h->action_dim == 9) hipLaunchKernelGGL(k_post_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
     else hipLaunchKernelGGL(k_post_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
     LAUNCH_CHECK("k_post_step");
-    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(256), 0, (hipStream_t)stream, h->d_params, n_waves(h));
+    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(WAVE), 0, (hipStream_t)stream, h->d_params, n_waves(h));
     LAUNCH_CHECK("k_reduce_stats");
     return TF_OK;
 }
