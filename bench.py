@@ -61,11 +61,27 @@ D4_REWARDS = {                   # scripts/rlg_hydra.py:140-174
 D4_SUCCESS = {"activate": False, "bonus": 5000.0, "orientation_tolerance": 0.25, "position_tolerance": 0.02}
 
 
-def workload_kwargs(asym):
-    return dict(command_mode="torque", task_difficulty=4, asymmetric_obs=asym, normalize_action=True,
-                normalize_obs=True, apply_safety_damping=True, episode_length=750, control_decimation=1,
-                robot_reset="default", object_reset="random", reward_terms=D4_REWARDS, success=D4_SUCCESS,
-                dt=0.02, substeps=2, solver_iterations=8)
+D1_REWARDS = {                   # scripts/rlg_hydra.py:83-109
+    "finger_move_penalty": {"activate": True, "weight": -0.1},
+    "finger_reach_object_rate": {"activate": True, "norm_p": 2, "weight": -750},
+    "object_dist": {"activate": True, "weight": 2000},
+    "object_rot": {"activate": False, "weight": 300},
+    "object_rot_delta": {"activate": False, "weight": -250},
+    "object_move": {"activate": False, "weight": -750},
+}
+FULL_DR = {"activate": True, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "friction": (0.7, 1.3),
+           "motor_torque": (0.9, 1.1), "link_mass": (0.9, 1.1), "restitution": (0.5, 1.5), "obs_noise": 0.02,
+           "action_repeat_prob": 0.1}
+
+
+def workload_kwargs(asym, difficulty=4, dr=False):
+    kw = dict(command_mode="torque", task_difficulty=difficulty, asymmetric_obs=asym, normalize_action=True,
+              normalize_obs=True, apply_safety_damping=True, episode_length=750, control_decimation=1,
+              robot_reset="default", object_reset="random", reward_terms=D4_REWARDS if difficulty == 4 else D1_REWARDS,
+              success=D4_SUCCESS, dt=0.02, substeps=2, solver_iterations=8)
+    if dr:
+        kw["domain_randomization"] = FULL_DR
+    return kw
 
 
 def cpu_baseline(asym, budget_s=12.0):
@@ -131,6 +147,10 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--symmetric", action="store_true", help="asymmetric_obs=False (obs only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--difficulty", type=int, default=4, choices=(1, 4),
+                    help="secondary runs only (BASELINE configs[1]: --difficulty 1 --envs 8192); the headline is 4")
+    ap.add_argument("--dr", action="store_true",
+                    help="secondary runs only: every domain-randomisation feature on (BASELINE configs[3]: --dr --envs 16384)")
     ap.add_argument("--time-stride", type=int, default=8,
                     help="bracket every S-th k_step launch of the timed region with a HIP event pair (an event pair "
                          "costs ~3 us of stream time, so timing every launch would slow the region it measures); 0: none")
@@ -153,8 +173,10 @@ def main():
 
     asym = not args.symmetric
     n = args.envs
+    headline = args.difficulty == 4 and not args.dr
     lib = _capi.load_hip_library()
-    cfg = make_config(lib, n, seed=7, env_id_offset=rank * n, global_num_envs=world * n, **workload_kwargs(asym))
+    cfg = make_config(lib, n, seed=7, env_id_offset=rank * n, global_num_envs=world * n,
+                      **workload_kwargs(asym, args.difficulty, args.dr))
     eng = TrifingerEngine(cfg, device=dev, lib=lib)
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     ring = [(torch.rand(n, eng.action_dim, device=dev, generator=gen) * 2 - 1).contiguous() for _ in range(16)]
@@ -202,9 +224,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"trifinger_difficulty_4, {n} envs/GPU x {world} GPU, torque mode, random actions 2*U-1, "
+            "workload": f"trifinger_difficulty_{args.difficulty}{' + full domain randomisation' if args.dr else ''}, "
+                        f"{n} envs/GPU x {world} GPU, torque mode, random actions 2*U-1, "
                         f"asymmetric_obs={asym}, episode_length 750, dt 0.02, 2 substeps, 8 solver iterations, "
-                        f"control_decimation 1 (BASELINE.json configs[2])",
+                        f"control_decimation 1 (BASELINE.json configs[{2 if (args.difficulty == 4 and not args.dr) else (3 if args.dr else 1)}])",
             "envs_per_gpu": n,
             "global_envs": world * n,
             "asymmetric_obs": asym,
@@ -216,8 +239,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": PMC_TRAFFIC.get((n, asym)),
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_i_pmc.txt" if (n, asym) in PMC_TRAFFIC else None,
+            "traffic": PMC_TRAFFIC.get((n, asym)) if headline else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_i_pmc.txt" if headline and (n, asym) in PMC_TRAFFIC else None,
             "kernel": "k_step<9,false>",
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
@@ -227,7 +250,7 @@ def main():
             "note": "north star asks for the HBM fraction; what binds is instruction issue: at <= 65536 envs the chip holds "
                     "one wave per SIMD, a lone wave issues one instruction per ~5 cycles, and k_step's ~27 k instructions "
                     "per wave account for ~97 % of its measured wave cycles (issue_bound; DESIGN.md section 4)",
-            "issue_bound": PMC_ISSUE.get((n, asym)),
+            "issue_bound": PMC_ISSUE.get((n, asym)) if headline else None,
             "fp32_frac_est": (FLOP_PER_ENV_STEP * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
         },
     }
