@@ -225,7 +225,7 @@ typedef struct TfBuffers {
     int32_t* steps;          /* [N] _steps_count_buf                                                  */
     uint32_t* reset_count;   /* [N] number of RNG draws consumed (Philox counter high word)           */
     float* info;             /* [TF_NUM_INFO]                                                         */
-    float* scratch;          /* [tf_scratch_floats(N)] reduction partials                             */
+    float* scratch;          /* [tf_scratch_floats(N)] per-wave scratch (developer instrumentation)   */
 } TfBuffers;
 
 typedef struct TfHandle_* tf_handle;

@@ -79,6 +79,7 @@ struct DevParams {
     gu32* reset_count;
     gfloat* info;
     gfloat* scratch;
+    gu32* tickets;           // library-owned accumulators of the in-kernel statistics fold (STAT_* below)
     // sizes
     int32_t N, A, OD, SD;
     int32_t env_id_offset;
@@ -1460,11 +1461,72 @@ DEV float wave_sum_lane63(float x) {
 }
 
 
+// Episode statistics without a second launch (a separate 11-wave reduction kernel cost 4.5 us per step, mostly fixed
+// launch and cold-miss latency).  Lane k < 11 of every wave adds the wave's sum of statistic k to a 64-bit accumulator with
+// ONE device-scope integer atomic: the sum as signed fixed point (2^-18) in the upper 47 bits, an arrival count in the
+// lower 17.  Integer addition commutes, so the result does not depend on the arrival order (deterministic, unlike float
+// atomics), and the returned old value tells each lane whether it was the last to arrive: that lane carries the total to
+// the next level (16 shards -> 1, so that a thousand waves finishing together do not queue on one word) and finally
+// writes info[].  The atomic is issued as soon as the rewards are known and its return is consumed at the very end of
+// the kernel, behind the observation tiles: its latency is off the critical path of every wave but the last.
+#define STAT_SHARDS 16
+#define STAT_STRIDE 8                            /* uint64 per accumulator: 64 B apart */
+#define STAT_WORDS ((STAT_SHARDS * 11 + 11) * STAT_STRIDE)
+#define STAT_COUNT_BITS 17
+#define STAT_FIX 262144.0                        /* 2^18 */
+typedef GLOBAL_AS unsigned long long gu64;
+struct StatsTicket { unsigned long long mine, old; };
+DEV void stats_begin(const DevParams& P, const LaneStats& st, int lane, StatsTicket& tk) {
+    float vals[11];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) vals[t] = st.rew[t];
+    vals[6] = st.pos_cnt; vals[7] = st.ori_cnt; vals[8] = st.succ; vals[9] = st.resets; vals[10] = st.nonfinite;
+    float sum = 0.0f;                            // lane k < 11 ends up holding the wave's sum of statistic k
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float s = wave_sum_lane63(vals[k]);
+        const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), WAVE - 1));
+        sum = (lane == k) ? b : sum;
+    }
+    const long long fx = (long long)((double)sum * STAT_FIX);
+    tk.mine = ((unsigned long long)fx << STAT_COUNT_BITS) + 1ull;
+    tk.old = 0ull;
+    const int shard = (int)blockIdx.x & (STAT_SHARDS - 1);
+    gu64* acc = (gu64*)P.tickets;
+    if (lane < 11)
+        tk.old = __hip_atomic_fetch_add(&acc[(shard * 11 + lane) * STAT_STRIDE], tk.mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV void stats_end(const DevParams& P, int lane, const StatsTicket& tk) {
+    const unsigned long long cmask = (1ull << STAT_COUNT_BITS) - 1ull;
+    const int nw = (int)gridDim.x;
+    const int shard = (int)blockIdx.x & (STAT_SHARDS - 1);
+    const unsigned long long members = (unsigned long long)((nw - shard + STAT_SHARDS - 1) / STAT_SHARDS);
+    const unsigned long long nshards = (unsigned long long)(nw < STAT_SHARDS ? nw : STAT_SHARDS);
+    gu64* acc = (gu64*)P.tickets;
+    if (lane < 11 && (tk.old & cmask) == members - 1ull) {          // last wave of this shard for statistic `lane`
+        const unsigned long long total1 = tk.old + tk.mine;          // count field == members, sum field == shard sum
+        __hip_atomic_store(&acc[(shard * 11 + lane) * STAT_STRIDE], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long v2 = (total1 & ~cmask) + 1ull;
+        gu64* top = &acc[(STAT_SHARDS * 11 + lane) * STAT_STRIDE];
+        const unsigned long long old2 = __hip_atomic_fetch_add(top, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old2 & cmask) == nshards - 1ull) {                     // last shard: the grand total is complete
+            __hip_atomic_store(top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long fxs = (long long)(old2 + v2) >> STAT_COUNT_BITS;
+            const float total = (float)((double)fxs / STAT_FIX);
+            const int k = lane;
+            const float o = (k < 6 || k == 8) ? total / (float)P.N : total;
+            const int slot = (k < 6) ? k : ((k == 6) ? TF_INFO_POS_COUNT : ((k == 7) ? TF_INFO_ORI_COUNT :
+                             ((k == 8) ? TF_INFO_SUCCESS_MEAN : ((k == 9) ? TF_INFO_NUM_RESETS : TF_INFO_NUM_NONFINITE))));
+            P.info[slot] = o;
+        }
+    }
+}
+
 // trifinger_env.py:500-559 + 959-1099 for the env of this lane.  prev_obj = history[1] pose (7).
 template <int A>
 DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame, int i, bool valid, int wave_first, int n_valid, Env& e,
                        const float* act, const float prev_obj[7], bool with_reward, float* lds, int lane, LaneStats& st,
-                       Carried& cy) {
+                       Carried& cy, StatsTicket& tk) {
     const TfModel& m = P.m;
     constexpr int OD = TF_OBS_DIM_BASE + A;
     constexpr int SD = OD + TF_STATES_EXTRA;
@@ -1504,6 +1566,73 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
             st.nonfinite += valid ? 1.0f : 0.0f;
         }
     }
+    PHASE_STAMP();
+    // ---- history: previous fingertip positions are whatever the last filled frame left ----
+    const float* tip_prev = cy.tip_prev;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { STST(TF_S_TIP_P + j, tips0[j]); STST(TF_S_TIP_P + 3 + j, tips1[j]); STST(TF_S_TIP_P + 6 + j, tips2[j]); }
+    }
+    // Rewards, termination and the episode statistics come BEFORE the observation tiles: the statistics atomic is in
+    // flight while the tiles are emitted and stored (stats_end at the end of the kernel consumes its return).
+    if (with_reward) {
+        // ---- rewards (reference rewards.py; order of trifinger_env.py:513-550) ----
+        float r[6];
+        {
+            float s = 0.0f;
+            s = s + (norm3d(tips0, e.cp) - norm3d(&tip_prev[0], prev_obj));
+            s = s + (norm3d(tips1, e.cp) - norm3d(&tip_prev[3], prev_obj));
+            s = s + (norm3d(tips2, e.cp) - norm3d(&tip_prev[6], prev_obj));
+            r[0] = rc.c_reach * s;
+        }
+        {
+            float s = 0.0f;
+    #pragma unroll
+            for (int j = 0; j < 3; ++j) { float vel = (tips0[j] - tip_prev[j]) / rc.dt; s = s + vel * vel; }
+    #pragma unroll
+            for (int j = 0; j < 3; ++j) { float vel = (tips1[j] - tip_prev[3 + j]) / rc.dt; s = s + vel * vel; }
+    #pragma unroll
+            for (int j = 0; j < 3; ++j) { float vel = (tips2[j] - tip_prev[6 + j]) / rc.dt; s = s + vel * vel; }
+            r[1] = rc.c_move_pen * s;
+        }
+        float dist = norm3d(e.cp, e.gp);
+        r[2] = rc.c_dist * lgsk(dist, 50.0f);
+        float ang = quat_diff_rad(e.cq, e.gq);
+        r[3] = rc.w_rot * (rc.rot_num / (rc.rot_scale * f_abs(ang) + rc.rot_scale));
+        float ang_prev = quat_diff_rad(&prev_obj[3], e.gq);
+        r[4] = rc.w_rot_delta * (rc.rot_delta_sched * (f_abs(ang) - f_abs(ang_prev)));
+        r[5] = rc.w_move * (dist - norm3d(prev_obj, e.gp));
+        float total = 0.0f;
+    #pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (P.rew_active[t]) { total = total + r[t]; st.rew[t] += valid ? r[t] : 0.0f; }
+        }
+        // ---- termination (trifinger_env.py:1053-1099) ----
+        bool pos_ok = dist <= P.pos_tol;
+        bool ori_ok = ang <= P.ori_tol;
+        st.pos_cnt += (valid && pos_ok) ? 1.0f : 0.0f;
+        st.ori_cnt += (valid && ori_ok) ? 1.0f : 0.0f;
+        bool done;
+        if (P.task_difficulty < 4) done = pos_ok;
+        else if (P.task_difficulty == 4) done = pos_ok && ori_ok;
+        else done = ori_ok;
+        bool succ = cy.successes;
+        if (P.success_activate) {
+            if (done) total = total + P.success_bonus;
+            if (valid) P.goal_reset_buf[(unsigned)i] = (uint8_t)done;
+            cy.goal_reset = done;
+            succ = succ || done;
+        } else {
+            succ = cy.goal_reset && succ;
+        }
+        cy.successes = succ;
+        if (valid) {
+            P.successes[(unsigned)i] = (uint8_t)succ;
+            P.reward[(unsigned)i] = total;
+        }
+        st.succ += (valid && succ) ? 1.0f : 0.0f;
+    }
+    stats_begin(P, st, lane, tk);
     PHASE_STAMP();
     // ---- observations: stage [lane][OD] in LDS, then one coalesced tile store ----
     const float* off = P.tables + TAB_OFF;
@@ -1594,68 +1723,6 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
 #undef TLO
 #undef THI
     PHASE_STAMP();
-    // ---- history: previous fingertip positions are whatever the last filled frame left ----
-    const float* tip_prev = cy.tip_prev;
-    if (valid) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { STST(TF_S_TIP_P + j, tips0[j]); STST(TF_S_TIP_P + 3 + j, tips1[j]); STST(TF_S_TIP_P + 6 + j, tips2[j]); }
-    }
-    if (!with_reward) return;
-    // ---- rewards (reference rewards.py; order of trifinger_env.py:513-550) ----
-    float r[6];
-    {
-        float s = 0.0f;
-        s = s + (norm3d(tips0, e.cp) - norm3d(&tip_prev[0], prev_obj));
-        s = s + (norm3d(tips1, e.cp) - norm3d(&tip_prev[3], prev_obj));
-        s = s + (norm3d(tips2, e.cp) - norm3d(&tip_prev[6], prev_obj));
-        r[0] = rc.c_reach * s;
-    }
-    {
-        float s = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { float vel = (tips0[j] - tip_prev[j]) / rc.dt; s = s + vel * vel; }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { float vel = (tips1[j] - tip_prev[3 + j]) / rc.dt; s = s + vel * vel; }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { float vel = (tips2[j] - tip_prev[6 + j]) / rc.dt; s = s + vel * vel; }
-        r[1] = rc.c_move_pen * s;
-    }
-    float dist = norm3d(e.cp, e.gp);
-    r[2] = rc.c_dist * lgsk(dist, 50.0f);
-    float ang = quat_diff_rad(e.cq, e.gq);
-    r[3] = rc.w_rot * (rc.rot_num / (rc.rot_scale * f_abs(ang) + rc.rot_scale));
-    float ang_prev = quat_diff_rad(&prev_obj[3], e.gq);
-    r[4] = rc.w_rot_delta * (rc.rot_delta_sched * (f_abs(ang) - f_abs(ang_prev)));
-    r[5] = rc.w_move * (dist - norm3d(prev_obj, e.gp));
-    float total = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        if (P.rew_active[t]) { total = total + r[t]; st.rew[t] += valid ? r[t] : 0.0f; }
-    }
-    // ---- termination (trifinger_env.py:1053-1099) ----
-    bool pos_ok = dist <= P.pos_tol;
-    bool ori_ok = ang <= P.ori_tol;
-    st.pos_cnt += (valid && pos_ok) ? 1.0f : 0.0f;
-    st.ori_cnt += (valid && ori_ok) ? 1.0f : 0.0f;
-    bool done;
-    if (P.task_difficulty < 4) done = pos_ok;
-    else if (P.task_difficulty == 4) done = pos_ok && ori_ok;
-    else done = ori_ok;
-    bool succ = cy.successes;
-    if (P.success_activate) {
-        if (done) total = total + P.success_bonus;
-        if (valid) P.goal_reset_buf[(unsigned)i] = (uint8_t)done;
-        cy.goal_reset = done;
-        succ = succ || done;
-    } else {
-        succ = cy.goal_reset && succ;
-    }
-    cy.successes = succ;
-    if (valid) {
-        P.successes[(unsigned)i] = (uint8_t)succ;
-        P.reward[(unsigned)i] = total;
-    }
-    st.succ += (valid && succ) ? 1.0f : 0.0f;
 }
 
 DEV void finish_env(const DevParams& P, int i, bool valid, const Carried& cy) {     // env_base.py:391-399
@@ -1680,19 +1747,6 @@ DEV void stats_zero(LaneStats& st) {
     for (int t = 0; t < 6; ++t) st.rew[t] = 0.0f;
     st.pos_cnt = 0.0f; st.ori_cnt = 0.0f; st.succ = 0.0f; st.resets = 0.0f; st.nonfinite = 0.0f;
 }
-DEV void stats_publish(const DevParams& P, const LaneStats& st, int lane) {
-    gfloat* out = P.scratch + (size_t)blockIdx.x * SCR_STRIDE;
-    float vals[11];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) vals[t] = st.rew[t];
-    vals[6] = st.pos_cnt; vals[7] = st.ori_cnt; vals[8] = st.succ; vals[9] = st.resets; vals[10] = st.nonfinite;
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        float s = wave_sum_lane63(vals[k]);
-        if (lane == WAVE - 1) out[k] = s;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------
 // kernels.  One 64-lane wave per workgroup, one env per lane.  __launch_bounds__(64, 1): 1 wave/SIMD is
 // all the chip ever holds at <= 65536 envs, so let the allocator use the whole VGPR file.
@@ -1829,45 +1883,15 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
         stats_zero(st);
         st.resets = n_resets;
         goal_advance(P, e, nsub, P.hsub);
-        post_step_env<A>(P, sa.rc, sa.frame, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st, cy);
+        StatsTicket tk;
+        post_step_env<A>(P, sa.rc, sa.frame, i, valid, wave_first, n_valid, e, act, prev_obj, !IS_RESET, lds, lane, st, cy, tk);
         PHASE_STAMP();
         store_dyn(P, i, e, valid);
         if (P.goal_rotation_activate) store_goal(P, i, e, valid);
         if (!IS_RESET) finish_env(P, i, valid, cy);
         PHASE_STAMP();
-        stats_publish(P, st, lane);
+        stats_end(P, lane, tk);
         PHASE_STAMP();
-    }
-}
-
-// fold the per-wave partials into info[] (deterministic order): one wave per statistic - every lane sums its strided
-// share in index order (the loads are independent: one memory round trip), then the DPP tree; no LDS, no barrier
-__global__ void __launch_bounds__(WAVE) k_reduce_stats(const DevParams* __restrict__ Pp, int n_waves) {
-    const DevParams& P = *Pp;
-    const int t = threadIdx.x;
-    const int k = blockIdx.x;
-    float s = 0.0f;
-    for (int base = 0; base < n_waves; base += 16 * WAVE) {      // 16 loads in flight per lane: one round trip per 1024 waves
-        float v[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int w = base + t + WAVE * m;
-            const int wc = (w < n_waves) ? w : (n_waves - 1);
-            const float x = P.scratch[(size_t)wc * SCR_STRIDE + k];
-            v[m] = (w < n_waves) ? x : 0.0f;
-        }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) s = s + v[m];
-    }
-    const float total = wave_sum_lane63(s);
-    if (t == WAVE - 1) {
-        float n = (float)P.N;
-        float out;
-        if (k < 6 || k == 8) out = total / n;
-        else out = total;
-        const int slot = (k < 6) ? k : ((k == 6) ? TF_INFO_POS_COUNT : ((k == 7) ? TF_INFO_ORI_COUNT :
-                         ((k == 8) ? TF_INFO_SUCCESS_MEAN : ((k == 9) ? TF_INFO_NUM_RESETS : TF_INFO_NUM_NONFINITE))));
-        P.info[slot] = out;
     }
 }
 
@@ -1949,10 +1973,11 @@ __global__ void __launch_bounds__(WAVE, 1) k_post_step(const DevParams* __restri
     load_prev_obj(P, i, prev_obj);
     Carried cy;
     load_carried(P, i, cy);
-    post_step_env<A>(P, sa.rc, sa.frame, i, valid, wave_first, n_valid, e, act, prev_obj, true, lds, lane, st, cy);
+    StatsTicket tk;
+    post_step_env<A>(P, sa.rc, sa.frame, i, valid, wave_first, n_valid, e, act, prev_obj, true, lds, lane, st, cy, tk);
     store_dyn(P, i, e, valid);
     store_ft(P, i, e, valid);
-    stats_publish(P, st, lane);
+    stats_end(P, lane, tk);
 }
 
 __global__ void __launch_bounds__(WAVE, 1) k_finish(const DevParams* __restrict__ Pp) {
@@ -2229,8 +2254,14 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     P.dt = cfg->dt; P.hsub = cfg->dt / (float)cfg->substeps;
     for (int i = 0; i < 3; ++i) P.grav[i] = cfg->gravity[i];
     P.m = cfg->model;
+    void* tk = nullptr;
+    e = hipMalloc(&tk, STAT_WORDS * sizeof(unsigned long long));
+    if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(tickets)"); }
+    P.tickets = (gu32*)tk;
+    e = hipMemset(tk, 0, STAT_WORDS * sizeof(unsigned long long));
+    if (e != hipSuccess) { (void)hipFree((void*)P.tickets); delete h; return hip_fail(e, "hipMemset(tickets)"); }
     e = hipMalloc((void**)&h->d_params, sizeof(DevParams));
-    if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(params)"); }
+    if (e != hipSuccess) { (void)hipFree((void*)P.tickets); delete h; return hip_fail(e, "hipMalloc(params)"); }
     e = hipMemcpy(h->d_params, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(h->d_params); delete h; return hip_fail(e, "hipMemcpy(params)"); }
     *out = h;
@@ -2240,6 +2271,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
 int tf_destroy(tf_handle h) {
     if (!h) return TF_OK;
     if (h->d_params) (void)hipFree(h->d_params);
+    if (h->dp.tickets) (void)hipFree((void*)h->dp.tickets);
     free_events(h);
     delete h;
     return TF_OK;
@@ -2339,8 +2371,6 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
 #undef LAUNCH_STEP
     LAUNCH_CHECK("k_step");
     if (timed) { HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], s)); h->ev_used += 1; }
-    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(WAVE), 0, s, h->d_params, n_waves(h));
-    LAUNCH_CHECK("k_reduce_stats");
     return TF_OK;
 }
 
@@ -2423,8 +2453,6 @@ int tf_post_step(tf_handle h, void* stream) {
     if (h->action_dim == 9) hipLaunchKernelGGL(k_post_step<9>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
     else hipLaunchKernelGGL(k_post_step<18>, grid, block, 0, (hipStream_t)stream, h->d_params, h->sa);
     LAUNCH_CHECK("k_post_step");
-    hipLaunchKernelGGL(k_reduce_stats, dim3(11), dim3(WAVE), 0, (hipStream_t)stream, h->d_params, n_waves(h));
-    LAUNCH_CHECK("k_reduce_stats");
     return TF_OK;
 }
 int tf_finish_step(tf_handle h, void* stream) {

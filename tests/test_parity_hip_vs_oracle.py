@@ -69,6 +69,10 @@ def test_full_size_properties(hip):
     for t in range(60):
         eng.step(torch.rand(n, 9, device=DEV, generator=g) * 2 - 1)
         total_resets += float(eng.info[capi.INFO_NUM_RESETS])
+        # the in-kernel fold of the 1024 per-wave partials: the four active reward means add up to the mean reward
+        active = [k for k, name in enumerate(capi.REWARD_TERM_ORDER) if pu.D4_REWARDS[name]["activate"]]
+        folded = float(sum(eng.info[k] for k in active))
+        assert abs(folded - float(eng.reward.double().mean())) < 2e-4 * max(1.0, abs(folded)), (t, folded)
     torch.cuda.synchronize()
     st = eng.state
     assert torch.isfinite(st).all() and torch.isfinite(eng.obs).all() and torch.isfinite(eng.states).all()

@@ -12,8 +12,8 @@ SUB = ["free motion (FK, dynamics, M^-1)", "finger contacts + rows", "cube-floor
        "limit rows", "PGS sweeps", "wrench + integrate"]
 LABELS = (["issue all loads", "wait for loads, action via LDS", "apply_resets", "action_buf store, torque, park"]
           + [f"sub0: {x}" for x in SUB] + [f"sub1: {x}" for x in SUB]
-          + ["(stamp 2)", "unpark, tip FK, NaN guard", "obs emit + store", "states emit + store",
-             "tip history, rewards, termination", "state stores, finish", "stats butterflies"])
+          + ["(stamp 2)", "unpark, tip FK, NaN guard", "tip history, rewards, termination, statistics atomic",
+             "obs emit + store", "states emit + store", "(stamp)", "state stores, finish", "statistics ticket check / fold"])
 
 lib = _capi.TfLib(os.path.join(REPO, "leibnizgym_amd", "csrc", "libtrifinger_hip_timing.so"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
