@@ -2356,6 +2356,9 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     h->sa.frame0 = (uint32_t)(h->frame_count - nsim);
     reward_coefs(h);
     dim3 grid(n_waves(h)), block(WAVE);
+    // a full reset also re-arms the statistics accumulators (they are left at zero by every completed launch; this only
+    // matters after a launch that did not complete)
+    if (is_reset) HIP_TRY(hipMemsetAsync((void*)h->dp.tickets, 0, STAT_WORDS * sizeof(unsigned long long), s));
     bool timed = !is_reset && h->ev && h->ev_used < h->ev_cap;
     if (timed) { timed = (h->ev_phase == 0); h->ev_phase = (h->ev_phase + 1) % h->ev_stride; }
     if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], s));
