@@ -209,6 +209,14 @@ DEV float f_rcp(float x) {
     r = FMA(r, FMA(-x, r, 1.0f), r);
     return r;
 }
+// Two Newton steps (relative error ~2.4e-4) for the 1/D of a contact row: 1/D only scales the Gauss-Seidel update of that
+// row, its fixed point (the complementarity solution) does not depend on it.
+DEV float f_rcp2(float x) {
+    float r = __uint_as_float(0x7EF311C7u - __float_as_uint(x));
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    r = FMA(r, FMA(-x, r, 1.0f), r);
+    return r;
+}
 DEV float f_rsqrt(float x) {
     float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
     const float h = 0.5f * x;
@@ -627,7 +635,7 @@ DEV void finger_rows(const TfModel& m, const FK& k, const float Pb[3], const flo
             D = FMA(dot3(rxd, rxd), inv_I, D + inv_m);
             c.dir[3 * d] = dw[0]; c.dir[3 * d + 1] = dw[1]; c.dir[3 * d + 2] = dw[2];
         }
-        c.Dinv[d] = f_rcp(D);
+        c.Dinv[d] = f_rcp2(D);
     }
     if (WITH_CUBE) { c.rc[0] = rc[0]; c.rc[1] = rc[1]; c.rc[2] = rc[2]; }
 }
@@ -958,9 +966,9 @@ DEV void substep(const DevParams& P, Env& e, float h) {
             float gap = e.cp[2] + c.r[2];
             if (__builtin_expect(gap < m.contact_margin, 1)) {
                 const float* r = c.r;
-                c.Dinv[0] = f_rcp(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
-                c.Dinv[1] = f_rcp(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
-                c.Dinv[2] = f_rcp(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
+                c.Dinv[0] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                c.Dinv[1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
+                c.Dinv[2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
                 float vn0 = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
                 c.bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
@@ -999,9 +1007,9 @@ DEV void substep(const DevParams& P, Env& e, float h) {
                 float a[3], b[3];
                 wall_arm_n(c, a);
                 wall_arm_t(c, b);
-                c.Dinv[0] = f_rcp(FMA(dot3(a, a), inv_I, inv_m));
-                c.Dinv[1] = f_rcp(FMA(dot3(b, b), inv_I, inv_m));
-                c.Dinv[2] = f_rcp(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                c.Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
+                c.Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
+                c.Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                 float vn0 = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c.n[1], v[1], c.n[0] * v[0]))));
                 c.bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
             }
