@@ -15,6 +15,8 @@
  *   tf_create / tf_destroy      gymapi.acquire_gym, create_sim, prepare_sim, destroy_sim
  *                               leibnizgym/envs/env_base.py:151,593,598,438
  *   tf_set_gravity              gymapi set_sim_params          env_base.py:175-193
+ *   tf_set_clipping             VecTaskPython.step / get_state clamps (fused into the step)
+ *                               leibnizgym/wrappers/vec_task.py:146-170
  *   tf_bind                     acquire_*_tensor + gymtorch.wrap_tensor (ownership inverted: the caller
  *                               allocates, the library receives pointers)
  *                               leibnizgym/envs/trifinger/trifinger_env.py:594-617
@@ -241,6 +243,11 @@ int tf_create(const TfConfig* cfg, tf_handle* out);
 int tf_destroy(tf_handle h);
 int tf_bind(tf_handle h, const TfBuffers* bufs);
 int tf_set_gravity(tf_handle h, const float g[3]);
+/* Fuse the wrapper's clipping (vec_task.py:146-170) into the step: incoming actions are limited to +-clip_actions
+ * before anything else sees them (`_action_buf` then holds the limited action, as it does in the reference, where the
+ * task receives the clamped tensor), every emitted obs / states value to +-clip_obs (after scaling and after the
+ * observation noise).  A bound <= 0 switches that clamp off (the default).  Cold path (blocking parameter copy). */
+int tf_set_clipping(tf_handle h, float clip_obs, float clip_actions);
 int64_t tf_frame_count(tf_handle h);
 int tf_set_frame_count(tf_handle h, int64_t frames);
 

@@ -119,6 +119,7 @@ SYMBOLS = {
     "tf_destroy": (C.c_int, [_P]),
     "tf_bind": (C.c_int, [_P, C.POINTER(TfBuffers)]),
     "tf_set_gravity": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "tf_set_clipping": (C.c_int, [_P, C.c_float, C.c_float]),
     "tf_frame_count": (C.c_int64, [_P]),
     "tf_set_frame_count": (C.c_int, [_P, C.c_int64]),
     "tf_step": (C.c_int, [_P, _P, _P]),

@@ -93,6 +93,7 @@ struct DevParams {
     float dr_cube_mass[2], dr_cube_size[2], dr_friction[2], dr_motor[2], dr_link_mass[2], dr_restitution[2];
     float dr_obs_noise;      // half-width of the observation noise; 0 when off (or when dr_enable is 0)
     float dr_action_repeat;  // probability of re-applying the previous step's torque; 0 when off
+    float clip_obs, clip_act; // fused wrapper clipping (tf_set_clipping); FLT_MAX when off
     int32_t rew_active[6];
     int32_t success_activate;
     float success_bonus, pos_tol, ori_tol;
@@ -1645,10 +1646,11 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
     // ---- observations: stage [lane][OD] in LDS, then one coalesced tile store ----
     const float* off = P.tables + TAB_OFF;
     const float* inv = P.tables + TAB_INV;
+    const float co = P.clip_obs;        // fused wrapper clipping of every emitted value (FLT_MAX when off)
 #define EMIT(W, col, val)                                                               \
     {                                                                                   \
         float x_ = (val);                                                               \
-        lds[lane * (W) + (col)] = nrm ? FMA(x_, 2.0f * inv[col], -(2.0f * off[col]) * inv[col]) : x_; \
+        lds[lane * (W) + (col)] = f_clamp(nrm ? FMA(x_, 2.0f * inv[col], -(2.0f * off[col]) * inv[col]) : x_, -co, co); \
     }
     // Every slot but the action one has limits that are constants of the MDP (reference trifinger_env.py:153-213):
     // with the loops unrolled, offset and 1/range fold into instruction literals - same fp32 values as the host-built
@@ -1658,7 +1660,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
     {                                                                                   \
         float x_ = (val);                                                               \
         const float o_ = ((lo_) + (hi_)) * 0.5f, i_ = 1.0f / ((hi_) - (lo_));           \
-        lds[lane * (W) + (col)] = nrm ? FMA(x_, 2.0f * i_, -(2.0f * o_) * i_) : x_;     \
+        lds[lane * (W) + (col)] = f_clamp(nrm ? FMA(x_, 2.0f * i_, -(2.0f * o_) * i_) : x_, -co, co); \
     }
 #define QLO(j) (((j) % 3 == 0) ? -0.33f : (((j) % 3 == 1) ? 0.0f : -2.7f))
 #define QHI(j) (((j) % 3 == 0) ? 1.0f : (((j) % 3 == 1) ? 1.57f : 0.0f))
@@ -1685,7 +1687,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
 #pragma unroll
         for (int b = 0; b < 7; ++b) rng4(P, gid, frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
 #pragma unroll
-        for (int j = 0; j < 25; ++j) lds[lane * OD + j] = FMA(P.dr_obs_noise, 2.0f * nz[j] - 1.0f, lds[lane * OD + j]);
+        for (int j = 0; j < 25; ++j) lds[lane * OD + j] = f_clamp(FMA(P.dr_obs_noise, 2.0f * nz[j] - 1.0f, lds[lane * OD + j]), -co, co);
     }
     WAVE_LDS_ORDER();
     store_tile<OD>(P.obs, lds, wave_first, n_valid, lane);
@@ -1812,7 +1814,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_step(const DevParams* __restrict__ 
             WAVE_LDS_ORDER();
             const int row = valid ? lane : (n_valid - 1);
 #pragma unroll
-            for (int j = 0; j < A; ++j) act[j] = lds[row * A + j];
+            for (int j = 0; j < A; ++j) act[j] = f_clamp(lds[row * A + j], -P.clip_act, P.clip_act);
             WAVE_LDS_ORDER();
         } else {
 #pragma unroll
@@ -1919,7 +1921,7 @@ __global__ void __launch_bounds__(WAVE, 1) k_apply_resets(const DevParams* __res
     float act[A];
     const int row = valid ? i : (P.N - 1);
 #pragma unroll
-    for (int j = 0; j < A; ++j) act[j] = did ? 0.0f : P.action_buf[(size_t)row * A + j];
+    for (int j = 0; j < A; ++j) act[j] = did ? 0.0f : f_clamp(P.action_buf[(size_t)row * A + j], -P.clip_act, P.clip_act);
 #pragma unroll
     for (int j = 0; j < A; ++j) lds[lane * A + j] = act[j];
     WAVE_LDS_ORDER();
@@ -2254,6 +2256,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     }
     P.dr_obs_noise = (cfg->dr_enable && cfg->dr_obs_noise > 0.0f) ? cfg->dr_obs_noise : 0.0f;
     P.dr_action_repeat = (cfg->dr_enable && cfg->dr_action_repeat > 0.0f) ? cfg->dr_action_repeat : 0.0f;
+    P.clip_obs = 3.402823466e38f; P.clip_act = 3.402823466e38f;
     P.dof_pos_stddev = cfg->dof_pos_stddev; P.dof_vel_stddev = cfg->dof_vel_stddev; P.goal_rate = cfg->goal_rotation_rate_magnitude;
     for (int t = 0; t < 6; ++t) P.rew_active[t] = cfg->reward[t].activate;
     P.success_activate = cfg->success_activate; P.success_bonus = cfg->success_bonus;
@@ -2302,6 +2305,13 @@ int tf_bind(tf_handle h, const TfBuffers* b) {
     return TF_OK;
 }
 
+int tf_set_clipping(tf_handle h, float clip_obs, float clip_actions) {
+    if (!h) return TF_ERR_INVALID_ARG;
+    h->dp.clip_obs = (clip_obs > 0.0f) ? clip_obs : 3.402823466e38f;
+    h->dp.clip_act = (clip_actions > 0.0f) ? clip_actions : 3.402823466e38f;
+    HIP_TRY(hipMemcpy(h->d_params, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice));
+    return TF_OK;
+}
 int tf_set_gravity(tf_handle h, const float g[3]) {
     if (!h || !g) return TF_ERR_INVALID_ARG;
     for (int i = 0; i < 3; ++i) { h->cfg.gravity[i] = g[i]; h->dp.grav[i] = g[i]; }

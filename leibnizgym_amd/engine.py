@@ -247,6 +247,10 @@ class TrifingerEngine:
     def frame_count(self, v):
         check(self.lib, self.lib.tf_set_frame_count(self._handle, int(v)), "tf_set_frame_count")
 
+    def set_clipping(self, clip_obs, clip_actions):
+        """Fuse the wrapper's clamps into the step (<= 0 switches a clamp off)."""
+        check(self.lib, self.lib.tf_set_clipping(self._handle, float(clip_obs), float(clip_actions)), "tf_set_clipping")
+
     def set_gravity(self, g):
         arr = (C.c_float * 3)(*[float(x) for x in g])
         check(self.lib, self.lib.tf_set_gravity(self._handle, arr), "tf_set_gravity")

@@ -228,6 +228,15 @@ class IsaacEnvBase:
         self._step_info = dict(self._info_items)
         return eng.obs, eng.reward, eng.dones, self._step_info
 
+    def fuse_clipping(self, clip_obs: float, clip_actions: float) -> bool:
+        """Let the native step do the wrapper's clamps (leibnizgym/wrappers/vec_task.py:146-170): actions are limited to
+        +-clip_actions as they are read, every emitted obs / states value to +-clip_obs.  Returns True when the engine
+        took them over; `VecTaskPython` then passes tensors through untouched.  Side effect to know about: `obs_buf` /
+        `states_buf` then hold the clipped values (the reference keeps the unclipped ones inside the task and clips a
+        copy) - they differ only beyond +-clip_obs, five times the nominal range of a scaled observation."""
+        self._engine.set_clipping(clip_obs, clip_actions)
+        return True
+
     def render(self):
         if self.visualize:
             print_warn("render(): the HIP environment is headless; no viewer is available.")

@@ -269,6 +269,7 @@ struct TfHandle_ {
     TfBuffers buf;
     int bound;
     int64_t frame_count;
+    float clip_obs, clip_act;           /* fused wrapper clipping; FLT_MAX when off */
     int action_dim, obs_dim, states_dim;
     float act_lo[18], act_hi[18];
     float obs_off[MAX_OBS], obs_inv[MAX_OBS];
@@ -430,6 +431,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
     struct TfHandle_* h = (struct TfHandle_*)calloc(1, sizeof(*h));
+    if (h) { h->clip_obs = 3.402823466e38f; h->clip_act = 3.402823466e38f; }
     if (!h) return TF_ERR_INVALID_ARG;
     h->cfg = *cfg;
     if (h->cfg.global_num_envs <= 0) h->cfg.global_num_envs = cfg->num_envs;
@@ -452,6 +454,12 @@ int tf_bind(tf_handle h, const TfBuffers* b) {
     return TF_OK;
 }
 
+int tf_set_clipping(tf_handle h, float clip_obs, float clip_actions) {
+    if (!h) return TF_ERR_INVALID_ARG;
+    h->clip_obs = (clip_obs > 0.0f) ? clip_obs : 3.402823466e38f;
+    h->clip_act = (clip_actions > 0.0f) ? clip_actions : 3.402823466e38f;
+    return TF_OK;
+}
 int tf_set_gravity(tf_handle h, const float g[3]) {
     if (!h || !g) return TF_ERR_INVALID_ARG;
     for (int i = 0; i < 3; ++i) h->cfg.gravity[i] = g[i];
@@ -1430,12 +1438,13 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
     const float* act = &h->buf.action_buf[(size_t)i * (size_t)A];
     for (int j = 0; j < A; ++j) raw[k++] = act[j];
     float* obs = &h->buf.obs[(size_t)i * (size_t)OD];
-    for (int j = 0; j < OD; ++j) obs[j] = c->normalize_obs ? scale_slot(raw[j], h->obs_off[j], h->obs_inv[j]) : raw[j];
+    /* every emitted value passes the fused wrapper clipping (a no-op when off) */
+    for (int j = 0; j < OD; ++j) obs[j] = f_clamp(c->normalize_obs ? scale_slot(raw[j], h->obs_off[j], h->obs_inv[j]) : raw[j], -h->clip_obs, h->clip_obs);
     if (c->dr_enable && c->dr_obs_noise > 0.0f) {      /* observation noise on q, qd, object pose (slots 0..24) */
         uint32_t gid = (uint32_t)(c->env_id_offset + i);
         float nz[28];
         for (int b = 0; b < 7; ++b) rng4(c->seed, gid, (uint32_t)h->frame_count, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
-        for (int j = 0; j < 25; ++j) obs[j] = FMA(c->dr_obs_noise, 2.0f * nz[j] - 1.0f, obs[j]);
+        for (int j = 0; j < 25; ++j) obs[j] = f_clamp(FMA(c->dr_obs_noise, 2.0f * nz[j] - 1.0f, obs[j]), -h->clip_obs, h->clip_obs);
     }
     if (c->asymmetric_obs) {
         for (int j = 0; j < 3; ++j) raw[k++] = e->cv[j];
@@ -1459,7 +1468,7 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
             }
         }
         float* sts = &h->buf.states[(size_t)i * (size_t)SD];
-        for (int j = 0; j < SD; ++j) sts[j] = c->normalize_obs ? scale_slot(raw[j], h->st_off[j], h->st_inv[j]) : raw[j];
+        for (int j = 0; j < SD; ++j) sts[j] = f_clamp(c->normalize_obs ? scale_slot(raw[j], h->st_off[j], h->st_inv[j]) : raw[j], -h->clip_obs, h->clip_obs);
     }
     /* history bookkeeping: previous fingertip positions are whatever the last filled frame left */
     float tip_prev[9];
@@ -1563,7 +1572,7 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
             env_load(h, i, &e);
             float* abuf = &h->buf.action_buf[(size_t)i * (size_t)A];
             if (is_reset) { for (int j = 0; j < A; ++j) abuf[j] = 0.0f; }   /* env_base.py:332-334 acts on the buffer */
-            else { for (int j = 0; j < A; ++j) abuf[j] = action[(size_t)i * (size_t)A + j]; }
+            else { for (int j = 0; j < A; ++j) abuf[j] = f_clamp(action[(size_t)i * (size_t)A + j], -h->clip_act, h->clip_act); }
             if (apply_resets(h, i, &e, is_reset)) {
                 for (int j = 0; j < A; ++j) abuf[j] = 0.0f;                  /* trifinger_env.py:387 */
                 local.resets += 1.0;
@@ -1623,7 +1632,9 @@ int tf_apply_resets(tf_handle h, void* stream) {
     for (int i = 0; i < h->cfg.num_envs; ++i) {
         Env e;
         env_load(h, i, &e);
-        if (apply_resets(h, i, &e, 0)) for (int j = 0; j < A; ++j) h->buf.action_buf[(size_t)i * (size_t)A + j] = 0.0f;
+        float* ab = &h->buf.action_buf[(size_t)i * (size_t)A];
+        for (int j = 0; j < A; ++j) ab[j] = f_clamp(ab[j], -h->clip_act, h->clip_act);
+        if (apply_resets(h, i, &e, 0)) for (int j = 0; j < A; ++j) ab[j] = 0.0f;
         env_store(h, i, &e, 1);
     }
     return TF_OK;

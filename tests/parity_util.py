@@ -46,8 +46,9 @@ CONFIGS = {
                                                           "action_repeat_prob": 0.2},
                                     success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.02,
                                              "orientation_tolerance": 0.25}),
-    # everything else: impedance actions (A=18), random robot reset, moving goal, difficulty 3, decimation 2
-    "impedance_random_moving": dict(command_mode="position_impedance", task_difficulty=3, asymmetric_obs=True,
+    # everything else: impedance actions (A=18), random robot reset, moving goal, difficulty 3, decimation 2, and the
+    # wrapper clipping fused into the step with bounds tight enough to bite (tf_set_clipping)
+    "impedance_random_moving": dict(_clipping=(0.8, 0.7), command_mode="position_impedance", task_difficulty=3, asymmetric_obs=True,
                                     robot_reset="random", goal_rotation=True, control_decimation=2,
                                     normalize_obs=False,
                                     success={"activate": True, "bonus": 100.0, "position_tolerance": 0.04,
@@ -72,8 +73,11 @@ def actions_for(step, n, a, seed):
 def rollout(lib, device, n, steps, cfg_name, seed=3, episode_length=40, extra=None):
     kw = dict(CONFIGS[cfg_name])
     kw.update(extra or {})
+    clipping = kw.pop("_clipping", None)
     cfg = make_config(lib, n, seed=seed, episode_length=episode_length, **kw)
     eng = TrifingerEngine(cfg, device=device, lib=lib)
+    if clipping:
+        eng.set_clipping(*clipping)
     eng.reset()
     snaps = [snapshot(eng)]
     for t in range(steps):

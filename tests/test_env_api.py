@@ -187,6 +187,27 @@ def test_vec_task_clamps_and_spaces(oracle):
         VecTaskPython(object(), rl_device="cpu")
 
 
+def test_fused_clipping_equals_wrapper_clamps(oracle):
+    """The clamps fused into the native step give what the literal three-operation wrapper gives (vec_task.py:146-170),
+    also when they bite: tiny bounds, actions outside +-clip_actions."""
+    kw = dict(asymmetric_obs=True, command_mode="torque", num_instances=64)
+    outs = []
+    for fused in (True, False):
+        env = make_env(oracle, **kw)
+        vec = VecTaskPython(env, rl_device="cpu", clip_obs=0.3, clip_actions=0.6, fuse_clipping=fused)
+        assert vec._fused is fused
+        g = torch.Generator().manual_seed(4)
+        o = [vec.reset().clone()]
+        for _ in range(12):
+            obs, rew, done, _ = vec.step(torch.rand(64, 9, generator=g) * 4 - 2)
+            o += [obs.clone(), vec.get_state().clone(), rew.clone(), env.action_buf.clone()]
+        outs.append(o)
+        env.close()
+    assert any(bool((t.abs() == 0.3).any()) for t in outs[0][1::4])      # the observation clamp did bite
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_rl_games_adapter_contract(oracle):
     env = make_env(oracle, asymmetric_obs=True)
     ad = RlGamesGpuEnvAdapter("rlgpu", 4, env=VecTaskPython(env, rl_device="cpu"))
