@@ -7,7 +7,7 @@ OUT=${ISA_OUT:-/tmp/dis}
 mkdir -p "$OUT"
 SRC=/root/repo/leibnizgym_amd/csrc/trifinger_hip.hip
 (cd "$OUT" && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
-    -fno-slp-vectorize -Wall -Wno-unused-function --save-temps=obj -c -o "$OUT/tf.o" "$SRC" 2>&1 | grep -E "error|warning" -A3 || true)
+    -fno-slp-vectorize -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 --save-temps=obj -c -o "$OUT/tf.o" "$SRC" 2>&1 | grep -E "error|warning" -A3 || true)
 S="$OUT/trifinger_hip-hip-amdgcn-amd-amdhsa-gfx950.s"
 awk -v k="^$K[^ ]*:" '$0 ~ k {f=1} f{print} /^\.Lfunc_end/{if(f)exit}' "$S" > "$OUT/kernel.s"
 echo "lines: $(wc -l < "$OUT/kernel.s")   ->  $OUT/kernel.s"
