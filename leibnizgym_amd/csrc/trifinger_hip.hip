@@ -12,17 +12,18 @@
 //
 // Execution model (CDNA4): one environment per lane, one 64-lane wavefront per workgroup, state in HBM
 // as structure-of-arrays rows [field][env] so that every global access of a wave is one coalesced 256-B
-// line.  Per-env matrices are at most 3x3 / 6x6: no MFMA.  The finger contact Jacobian rows (J, M^-1 J^T,
-// directions) are staged in LDS as [slot][lane] (bank = lane: conflict free) and re-read by every solver
-// iteration; everything else lives in VGPRs (the kernel is compiled for 1 wave per SIMD: at 65536 envs the
-// chip holds exactly one wave per SIMD, so the register file is there to be used).  The row-major API
-// tensors (action [N,A], obs [N,41], states [N,113]) are transposed through LDS so global traffic stays
-// coalesced (dwordx4).  Episode statistics are reduced with wave shuffles into per-wave partials and
-// folded by a one-block kernel: no atomics, no host sync, deterministic.
+// line.  Per-env matrices are at most 3x3 / 6x6: no MFMA.  All contact rows of the solver (J, M^-1 J^T, directions,
+// 1/D, impulses) live in the register file - the kernel is compiled for 1 wave per SIMD: at 65536 envs the chip
+// holds exactly one wave per SIMD, so all 512 registers per lane are there to be used, and what binds is how fast
+// one wave issues instructions (~5 cycles each), i.e. the instruction count.  LDS holds the
+// [64][W] transposes of the row-major API tensors (action [N,A], obs [N,41], states [N,113]: global traffic stays
+// coalesced, dwordx4) and, between them, the values that are cold during the solve.  Episode statistics are reduced
+// with DPP butterflies per wave and folded across waves with fixed-point integer atomics (order independent, hence
+// deterministic; the last arriving wave writes info[]): one launch per step, no host sync.
 //
-// Arithmetic contract (shared with the CPU oracle used by the tests): fp32 IEEE add/mul/div/sqrt, no FMA
-// contraction (-ffp-contract=off), own polynomial sin/cos/exp/asin/log, fixed evaluation order.  Per-env
-// outputs are expected to be bit-identical to the oracle's.
+// Arithmetic contract (shared with the CPU oracle used by the tests): fp32 IEEE add/mul/div/sqrt, explicitly written
+// fused multiply-adds and no compiler contraction (-ffp-contract=off), own polynomial sin/cos/exp/asin/log and Newton
+// reciprocal / rsqrt, fixed evaluation order.  Per-env outputs are bit-identical to the oracle's.
 //
 // Physics is this build's own spec (the reference's lives in closed-source PhysX): DESIGN.md "Physics spec".
 #include <hip/hip_runtime.h>
