@@ -26,6 +26,14 @@ def print_info(msg):
     print(f"[INFO] {msg}")
 
 
+def print_debug(msg):
+    print(f"[DEBUG] {msg}")
+
+
+def print_notify(msg):
+    print(f"[NOTIFY] {msg}")
+
+
 def print_warn(msg):
     print(f"[WARN] {msg}")
 
