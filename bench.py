@@ -36,14 +36,14 @@ from leibnizgym_amd import _capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per k_step launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, raw
-# counter expressions; profiles/r1_j_pmc.txt).  Only valid for the exact workload it was measured on.
-PMC_TRAFFIC = {(65536, True): (9229.337 + 57067.409) * 1024.0}
+# counter expressions; profiles/r1_k_pmc.txt).  Only valid for the exact workload it was measured on.
+PMC_TRAFFIC = {(65536, True): (9235.130 + 57067.409) * 1024.0}
 # SQ counters of the same profile (per wave, 1024 waves): what actually bounds the kernel.  One wave per SIMD issues one
 # instruction per ~5.0-5.1 cycles whatever the instruction is (tools/microbench/valu_issue.hip, valu_pk.hip).
-PMC_ISSUE = {(65536, True): {"valu_insts_per_wave": 25637546.162 / 1024, "salu_insts_per_wave": 877094.752 / 1024,
-                             "lds_insts_per_wave": 180224.0 / 1024, "wave_cycles": 36546464.990 * 4 / 1024,
+PMC_ISSUE = {(65536, True): {"valu_insts_per_wave": 25591047.552 / 1024, "salu_insts_per_wave": 873000.305 / 1024,
+                             "lds_insts_per_wave": 180224.0 / 1024, "wave_cycles": 36547658.390 * 4 / 1024,
                              "single_wave_cycles_per_inst": 5.0,
-                             "source": "rocprofv3 --pmc SQ_*, profiles/r1_j_pmc.txt; tools/microbench"}}
+                             "source": "rocprofv3 --pmc SQ_*, profiles/r1_k_pmc.txt; tools/microbench"}}
 FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
@@ -240,7 +240,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": PMC_TRAFFIC.get((n, asym)) if headline else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_j_pmc.txt" if headline and (n, asym) in PMC_TRAFFIC else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_k_pmc.txt" if headline and (n, asym) in PMC_TRAFFIC else None,
             "kernel": "k_step<9,false>",
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
