@@ -1473,7 +1473,7 @@ DEV float wave_sum_lane63(float x) {
 
 // Episode statistics without a second launch (a separate 11-wave reduction kernel cost 4.5 us per step, mostly fixed
 // launch and cold-miss latency).  Lane k < 11 of every wave adds the wave's sum of statistic k to a 64-bit accumulator with
-// ONE device-scope integer atomic: the sum as signed fixed point (2^-18) in the upper 47 bits, an arrival count in the
+// ONE device-scope integer atomic: the sum as signed fixed point (2^-16) in the upper 47 bits, an arrival count in the
 // lower 17.  Integer addition commutes, so the result does not depend on the arrival order (deterministic, unlike float
 // atomics), and the returned old value tells each lane whether it was the last to arrive: that lane carries the total to
 // the next level (16 shards -> 1, so that a thousand waves finishing together do not queue on one word) and finally
@@ -1483,7 +1483,7 @@ DEV float wave_sum_lane63(float x) {
 #define STAT_STRIDE 8                            /* uint64 per accumulator: 64 B apart */
 #define STAT_WORDS ((STAT_SHARDS * 11 + 11) * STAT_STRIDE)
 #define STAT_COUNT_BITS 17
-#define STAT_FIX 262144.0                        /* 2^18 */
+#define STAT_FIX 65536.0                         /* 2^16: |sum| < 2^30 = 1e9 fits the 47-bit field (4 Mi envs x |term| <= 250) */
 typedef GLOBAL_AS unsigned long long gu64;
 struct StatsTicket { unsigned long long mine, old; };
 DEV void stats_begin(const DevParams& P, const LaneStats& st, int lane, StatsTicket& tk) {
