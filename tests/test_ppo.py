@@ -106,3 +106,24 @@ def test_graph_captured_update_matches_eager(hip):
         assert torch.allclose(a, b, atol=2e-5, rtol=1e-4) and torch.allclose(a, c, atol=2e-5, rtol=1e-4)
     assert abs(s0[-1]["loss"] - s1[-1]["loss"]) < 1e-3 * max(1.0, abs(s0[-1]["loss"]))
     assert abs(s0[-1]["kl"] - s2[-1]["kl"]) < 1e-4
+
+
+def test_split_k_linear_matches_linear():
+    """The batch-parallel weight gradient of the trainer's linear layers is the ordinary one."""
+    from leibnizgym_amd.ppo import _SplitKLinear
+    torch.manual_seed(0)
+    x = torch.randn(2048, 41, requires_grad=True)
+    w = torch.randn(400, 41, requires_grad=True)
+    b = torch.randn(400, requires_grad=True)
+    g = torch.randn(2048, 400)
+    _SplitKLinear.apply(x, w, b).backward(g)
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    torch.nn.functional.linear(x, w, b).backward(g)
+    for a, t in zip(got, (x, w, b)):
+        assert torch.allclose(a, t.grad, rtol=1e-5, atol=1e-3 * float(t.grad.abs().max()))
+    # a batch the slices do not divide falls back to the single GEMM
+    x2 = torch.randn(100, 41, requires_grad=True)
+    _SplitKLinear.apply(x2, w, b).sum().backward()
+    assert x2.grad.shape == (100, 41)
