@@ -91,3 +91,32 @@ def test_full_size_properties(hip):
     obs_q = eng.obs[:, 0:9].T * (hi - lo) * 0.5 + (hi + lo) * 0.5       # obs is the normalised state
     assert (obs_q - q).abs().max() < 1e-5
     eng.close()
+
+
+def test_maximum_size_matches_the_oracle_at_the_far_end(hip, oracle):
+    """TF_MAX_ENVS (4 Mi envs, 1.5 GB of state rows addressed with 32-bit byte offsets): the last 256 envs of the full
+    population equal an oracle shard of exactly those envs (the RNG is keyed by the global env id), step by step; one
+    env more is refused."""
+    from leibnizgym_amd import _capi as capi
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    n, tail = 4194304, 256
+    kw = dict(pu.CONFIGS["d4_domain_randomization"])
+    big = TrifingerEngine(make_config(hip, n, seed=9, episode_length=4, **kw), device=DEV, lib=hip)
+    ref = TrifingerEngine(make_config(oracle, tail, seed=9, episode_length=4, env_id_offset=n - tail, global_num_envs=n, **kw),
+                          device="cpu", lib=oracle)
+    big.reset(), ref.reset()
+    g = torch.Generator().manual_seed(21)
+    for t in range(7):
+        act_tail = torch.rand(tail, 9, generator=g) * 2 - 1
+        act = torch.zeros(n, 9, device=DEV)
+        act[n - tail:] = act_tail.to(DEV)
+        big.step(act), ref.step(act_tail)
+        for name in ("obs", "states", "reward", "reset_buf", "steps", "reset_count"):
+            a = getattr(big, name)[n - tail:].cpu()
+            assert torch.equal(a, getattr(ref, name)), (t, name)
+        assert torch.equal(big.state[:, n - tail:].cpu(), ref.state), t
+        assert float(big.info[capi.INFO_NUM_RESETS]) == (n if t == 4 else 0.0)      # time-out of every env, counted exactly
+    assert torch.isfinite(big.reward).all()
+    big.close(), ref.close()
+    with pytest.raises(ValueError):
+        TrifingerEngine(make_config(hip, n + 1, **kw), device=DEV, lib=hip)
