@@ -1548,7 +1548,9 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
     tip_state<0>(m, pk0, &e.q[0], &e.qd[0], tips0);
     tip_state<1>(m, pk1, &e.q[3], &e.qd[3], tips1);
     tip_state<2>(m, pk2, &e.q[6], &e.qd[6], tips2);
-    {   // NaN guard: a non-finite env is flagged for reset and parked at the default pose
+    bool guarded = false;
+    {   // NaN guard: a non-finite env is flagged for reset and parked at the default pose; its reward terms of this step
+        // (they involve the histories that were non-finite) are zero: neither the learner nor the logged means see it
         float acc = 0.0f;
 #pragma unroll
         for (int j = 0; j < 9; ++j) acc = acc + e.q[j] * 0.0f + e.qd[j] * 0.0f;
@@ -1573,6 +1575,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
             tip_state<2>(m, pk2, &e.q[6], &e.qd[6], tips2);
             if (valid) P.reset_buf[(unsigned)i] = 1;
             cy.reset = true;
+            guarded = true;
             st.nonfinite += valid ? 1.0f : 0.0f;
         }
     }
@@ -1615,6 +1618,7 @@ DEV void post_step_env(const DevParams& P, const RewardCoef& rc, uint32_t frame,
         float total = 0.0f;
     #pragma unroll
         for (int t = 0; t < 6; ++t) {
+            r[t] = guarded ? 0.0f : r[t];
             if (P.rew_active[t]) { total = total + r[t]; st.rew[t] += valid ? r[t] : 0.0f; }
         }
         // ---- termination (trifinger_env.py:1053-1099) ----

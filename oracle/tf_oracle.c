@@ -1409,7 +1409,9 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
     int A = h->action_dim, OD = h->obs_dim, SD = h->states_dim;
     float tips[3][13];
     for (int f = 0; f < 3; ++f) tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
-    /* NaN guard: a non-finite env is flagged for reset and parked at the default pose */
+    /* NaN guard: a non-finite env is flagged for reset and parked at the default pose; its reward terms of this step
+     * (they involve the histories that were non-finite) are zero, so neither the learner nor the logged means see it */
+    int guarded = 0;
     {
         float acc = 0.0f;
         for (int j = 0; j < 9; ++j) acc = acc + e->q[j] * 0.0f + e->qd[j] * 0.0f;
@@ -1424,6 +1426,7 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
             for (int f = 0; f < 3; ++f) tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
             h->buf.reset_buf[i] = 1;
             st->nonfinite += 1.0;
+            guarded = 1;
         }
     }
     /* observations (trifinger_env.py:996-1019) and states (:1021-1051) */
@@ -1501,6 +1504,7 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
     float ang_prev = quat_diff_rad(&prev_obj[3], e->gq);
     r[4] = rc->w_rot_delta * (rc->rot_delta_sched * (f_abs(ang) - f_abs(ang_prev)));
     r[5] = rc->w_move * (dist - norm3d(prev_obj, e->gp));
+    if (guarded) for (int t = 0; t < 6; ++t) r[t] = 0.0f;
     float total = 0.0f;
     for (int t = 0; t < 6; ++t) if (c->reward[t].activate) { total = total + r[t]; st->rew[t] += (double)r[t]; }
     /* termination (trifinger_env.py:1053-1099) */
