@@ -19,6 +19,38 @@ def test_rollout_bit_exact(hip, oracle, cfg_name):
         pu.assert_bit_equal(a, b, f"{cfg_name} step {t}")
 
 
+@pytest.mark.parametrize("extra", [dict(substeps=1, solver_iterations=4), dict(substeps=3, solver_iterations=1),
+                                   dict(dt=0.01, solver_iterations=12, control_decimation=3),
+                                   dict(gravity=(0.3, -0.2, -3.7)), dict(normalize_action=False, apply_safety_damping=False)])
+def test_solver_and_stepping_settings(hip, oracle, extra):
+    """Loop bounds and stepping parameters other than the Hydra defaults (the env's own default dict asks for 4 position
+    iterations; the reference's tests use control_decimation 5): still bit for bit."""
+    got = pu.rollout(hip, DEV, 300, 50, "envdefault_position", extra=extra)
+    want = pu.rollout(oracle, "cpu", 300, 50, "envdefault_position", extra=extra)
+    for t, (a, b) in enumerate(zip(got, want)):
+        pu.assert_bit_equal(a, b, f"{extra} step {t}")
+
+
+def test_gravity_setter_takes_effect(hip, oracle):
+    """tf_set_gravity after creation (IsaacEnvBase's set_sim_params path, env_base.py:175-193) == gravity at creation."""
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    kw = dict(pu.CONFIGS["d4_torque_asym"])
+    a = TrifingerEngine(make_config(hip, 128, seed=2, gravity=(0.0, 0.0, -1.62), **kw), device=DEV, lib=hip)
+    b = TrifingerEngine(make_config(hip, 128, seed=2, **kw), device=DEV, lib=hip)
+    b.set_gravity((0.0, 0.0, -1.62))
+    a.reset(), b.reset()
+    for t in range(10):
+        act = pu.actions_for(t, 128, 9, 2).to(DEV)
+        a.step(act), b.step(act)
+    assert torch.equal(a.state, b.state) and torch.equal(a.obs, b.obs)
+    c = TrifingerEngine(make_config(hip, 128, seed=2, **kw), device=DEV, lib=hip)
+    c.reset()
+    for t in range(10):
+        c.step(pu.actions_for(t, 128, 9, 2).to(DEV))
+    assert not torch.equal(a.state, c.state)
+    a.close(), b.close(), c.close()
+
+
 @pytest.mark.parametrize("n", [1, 4, 63, 64, 65])
 def test_ragged_sizes(hip, oracle, n):
     got = pu.rollout(hip, DEV, n, 45, "d4_torque_asym")
