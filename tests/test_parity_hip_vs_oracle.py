@@ -31,6 +31,19 @@ def test_solver_and_stepping_settings(hip, oracle, extra):
         pu.assert_bit_equal(a, b, f"{extra} step {t}")
 
 
+@pytest.mark.parametrize("difficulty", [-1, 2, 5, 6])
+def test_remaining_difficulties_and_reset_modes(hip, oracle, difficulty):
+    """Goal samplers of the difficulties the Hydra configs do not use (trifinger_env.py:1211-1243), with success goal
+    resets on, the object spawned at its default pose and the robot at a random one."""
+    extra = dict(task_difficulty=difficulty, object_reset="default", robot_reset="random",
+                 success={"activate": True, "bonus": 10.0, "position_tolerance": 0.08, "orientation_tolerance": 3.2})
+    got = pu.rollout(hip, DEV, 200, 40, "envdefault_position", episode_length=15, extra=extra)
+    want = pu.rollout(oracle, "cpu", 200, 40, "envdefault_position", episode_length=15, extra=extra)
+    for t, (a, b) in enumerate(zip(got, want)):
+        pu.assert_bit_equal(a, b, f"difficulty {difficulty} step {t}")
+    assert any(s["goal_reset_buf"].any() for s in want), "the scenario should exercise goal resets"
+
+
 def test_gravity_setter_takes_effect(hip, oracle):
     """tf_set_gravity after creation (IsaacEnvBase's set_sim_params path, env_base.py:175-193) == gravity at creation."""
     from leibnizgym_amd.engine import TrifingerEngine, make_config
