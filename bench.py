@@ -36,14 +36,14 @@ from leibnizgym_amd import _capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per k_step launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, raw
-# counter expressions; profiles/r1_k_pmc.txt).  Only valid for the exact workload it was measured on.
-PMC_TRAFFIC = {(65536, True): (9235.130 + 57067.409) * 1024.0}
+# counter expressions; profiles/r1_l_pmc.txt).  Only valid for the exact workload it was measured on.
+PMC_TRAFFIC = {(65536, True): (9234.968 + 57067.408) * 1024.0}
 # SQ counters of the same profile (per wave, 1024 waves): what actually bounds the kernel.  One wave per SIMD issues one
 # instruction per ~5.0-5.1 cycles whatever the instruction is (tools/microbench/valu_issue.hip, valu_pk.hip).
 PMC_ISSUE = {(65536, True): {"valu_insts_per_wave": 25591047.552 / 1024, "salu_insts_per_wave": 873000.305 / 1024,
                              "lds_insts_per_wave": 180224.0 / 1024, "wave_cycles": 36547658.390 * 4 / 1024,
                              "single_wave_cycles_per_inst": 5.0,
-                             "source": "rocprofv3 --pmc SQ_*, profiles/r1_k_pmc.txt; tools/microbench"}}
+                             "source": "rocprofv3 --pmc SQ_*, profiles/r1_l_pmc.txt; tools/microbench"}}
 FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
@@ -151,9 +151,10 @@ def main():
                     help="secondary runs only (BASELINE configs[1]: --difficulty 1 --envs 8192); the headline is 4")
     ap.add_argument("--dr", action="store_true",
                     help="secondary runs only: every domain-randomisation feature on (BASELINE configs[3]: --dr --envs 16384)")
-    ap.add_argument("--time-stride", type=int, default=8,
-                    help="bracket every S-th k_step launch of the timed region with a HIP event pair (an event pair "
-                         "costs ~3 us of stream time, so timing every launch would slow the region it measures); 0: none")
+    ap.add_argument("--time-window", type=int, default=8,
+                    help="one HIP event pair per window of W consecutive k_step launches of the timed region (an event "
+                         "pair costs ~3 us of stream time: per launch it would slow the region it measures and read "
+                         "2-3 us long; over 8 back-to-back launches it is amortised); 0: no kernel timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,7 +190,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.enable_kernel_timing(8192 if args.time_stride > 0 else 0, max(1, args.time_stride))
+    eng.enable_kernel_timing(8192 if args.time_window > 0 else 0, max(1, args.time_window))
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -240,12 +241,12 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": PMC_TRAFFIC.get((n, asym)) if headline else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_k_pmc.txt" if headline and (n, asym) in PMC_TRAFFIC else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_l_pmc.txt" if headline and (n, asym) in PMC_TRAFFIC else None,
             "kernel": "k_step<9,false>",
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
-            "kernel_timing": f"HIP event pair on the launch stream around every {max(1, args.time_stride)}-th k_step launch "
-                             f"of the timed region",
+            "kernel_timing": f"one HIP event pair on the launch stream around every window of {max(1, args.time_window)} "
+                             f"consecutive k_step launches of the timed region; kernel_avg_us = window time / launches",
             "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP[asym],
             "note": "north star asks for the HBM fraction; what binds is instruction issue: at <= 65536 envs the chip holds "
                     "one wave per SIMD, a lone wave issues one instruction per ~5 cycles, and k_step's ~27 k instructions "

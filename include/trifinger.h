@@ -260,9 +260,10 @@ int tf_reset(tf_handle h, void* stream);
  * events recorded on its launch stream, for up to `max_launches` launches (0 disables).  tf_kernel_time_ms
  * waits for the recorded events and returns the summed kernel duration and the number of launches summed. */
 int tf_enable_kernel_timing(tf_handle h, int32_t max_launches);
-/* Bracket only every `stride`-th launch (default 1): an event pair costs ~3 us of stream time per launch, so a sparse
- * sample keeps the measurement from slowing down the region it measures. */
-int tf_set_kernel_timing_stride(tf_handle h, int32_t stride);
+/* Bracket windows of `window` consecutive launches with one event pair each (default 1): an event pair costs ~3 us of
+ * stream time, so bracketing every launch slows the region it measures and reads 2-3 us too long per kernel; over a window
+ * of 8 back-to-back launches that cost is amortised.  tf_kernel_time_ms then reports the launches of complete windows. */
+int tf_set_kernel_timing_window(tf_handle h, int32_t window);
 int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches);
 
 /* Split path (same arithmetic, one hook per launch) kept for the parity tests. */

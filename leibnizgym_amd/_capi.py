@@ -125,7 +125,7 @@ SYMBOLS = {
     "tf_step": (C.c_int, [_P, _P, _P]),
     "tf_reset": (C.c_int, [_P, _P]),
     "tf_enable_kernel_timing": (C.c_int, [_P, C.c_int32]),
-    "tf_set_kernel_timing_stride": (C.c_int, [_P, C.c_int32]),
+    "tf_set_kernel_timing_window": (C.c_int, [_P, C.c_int32]),
     "tf_kernel_time_ms": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tf_apply_resets": (C.c_int, [_P, _P]),
     "tf_pre_step": (C.c_int, [_P, _P]),

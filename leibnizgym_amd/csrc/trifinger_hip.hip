@@ -2081,7 +2081,7 @@ struct TfHandle_ {
     // optional kernel timing (bench.py): event pairs around the fused step kernel
     hipEvent_t* ev;          // [2 * ev_cap]
     int ev_cap, ev_used;
-    int ev_stride, ev_phase; // every ev_stride-th launch is bracketed
+    int ev_stride, ev_phase; // one event pair per window of ev_stride consecutive launches
 };
 
 static thread_local char g_err[512] = "";
@@ -2382,9 +2382,8 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     // a full reset also re-arms the statistics accumulators (they are left at zero by every completed launch; this only
     // matters after a launch that did not complete)
     if (is_reset) HIP_TRY(hipMemsetAsync((void*)h->dp.tickets, 0, STAT_WORDS * sizeof(unsigned long long), s));
-    bool timed = !is_reset && h->ev && h->ev_used < h->ev_cap;
-    if (timed) { timed = (h->ev_phase == 0); h->ev_phase = (h->ev_phase + 1) % h->ev_stride; }
-    if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], s));
+    const bool timing = !is_reset && h->ev && h->ev_used < h->ev_cap;
+    if (timing && h->ev_phase == 0) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], s));      // window opens
     const bool asym = h->cfg.asymmetric_obs != 0;
 #define LAUNCH_STEP(AA, RR, SS) hipLaunchKernelGGL((k_step<AA, RR, SS>), grid, block, 0, s, h->d_params, h->sa, action)
     if (h->action_dim == 9) {
@@ -2396,7 +2395,13 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     }
 #undef LAUNCH_STEP
     LAUNCH_CHECK("k_step");
-    if (timed) { HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], s)); h->ev_used += 1; }
+    if (timing) {
+        h->ev_phase += 1;
+        if (h->ev_phase == h->ev_stride) {                                                   // window closes
+            HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], s));
+            h->ev_used += 1; h->ev_phase = 0;
+        }
+    }
     return TF_OK;
 }
 
@@ -2428,9 +2433,9 @@ int tf_enable_kernel_timing(tf_handle h, int32_t max_launches) {
     h->ev_cap = max_launches;
     return TF_OK;
 }
-int tf_set_kernel_timing_stride(tf_handle h, int32_t stride) {
-    if (!h || stride <= 0) return TF_ERR_INVALID_ARG;
-    h->ev_stride = stride; h->ev_phase = 0;
+int tf_set_kernel_timing_window(tf_handle h, int32_t window) {
+    if (!h || window <= 0) return TF_ERR_INVALID_ARG;
+    h->ev_stride = window; h->ev_phase = 0;
     return TF_OK;
 }
 int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {
@@ -2443,7 +2448,7 @@ int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {
         sum += (double)ms;
     }
     *total_ms = sum;
-    *launches = h->ev_used;
+    *launches = (int64_t)h->ev_used * h->ev_stride;
     return TF_OK;
 }
 

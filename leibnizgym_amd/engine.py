@@ -270,9 +270,10 @@ class TrifingerEngine:
         with self._on_device():
             check(self.lib, self.lib.tf_reset(self._handle, self._stream()), "tf_reset")
 
-    def enable_kernel_timing(self, max_launches, stride=1):
-        check(self.lib, self.lib.tf_enable_kernel_timing(self._handle, int(max_launches)), "tf_enable_kernel_timing")
-        check(self.lib, self.lib.tf_set_kernel_timing_stride(self._handle, int(stride)), "tf_set_kernel_timing_stride")
+    def enable_kernel_timing(self, max_windows, window=1):
+        """One event pair per `window` consecutive launches of the fused step kernel, for at most `max_windows` windows."""
+        check(self.lib, self.lib.tf_enable_kernel_timing(self._handle, int(max_windows)), "tf_enable_kernel_timing")
+        check(self.lib, self.lib.tf_set_kernel_timing_window(self._handle, int(window)), "tf_set_kernel_timing_window")
 
     def kernel_time_ms(self):
         """(summed duration of the timed fused-step kernels in ms, number of launches); synchronises."""

@@ -1609,8 +1609,8 @@ int tf_enable_kernel_timing(tf_handle h, int32_t max_launches) {
     h->timing_on = max_launches > 0; h->timed_ms = 0.0; h->timed_launches = 0;
     return TF_OK;
 }
-int tf_set_kernel_timing_stride(tf_handle h, int32_t stride) {
-    if (!h || stride <= 0) return TF_ERR_INVALID_ARG;
+int tf_set_kernel_timing_window(tf_handle h, int32_t window) {
+    if (!h || window <= 0) return TF_ERR_INVALID_ARG;
     return TF_OK;                       /* host timing costs nothing: every launch stays timed */
 }
 int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {
