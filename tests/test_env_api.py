@@ -266,3 +266,47 @@ def test_hydra_schema_loader():
         gym_config("trifinger_difficulty_9")
     with pytest.raises(InvalidTaskNameError):
         raise InvalidTaskNameError("Foo")
+
+
+def test_fingertip_history_keeps_the_pre_reset_tips_for_one_step(oracle):
+    """Quirk 4 of SURVEY 8a-Q: `_reset_impl` zeroes only the OLDER fingertip history entry, which the next fill shifts out
+    (trifinger_env.py:1146-1147, :974), so on the first step after a reset the fingertip terms difference against the
+    PRE-reset fingertips - a spurious jump - while the object history is rewritten with the reset pose (:1183-1187) and the
+    object terms are clean.  Checked with one term active at a time against the host-side reward classes."""
+    from leibnizgym_amd import _capi as capi
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    from leibnizgym_amd.envs.trifinger import rewards as rw
+    n, dt = 64, 0.02
+    only = lambda name, **kw: {k: dict(activate=(k == name), **(kw if k == name else {})) for k in capi.REWARD_TERM_ORDER}  # noqa: E731
+    for term in ("finger_move_penalty", "object_move"):
+        weight = -0.1 if term == "finger_move_penalty" else -750.0
+        cfg = make_config(oracle, n, seed=6, command_mode="torque", robot_reset="random", episode_length=5,
+                          reward_terms=only(term, weight=weight), success={"activate": False}, task_difficulty=1)
+        eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
+        eng.reset()
+        g = torch.Generator().manual_seed(1)
+        for t in range(7):
+            tips_before = eng.state[capi.S_TIP_P:capi.S_TIP_P + 9].T.clone().view(n, 3, 3)      # history[0] going in
+            was_flagged = eng.reset_buf.clone().bool()
+            eng.step(torch.rand(n, 9, generator=g) * 2 - 1)
+            tips_now = eng.state[capi.S_TIP_P:capi.S_TIP_P + 9].T.view(n, 3, 3)
+            if t != 5:
+                assert not was_flagged.any()
+                continue
+            assert was_flagged.all()                       # every env timed out at step 5 and was reset inside this step
+            if term == "finger_move_penalty":
+                pad = lambda x: torch.cat([x, torch.zeros(n, 3, 10)], dim=-1)   # noqa: E731
+                want = rw.FingertipMovementPenalty(activate=True, weight=weight).compute(dt, pad(tips_now), pad(tips_before))
+                assert torch.allclose(eng.reward, want, rtol=1e-4, atol=1e-5)
+                # and it IS a jump: the pre-reset tips are far from where the freshly reset fingers are
+                assert float(eng.reward.abs().median()) > 5 * 0.1 * (0.01 / dt) ** 2
+            else:
+                obj_prev = eng.state[capi.S_PREV_OBJ_P:capi.S_PREV_OBJ_P + 3].T       # the reset pose the physics started from
+                obj_now = eng.state[capi.S_CUBE_P:capi.S_CUBE_P + 3].T
+                goal = eng.state[capi.S_GOAL_P:capi.S_GOAL_P + 3].T
+                pad13 = lambda p: torch.cat([p, torch.zeros(n, 10)], dim=-1)          # noqa: E731
+                want = rw.ObjectMoveReward(activate=True, weight=weight).compute(pad13(obj_now), pad13(obj_prev),
+                                                                                 torch.cat([goal, torch.zeros(n, 4)], dim=-1))
+                assert torch.allclose(eng.reward, want, rtol=1e-4, atol=2e-4)
+                assert float(eng.reward.abs().max()) < 750 * 0.01     # one step of a resting cube: no jump
+        eng.close()
