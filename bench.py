@@ -161,12 +161,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # Test hook for boxes with ONE GPU: every rank uses cuda:0 and the (timing-only) collectives go through gloo, so that the
+    # multi-process path - rank offsets, barrier, max over ranks, rank-0 JSON - can be exercised without a second device.
+    one_device = os.environ.get("TF_BENCH_SINGLE_DEVICE_TEST", "") == "1"
+    if one_device:
+        local_rank = 0
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if one_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert world == max(1, args.gpus) or not distributed, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path in the product)"
     dev = f"cuda:{local_rank}"
