@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TF_API_VERSION 2
+#define TF_API_VERSION 3
 
 typedef enum TfStatus {
     TF_OK = 0,
@@ -97,12 +97,22 @@ enum {
     TF_S_DR = 84,        /*  6 per-env domain-randomisation scale factors drawn at reset (1.0 when DR is off):
                               cube mass, cube size, contact friction, motor torque, finger link mass,
                               finger contact restitution                                           */
-    TF_STATE_ROWS = 90
+    /* Warm start of the contact solver (an implementation choice, not algorithmic traffic: SURVEY 8d).  The impulses
+     * of the last substep seed the next one when the contact kept its identity; a reset clears them.               */
+    TF_S_LAM_FC = 90,    /* 12 finger-cube contact of finger f at [4f..4f+3]: normal impulse, world friction impulse (3) */
+    TF_S_FC_LINK = 102,  /*  3 link that held the finger-cube contact (0 none, 1 upper, 2 middle, 3 distal)       */
+    TF_S_LAM_TF = 105,   /*  9 fingertip-floor contact of finger f at [3f..3f+2]: normal, tangent 1, tangent 2       */
+    TF_S_LAM_TW = 114,   /*  9 fingertip-boundary-wall contact of finger f, same layout                             */
+    TF_S_LAM_CF = 123,   /* 12 cube corner i against the floor at [3i..3i+2]: +z (normal), +x, +y                   */
+    TF_S_CF_FACE = 135,  /*  1 cube face whose corners those were (0 none, 1..6)                                   */
+    TF_S_LAM_CW = 136,   /* 12 cube corner i against the boundary wall at [3i..3i+2]: normal, tangent, +z          */
+    TF_S_CW_FACE = 148,  /*  1 cube face whose corners those were                                                  */
+    TF_STATE_ROWS = 149
 };
 #define TF_NUM_DR 6
 /* Largest num_envs of one handle: the kernels address state[TF_STATE_ROWS][num_envs] with 32-bit byte offsets
- * (90 * 4 Mi * 4 B = 1.5 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
-#define TF_MAX_ENVS 4194304
+ * (149 * 2 Mi * 4 B = 1.25 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
+#define TF_MAX_ENVS 2097152
 
 #define TF_OBS_DIM_BASE 32    /* 9 + 9 + 7 + 7; the action slot (9 or 18) follows  trifinger_env.py:280-286 */
 #define TF_STATES_EXTRA 72    /* 6 + 39 + 9 + 18                                   trifinger_env.py:296-300 */
@@ -146,25 +156,35 @@ typedef struct TfModel {
     float tau_max;                /* 0.36 Nm                                                         */
     float link_angular_damping;   /* 0.01 (trifinger_env.py:866)                                     */
     float q_default[3];           /* (0, 0.9, -1.7)                                                  */
-    /* collision primitives (build's choice; SURVEY 8a-P "measured") */
+    /* collision primitives (build's choice: capsules fitted to the convex hulls of the link meshes
+     * meshes/stl/pro/SIM__BL-Finger_{Proximal,Intermediate,Tip_without_tip,Tip_actual_tip}.obj with the collision
+     * origins of trifingerpro.urdf:88-153; every finger link has a shape, trifinger_env.py:874-879) */
     float cap_a[3], cap_b[3];     /* distal-link capsule end points in the lower frame; b = tip sphere centre */
     float cap_radius;             /* 0.0102                                                          */
+    float cap2_a[3], cap2_b[3];   /* middle-link capsule in the middle frame                         */
+    float cap2_radius;            /* 0.022                                                           */
+    float cap1_a[3], cap1_b[3];   /* upper-link capsule in the upper frame (along the joint-1 axis)  */
+    float cap1_radius;            /* 0.024                                                           */
+    float upper_check_z;          /* the upper-link candidate is only tested for a cube centre above this height */
     /* cube (cube_multicolor_rrc.urdf:10-18) */
     float cube_half;              /* 0.0325 */
     float cube_mass;              /* 291.3 * 0.065^3 */
     float cube_inertia;           /* m s^2 / 6 (isotropic)                                           */
     float cube_linear_damping, cube_angular_damping;
-    /* arena */
-    float wall_radius;            /* inner radius of the boundary annulus (0.192)                    */
-    float wall_height;            /* the vertical part of the wall ends here (0.06)                  */
+    /* arena: the boundary annulus as a stack of vertical cylinders, inner radius wall_r[i] for heights below
+     * wall_z[i] (measured from meshes/convex_table_boundary/convex_*.obj; high_table_boundary.urdf:20-259);
+     * nothing above wall_z[3] */
+    float wall_r[4], wall_z[4];
     /* materials: PhysX "average" combine of trifinger_env.py:364-365,876-878,914-915,934-936 */
-    float mu_finger_cube, mu_cube_floor, mu_tip_floor, mu_cube_wall;
-    float restitution_finger;     /* average(0.8, 0) */
+    float mu_finger_cube, mu_cube_floor, mu_tip_floor, mu_cube_wall, mu_tip_wall, mu_finger_finger;
+    float restitution_finger;     /* finger shape vs cube / arena: average(0.8, 0)                   */
+    float restitution_ff;         /* finger shape vs finger shape: 0.8                               */
     float bounce_threshold;       /* 0.5 m/s  (scripts/rlg_hydra.py:32)                              */
     float contact_margin;         /* rows are generated for gaps below this                          */
     float contact_offset;         /* 0.002 (scripts/rlg_hydra.py:30): restitution applies below it   */
     float erp;                    /* fraction of penetration removed per substep                     */
     float max_depenetration_velocity;
+    float warm_start;             /* fraction of the previous substep's impulses that seeds the solver */
 } TfModel;
 
 typedef struct TfConfig {

@@ -11,10 +11,10 @@ same binding at the CPU oracle; nothing in this package ever does.
 import ctypes as C
 import os
 
-TF_API_VERSION = 2
+TF_API_VERSION = 3
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
-TF_STATE_ROWS = 90
+TF_STATE_ROWS = 149
 TF_NUM_DR = 6
 
 # status codes (include/trifinger.h: TfStatus)
@@ -43,6 +43,8 @@ REWARD_TERM_ORDER = (
 S_Q, S_QD, S_CUBE_P, S_CUBE_Q, S_CUBE_V, S_CUBE_W = 0, 9, 18, 21, 25, 28
 S_GOAL_P, S_GOAL_Q, S_GOAL_W, S_TIP_P, S_TAU = 31, 34, 38, 41, 50
 S_PREV_OBJ_P, S_PREV_OBJ_Q, S_FT, S_DR = 59, 62, 66, 84
+# warm-start rows of the contact solver
+S_LAM_FC, S_FC_LINK, S_LAM_TF, S_LAM_TW, S_LAM_CF, S_CF_FACE, S_LAM_CW, S_CW_FACE = 90, 102, 105, 114, 123, 135, 136, 148
 
 INFO_POS_COUNT, INFO_ORI_COUNT, INFO_SUCCESS_MEAN, INFO_NUM_RESETS, INFO_NUM_NONFINITE = 6, 7, 8, 9, 10
 
@@ -63,14 +65,18 @@ class TfModel(C.Structure):
         ("qd_max", C.c_float), ("tau_max", C.c_float), ("link_angular_damping", C.c_float),
         ("q_default", C.c_float * 3),
         ("cap_a", C.c_float * 3), ("cap_b", C.c_float * 3), ("cap_radius", C.c_float),
+        ("cap2_a", C.c_float * 3), ("cap2_b", C.c_float * 3), ("cap2_radius", C.c_float),
+        ("cap1_a", C.c_float * 3), ("cap1_b", C.c_float * 3), ("cap1_radius", C.c_float),
+        ("upper_check_z", C.c_float),
         ("cube_half", C.c_float), ("cube_mass", C.c_float), ("cube_inertia", C.c_float),
         ("cube_linear_damping", C.c_float), ("cube_angular_damping", C.c_float),
-        ("wall_radius", C.c_float), ("wall_height", C.c_float),
+        ("wall_r", C.c_float * 4), ("wall_z", C.c_float * 4),
         ("mu_finger_cube", C.c_float), ("mu_cube_floor", C.c_float),
         ("mu_tip_floor", C.c_float), ("mu_cube_wall", C.c_float),
-        ("restitution_finger", C.c_float), ("bounce_threshold", C.c_float),
+        ("mu_tip_wall", C.c_float), ("mu_finger_finger", C.c_float),
+        ("restitution_finger", C.c_float), ("restitution_ff", C.c_float), ("bounce_threshold", C.c_float),
         ("contact_margin", C.c_float), ("contact_offset", C.c_float), ("erp", C.c_float),
-        ("max_depenetration_velocity", C.c_float),
+        ("max_depenetration_velocity", C.c_float), ("warm_start", C.c_float),
     ]
 
 

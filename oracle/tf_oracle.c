@@ -354,22 +354,40 @@ void tf_default_model(TfModel* m) {
     m->cap_a[0] = 0.0135f; m->cap_a[1] = 0.0f; m->cap_a[2] = 0.0f;
     m->cap_b[0] = 0.0185f; m->cap_b[1] = 0.0f; m->cap_b[2] = -0.1592f; /* tip origin + (0,0,0.0034) */
     m->cap_radius = 0.0102f;
+    /* middle link: bar along -z of the middle frame, hull x[0,0.050] y[-0.029,0.024] z[-0.184,0.022] (mesh rotated by the
+     * collision rpy of trifingerpro.urdf:108-113) */
+    m->cap2_a[0] = 0.028f; m->cap2_a[1] = 0.0f; m->cap2_a[2] = 0.0f;
+    m->cap2_b[0] = 0.028f; m->cap2_b[1] = 0.0f; m->cap2_b[2] = -0.16f;
+    m->cap2_radius = 0.022f;
+    /* upper link: motor housing along the joint-1 axis, hull x[-0.022,0.032] y[0.0235,0.233] z[-0.0255,0.0255]
+     * (trifingerpro.urdf:88-93) */
+    m->cap1_a[0] = 0.005f; m->cap1_a[1] = 0.045f; m->cap1_a[2] = 0.0f;
+    m->cap1_b[0] = 0.005f; m->cap1_b[1] = 0.21f; m->cap1_b[2] = 0.0f;
+    m->cap1_radius = 0.024f;
+    m->upper_check_z = 0.17f;             /* base height 0.29 - capsule radius - cube half diagonal - margin */
     m->cube_half = 0.0325f;               /* trifinger_env.py:143 */
     m->cube_mass = (float)(291.3 * 0.065 * 0.065 * 0.065);
     m->cube_inertia = (float)(291.3 * 0.065 * 0.065 * 0.065 * 0.065 * 0.065 / 6.0);
     m->cube_linear_damping = 0.0f;
     m->cube_angular_damping = 0.05f;
-    m->wall_radius = 0.192f;
-    m->wall_height = 0.06f;
+    /* boundary: inner radius by height (measured from convex_table_boundary/convex_*.obj) */
+    m->wall_r[0] = 0.192f; m->wall_z[0] = 0.06f;
+    m->wall_r[1] = 0.208f; m->wall_z[1] = 0.10f;
+    m->wall_r[2] = 0.249f; m->wall_z[2] = 0.14f;
+    m->wall_r[3] = 0.260f; m->wall_z[3] = 0.176f;
     m->mu_finger_cube = 1.0f;             /* avg(1.0, 1.0) */
     m->mu_cube_floor = 0.55f;             /* avg(1.0, 0.1) */
     m->mu_tip_floor = 0.55f;
     m->mu_cube_wall = 1.0f;
+    m->mu_tip_wall = 1.0f;
+    m->mu_finger_finger = 1.0f;
     m->restitution_finger = 0.4f;         /* avg(0.8, 0.0) */
+    m->restitution_ff = 0.8f;             /* avg(0.8, 0.8) */
     m->bounce_threshold = 0.5f;
     m->contact_margin = 0.04f;
     m->contact_offset = 0.002f;
     m->erp = 0.2f;
+    m->warm_start = 0.9f;
     m->max_depenetration_velocity = 1000.0f;
 }
 
@@ -672,25 +690,20 @@ typedef struct {
     float tau[9];
     float ft[18];      /* accumulated fingertip wrench (world), summed over substeps */
     float dr[TF_NUM_DR]; /* domain-randomisation scale factors: cube mass, cube size, friction, motor torque, link mass, restitution */
+    /* warm start of the contact solver (state rows TF_S_LAM_* / TF_S_*_LINK|TYPE|FACE) */
+    float lam_fc[3][4];  /* normal impulse, world friction impulse */
+    float fc_link[3];
+    float lam_tf[3][3];  /* fingertip - floor */
+    float lam_tw[3][3];  /* fingertip - boundary wall */
+    float lam_cf[4][3];
+    float cf_face;
+    float lam_cw[4][3];
+    float cw_face;
 } Env;
-
-/* one contact between finger f and something: three rows (normal + two tangents) */
-typedef struct {
-    int active;
-    float Jf[3][3];    /* row d: J^T dir_d (joint space) */
-    float Wf[3][3];    /* Minv Jf */
-    float dir[3][3];   /* world directions n, t1, t2 (cube side)            */
-    float rc[3];       /* contact point on the cube relative to its centre  */
-    float Dinv[3];
-    float bias;
-    float arm[3];      /* world contact point - tip-link origin (for the wrench sensor) */
-    float lam[3];
-} FingerContact;
 
 /* one cube corner against the floor or the wall.  Rows are always evaluated: an inactive contact has
  * Dinv = 0 and bias = 0, so its impulses stay exactly zero (the kernel does the same, branch-free). */
 typedef struct {
-    int active;
     float r[3];
     float n[2];        /* wall: horizontal inward normal */
     float Dinv[3];
@@ -703,6 +716,12 @@ static void base_to_world(const TfModel* m, int f, const float b[3], float w[3])
     w[0] = FMA(c, b[0], -(s * b[1]));
     w[1] = FMA(s, b[0], c * b[1]);
     w[2] = b[2] + m->base_height;
+}
+static void world_to_base(const TfModel* m, int f, const float w[3], float b[3]) {
+    float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
+    b[0] = FMA(c, w[0], s * w[1]);
+    b[1] = FMA(c, w[1], -(s * w[0]));
+    b[2] = w[2] - m->base_height;
 }
 static void dir_world_to_base(const TfModel* m, int f, const float w[3], float b[3]) {
     float c = m->base_yaw_cos[f], s = m->base_yaw_sin[f];
@@ -748,29 +767,116 @@ static float contact_bias(const TfModel* m, float gap, float vn0, float inv_h, f
     return b;
 }
 
-/* Rows of one finger contact once point P (base frame), world normal n and cube arm r_c are known. */
-static void finger_rows(const TfModel* m, int f, const FK* k, const float Pb[3], const float n_w[3],
-                        const float rc[3], int with_cube, float inv_m, float inv_I, FingerContact* c) {
-    float t1[3], t2[3];
-    tangent_basis(n_w, t1, t2);
-    const float* dw[3] = {n_w, t1, t2};
+/* base-frame position of a point given in the frame of link 1..3 */
+static void link_point(const FK* k, int link, const float local[3], float out[3]) {
+    float t[3];
+    rot_link(k, link, local, t);
+    if (link == 1) { out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; }
+    else if (link == 2) { out[0] = k->p2[0] + t[0]; out[1] = k->p2[1] + t[1]; out[2] = k->p2[2] + t[2]; }
+    else { out[0] = k->p3[0] + t[0]; out[1] = k->p3[1] + t[1]; out[2] = k->p3[2] + t[2]; }
+}
+
+/* Joint-space rows of a contact on link `link` of finger f at base-frame point Pb for the three world directions
+ * dirs[d]: J[d] = (L1.d, L2.d, L3.d) with the levers of the joints that do not move the link zeroed, W[d] = M^-1 J[d],
+ * Dd[d] = J[d].W[d]. */
+static void finger_jac(const TfModel* m, int f, const FK* k, int link, const float Pb[3], float dirs[3][3],
+                       float J[3][3], float W[3][3], float Dd[3]) {
     float L1[3], L2[3], L3[3];
     levers(k, Pb, L1, L2, L3);
+    if (link < 2) { L2[0] = 0.0f; L2[1] = 0.0f; L2[2] = 0.0f; }
+    if (link < 3) { L3[0] = 0.0f; L3[1] = 0.0f; L3[2] = 0.0f; }
     for (int d = 0; d < 3; ++d) {
         float db[3];
-        dir_world_to_base(m, f, dw[d], db);
-        c->dir[d][0] = dw[d][0]; c->dir[d][1] = dw[d][1]; c->dir[d][2] = dw[d][2];
-        c->Jf[d][0] = dot3(L1, db); c->Jf[d][1] = dot3(L2, db); c->Jf[d][2] = dot3(L3, db);
-        sym3_mul(k->Minv, c->Jf[d], c->Wf[d]);
-        float D = dot3(c->Jf[d], c->Wf[d]);
-        if (with_cube) {
-            float rxd[3];
-            cross3(rc, dw[d], rxd);
-            D = FMA(dot3(rxd, rxd), inv_I, D + inv_m);
-        }
-        c->Dinv[d] = f_rcp2(D);
+        dir_world_to_base(m, f, dirs[d], db);
+        J[d][0] = dot3(L1, db); J[d][1] = dot3(L2, db); J[d][2] = dot3(L3, db);
+        sym3_mul(k->Minv, J[d], W[d]);
+        Dd[d] = dot3(J[d], W[d]);
     }
-    c->rc[0] = rc[0]; c->rc[1] = rc[1]; c->rc[2] = rc[2];
+}
+
+/* g(s) = d . (x - clamp(x)) with x = a + s d: half the derivative of the squared distance between the segment point
+ * x(s) and the box [-hc, hc]^3; monotone non-decreasing and piecewise linear in s */
+static inline float seg_box_g(const float a[3], const float d[3], float s, float hc) {
+    float e[3];
+    for (int i = 0; i < 3; ++i) { float x = FMA(s, d[i], a[i]); e[i] = x - f_clamp(x, -hc, hc); }
+    return dot3(d, e);
+}
+/* Closest points between the segment a + s (b - a) and the box [-hc, hc]^3, all in the box frame, EXACT: g changes
+ * slope only where a coordinate of x(s) crosses +-hc (at most six breakpoints), so the root of g lies on the straight
+ * piece between the last breakpoint with g <= 0 and the first with g > 0 (end points included) and is found by one
+ * linear interpolation - no iteration (4 alternating projections, the round-1 method, were off by up to 18 mm when the
+ * segment runs nearly parallel to a face; tests/test_contact_lcp_reference.py caught it).  x on the segment, y on the
+ * box, unit direction nc from y to x, gap = |x - y| - radius.  A segment point inside the box is pushed out through
+ * the nearest face. */
+static void seg_box(const float a[3], const float b[3], float hc, float radius, float* gap_out, float x[3], float y[3],
+                    float nc[3]) {
+    float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    const float g0 = seg_box_g(a, d, 0.0f, hc), g1 = seg_box_g(a, d, 1.0f, hc);
+    float lo = 0.0f, glo = g0, hi = 1.0f, ghi = g1;
+    for (int i = 0; i < 3; ++i) {
+        const float ad = f_abs(d[i]);
+        const int ok = ad > 1e-9f;
+        float inv = ok ? f_rcp(ad) : 0.0f;
+        inv = (d[i] < 0.0f) ? -inv : inv;
+        for (int side = 0; side < 2; ++side) {
+            const float sb = ((side ? hc : -hc) - a[i]) * inv;
+            const float gb = seg_box_g(a, d, sb, hc);
+            const int valid = ok && sb > 0.0f && sb < 1.0f;
+            if (valid && gb <= 0.0f && sb > lo) { lo = sb; glo = gb; }
+            if (valid && gb > 0.0f && sb < hi) { hi = sb; ghi = gb; }
+        }
+    }
+    float s = f_clamp(FMA(-glo, (hi - lo) * f_rcp(f_max(ghi - glo, 1e-30f)), lo), lo, hi);
+    if (g0 > 0.0f) s = 0.0f;
+    if (!(g1 > 0.0f)) s = 1.0f;
+    for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
+    float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
+    float dist2 = dot3(ev, ev);
+    if (dist2 > 1e-12f) {
+        float inv = f_rsqrt(dist2);
+        float dist = dist2 * inv;
+        nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
+        *gap_out = dist - radius;
+    } else {
+        int bi = 0;
+        float best = f_abs(x[0]) - hc;
+        for (int i = 1; i < 3; ++i) {
+            float p = f_abs(x[i]) - hc;
+            if (p > best) { best = p; bi = i; }
+        }
+        nc[0] = 0.0f; nc[1] = 0.0f; nc[2] = 0.0f;
+        float sg = (x[bi] < 0.0f) ? -1.0f : 1.0f;
+        nc[bi] = sg;
+        y[bi] = sg * hc;
+        *gap_out = best - radius;
+    }
+}
+
+/* closest points of two segments p1-q1 and p2-q2 (Ericson, Real-Time Collision Detection 5.1.9; both segments have
+ * positive length) */
+static void seg_seg(const float p1[3], const float q1[3], const float p2[3], const float q2[3], float c1[3], float c2[3]) {
+    float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]};
+    float d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
+    float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2);
+    float denom = FMA(a, e, -(b * b));
+    float ia = f_rcp(a), ie = f_rcp(e);
+    float s = 0.0f;
+    if (denom > 1e-12f) s = f_clamp(FMA(b, f, -(c * e)) * f_rcp(denom), 0.0f, 1.0f);
+    float t = FMA(b, s, f) * ie;
+    if (t < 0.0f) { t = 0.0f; s = f_clamp(-c * ia, 0.0f, 1.0f); }
+    else if (t > 1.0f) { t = 1.0f; s = f_clamp((b - c) * ia, 0.0f, 1.0f); }
+    for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
+}
+
+/* inner radius of the boundary at height z (a stack of vertical cylinders; 1e3 = no wall) */
+static float wall_radius_at(const TfModel* m, float z) {
+    float r = 1000.0f;
+    if (z < m->wall_z[3]) r = m->wall_r[3];
+    if (z < m->wall_z[2]) r = m->wall_r[2];
+    if (z < m->wall_z[1]) r = m->wall_r[1];
+    if (z < m->wall_z[0]) r = m->wall_r[0];
+    return r;
 }
 
 static void cube_corner(const float R[9], float hc, int k, float sk, int idx, float r[3]) {
@@ -782,6 +888,8 @@ static void cube_corner(const float R[9], float hc, int k, float sk, int idx, fl
     y[b] = (idx & 2) ? hc : -hc;
     mat3_mul(R, y, r);
 }
+
+#define TF_FF_ITERATIONS 4
 
 /* ---- PGS row kernels (identical arithmetic in the HIP file) ---- */
 static inline float solve_normal(float* lam, float Dinv, float vrel, float bias) {
@@ -796,30 +904,24 @@ static inline float solve_tangent(float* lam, float Dinv, float vrel, float lim)
     *lam = ln;
     return dl;
 }
-/* axis-aligned rows of a cube corner with arm r: direction +z / +x / +y */
-static inline void cube_row_z(CubeContact* c, int slot, int is_normal, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
-    const float* r = c->r;
-    float vrel = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
-    float dl = is_normal ? solve_normal(&c->lam[slot], c->Dinv[slot], vrel, c->bias)
-                         : solve_tangent(&c->lam[slot], c->Dinv[slot], vrel, mu * c->lam[0]);
+/* axis-aligned rows of a cube corner with arm r: direction +z / +x / +y.  *_vrel: relative velocity of the row,
+ * *_apply: effect of the impulse dl on the cube */
+static inline float cz_vrel(const float r[3], const float v[3], const float w[3]) { return FMA(r[1], w[0], FMA(-r[0], w[1], v[2])); }
+static inline void cz_apply(const float r[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
     float s = dl * inv_m, q = dl * inv_I;
     v[2] = v[2] + s;
     w[0] = FMA(r[1], q, w[0]);
     w[1] = FMA(-r[0], q, w[1]);
 }
-static inline void cube_row_x(CubeContact* c, int slot, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
-    const float* r = c->r;
-    float vrel = FMA(r[2], w[1], FMA(-r[1], w[2], v[0]));
-    float dl = solve_tangent(&c->lam[slot], c->Dinv[slot], vrel, mu * c->lam[0]);
+static inline float cx_vrel(const float r[3], const float v[3], const float w[3]) { return FMA(r[2], w[1], FMA(-r[1], w[2], v[0])); }
+static inline void cx_apply(const float r[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
     float s = dl * inv_m, q = dl * inv_I;
     v[0] = v[0] + s;
     w[1] = FMA(r[2], q, w[1]);
     w[2] = FMA(-r[1], q, w[2]);
 }
-static inline void cube_row_y(CubeContact* c, int slot, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
-    const float* r = c->r;
-    float vrel = FMA(-r[2], w[0], FMA(r[0], w[2], v[1]));
-    float dl = solve_tangent(&c->lam[slot], c->Dinv[slot], vrel, mu * c->lam[0]);
+static inline float cy_vrel(const float r[3], const float v[3], const float w[3]) { return FMA(-r[2], w[0], FMA(r[0], w[2], v[1])); }
+static inline void cy_apply(const float r[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
     float s = dl * inv_m, q = dl * inv_I;
     v[1] = v[1] + s;
     w[0] = FMA(-r[2], q, w[0]);
@@ -838,28 +940,57 @@ static inline void wall_arm_t(const CubeContact* c, float b[3]) {
     b[1] = -(r[2] * c->n[1]);
     b[2] = FMA(r[0], c->n[0], r[1] * c->n[1]);
 }
-static inline void wall_row_n(CubeContact* c, float inv_m, float inv_I, float v[3], float w[3]) {
-    float a[3];
-    wall_arm_n(c, a);
-    float vrel = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c->n[1], v[1], c->n[0] * v[0]))));
-    float dl = solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias);
+static inline float wn_vrel(const CubeContact* c, const float a[3], const float v[3], const float w[3]) {
+    return FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c->n[1], v[1], c->n[0] * v[0]))));
+}
+static inline void wn_apply(const CubeContact* c, const float a[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
     float s = dl * inv_m, q = dl * inv_I;
     v[0] = FMA(c->n[0], s, v[0]);
     v[1] = FMA(c->n[1], s, v[1]);
     w[0] = FMA(a[0], q, w[0]); w[1] = FMA(a[1], q, w[1]); w[2] = FMA(a[2], q, w[2]);
 }
-static inline void wall_row_t(CubeContact* c, float mu, float inv_m, float inv_I, float v[3], float w[3]) {
-    float b[3];
-    wall_arm_t(c, b);
-    float vrel = FMA(b[2], w[2], FMA(b[1], w[1], FMA(b[0], w[0], FMA(c->n[0], v[1], -(c->n[1] * v[0])))));
-    float dl = solve_tangent(&c->lam[1], c->Dinv[1], vrel, mu * c->lam[0]);
+static inline float wt_vrel(const CubeContact* c, const float b[3], const float v[3], const float w[3]) {
+    return FMA(b[2], w[2], FMA(b[1], w[1], FMA(b[0], w[0], FMA(c->n[0], v[1], -(c->n[1] * v[0])))));
+}
+static inline void wt_apply(const CubeContact* c, const float b[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
     float s = dl * inv_m, q = dl * inv_I;
     v[0] = FMA(-c->n[1], s, v[0]);
     v[1] = FMA(c->n[0], s, v[1]);
     w[0] = FMA(b[0], q, w[0]); w[1] = FMA(b[1], q, w[1]); w[2] = FMA(b[2], q, w[2]);
 }
 
-/* One solver substep of length h for one env. */
+/* fingertip sphere against one feature of the arena: finger-only rows */
+typedef struct {
+    int active;
+    float J[3][3], W[3][3], dir[3][3], Dinv[3], bias, lam[3], arm[3], mu;
+} TipContact;
+
+/* What one finger keeps through a substep (the "finger role": in the HIP kernel one wavefront per finger). */
+typedef struct {
+    FK k;
+    float vq[3];                  /* joint velocity being solved */
+    float Aw[3], Bw[3], Tw[3];    /* distal capsule end points and tip-link origin, world */
+    float Bb[3];                  /* tip sphere centre, base frame */
+    /* finger-cube contact: joint-space rows (the contact-space record goes to the cube role) */
+    int fc_link;
+    float fcJ[3][3], fcW[3][3], fc_arm[3];
+    /* fingertip sphere against the floor (tc[0]) and against the boundary wall (tc[1]) */
+    TipContact tc[2];
+    /* joint / velocity limit rows */
+    float vlo[3], vhi[3], lim_dinv[3], lim_lam[3];
+} FingerRole;
+
+/* Contact-space record of one finger-cube contact, handed to the cube role (LDS in the HIP kernel): the 3x3 block
+ * A = J M^-1 J^T of the finger side, the cube-side directions and arms, and the running contact-point velocity u. */
+typedef struct {
+    float A[6];                   /* 00 01 02 11 12 22 */
+    float Dinv[3], bias, lam[3];
+    float dir[3][3], rxd[3][3];
+    float u[3], dl[3];
+} FcRecord;
+
+/* One solver substep of length h for one env.  Phases and roles: F1 free motion of each finger,
+ * C1 cube free motion and corner contacts, FF finger-finger pre-pass, F2 finger contact generation, then the sweeps. */
 static void substep(const struct TfHandle_* H, Env* e, float h) {
     const TfConfig* cfg = &H->cfg;
     const TfModel* m = &cfg->model;
@@ -868,25 +999,35 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     const float cube_mass = m->cube_mass * e->dr[0];
     const float cube_inertia = m->cube_inertia * e->dr[0] * e->dr[1] * e->dr[1];
     const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
-    const float mu_fc = m->mu_finger_cube * e->dr[2], mu_tf = m->mu_tip_floor * e->dr[2];
-    const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2];
-    const float rest_f = m->restitution_finger * e->dr[5];
-    FK fk[3];
-    float vq[9];                 /* joint velocities being solved */
+    const float mu_fc = m->mu_finger_cube * e->dr[2], mu_tf = m->mu_tip_floor * e->dr[2], mu_tw = m->mu_tip_wall * e->dr[2];
+    const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2], mu_ff = m->mu_finger_finger * e->dr[2];
+    const float rest_f = m->restitution_finger * e->dr[5], rest_ff = m->restitution_ff * e->dr[5];
+    const float ws = m->warm_start;
+    FingerRole fr[3];
+    FcRecord rec[3];
     float v[3], w[3];            /* cube velocities being solved  */
-    /* ---- free motion ---- */
+    /* ---- F1: free motion of the fingers ---- */
     for (int f = 0; f < 3; ++f) {
+        FingerRole* g = &fr[f];
         float M[6], bias[3], rhs[3], acc[3];
-        fk_setup(m, &e->q[3 * f], &fk[f]);
-        finger_dynamics(m, &fk[f], &e->qd[3 * f], cfg->gravity, M, bias);
+        fk_setup(m, &e->q[3 * f], &g->k);
+        finger_dynamics(m, &g->k, &e->qd[3 * f], cfg->gravity, M, bias);
         for (int j = 0; j < 6; ++j) M[j] = M[j] * e->dr[4];       /* link-mass factor: masses and inertias scale together */
         for (int j = 0; j < 3; ++j) bias[j] = bias[j] * e->dr[4];
-        inv3sym(M, fk[f].Minv);
+        inv3sym(M, g->k.Minv);
         for (int j = 0; j < 3; ++j) rhs[j] = e->tau[3 * f + j] - bias[j];
-        sym3_mul(fk[f].Minv, rhs, acc);
+        sym3_mul(g->k.Minv, rhs, acc);
         float damp = 1.0f - h * m->link_angular_damping;
-        for (int j = 0; j < 3; ++j) vq[3 * f + j] = FMA(h, acc[j], e->qd[3 * f + j]) * damp;
+        for (int j = 0; j < 3; ++j) g->vq[j] = FMA(h, acc[j], e->qd[3 * f + j]) * damp;
+        float Ab[3], To[3];
+        link_point(&g->k, 3, m->cap_a, Ab);
+        link_point(&g->k, 3, m->cap_b, g->Bb);
+        link_point(&g->k, 3, m->tip_origin, To);
+        base_to_world(m, f, Ab, g->Aw);
+        base_to_world(m, f, g->Bb, g->Bw);
+        base_to_world(m, f, To, g->Tw);
     }
+    /* ---- C1: free motion of the cube, corner contacts against the arena ---- */
     {
         float dl = 1.0f - h * m->cube_linear_damping, da = 1.0f - h * m->cube_angular_damping;
         for (int i = 0; i < 3; ++i) {
@@ -894,104 +1035,19 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             w[i] = e->cw[i] * da;
         }
     }
-    /* ---- contact generation (positions at the start of the substep) ---- */
     float R[9];
     quat_to_rot(e->cq, R);
     const float hc = m->cube_half * e->dr[1];
-    FingerContact fc[3], tf_[3];
     CubeContact cf[4], cwl[4];
-    for (int f = 0; f < 3; ++f) {
-        const FK* k = &fk[f];
-        float t[3], Ab[3], Bb[3], Aw[3], Bw[3], To[3], Tw[3];
-        rot_link(k, 3, m->cap_a, t);
-        Ab[0] = k->p3[0] + t[0]; Ab[1] = k->p3[1] + t[1]; Ab[2] = k->p3[2] + t[2];
-        rot_link(k, 3, m->cap_b, t);
-        Bb[0] = k->p3[0] + t[0]; Bb[1] = k->p3[1] + t[1]; Bb[2] = k->p3[2] + t[2];
-        rot_link(k, 3, m->tip_origin, t);
-        To[0] = k->p3[0] + t[0]; To[1] = k->p3[1] + t[1]; To[2] = k->p3[2] + t[2];
-        base_to_world(m, f, Ab, Aw);
-        base_to_world(m, f, Bb, Bw);
-        base_to_world(m, f, To, Tw);
-        /* --- capsule (distal link) vs cube: closest points by alternating projection, cube frame --- */
-        FingerContact* c = &fc[f];
-        memset(c, 0, sizeof(*c));
-        float da[3] = {Aw[0] - e->cp[0], Aw[1] - e->cp[1], Aw[2] - e->cp[2]};
-        float db[3] = {Bw[0] - e->cp[0], Bw[1] - e->cp[1], Bw[2] - e->cp[2]};
-        float a[3], b[3];
-        mat3T_mul(R, da, a);
-        mat3T_mul(R, db, b);
-        float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-        float inv_dd = f_rcp(dot3(d, d));
-        float s = 1.0f, x[3], y[3];
-        for (int it = 0; it < 4; ++it) {
-            for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
-            float ya[3] = {y[0] - a[0], y[1] - a[1], y[2] - a[2]};
-            s = f_clamp(dot3(ya, d) * inv_dd, 0.0f, 1.0f);
-        }
-        for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
-        float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
-        float dist2 = dot3(ev, ev);
-        float nc[3], gap;
-        if (dist2 > 1e-12f) {
-            float inv = f_rsqrt(dist2);
-            float dist = dist2 * inv;
-            nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
-            gap = dist - m->cap_radius;
-        } else {
-            /* capsule axis inside the box: push out through the nearest face */
-            int bi = 0;
-            float best = f_abs(x[0]) - hc;
-            for (int i = 1; i < 3; ++i) {
-                float p = f_abs(x[i]) - hc;
-                if (p > best) { best = p; bi = i; }
-            }
-            nc[0] = 0.0f; nc[1] = 0.0f; nc[2] = 0.0f;
-            float sg = (x[bi] < 0.0f) ? -1.0f : 1.0f;
-            nc[bi] = sg;
-            y[bi] = sg * hc;
-            gap = best - m->cap_radius;
-        }
-        if (gap < m->contact_margin) {
-            float n_w[3], rc[3], xw[3];
-            mat3_mul(R, nc, n_w);
-            mat3_mul(R, y, rc);
-            mat3_mul(R, x, xw);
-            /* finger-side contact point (world): axis point minus r n */
-            float Pw[3] = {FMA(-m->cap_radius, n_w[0], e->cp[0] + xw[0]), FMA(-m->cap_radius, n_w[1], e->cp[1] + xw[1]),
-                           FMA(-m->cap_radius, n_w[2], e->cp[2] + xw[2])};
-            float Pr[3] = {Pw[0], Pw[1], Pw[2] - m->base_height};
-            float Pb[3];
-            dir_world_to_base(m, f, Pr, Pb);
-            c->active = 1;
-            finger_rows(m, f, k, Pb, n_w, rc, 1, inv_m, inv_I, c);
-            for (int i = 0; i < 3; ++i) c->arm[i] = Pw[i] - Tw[i];
-            float rxn[3];
-            cross3(rc, c->dir[0], rxn);
-            float vn0 = dot3(c->Jf[0], &vq[3 * f]) - (dot3(c->dir[0], v) + dot3(rxn, w));
-            c->bias = contact_bias(m, gap, vn0, inv_h, rest_f);
-        }
-        /* --- tip sphere vs floor --- */
-        FingerContact* g = &tf_[f];
-        memset(g, 0, sizeof(*g));
-        float gapf = Bw[2] - m->cap_radius;
-        if (gapf < m->contact_margin) {
-            float n_w[3] = {0.0f, 0.0f, 1.0f}, zero[3] = {0.0f, 0.0f, 0.0f};
-            float Pb[3] = {Bb[0], Bb[1], Bb[2] - m->cap_radius};
-            float Pw[3] = {Bw[0], Bw[1], Bw[2] - m->cap_radius};
-            g->active = 1;
-            finger_rows(m, f, k, Pb, n_w, zero, 0, inv_m, inv_I, g);
-            for (int i = 0; i < 3; ++i) g->arm[i] = Pw[i] - Tw[i];
-            float vn0 = dot3(g->Jf[0], &vq[3 * f]);
-            g->bias = contact_bias(m, gapf, vn0, inv_h, rest_f);
-        }
-    }
-    /* --- cube vs floor: the four corners of the face that points down most --- */
-    {
+    float cf_face, cw_face;
+    {   /* cube vs floor: the four corners of the face that points down most */
         int k = 0;
         float best = f_abs(R[6]);
         if (f_abs(R[7]) > best) { best = f_abs(R[7]); k = 1; }
         if (f_abs(R[8]) > best) { best = f_abs(R[8]); k = 2; }
         float sk = (R[6 + k] > 0.0f) ? -1.0f : 1.0f;
+        cf_face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
+        const float keep = (cf_face == e->cf_face) ? ws : 0.0f;
         for (int i = 0; i < 4; ++i) {
             CubeContact* c = &cf[i];
             memset(c, 0, sizeof(*c));
@@ -999,17 +1055,16 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             float gap = e->cp[2] + c->r[2];
             if (gap < m->contact_margin) {
                 const float* r = c->r;
-                c->active = 1;
                 c->Dinv[0] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));   /* +z */
                 c->Dinv[1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));   /* +x */
                 c->Dinv[2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));   /* +y */
-                float vn0 = FMA(r[1], w[0], FMA(-r[0], w[1], v[2]));
+                float vn0 = cz_vrel(r, v, w);
                 c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
+                for (int d = 0; d < 3; ++d) c->lam[d] = e->lam_cf[i][d] * keep;
             }
         }
     }
-    /* --- cube vs boundary wall: the four corners of the face that points outward most --- */
-    {
+    {   /* cube vs boundary wall: the four corners of the face that points outward most */
         float rc2 = FMA(e->cp[0], e->cp[0], e->cp[1] * e->cp[1]);
         float irc = f_rsqrt(f_max(rc2, 1e-24f));
         float rho_c = rc2 * irc;
@@ -1023,18 +1078,19 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
         if (f_abs(pr[2]) > best) { best = f_abs(pr[2]); k = 2; }
         float sk = (pr[k] < 0.0f) ? -1.0f : 1.0f;
+        cw_face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
+        const float keep = (cw_face == e->cw_face) ? ws : 0.0f;
         for (int i = 0; i < 4; ++i) {
             CubeContact* c = &cwl[i];
             memset(c, 0, sizeof(*c));
             cube_corner(R, hc, k, sk, i, c->r);
-            float px = e->cp[0] + c->r[0], py = e->cp[1] + c->r[1];
+            float px = e->cp[0] + c->r[0], py = e->cp[1] + c->r[1], pz = e->cp[2] + c->r[2];
             float rho2 = FMA(px, px, py * py);
             float inv = f_rsqrt(f_max(rho2, 1e-24f));
             float rho = rho2 * inv;
-            float gap = m->wall_radius - rho;
+            float gap = wall_radius_at(m, pz) - rho;
             if (any && gap < m->contact_margin && rho > 1e-6f) {
                 const float* r = c->r;
-                c->active = 1;
                 c->n[0] = -px * inv; c->n[1] = -py * inv;
                 float a[3], b[3];
                 wall_arm_n(c, a);
@@ -1042,98 +1098,311 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 c->Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
                 c->Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
                 c->Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
-                float vn0 = FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(c->n[1], v[1], c->n[0] * v[0]))));
+                float vn0 = wn_vrel(c, a, v, w);
                 c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
+                for (int d = 0; d < 3; ++d) c->lam[d] = e->lam_cw[i][d] * keep;
             }
         }
     }
-    /* --- joint limit / velocity limit rows --- */
-    float vlo[9], vhi[9], lim_dinv[9], lim_lam[9];
-    for (int j = 0; j < 9; ++j) {
-        int f = j / 3, jj = j % 3;
-        static const int diag[3] = {0, 3, 5};
-        vlo[j] = f_clamp((m->q_lo[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
-        vhi[j] = f_clamp((m->q_hi[jj] - e->q[j]) * inv_h, -m->qd_max, m->qd_max);
-        lim_dinv[j] = f_rcp(fk[f].Minv[diag[jj]]);
-        lim_lam[j] = 0.0f;
+    /* ---- FF: finger-finger contacts (distal capsules), solved before the sweeps on the free velocities: the pairs (0,1),
+     * (1,2), (2,0) in turn, TF_FF_ITERATIONS Gauss-Seidel iterations over the three rows of each pair; the finger contacts below measure their approach speeds on the velocities before this pass ---- */
+    float vq_ff[3][3];
+    for (int f = 0; f < 3; ++f) for (int j = 0; j < 3; ++j) vq_ff[f][j] = fr[f].vq[j];
+    for (int p = 0; p < 3; ++p) {
+        const int fa = p, fb = (p + 1) % 3;
+        float Pa[3], Pb[3];
+        seg_seg(fr[fa].Aw, fr[fa].Bw, fr[fb].Aw, fr[fb].Bw, Pa, Pb);
+        float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
+        float dist2 = dot3(dv, dv);
+        if (!(dist2 > 1e-12f)) continue;
+        float inv = f_rsqrt(dist2);
+        float dist = dist2 * inv;
+        float gap = dist - 2.0f * m->cap_radius;
+        if (!(gap < m->contact_margin)) continue;
+        float dirs[3][3];
+        for (int i = 0; i < 3; ++i) dirs[0][i] = dv[i] * inv;          /* from finger b to finger a */
+        tangent_basis(dirs[0], dirs[1], dirs[2]);
+        float Ca[3], Cb[3], Cab[3], Cbb[3];
+        for (int i = 0; i < 3; ++i) { Ca[i] = FMA(-m->cap_radius, dirs[0][i], Pa[i]); Cb[i] = FMA(m->cap_radius, dirs[0][i], Pb[i]); }
+        world_to_base(m, fa, Ca, Cab);
+        world_to_base(m, fb, Cb, Cbb);
+        float Ja[3][3], Wa[3][3], Da[3], Jb[3][3], Wb[3][3], Db[3];
+        finger_jac(m, fa, &fr[fa].k, 3, Cab, dirs, Ja, Wa, Da);
+        finger_jac(m, fb, &fr[fb].k, 3, Cbb, dirs, Jb, Wb, Db);
+        float* va = vq_ff[fa];
+        float* vb = vq_ff[fb];
+        float vn0 = dot3(Ja[0], va) - dot3(Jb[0], vb);
+        float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+        float Dinv[3], lam[3] = {0.0f, 0.0f, 0.0f};
+        for (int d = 0; d < 3; ++d) Dinv[d] = f_rcp2(Da[d] + Db[d]);
+        for (int it = 0; it < TF_FF_ITERATIONS; ++it) {
+            for (int d = 0; d < 3; ++d) {
+                float vrel = dot3(Ja[d], va) - dot3(Jb[d], vb);
+                float dl = (d == 0) ? solve_normal(&lam[0], Dinv[0], vrel, bias) : solve_tangent(&lam[d], Dinv[d], vrel, mu_ff * lam[0]);
+                for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[d][j], dl, va[j]); vb[j] = FMA(-Wb[d][j], dl, vb[j]); }
+            }
+        }
+    }
+    /* ---- F2: contacts of each finger ---- */
+    float cube_top_check = e->cp[2];
+    for (int f = 0; f < 3; ++f) {
+        FingerRole* g = &fr[f];
+        const FK* k = &g->k;
+        FcRecord* rc_ = &rec[f];
+        memset(rc_, 0, sizeof(*rc_));
+        /* --- finger vs cube: the link capsule with the smallest gap holds the contact --- */
+        float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
+        int link = 0;
+        for (int cand = 3; cand >= 1; --cand) {
+            if (cand == 1 && !(cube_top_check > m->upper_check_z)) continue;
+            const float* la = (cand == 3) ? m->cap_a : ((cand == 2) ? m->cap2_a : m->cap1_a);
+            const float* lb = (cand == 3) ? m->cap_b : ((cand == 2) ? m->cap2_b : m->cap1_b);
+            const float rad = (cand == 3) ? m->cap_radius : ((cand == 2) ? m->cap2_radius : m->cap1_radius);
+            float Ab[3], Bb[3], Aw[3], Bw[3];
+            if (cand == 3) { for (int i = 0; i < 3; ++i) { Aw[i] = g->Aw[i]; Bw[i] = g->Bw[i]; } }
+            else {
+                link_point(k, cand, la, Ab);
+                link_point(k, cand, lb, Bb);
+                base_to_world(m, f, Ab, Aw);
+                base_to_world(m, f, Bb, Bw);
+            }
+            float da[3] = {Aw[0] - e->cp[0], Aw[1] - e->cp[1], Aw[2] - e->cp[2]};
+            float db[3] = {Bw[0] - e->cp[0], Bw[1] - e->cp[1], Bw[2] - e->cp[2]};
+            float a[3], b[3], gx[3], gy[3], gn[3], gg;
+            mat3T_mul(R, da, a);
+            mat3T_mul(R, db, b);
+            seg_box(a, b, hc, rad, &gg, gx, gy, gn);
+            if (link == 0 || gg < gap) {
+                link = cand; gap = gg; radius = rad;
+                for (int i = 0; i < 3; ++i) { x[i] = gx[i]; y[i] = gy[i]; nc[i] = gn[i]; }
+            }
+        }
+        g->fc_link = 0;
+        for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) { g->fcJ[d][j] = 0.0f; g->fcW[d][j] = 0.0f; }
+        g->fc_arm[0] = 0.0f; g->fc_arm[1] = 0.0f; g->fc_arm[2] = 0.0f;
+        if (gap < m->contact_margin) {
+            float rcv[3], xw[3], Dd[3];
+            mat3_mul(R, nc, rc_->dir[0]);
+            mat3_mul(R, y, rcv);
+            mat3_mul(R, x, xw);
+            tangent_basis(rc_->dir[0], rc_->dir[1], rc_->dir[2]);
+            /* finger-side contact point (world): axis point minus r n */
+            float Pw[3] = {FMA(-radius, rc_->dir[0][0], e->cp[0] + xw[0]), FMA(-radius, rc_->dir[0][1], e->cp[1] + xw[1]),
+                           FMA(-radius, rc_->dir[0][2], e->cp[2] + xw[2])};
+            float Pb[3];
+            world_to_base(m, f, Pw, Pb);
+            g->fc_link = link;
+            finger_jac(m, f, k, link, Pb, rc_->dir, g->fcJ, g->fcW, Dd);
+            for (int d = 0; d < 3; ++d) {
+                cross3(rcv, rc_->dir[d], rc_->rxd[d]);
+                rc_->Dinv[d] = f_rcp2(FMA(dot3(rc_->rxd[d], rc_->rxd[d]), inv_I, Dd[d] + inv_m));
+            }
+            rc_->A[0] = Dd[0];                        rc_->A[1] = dot3(g->fcJ[0], g->fcW[1]); rc_->A[2] = dot3(g->fcJ[0], g->fcW[2]);
+            rc_->A[3] = Dd[1];                        rc_->A[4] = dot3(g->fcJ[1], g->fcW[2]);
+            rc_->A[5] = Dd[2];
+            if (link == 3) for (int i = 0; i < 3; ++i) g->fc_arm[i] = Pw[i] - g->Tw[i];
+            float vn0 = dot3(g->fcJ[0], g->vq) - (dot3(rc_->dir[0], v) + dot3(rc_->rxd[0], w));
+            rc_->bias = contact_bias(m, gap, vn0, inv_h, rest_f);
+            if ((float)link == e->fc_link[f]) {          /* same link as in the last substep: seed the impulses */
+                const float* pl = e->lam_fc[f];
+                float l0 = pl[0] * ws;
+                float lim = mu_fc * l0;
+                rc_->lam[0] = l0;
+                rc_->lam[1] = f_clamp(dot3(&pl[1], rc_->dir[1]) * ws, -lim, lim);
+                rc_->lam[2] = f_clamp(dot3(&pl[1], rc_->dir[2]) * ws, -lim, lim);
+            }
+        }
+        /* --- fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1) --- */
+        {
+            float rho2 = FMA(g->Bw[0], g->Bw[0], g->Bw[1] * g->Bw[1]);
+            float inv = f_rsqrt(f_max(rho2, 1e-24f));
+            float rho = rho2 * inv;
+            for (int t = 0; t < 2; ++t) {
+                TipContact* c = &g->tc[t];
+                memset(c, 0, sizeof(*c));
+                float gp_ = (t == 0) ? (g->Bw[2] - m->cap_radius) : ((wall_radius_at(m, g->Bw[2]) - rho) - m->cap_radius);
+                if (t == 1 && !(rho > 1e-6f)) continue;
+                if (!(gp_ < m->contact_margin)) continue;
+                float n_w[3] = {0.0f, 0.0f, 1.0f};
+                if (t == 1) { n_w[0] = -g->Bw[0] * inv; n_w[1] = -g->Bw[1] * inv; n_w[2] = 0.0f; }
+                for (int i = 0; i < 3; ++i) c->dir[0][i] = n_w[i];
+                tangent_basis(c->dir[0], c->dir[1], c->dir[2]);
+                float Pw[3] = {FMA(-m->cap_radius, n_w[0], g->Bw[0]), FMA(-m->cap_radius, n_w[1], g->Bw[1]),
+                               FMA(-m->cap_radius, n_w[2], g->Bw[2])};
+                float Pb[3], Dd[3];
+                world_to_base(m, f, Pw, Pb);
+                c->active = 1;
+                c->mu = (t == 0) ? mu_tf : mu_tw;
+                finger_jac(m, f, k, 3, Pb, c->dir, c->J, c->W, Dd);
+                for (int d = 0; d < 3; ++d) c->Dinv[d] = f_rcp2(Dd[d]);
+                for (int i = 0; i < 3; ++i) c->arm[i] = Pw[i] - g->Tw[i];
+                float vn0 = dot3(c->J[0], g->vq);
+                c->bias = contact_bias(m, gp_, vn0, inv_h, rest_f);
+                const float* pl = (t == 0) ? e->lam_tf[f] : e->lam_tw[f];      /* zero when the contact was not there */
+                float l0 = pl[0] * ws;
+                float lim = c->mu * l0;
+                c->lam[0] = l0;
+                c->lam[1] = f_clamp(pl[1] * ws, -lim, lim);
+                c->lam[2] = f_clamp(pl[2] * ws, -lim, lim);
+            }
+        }
+        /* --- joint limit / velocity limit rows --- */
+        for (int jj = 0; jj < 3; ++jj) {
+            static const int diag[3] = {0, 3, 5};
+            g->vlo[jj] = f_clamp((m->q_lo[jj] - e->q[3 * f + jj]) * inv_h, -m->qd_max, m->qd_max);
+            g->vhi[jj] = f_clamp((m->q_hi[jj] - e->q[3 * f + jj]) * inv_h, -m->qd_max, m->qd_max);
+            g->lim_dinv[jj] = f_rcp(k->Minv[diag[jj]]);
+            g->lim_lam[jj] = 0.0f;
+        }
+        /* --- velocity after the finger-finger pass, seeded impulses applied on the finger side, contact-point velocity --- */
+        for (int j = 0; j < 3; ++j) g->vq[j] = vq_ff[f][j];
+        for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) g->vq[j] = FMA(g->fcW[d][j], rc_->lam[d], g->vq[j]);
+        for (int t = 0; t < 2; ++t)
+            for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) g->vq[j] = FMA(g->tc[t].W[d][j], g->tc[t].lam[d], g->vq[j]);
+        for (int d = 0; d < 3; ++d) rc_->u[d] = dot3(g->fcJ[d], g->vq);
+    }
+    /* ---- seeded impulses on the cube side: finger contacts, floor corners, wall corners ---- */
+    for (int f = 0; f < 3; ++f) {
+        const FcRecord* c = &rec[f];
+        for (int d = 0; d < 3; ++d) {
+            float sc = c->lam[d] * inv_m, q = c->lam[d] * inv_I;
+            for (int j = 0; j < 3; ++j) { v[j] = FMA(-c->dir[d][j], sc, v[j]); w[j] = FMA(-c->rxd[d][j], q, w[j]); }
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        cz_apply(cf[i].r, cf[i].lam[0], inv_m, inv_I, v, w);
+        cx_apply(cf[i].r, cf[i].lam[1], inv_m, inv_I, v, w);
+        cy_apply(cf[i].r, cf[i].lam[2], inv_m, inv_I, v, w);
+    }
+    for (int i = 0; i < 4; ++i) {
+        float a[3], b[3];
+        wall_arm_n(&cwl[i], a);
+        wall_arm_t(&cwl[i], b);
+        wn_apply(&cwl[i], a, cwl[i].lam[0], inv_m, inv_I, v, w);
+        wt_apply(&cwl[i], b, cwl[i].lam[1], inv_m, inv_I, v, w);
+        cz_apply(cwl[i].r, cwl[i].lam[2], inv_m, inv_I, v, w);
     }
     /* ---- projected Gauss-Seidel ---- */
     for (int it = 0; it < cfg->solver_iterations; ++it) {
-        for (int f = 0; f < 3; ++f) {             /* finger - cube */
-            FingerContact* c = &fc[f];
-            if (!c->active) continue;
-            float* vf = &vq[3 * f];
+        /* cube role: finger-cube rows in contact space */
+        for (int f = 0; f < 3; ++f) {
+            FcRecord* c = &rec[f];
             for (int d = 0; d < 3; ++d) {
-                float rxd[3];
-                cross3(c->rc, c->dir[d], rxd);
-                float vrel = dot3(c->Jf[d], vf) - (dot3(c->dir[d], v) + dot3(rxd, w));
+                float vrel = c->u[d] - (dot3(c->dir[d], v) + dot3(c->rxd[d], w));
                 float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
                                     : solve_tangent(&c->lam[d], c->Dinv[d], vrel, mu_fc * c->lam[0]);
-                for (int j = 0; j < 3; ++j) vf[j] = FMA(c->Wf[d][j], dl, vf[j]);
+                c->dl[d] = dl;
+                const int i0 = (d == 0) ? 0 : ((d == 1) ? 1 : 2), i1 = (d == 0) ? 1 : ((d == 1) ? 3 : 4), i2 = (d == 0) ? 2 : ((d == 1) ? 4 : 5);
+                c->u[0] = FMA(c->A[i0], dl, c->u[0]);
+                c->u[1] = FMA(c->A[i1], dl, c->u[1]);
+                c->u[2] = FMA(c->A[i2], dl, c->u[2]);
                 float sc = dl * inv_m, q = dl * inv_I;
-                for (int j = 0; j < 3; ++j) { v[j] = FMA(-c->dir[d][j], sc, v[j]); w[j] = FMA(-rxd[j], q, w[j]); }
+                for (int j = 0; j < 3; ++j) { v[j] = FMA(-c->dir[d][j], sc, v[j]); w[j] = FMA(-c->rxd[d][j], q, w[j]); }
             }
         }
-        for (int f = 0; f < 3; ++f) {             /* fingertip - floor */
-            FingerContact* c = &tf_[f];
-            if (!c->active) continue;
-            float* vf = &vq[3 * f];
-            for (int d = 0; d < 3; ++d) {
-                float vrel = dot3(c->Jf[d], vf);
-                float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
-                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, mu_tf * c->lam[0]);
-                for (int j = 0; j < 3; ++j) vf[j] = FMA(c->Wf[d][j], dl, vf[j]);
+        /* finger roles: take the impulses of the finger-cube rows, then the finger-only rows, then publish u */
+        for (int f = 0; f < 3; ++f) {
+            FingerRole* g = &fr[f];
+            FcRecord* c = &rec[f];
+            float* vf = g->vq;
+            for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) vf[j] = FMA(g->fcW[d][j], c->dl[d], vf[j]);
+            for (int t = 0; t < 2; ++t) {             /* fingertip - floor, fingertip - wall */
+                TipContact* tcn = &g->tc[t];
+                for (int d = 0; d < 3; ++d) {
+                    float vrel = dot3(tcn->J[d], vf);
+                    float dl = (d == 0) ? solve_normal(&tcn->lam[0], tcn->Dinv[0], vrel, tcn->bias)
+                                        : solve_tangent(&tcn->lam[d], tcn->Dinv[d], vrel, tcn->mu * tcn->lam[0]);
+                    for (int j = 0; j < 3; ++j) vf[j] = FMA(tcn->W[d][j], dl, vf[j]);
+                }
             }
+            for (int jj = 0; jj < 3; ++jj) {          /* joint limits + velocity limit */
+                static const int col[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+                static const int diag[3] = {0, 3, 5};
+                const float* Mi = g->k.Minv;
+                float v0 = FMA(-Mi[diag[jj]], g->lim_lam[jj], vf[jj]);
+                float tgt = f_clamp(v0, g->vlo[jj], g->vhi[jj]);
+                float lam_new = (tgt - v0) * g->lim_dinv[jj];
+                float dl = lam_new - g->lim_lam[jj];
+                g->lim_lam[jj] = lam_new;
+                vf[0] = FMA(Mi[col[jj][0]], dl, vf[0]);
+                vf[1] = FMA(Mi[col[jj][1]], dl, vf[1]);
+                vf[2] = FMA(Mi[col[jj][2]], dl, vf[2]);
+            }
+            for (int d = 0; d < 3; ++d) c->u[d] = dot3(g->fcJ[d], vf);
         }
+        /* cube role: corner rows */
         for (int i = 0; i < 4; ++i) {             /* cube - floor: rows +z (normal), +x, +y */
-            cube_row_z(&cf[i], 0, 1, mu_cf, inv_m, inv_I, v, w);
-            cube_row_x(&cf[i], 1, mu_cf, inv_m, inv_I, v, w);
-            cube_row_y(&cf[i], 2, mu_cf, inv_m, inv_I, v, w);
+            CubeContact* c = &cf[i];
+            float dl = solve_normal(&c->lam[0], c->Dinv[0], cz_vrel(c->r, v, w), c->bias);
+            cz_apply(c->r, dl, inv_m, inv_I, v, w);
+            dl = solve_tangent(&c->lam[1], c->Dinv[1], cx_vrel(c->r, v, w), mu_cf * c->lam[0]);
+            cx_apply(c->r, dl, inv_m, inv_I, v, w);
+            dl = solve_tangent(&c->lam[2], c->Dinv[2], cy_vrel(c->r, v, w), mu_cf * c->lam[0]);
+            cy_apply(c->r, dl, inv_m, inv_I, v, w);
         }
         for (int i = 0; i < 4; ++i) {             /* cube - wall: rows n (normal), t, +z */
-            wall_row_n(&cwl[i], inv_m, inv_I, v, w);
-            wall_row_t(&cwl[i], mu_cw, inv_m, inv_I, v, w);
-            cube_row_z(&cwl[i], 2, 0, mu_cw, inv_m, inv_I, v, w);
-        }
-        for (int j = 0; j < 9; ++j) {             /* joint limits + velocity limit */
-            int f = j / 3, jj = j % 3;
-            static const int col[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-            static const int diag[3] = {0, 3, 5};
-            const float* Mi = fk[f].Minv;
-            float v0 = FMA(-Mi[diag[jj]], lim_lam[j], vq[j]);
-            float tgt = f_clamp(v0, vlo[j], vhi[j]);
-            float lam_new = (tgt - v0) * lim_dinv[j];
-            float dl = lam_new - lim_lam[j];
-            lim_lam[j] = lam_new;
-            vq[3 * f + 0] = FMA(Mi[col[jj][0]], dl, vq[3 * f + 0]);
-            vq[3 * f + 1] = FMA(Mi[col[jj][1]], dl, vq[3 * f + 1]);
-            vq[3 * f + 2] = FMA(Mi[col[jj][2]], dl, vq[3 * f + 2]);
+            CubeContact* c = &cwl[i];
+            float a[3], b[3];
+            wall_arm_n(c, a);
+            wall_arm_t(c, b);
+            float dl = solve_normal(&c->lam[0], c->Dinv[0], wn_vrel(c, a, v, w), c->bias);
+            wn_apply(c, a, dl, inv_m, inv_I, v, w);
+            dl = solve_tangent(&c->lam[1], c->Dinv[1], wt_vrel(c, b, v, w), mu_cw * c->lam[0]);
+            wt_apply(c, b, dl, inv_m, inv_I, v, w);
+            dl = solve_tangent(&c->lam[2], c->Dinv[2], cz_vrel(c->r, v, w), mu_cw * c->lam[0]);
+            cz_apply(c->r, dl, inv_m, inv_I, v, w);
         }
     }
-    /* ---- fingertip wrench sensor: contact impulses / h, world frame, about the tip-link origin ---- */
+    /* ---- impulses kept for the next substep; fingertip wrench sensor: contact impulses / h, world frame, about the
+     * tip-link origin (contacts on the distal link and the fingertip only) ---- */
     for (int f = 0; f < 3; ++f) {
-        for (int pass = 0; pass < 2; ++pass) {
-            const FingerContact* c = (pass == 0) ? &fc[f] : &tf_[f];
-            if (!c->active) continue;
-            float F[3];
-            for (int i = 0; i < 3; ++i)
-                F[i] = FMA(c->dir[2][i], c->lam[2], FMA(c->dir[1][i], c->lam[1], c->dir[0][i] * c->lam[0])) * inv_h;
+        const FingerRole* g = &fr[f];
+        const FcRecord* c = &rec[f];
+        float ftv[3], Fc[3];
+        for (int i = 0; i < 3; ++i) {
+            ftv[i] = FMA(c->dir[2][i], c->lam[2], c->dir[1][i] * c->lam[1]);
+            Fc[i] = FMA(c->dir[0][i], c->lam[0], ftv[i]) * inv_h;
+        }
+        e->lam_fc[f][0] = c->lam[0];
+        for (int i = 0; i < 3; ++i) e->lam_fc[f][1 + i] = ftv[i];
+        e->fc_link[f] = (float)g->fc_link;
+        for (int d = 0; d < 3; ++d) { e->lam_tf[f][d] = g->tc[0].lam[d]; e->lam_tw[f][d] = g->tc[1].lam[d]; }
+        if (g->fc_link == 3) {
             float T[3];
-            cross3(c->arm, F, T);
+            cross3(g->fc_arm, Fc, T);
+            for (int i = 0; i < 3; ++i) { e->ft[6 * f + i] += Fc[i]; e->ft[6 * f + 3 + i] += T[i]; }
+        }
+        for (int t = 0; t < 2; ++t) {
+            const TipContact* tcn = &g->tc[t];
+            if (!tcn->active) continue;
+            float F[3], T[3];
+            for (int i = 0; i < 3; ++i)
+                F[i] = FMA(tcn->dir[2][i], tcn->lam[2], FMA(tcn->dir[1][i], tcn->lam[1], tcn->dir[0][i] * tcn->lam[0])) * inv_h;
+            cross3(tcn->arm, F, T);
             for (int i = 0; i < 3; ++i) { e->ft[6 * f + i] += F[i]; e->ft[6 * f + 3 + i] += T[i]; }
         }
     }
+    for (int i = 0; i < 4; ++i) for (int d = 0; d < 3; ++d) { e->lam_cf[i][d] = cf[i].lam[d]; e->lam_cw[i][d] = cwl[i].lam[d]; }
+    e->cf_face = cf_face;
+    e->cw_face = cw_face;
     /* ---- integrate ---- */
-    for (int j = 0; j < 9; ++j) {
-        e->qd[j] = vq[j];
-        e->q[j] = f_clamp(FMA(h, vq[j], e->q[j]), m->q_lo[j % 3], m->q_hi[j % 3]);
+    for (int f = 0; f < 3; ++f) for (int jj = 0; jj < 3; ++jj) {
+        const int j = 3 * f + jj;
+        e->qd[j] = fr[f].vq[jj];
+        e->q[j] = f_clamp(FMA(h, fr[f].vq[jj], e->q[j]), m->q_lo[jj], m->q_hi[jj]);
     }
     for (int i = 0; i < 3; ++i) {
         e->cv[i] = v[i]; e->cw[i] = w[i];
         e->cp[i] = FMA(h, v[i], e->cp[i]);
     }
     quat_integrate(e->cq, e->cw, h);
-    if (cfg->goal_rotation_activate) quat_integrate(e->gq, e->gw, h);
+}
+
+/* the moving goal (goal_movement.rotation) is a free body nothing interacts with: its orientation is integrated with
+ * the same substep sequence AFTER observations, rewards and termination of the step have used the pose the step started
+ * with (reference trifinger_env.py:500-559: __update_goal_movement_post comes last) */
+static void goal_advance(const struct TfHandle_* H, Env* e, int nsub, float h) {
+    if (H->cfg.goal_rotation_activate) for (int s = 0; s < nsub; ++s) quat_integrate(e->gq, e->gw, h);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1150,6 +1419,17 @@ static void env_load(const struct TfHandle_* h, int i, Env* e) {
     for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
     for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
     for (int j = 0; j < TF_NUM_DR; ++j) e->dr[j] = ST(h, TF_S_DR + j, i);
+    for (int f = 0; f < 3; ++f) {
+        for (int j = 0; j < 4; ++j) e->lam_fc[f][j] = ST(h, TF_S_LAM_FC + 4 * f + j, i);
+        for (int j = 0; j < 3; ++j) { e->lam_tf[f][j] = ST(h, TF_S_LAM_TF + 3 * f + j, i); e->lam_tw[f][j] = ST(h, TF_S_LAM_TW + 3 * f + j, i); }
+        e->fc_link[f] = ST(h, TF_S_FC_LINK + f, i);
+    }
+    for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) {
+        e->lam_cf[c][j] = ST(h, TF_S_LAM_CF + 3 * c + j, i);
+        e->lam_cw[c][j] = ST(h, TF_S_LAM_CW + 3 * c + j, i);
+    }
+    e->cf_face = ST(h, TF_S_CF_FACE, i);
+    e->cw_face = ST(h, TF_S_CW_FACE, i);
 }
 static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_ft) {
     for (int j = 0; j < 9; ++j) { ST(h, TF_S_Q + j, i) = e->q[j]; ST(h, TF_S_QD + j, i) = e->qd[j]; ST(h, TF_S_TAU + j, i) = e->tau[j]; }
@@ -1160,6 +1440,17 @@ static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_
     for (int j = 0; j < 4; ++j) { ST(h, TF_S_CUBE_Q + j, i) = e->cq[j]; ST(h, TF_S_GOAL_Q + j, i) = e->gq[j]; }
     if (store_ft) for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
     for (int j = 0; j < TF_NUM_DR; ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
+    for (int f = 0; f < 3; ++f) {
+        for (int j = 0; j < 4; ++j) ST(h, TF_S_LAM_FC + 4 * f + j, i) = e->lam_fc[f][j];
+        for (int j = 0; j < 3; ++j) { ST(h, TF_S_LAM_TF + 3 * f + j, i) = e->lam_tf[f][j]; ST(h, TF_S_LAM_TW + 3 * f + j, i) = e->lam_tw[f][j]; }
+        ST(h, TF_S_FC_LINK + f, i) = e->fc_link[f];
+    }
+    for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) {
+        ST(h, TF_S_LAM_CF + 3 * c + j, i) = e->lam_cf[c][j];
+        ST(h, TF_S_LAM_CW + 3 * c + j, i) = e->lam_cw[c][j];
+    }
+    ST(h, TF_S_CF_FACE, i) = e->cf_face;
+    ST(h, TF_S_CW_FACE, i) = e->cw_face;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1241,6 +1532,10 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
         h->buf.steps[i] = 0;
         h->buf.successes[i] = 0;
         for (int j = 0; j < 9; ++j) e->tau[j] = 0.0f;      /* the stored torque (what an action repeat re-applies) */
+        memset(e->lam_fc, 0, sizeof(e->lam_fc)); memset(e->lam_tf, 0, sizeof(e->lam_tf)); memset(e->lam_tw, 0, sizeof(e->lam_tw));   /* solver warm start */
+        memset(e->lam_cf, 0, sizeof(e->lam_cf)); memset(e->lam_cw, 0, sizeof(e->lam_cw));
+        for (int f = 0; f < 3; ++f) e->fc_link[f] = 0.0f;
+        e->cf_face = 0.0f; e->cw_face = 0.0f;
         if (c->dr_enable) {     /* build-defined domain randomisation: scale = lo + (hi - lo) u */
             float u[4];
             rng4(c->seed, gid, count, RNG_DR, u);
@@ -1589,6 +1884,7 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
             for (int j = 0; j < 18; ++j) e.ft[j] = 0.0f;
             for (int s = 0; s < nsim * c->substeps; ++s) substep(h, &e, hsub);
             post_step_env(h, i, &e, prev_obj, &rc, !is_reset, &local);
+            goal_advance(h, &e, nsim * c->substeps, hsub);
             env_store(h, i, &e, 0);      /* the wrench accumulator rows belong to the split path */
             if (!is_reset) finish_env(h, i);
         }
@@ -1688,6 +1984,7 @@ int tf_post_step(tf_handle h, void* stream) {
         for (int j = 0; j < 3; ++j) prev_obj[j] = ST(h, TF_S_PREV_OBJ_P + j, i);
         for (int j = 0; j < 4; ++j) prev_obj[3 + j] = ST(h, TF_S_PREV_OBJ_Q + j, i);
         post_step_env(h, i, &e, prev_obj, &rc, 1, &st);
+        goal_advance(h, &e, h->cfg.control_decimation * h->cfg.substeps, h->cfg.dt / (float)h->cfg.substeps);
         env_store(h, i, &e, 1);
     }
     write_info(h, &st);

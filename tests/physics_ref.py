@@ -1,0 +1,340 @@
+"""Independent fp64 restatement of ONE solver substep of this build's physics spec.
+
+TEST INFRASTRUCTURE.  Nothing here shares code with oracle/tf_oracle.c or the HIP kernels: the kinematic chain is the
+fp64 URDF model of tests/test_physics_analytic.py, contact Jacobians are finite differences of that model's forward
+kinematics, closest points come from scipy's bounded minimisers (not from the alternating projections of the C code),
+and the mixed complementarity problem of the substep is solved by projected Gauss-Seidel iterated to a fixed point
+(1e-13) instead of the 8 sweeps the product runs.  tests/test_contact_lcp_reference.py checks that the oracle's result
+approaches this solution as its sweep count grows, on random contact configurations.
+
+What is restated from the spec (these are modelling choices, so they are part of what is compared): the collision
+primitives and their selection rules, the tangent basis of a normal, the speculative / Baumgarte / restitution bias of a
+normal row, the friction pyramid, the joint-limit box rows, the finger-finger pre-solve on the free
+velocities, damping factors and symplectic Euler.
+"""
+import numpy as np
+from scipy.optimize import minimize, minimize_scalar
+
+from test_physics_analytic import LINKS, frames, kinetic_matrix, potential, G  # noqa: F401  fp64 URDF model
+
+H_BASE = 0.29
+YAW = (0.0, -2.09439510239, -4.18879020479)
+CAPS = {3: (np.array([0.0135, 0.0, 0.0]), np.array([0.0185, 0.0, -0.1592]), 0.0102),
+        2: (np.array([0.028, 0.0, 0.0]), np.array([0.028, 0.0, -0.16]), 0.022),
+        1: (np.array([0.005, 0.045, 0.0]), np.array([0.005, 0.21, 0.0]), 0.024)}
+UPPER_CHECK_Z = 0.17
+CUBE_HALF = 0.0325
+CUBE_MASS = 291.3 * 0.065 ** 3
+CUBE_INERTIA = CUBE_MASS * 0.065 ** 2 / 6.0
+LINK_DAMP, CUBE_LIN_DAMP, CUBE_ANG_DAMP = 0.01, 0.0, 0.05
+MU = dict(fc=1.0, cf=0.55, tf=0.55, cw=1.0, tw=1.0, ff=1.0)
+REST_F, REST_FF, BOUNCE = 0.4, 0.8, 0.5
+MARGIN, OFFSET, ERP, MAX_DEPEN = 0.04, 0.002, 0.2, 1000.0
+Q_LO = np.array([-0.33, 0.0, -2.7])
+Q_HI = np.array([1.0, 1.57, 0.0])
+QD_MAX = 10.0
+FF_ITERATIONS = 4
+WALL_R = (0.192, 0.208, 0.249, 0.260)
+WALL_Z = (0.06, 0.10, 0.14, 0.176)
+
+
+def rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def quat_rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def link_point_world(f, q, link, local):
+    R, p = frames(q)[link - 1]
+    return rot_z(YAW[f]) @ (p + R @ local) + np.array([0.0, 0.0, H_BASE])
+
+
+def point_jacobian(f, q, link, world_point):
+    """d(world position)/dq of the material point of `link` that currently sits at world_point (central differences)."""
+    R, p = frames(q)[link - 1]
+    local = R.T @ (rot_z(YAW[f]).T @ (world_point - np.array([0.0, 0.0, H_BASE])) - p)
+    J = np.zeros((3, 3))
+    eps = 1e-6
+    for j in range(3):
+        dq = np.zeros(3)
+        dq[j] = eps
+        J[:, j] = (link_point_world(f, q + dq, link, local) - link_point_world(f, q - dq, link, local)) / (2 * eps)
+    return J
+
+
+def bias_forces(q, qd, gravity_z):
+    """h(q, qd) = Mdot qd - 1/2 d(qd^T M qd)/dq + dV/dq, every derivative numerical."""
+    eps = 1e-5
+    dM = [(kinetic_matrix(q + eps * e) - kinetic_matrix(q - eps * e)) / (2 * eps) for e in np.eye(3)]
+    Mdot = sum(dM[k] * qd[k] for k in range(3))
+    dT = np.array([0.5 * qd @ dM[k] @ qd for k in range(3)])
+    dV = np.array([(potential(q + eps * e) - potential(q - eps * e)) / (2 * eps) for e in np.eye(3)]) * (-gravity_z / G)
+    return Mdot @ qd - dT + dV
+
+
+def tangent_basis(n):
+    if abs(n[2]) < 0.9:
+        t1 = np.array([-n[1], n[0], 0.0]) / np.hypot(n[0], n[1])
+    else:
+        t1 = np.array([0.0, -n[2], n[1]]) / np.hypot(n[1], n[2])
+    return t1, np.cross(n, t1)
+
+
+def contact_bias(gap, vn0, h, restitution):
+    b = gap / h if gap >= 0.0 else max(ERP * gap / h, -MAX_DEPEN)
+    if restitution > 0.0 and gap < OFFSET and vn0 < -BOUNCE:
+        b = min(b, restitution * vn0)
+    return b
+
+
+def wall_radius_at(z):
+    for r, zz in zip(WALL_R, WALL_Z):
+        if z < zz:
+            return r
+    return 1000.0
+
+
+def segment_box(a, b, hc):
+    """closest points of the segment a-b and the box [-hc, hc]^3 (box frame): bounded scalar minimisation."""
+    def dist2(s):
+        x = a + s * (b - a)
+        return float(np.sum((x - np.clip(x, -hc, hc)) ** 2))
+    best = None
+    for lo, hi in ((0.0, 0.5), (0.5, 1.0), (0.0, 1.0)):
+        r = minimize_scalar(dist2, bounds=(lo, hi), method="bounded", options={"xatol": 1e-13})
+        if best is None or r.fun < best.fun:
+            best = r
+    for s_end in (0.0, 1.0):
+        if dist2(s_end) < best.fun:
+            best = type("R", (), {"x": s_end, "fun": dist2(s_end)})
+    x = a + best.x * (b - a)
+    return x, np.clip(x, -hc, hc)
+
+
+def segment_segment(p1, q1, p2, q2):
+    d1, d2 = q1 - p1, q2 - p2
+
+    def fun(st):
+        return float(np.sum((p1 + st[0] * d1 - p2 - st[1] * d2) ** 2))
+    best = None
+    for s0 in (0.0, 0.5, 1.0):
+        for t0 in (0.0, 0.5, 1.0):
+            r = minimize(fun, [s0, t0], bounds=[(0, 1), (0, 1)], method="L-BFGS-B", options={"ftol": 1e-16, "gtol": 1e-14})
+            if best is None or r.fun < best.fun:
+                best = r
+    s, t = best.x
+    return p1 + s * d1, p2 + t * d2
+
+
+class Row:
+    """One scalar constraint row over the 15 velocity dofs [9 joint, cube v, cube w]."""
+    def __init__(self, J, kind, bias=0.0, parent=None, mu=0.0, lo=0.0, hi=0.0):
+        self.J, self.kind, self.bias, self.parent, self.mu, self.lo, self.hi = J, kind, bias, parent, mu, lo, hi
+        self.lam = 0.0
+
+
+def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_sweeps=200000):
+    """One substep of length h in fp64.  q, qd, tau: (9,), cube: (13,) [p, quat xyzw, v, w].
+    Returns (qd_new (9,), cube_v (3,), cube_w (3,), details)."""
+    q, qd, cube, tau = (np.asarray(a, dtype=np.float64) for a in (q, qd, cube, tau))
+    cp, cq, cv, cw = cube[0:3], cube[3:7], cube[7:10], cube[10:13]
+    gz = gravity[2]
+    Minv = np.zeros((15, 15))
+    vfree = np.zeros(15)
+    for f in range(3):
+        sl = slice(3 * f, 3 * f + 3)
+        M = kinetic_matrix(q[sl])
+        Mi = np.linalg.inv(M)
+        Minv[sl, sl] = Mi
+        acc = Mi @ (tau[sl] - bias_forces(q[sl], qd[sl], gz))
+        vfree[sl] = (qd[sl] + h * acc) * (1.0 - h * LINK_DAMP)
+    Minv[9:12, 9:12] = np.eye(3) / CUBE_MASS
+    Minv[12:15, 12:15] = np.eye(3) / CUBE_INERTIA
+    vfree[9:12] = (cv + h * np.asarray(gravity)) * (1.0 - h * CUBE_LIN_DAMP)
+    vfree[12:15] = cw * (1.0 - h * CUBE_ANG_DAMP)
+    R = quat_rot(cq)
+    hc = CUBE_HALF
+    rows = []
+    details = {"fc": [], "te": [], "ff": [], "n_floor": 0, "n_wall": 0}
+
+    def add_contact(Jn_dofs, dirs, gap, restitution, mu, vref):
+        """three rows for the 3x15 map `Jn_dofs` (velocity of body A minus body B at the contact, world) and dirs n,t1,t2"""
+        Jr = [d @ Jn_dofs for d in dirs]
+        vn0 = float(Jr[0] @ vref)
+        n_row = Row(Jr[0], "normal", bias=contact_bias(gap, vn0, h, restitution))
+        rows.append(n_row)
+        rows.append(Row(Jr[1], "tangent", parent=n_row, mu=mu))
+        rows.append(Row(Jr[2], "tangent", parent=n_row, mu=mu))
+        return n_row
+
+    def cube_map(r):      # velocity of the cube point with arm r: v + w x r
+        Jc = np.zeros((3, 15))
+        Jc[:, 9:12] = np.eye(3)
+        Jc[:, 12:15] = -np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+        return Jc
+
+    tipsphere = []
+    distal = []
+    for f in range(3):
+        sl = slice(3 * f, 3 * f + 3)
+        a3 = link_point_world(f, q[sl], 3, CAPS[3][0])
+        b3 = link_point_world(f, q[sl], 3, CAPS[3][1])
+        distal.append((a3, b3))
+        tipsphere.append(b3)
+    # ---- finger-finger pre-pass on the free velocities: pairs in turn, FF_ITERATIONS local Gauss-Seidel iterations each ----
+    v_ff = vfree.copy()
+    for p in range(3):
+        fa, fb = p, (p + 1) % 3
+        Pa, Pb = segment_segment(distal[fa][0], distal[fa][1], distal[fb][0], distal[fb][1])
+        dist = np.linalg.norm(Pa - Pb)
+        if not dist > 1e-6:
+            continue
+        rad = CAPS[3][2]
+        gap = dist - 2 * rad
+        if not gap < MARGIN:
+            continue
+        n = (Pa - Pb) / dist
+        t1, t2 = tangent_basis(n)
+        Jm = np.zeros((3, 15))
+        Jm[:, 3 * fa:3 * fa + 3] = point_jacobian(fa, q[3 * fa:3 * fa + 3], 3, Pa - rad * n)
+        Jm[:, 3 * fb:3 * fb + 3] = -point_jacobian(fb, q[3 * fb:3 * fb + 3], 3, Pb + rad * n)
+        bias = contact_bias(gap, float(n @ Jm @ v_ff), h, REST_FF)
+        lam = [0.0, 0.0, 0.0]
+        for _ in range(FF_ITERATIONS):
+            for d, dvec in enumerate((n, t1, t2)):
+                Jr = dvec @ Jm
+                D = Jr @ Minv @ Jr
+                vrel = Jr @ v_ff
+                if d == 0:
+                    new = max(lam[0] - (vrel + bias) / D, 0.0)
+                else:
+                    new = float(np.clip(lam[d] - vrel / D, -MU["ff"] * lam[0], MU["ff"] * lam[0]))
+                v_ff = v_ff + Minv @ Jr * (new - lam[d])
+                lam[d] = new
+        lam_n = lam[0]
+        details["ff"].append((fa, fb, gap, lam_n))
+    # ---- finger contacts ----
+    for f in range(3):
+        sl = slice(3 * f, 3 * f + 3)
+        qf = q[sl]
+        best = None
+        for cand in (3, 2, 1):
+            if cand == 1 and not cp[2] > UPPER_CHECK_Z:
+                continue
+            la, lb, rad = CAPS[cand]
+            a = R.T @ (link_point_world(f, qf, cand, la) - cp)
+            b = R.T @ (link_point_world(f, qf, cand, lb) - cp)
+            x, y = segment_box(a, b, hc)
+            dist = np.linalg.norm(x - y)
+            if dist <= 1e-6:
+                raise ValueError("capsule axis inside the cube: outside the domain of the reference")
+            gap = dist - rad
+            if best is None or gap < best[0]:
+                best = (gap, cand, x, y, rad)
+        gap, link, x, y, rad = best
+        if gap < MARGIN:
+            n = R @ ((x - y) / np.linalg.norm(x - y))
+            t1, t2 = tangent_basis(n)
+            Pw = cp + R @ x - rad * n
+            rc = R @ y
+            Jm = -cube_map(rc)
+            Jm[:, sl] = point_jacobian(f, qf, link, Pw)
+            nr = add_contact(Jm, (n, t1, t2), gap, REST_F, MU["fc"], vfree)
+            details["fc"].append((f, link, gap, nr))
+        # fingertip sphere against the floor and against the boundary wall
+        B = tipsphere[f]
+        rad = CAPS[3][2]
+        rho = np.hypot(B[0], B[1])
+        for kind in ("floor", "wall"):
+            if kind == "floor":
+                gp, n = B[2] - rad, np.array([0.0, 0.0, 1.0])
+            else:
+                if not rho > 1e-6:
+                    continue
+                gp, n = wall_radius_at(B[2]) - rho - rad, np.array([-B[0] / rho, -B[1] / rho, 0.0])
+            if gp < MARGIN:
+                t1, t2 = tangent_basis(n)
+                Jm = np.zeros((3, 15))
+                Jm[:, sl] = point_jacobian(f, qf, 3, B - rad * n)
+                nr = add_contact(Jm, (n, t1, t2), gp, REST_F, MU["tf"] if kind == "floor" else MU["tw"], vfree)
+                details["te"].append((f, kind, gp, nr))
+    # ---- cube corners against the floor ----
+    k = int(np.argmax(np.abs(R[2, :])))
+    sk = -1.0 if R[2, k] > 0 else 1.0
+    others = [i for i in range(3) if i != k]
+    for idx in range(4):
+        yv = np.zeros(3)
+        yv[k] = sk * hc
+        yv[others[0]] = hc if idx & 1 else -hc
+        yv[others[1]] = hc if idx & 2 else -hc
+        r = R @ yv
+        gap = cp[2] + r[2]
+        if gap < MARGIN:
+            Jm = cube_map(r)
+            ez, ex, ey = np.eye(3)[2], np.eye(3)[0], np.eye(3)[1]
+            add_contact(Jm, (ez, ex, ey), gap, 0.0, MU["cf"], vfree)
+            details["n_floor"] += 1
+    # ---- cube corners against the boundary wall ----
+    rho_c = np.hypot(cp[0], cp[1])
+    if rho_c > 1e-6:
+        dvec = np.array([cp[0] / rho_c, cp[1] / rho_c, 0.0])
+        pr = R.T @ dvec
+        k = int(np.argmax(np.abs(pr)))
+        sk = -1.0 if pr[k] < 0 else 1.0
+        others = [i for i in range(3) if i != k]
+        for idx in range(4):
+            yv = np.zeros(3)
+            yv[k] = sk * hc
+            yv[others[0]] = hc if idx & 1 else -hc
+            yv[others[1]] = hc if idx & 2 else -hc
+            r = R @ yv
+            P = cp + r
+            rho = np.hypot(P[0], P[1])
+            gap = wall_radius_at(P[2]) - rho
+            if gap < MARGIN and rho > 1e-6:
+                n = np.array([-P[0] / rho, -P[1] / rho, 0.0])
+                t = np.array([-n[1], n[0], 0.0])
+                add_contact(cube_map(r), (n, t, np.array([0.0, 0.0, 1.0])), gap, 0.0, MU["cw"], vfree)
+                details["n_wall"] += 1
+    # ---- joint / velocity limit rows ----
+    for j in range(9):
+        Jr = np.zeros(15)
+        Jr[j] = 1.0
+        lo = float(np.clip((Q_LO[j % 3] - q[j]) / h, -QD_MAX, QD_MAX))
+        hi = float(np.clip((Q_HI[j % 3] - q[j]) / h, -QD_MAX, QD_MAX))
+        rows.append(Row(Jr, "limit", lo=lo, hi=hi))
+    # ---- projected Gauss-Seidel to a fixed point ----
+    v = v_ff.copy()
+    W = [Minv @ r.J for r in rows]
+    D = [float(r.J @ w) for r, w in zip(rows, W)]
+    sweeps = 0
+    for sweeps in range(1, max_sweeps + 1):
+        change = 0.0
+        for r, w, d in zip(rows, W, D):
+            if d <= 0.0:
+                continue
+            vrel = float(r.J @ v)
+            if r.kind == "normal":
+                new = max(r.lam - (vrel + r.bias) / d, 0.0)
+            elif r.kind == "tangent":
+                lim = r.mu * r.parent.lam
+                new = float(np.clip(r.lam - vrel / d, -lim, lim))
+            else:
+                v0 = vrel - d * r.lam
+                new = (float(np.clip(v0, r.lo, r.hi)) - v0) / d
+            dl = new - r.lam
+            if dl != 0.0:
+                v = v + w * dl
+                r.lam = new
+                change = max(change, abs(dl) * np.sqrt(d))
+        if change < tol:
+            break
+    details["sweeps"] = sweeps
+    details["rows"] = rows
+    return v[0:9].copy(), v[9:12].copy(), v[12:15].copy(), details
