@@ -1,0 +1,199 @@
+// tf_contact.h - contact geometry and solver rows shared by the finger and cube roles (tf_roles.h).
+// Every function is the arithmetic twin of the function of the same name in the test oracle (oracle/tf_oracle.c):
+// same operations in the same order, so that per-env results agree bit for bit.
+#pragma once
+#include "tf_params.h"
+
+// ---- PGS row kernels ----
+DEV float solve_normal(float& lam, float Dinv, float vrel, float bias) {
+    float ln = f_max(FMA(-Dinv, vrel + bias, lam), 0.0f);
+    float dl = ln - lam;
+    lam = ln;
+    return dl;
+}
+DEV float solve_tangent(float& lam, float Dinv, float vrel, float lim) {
+    float ln = f_clamp(FMA(-Dinv, vrel, lam), -lim, lim);
+    float dl = ln - lam;
+    lam = ln;
+    return dl;
+}
+
+// base-frame position of a point given in the frame of link LINK (1..3)
+template <int LINK> DEV void link_point(const FK& k, const float local[3], float out[3]) {
+    float t[3];
+    rot_link<LINK>(k, local, t);
+    if (LINK == 1) { out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; }
+    else if (LINK == 2) { out[0] = k.p2[0] + t[0]; out[1] = k.p2[1] + t[1]; out[2] = k.p2[2] + t[2]; }
+    else { out[0] = k.p3[0] + t[0]; out[1] = k.p3[1] + t[1]; out[2] = k.p3[2] + t[2]; }
+}
+
+// Joint-space rows of a contact on link `link` (per-lane value) at base-frame point Pb for the three world directions
+// dirs[3d..3d+2]: J[3d..] = (L1.d, L2.d, L3.d) with the levers of the joints that do not move the link zeroed,
+// W[3d..] = M^-1 J, Dd[d] = J.W.
+DEV void finger_jac(const Yaw& y, const FK& k, int link, const float Pb[3], const float dirs[9], float J[9], float W[9], float Dd[3]) {
+    float L1[3], L2[3], L3[3];
+    levers(k, Pb, L1, L2, L3);
+    if (link < 2) { L2[0] = 0.0f; L2[1] = 0.0f; L2[2] = 0.0f; }
+    if (link < 3) { L3[0] = 0.0f; L3[1] = 0.0f; L3[2] = 0.0f; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float db[3];
+        dir_world_to_base(y, &dirs[3 * d], db);
+        J[3 * d] = dot3(L1, db); J[3 * d + 1] = dot3(L2, db); J[3 * d + 2] = dot3(L3, db);
+        sym3_mul(k.Minv, &J[3 * d], &W[3 * d]);
+        Dd[d] = dot3(&J[3 * d], &W[3 * d]);
+    }
+}
+
+// g(s) = d . (x - clamp(x)) with x = a + s d: half the derivative of the squared distance between the segment point x(s)
+// and the box [-hc, hc]^3; monotone non-decreasing and piecewise linear in s
+DEV float seg_box_g(const float a[3], const float d[3], float s, float hc) {
+    float e[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float x = FMA(s, d[i], a[i]); e[i] = x - f_clamp(x, -hc, hc); }
+    return dot3(d, e);
+}
+// Closest points between the segment a + s (b - a) and the box [-hc, hc]^3 (box frame), exact: g changes slope only where
+// a coordinate of x(s) crosses +-hc (at most six breakpoints), so its root lies on the straight piece between the last
+// breakpoint with g <= 0 and the first with g > 0 (end points included): one linear interpolation, no iteration, no
+// branches.  x on the segment, y on the box, unit direction nc from y to x, gap = |x - y| - radius.  A segment point inside
+// the box is pushed out through the nearest face.
+DEV void seg_box(const float a[3], const float b[3], float hc, float radius, float& gap_out, float x[3], float y[3], float nc[3]) {
+    float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    const float g0 = seg_box_g(a, d, 0.0f, hc), g1 = seg_box_g(a, d, 1.0f, hc);
+    float lo = 0.0f, glo = g0, hi = 1.0f, ghi = g1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float ad = f_abs(d[i]);
+        const bool ok = ad > 1e-9f;
+        float inv = ok ? f_rcp(ok ? ad : 1.0f) : 0.0f;
+        inv = (d[i] < 0.0f) ? -inv : inv;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const float sb = ((side ? hc : -hc) - a[i]) * inv;
+            const float gb = seg_box_g(a, d, sb, hc);
+            const bool valid = ok && sb > 0.0f && sb < 1.0f;
+            const bool take_lo = valid && gb <= 0.0f && sb > lo;
+            lo = take_lo ? sb : lo; glo = take_lo ? gb : glo;
+            const bool take_hi = valid && gb > 0.0f && sb < hi;
+            hi = take_hi ? sb : hi; ghi = take_hi ? gb : ghi;
+        }
+    }
+    float s = f_clamp(FMA(-glo, (hi - lo) * f_rcp(f_max(ghi - glo, 1e-30f)), lo), lo, hi);
+    if (g0 > 0.0f) s = 0.0f;
+    if (!(g1 > 0.0f)) s = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
+    float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
+    float dist2 = dot3(ev, ev);
+    if (__builtin_expect(dist2 > 1e-12f, 1)) {
+        float inv = f_rsqrt(dist2);
+        float dist = dist2 * inv;
+        nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
+        gap_out = dist - radius;
+    } else {
+        int bi = 0;
+        float best = f_abs(x[0]) - hc;
+        float p1 = f_abs(x[1]) - hc;
+        if (p1 > best) { best = p1; bi = 1; }
+        float p2 = f_abs(x[2]) - hc;
+        if (p2 > best) { best = p2; bi = 2; }
+        float xb = (bi == 0) ? x[0] : ((bi == 1) ? x[1] : x[2]);
+        float sg = (xb < 0.0f) ? -1.0f : 1.0f;
+        nc[0] = (bi == 0) ? sg : 0.0f; nc[1] = (bi == 1) ? sg : 0.0f; nc[2] = (bi == 2) ? sg : 0.0f;
+        y[0] = (bi == 0) ? sg * hc : y[0]; y[1] = (bi == 1) ? sg * hc : y[1]; y[2] = (bi == 2) ? sg * hc : y[2];
+        gap_out = best - radius;
+    }
+}
+
+// closest points of two segments p1-q1 and p2-q2 (Ericson, Real-Time Collision Detection 5.1.9; both of positive length)
+DEV void seg_seg(const float p1[3], const float q1[3], const float p2[3], const float q2[3], float c1[3], float c2[3]) {
+    float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]};
+    float d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
+    float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2);
+    float denom = FMA(a, e, -(b * b));
+    float ia = f_rcp(a), ie = f_rcp(e);
+    float s = 0.0f;
+    if (denom > 1e-12f) s = f_clamp(FMA(b, f, -(c * e)) * f_rcp(denom), 0.0f, 1.0f);
+    float t = FMA(b, s, f) * ie;
+    if (t < 0.0f) { t = 0.0f; s = f_clamp(-c * ia, 0.0f, 1.0f); }
+    else if (t > 1.0f) { t = 1.0f; s = f_clamp((b - c) * ia, 0.0f, 1.0f); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
+}
+
+// inner radius of the boundary at height z (a stack of vertical cylinders; 1e3 = no wall)
+DEV float wall_radius_at(const TfModel& m, float z) {
+    float r = 1000.0f;
+    if (z < m.wall_z[3]) r = m.wall_r[3];
+    if (z < m.wall_z[2]) r = m.wall_r[2];
+    if (z < m.wall_z[1]) r = m.wall_r[1];
+    if (z < m.wall_z[0]) r = m.wall_r[0];
+    return r;
+}
+
+DEV void cube_corner(const float R[9], float hc, int k, float sk, int idx, float r[3]) {
+    // axes a < b are the two that are not k
+    float y[3];
+    float sa = (idx & 1) ? hc : -hc;
+    float sb = (idx & 2) ? hc : -hc;
+    float fk_ = sk * hc;
+    y[0] = (k == 0) ? fk_ : sa;
+    y[1] = (k == 1) ? fk_ : ((k == 0) ? sa : sb);
+    y[2] = (k == 2) ? fk_ : sb;
+    mat3_mul(R, y, r);
+}
+
+// axis-aligned rows of a cube corner with arm r: direction +z / +x / +y.  *_vrel: relative velocity of the row, *_apply:
+// effect of the impulse dl on the cube
+DEV float cz_vrel(const float r[3], const float v[3], const float w[3]) { return FMA(r[1], w[0], FMA(-r[0], w[1], v[2])); }
+DEV void cz_apply(const float r[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
+    float s = dl * inv_m, q = dl * inv_I;
+    v[2] = v[2] + s;
+    w[0] = FMA(r[1], q, w[0]);
+    w[1] = FMA(-r[0], q, w[1]);
+}
+DEV float cx_vrel(const float r[3], const float v[3], const float w[3]) { return FMA(r[2], w[1], FMA(-r[1], w[2], v[0])); }
+DEV void cx_apply(const float r[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = v[0] + s;
+    w[1] = FMA(r[2], q, w[1]);
+    w[2] = FMA(-r[1], q, w[2]);
+}
+DEV float cy_vrel(const float r[3], const float v[3], const float w[3]) { return FMA(-r[2], w[0], FMA(r[0], w[2], v[1])); }
+DEV void cy_apply(const float r[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
+    float s = dl * inv_m, q = dl * inv_I;
+    v[1] = v[1] + s;
+    w[0] = FMA(-r[2], q, w[0]);
+    w[2] = FMA(r[0], q, w[2]);
+}
+// wall rows: inward horizontal normal n = (n0, n1, 0) and tangent t = (-n1, n0, 0)
+DEV void wall_arm_n(const float r[3], const float n[2], float a[3]) {
+    a[0] = -(r[2] * n[1]);
+    a[1] = r[2] * n[0];
+    a[2] = FMA(r[0], n[1], -(r[1] * n[0]));
+}
+DEV void wall_arm_t(const float r[3], const float n[2], float b[3]) {
+    b[0] = -(r[2] * n[0]);
+    b[1] = -(r[2] * n[1]);
+    b[2] = FMA(r[0], n[0], r[1] * n[1]);
+}
+DEV float wn_vrel(const float n[2], const float a[3], const float v[3], const float w[3]) {
+    return FMA(a[2], w[2], FMA(a[1], w[1], FMA(a[0], w[0], FMA(n[1], v[1], n[0] * v[0]))));
+}
+DEV void wn_apply(const float n[2], const float a[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = FMA(n[0], s, v[0]);
+    v[1] = FMA(n[1], s, v[1]);
+    w[0] = FMA(a[0], q, w[0]); w[1] = FMA(a[1], q, w[1]); w[2] = FMA(a[2], q, w[2]);
+}
+DEV float wt_vrel(const float n[2], const float b[3], const float v[3], const float w[3]) {
+    return FMA(b[2], w[2], FMA(b[1], w[1], FMA(b[0], w[0], FMA(n[0], v[1], -(n[1] * v[0])))));
+}
+DEV void wt_apply(const float n[2], const float b[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
+    float s = dl * inv_m, q = dl * inv_I;
+    v[0] = FMA(-n[1], s, v[0]);
+    v[1] = FMA(n[0], s, v[1]);
+    w[0] = FMA(b[0], q, w[0]); w[1] = FMA(b[1], q, w[1]); w[2] = FMA(b[2], q, w[2]);
+}

@@ -1,0 +1,1488 @@
+// tf_roles.h - the two wavefront roles of the fused TriFinger step.
+//
+// A workgroup is 256 threads = 4 wavefronts and owns 64 environments, one per lane.  Wavefronts 0..2 are the FINGER ROLE of
+// finger 0 / 120 / 240 for those 64 environments, wavefront 3 is the CUBE ROLE (cube, goal, task bookkeeping).  Every
+// wavefront is homogeneous (all lanes run the same code on different environments), the four roles of an environment run
+// concurrently on the four SIMDs of a CU and meet at workgroup barriers, exchanging a few floats per lane through LDS.
+// With 4 workgroups per CU there are 4 wavefronts per SIMD: the latency of one wavefront's dependent instruction stream
+// (a lone wavefront issues once per ~5 cycles on a SIMD that can take one instruction per 2) is filled by the others.
+//
+// The contact solve follows the same split: the finger-cube rows are solved by the cube role in CONTACT SPACE (3x3 block
+// A = J M^-1 J^T and contact-point velocity u per finger, published by the finger role), the finger role owns the rows that
+// touch only its finger (fingertip-floor, fingertip-wall, joint / velocity limits) and runs them while the cube role runs
+// the corner rows (cube-floor, cube-wall): two barriers per sweep.
+//
+// Every function is the arithmetic twin of its namesake in the test oracle (oracle/tf_oracle.c).
+#pragma once
+#include <type_traits>
+
+#include "tf_contact.h"
+
+#define NT 256                          // threads per workgroup
+#define TF_FF_ITERATIONS 4
+
+// kernel modes: which hooks of the reference step a launch performs (the fused step does all of them)
+enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINISH = 32 };
+#define M_FUSED_STEP (M_ACT_IN | M_RESETS | M_TORQUE | M_SIM | M_POST | M_FINISH)
+#define M_FUSED_RESET (M_RESETS | M_TORQUE | M_SIM | M_POST)
+
+// ---- LDS map: float slots of 64 lanes each, lds[slot * 64 + lane] --------------------------------------------------
+// physics phase
+#define L_REC(f) (30 * (f))             // contact-space record of finger f
+#define R_A 0                           //   6  A = J M^-1 J^T (00 01 02 11 12 22)
+#define R_DIR 6                         //   9  world directions n, t1, t2
+#define R_RXD 15                        //   9  cube arms r x d
+#define R_U 24                          //   3  contact-point velocity of the finger side
+#define R_DL 27                         //   3  impulse increments of the sweep (cube role -> finger role)
+// the same slots before the records exist: what a finger publishes after its free motion (read by the finger-finger pass)
+#define P_AW 0
+#define P_BW 3
+#define P_MINV 6
+#define P_S1 12
+#define P_C1 13
+#define P_P2 14
+#define P_P3 17
+#define P_VQ 20                         //   -> 23 slots
+// cube pose and free velocity published by the cube role for contact generation (free tails of records 0 and 1)
+#define L_POSE_A 23                     //   7: cp[3], cq[4]
+#define L_POSE_B 53                     //   6: v*[3], w*[3]
+#define L_WALL 90                       //  48: corner c at 12 c: r[3], n[2], Dinv[3], bias, lam[3]
+#define L_VQFF 138                      //   9: joint velocities after the finger-finger pass; then Dinv[3] of finger f at 3 f
+#define L_INIT 147                      //   3: bias of finger f; after the last sweep the normal impulse of finger f
+#define LDS_SLOTS 150
+// post phase (aliases the above)
+#define L_XCH (MAX_STATES)              //  18: fingertip position (3) and previous fingertip position (3) of finger f at 6 f
+#define L_NAN (MAX_STATES + 18)         //   4: non-finite flag of each role
+static_assert(MAX_STATES + 22 <= LDS_SLOTS, "post-phase LDS map");
+#define LD(slot) lds[(slot) * WAVE + lane]
+
+struct Ctx {
+    int tid, lane, role;
+    int wave_first, i, n_valid;
+    bool valid;
+};
+
+#define ST_RSRC() __builtin_amdgcn_make_buffer_rsrc((void*)P.state, 0, TF_STATE_ROWS * P.N * 4, 0x00020000)
+#define LDST(row) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ST_RSRC(), (unsigned)cx.i * 4u, (row) * P.N * 4, 0))
+#define STST(row, val) do { if (cx.valid) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), ST_RSRC(), (unsigned)cx.i * 4u, (row) * P.N * 4, 0); } while (0)
+#define BAR() __syncthreads()
+
+// ---- cooperative tile moves by the whole workgroup -----------------------------------------------------------------
+// store a [n_valid][W] tile staged in LDS as lds[env * W + j] to dst[(wave_first + env) * W + j]: dwordx4, coalesced; the tile
+// is a raw buffer of total4 * 16 bytes, so the hardware range check drops the lanes past its end
+template <int W>
+DEV void coop_store_tile(gfloat* __restrict__ dst, const float* lds, const Ctx& cx) {
+    const unsigned total = (unsigned)(cx.n_valid * W);
+    gfloat* base = dst + (size_t)cx.wave_first * (size_t)W;
+    const unsigned total4 = total >> 2;
+    const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(total4 * 16u), 0x00020000);
+    constexpr int ITER = (16 * W + NT - 1) / NT;
+    const unsigned last4 = total4 - 1u;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const unsigned idx = (unsigned)cx.tid + (unsigned)(NT * k);
+        const unsigned src = (idx < last4) ? idx : last4;
+        u32x4 vv = *reinterpret_cast<const u32x4*>(&lds[src * 4u]);
+        __builtin_amdgcn_raw_buffer_store_b128(vv, tile, idx * 16u, 0, 0);
+    }
+    const unsigned tail = (total4 << 2) + (unsigned)cx.tid;
+    if (tail < total) base[tail] = lds[tail];
+}
+// the same for a [n_valid][W] global tile whose rows sit in LDS with row stride LS >= W (obs = first columns of states)
+template <int W, int LS>
+DEV void coop_store_tile_strided(gfloat* __restrict__ dst, const float* lds, const Ctx& cx) {
+    const unsigned total = (unsigned)(cx.n_valid * W);
+    gfloat* base = dst + (size_t)cx.wave_first * (size_t)W;
+    const unsigned total4 = total >> 2;
+    const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(total4 * 16u), 0x00020000);
+    constexpr int ITER = (16 * W + NT - 1) / NT;
+    const unsigned lastf = total - 1u;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const unsigned idx = (unsigned)cx.tid + (unsigned)(NT * k);
+        u32x4 vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned g = idx * 4u + (unsigned)e;
+            g = (g < lastf) ? g : lastf;
+            const unsigned row = g / (unsigned)W, col = g - row * (unsigned)W;
+            vv[e] = __builtin_bit_cast(unsigned, lds[row * (unsigned)LS + col]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(vv, tile, idx * 16u, 0, 0);
+    }
+    const unsigned tail = (total4 << 2) + (unsigned)cx.tid;
+    if (tail < total) { const unsigned row = tail / (unsigned)W, col = tail - row * (unsigned)W; base[tail] = lds[row * (unsigned)LS + col]; }
+}
+// load the [n_valid][A] tile src[(wave_first + env) * A + j] into lds[env * A + j] (index clamped instead of branching)
+template <int A>
+DEV void coop_load_tile(const float* __restrict__ src, float* lds, const Ctx& cx) {
+    const float* base = src + (size_t)cx.wave_first * (size_t)A;
+    const unsigned last = (unsigned)(cx.n_valid * A) - 1u;
+    constexpr int ITER = (WAVE * A + NT - 1) / NT;
+    float t[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const unsigned idx = (unsigned)cx.tid + (unsigned)(NT * k);
+        t[k] = base[idx < last ? idx : last];
+    }
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const unsigned idx = (unsigned)cx.tid + (unsigned)(NT * k);
+        if (idx < (unsigned)(WAVE * A)) lds[idx] = t[k];
+    }
+}
+
+// ---- task-layer samplers (reference sample.py) -------------------------------------------------------------------------
+DEV void sample_xy(float u_r, float u_t, float r_max, float& x, float& y) {   // sample.py:22-34
+    float radius = f_sqrt(u_r) * r_max;
+    float s, c;
+    tf_sincos(6.2831855f * u_t, s, c);
+    x = radius * c;
+    y = radius * s;
+}
+DEV void sample_yaw_quat(float u, float q[4]) {                                 // sample.py:77-84
+    float s, c;
+    tf_sincos((6.2831855f * u) * 0.5f, s, c);
+    q[0] = 0.0f; q[1] = 0.0f; q[2] = s; q[3] = c;
+}
+DEV void normalize_quat(const float n[4], float q[4]) {                         // sample.py:55-65
+    float nrm = f_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3]);
+    float inv = 1.0f / f_max(nrm, 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = n[i] * inv;
+}
+#define CUBE_RADIUS_3D 0.05629165f      // CuboidalObject(0.065).radius_3d, reference envs/trifinger/utils.py:122-131
+#define CUBE_MAX_COM_DIST 0.13870835f
+#define CUBE_MIN_HEIGHT 0.0325f
+
+DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, float gp[3], float gq[4], float gw[3]) {   // trifinger_env.py:1194-1265
+    int d = P.task_difficulty;
+    float u[4];
+    rng4(P, gid, count, RNG_GOAL_POS, u);
+    float x = 0.0f, y = 0.0f, z;
+    float quat[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, x, y);
+    if (d == -1 || d == 1) z = CUBE_MIN_HEIGHT;
+    else if (d == 2 || d == 6) z = CUBE_MIN_HEIGHT + 0.05f;
+    else if (d == 3) z = 0.0675f * u[2] + CUBE_MIN_HEIGHT;
+    else z = 0.04370835f * u[2] + CUBE_RADIUS_3D;
+    if (d == -1) sample_yaw_quat(u[3], quat);
+    if (d == 4 || d == 5 || d == 6) {
+        float v[4], n[4];
+        rng4(P, gid, count, RNG_GOAL_QUAT, v);
+        box_muller(v[0], v[1], n[0], n[1]);
+        box_muller(v[2], v[3], n[2], n[3]);
+        normalize_quat(n, quat);
+    }
+    if (P.goal_rotation_activate) {
+        float v[4], n[4];
+        rng4(P, gid, count, RNG_GOAL_ANGVEL, v);
+        box_muller(v[0], v[1], n[0], n[1]);
+        box_muller(v[2], v[3], n[2], n[3]);
+        float nrm = f_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        float mag = n[3] * P.goal_rate;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gw[i] = mag * (n[i] / nrm);
+    } else {
+        gw[0] = 0.0f; gw[1] = 0.0f; gw[2] = 0.0f;
+    }
+    gp[0] = x; gp[1] = y; gp[2] = z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gq[i] = quat[i];
+}
+
+// per-env domain-randomisation factors drawn at a reset (build-defined): scale = lo + (hi - lo) u
+DEV void draw_dr(const DevParams& P, uint32_t gid, uint32_t count, float dr[TF_NUM_DR]) {
+    float u[4];
+    rng4(P, gid, count, RNG_DR, u);
+    dr[0] = FMA(P.dr_cube_mass[1] - P.dr_cube_mass[0], u[0], P.dr_cube_mass[0]);
+    dr[1] = FMA(P.dr_cube_size[1] - P.dr_cube_size[0], u[1], P.dr_cube_size[0]);
+    dr[2] = FMA(P.dr_friction[1] - P.dr_friction[0], u[2], P.dr_friction[0]);
+    dr[3] = FMA(P.dr_motor[1] - P.dr_motor[0], u[3], P.dr_motor[0]);
+    rng4(P, gid, count, RNG_DR + 1u, u);
+    dr[4] = FMA(P.dr_link_mass[1] - P.dr_link_mass[0], u[0], P.dr_link_mass[0]);
+    dr[5] = FMA(P.dr_restitution[1] - P.dr_restitution[0], u[1], P.dr_restitution[0]);
+}
+
+// ---- observation emission: scale_transform (reference torch_utils.py:18-36) as one FMA per slot, then the fused wrapper
+// clipping.  Every slot but the action one has limits that are constants of the MDP (trifinger_env.py:153-213). ----------
+DEV float emit_scaled(float x, float lo, float hi, bool nrm, float co) {
+    const float o_ = (lo + hi) * 0.5f, i_ = 1.0f / (hi - lo);
+    return f_clamp(nrm ? FMA(x, 2.0f * i_, -(2.0f * o_) * i_) : x, -co, co);
+}
+DEV float emit_table(const DevParams& P, int col, float x, bool nrm, float co) {
+    const float off = P.tables[TAB_OFF + col], inv = P.tables[TAB_INV + col];
+    return f_clamp(nrm ? FMA(x, 2.0f * inv, -(2.0f * off) * inv) : x, -co, co);
+}
+#define QLO(j) (((j) % 3 == 0) ? -0.33f : (((j) % 3 == 1) ? 0.0f : -2.7f))
+#define QHI(j) (((j) % 3 == 0) ? 1.0f : (((j) % 3 == 1) ? 1.57f : 0.0f))
+#define PLO(j) (((j) == 2) ? 0.0f : -0.3f)
+#define TLO(j) (((j) < 2) ? -0.4f : (((j) == 2) ? 0.0f : (((j) < 7) ? -1.0f : -0.2f)))
+#define THI(j) (((j) < 2) ? 0.4f : (((j) == 2) ? 0.5f : (((j) < 7) ? 1.0f : 0.2f)))
+
+DEV float norm3d(const float a[3], const float b[3]) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return f_sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+// fingertip link state in the world frame: position, quaternion (xyzw), linear and angular velocity
+DEV void tip_state(const TfModel& m, const Yaw& y, const FK& k, const float q[3], const float qd[3], float out[13]) {
+    float To[3];
+    link_point<3>(k, m.tip_origin, To);
+    base_to_world(y, To, &out[0]);
+    float sy, cy, sx, cxx;
+    tf_sincos(0.5f * q[0], sy, cy);
+    tf_sincos(0.5f * (q[1] + q[2]), sx, cxx);
+    float qyx[4] = {cy * sx, sy * cxx, -(sy * sx), cy * cxx};
+    float qz[4] = {0.0f, 0.0f, y.hs, y.hc};
+    quat_mul(qz, qyx, &out[3]);
+    float L1[3], L2[3], L3[3], vb[3], wb[3];
+    levers(k, To, L1, L2, L3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vb[i] = L1[i] * qd[0] + L2[i] * qd[1] + L3[i] * qd[2];
+    wb[0] = k.ax[0] * qd[1] + k.ax[0] * qd[2];
+    wb[1] = qd[0];
+    wb[2] = k.ax[2] * qd[1] + k.ax[2] * qd[2];
+    dir_base_to_world(y, vb, &out[7]);
+    dir_base_to_world(y, wb, &out[10]);
+}
+
+// =====================================================================================================================
+// FINGER ROLE
+// =====================================================================================================================
+struct TipContact {            // fingertip sphere against one feature of the arena: finger-only rows
+    bool active;
+    float J[9], Dinv[3], bias, lam[3], mu;
+    float dir[9], arm[3];
+};
+
+template <int A, bool IS_RESET, bool ASYM, int MODE>
+DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
+    const TfModel& m = P.m;
+    const int f = cx.role, lane = cx.lane;
+    constexpr int OD = TF_OBS_DIM_BASE + A, SD = OD + TF_STATES_EXTRA;
+    constexpr int TW = ASYM ? SD : OD;                 // width of the tile staged in LDS in the post phase
+    constexpr int AJ = A / 3;                          // action values of one finger: 3, or 3 + 3 stiffnesses
+    const Yaw yw = {m.base_yaw_cos[f], m.base_yaw_sin[f], m.base_half_yaw_cos[f], m.base_half_yaw_sin[f], m.base_height};
+    const uint32_t gid = (uint32_t)(P.env_id_offset + cx.i);
+    // ---- loads ----
+    float q[3], qd[3], tau[3], ft[6], dr[TF_NUM_DR];
+    float lam_fc[4], fc_link, lam_tf[3], lam_tw[3];
+    uint8_t fl_reset = 0;
+    uint32_t fl_count = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { q[j] = LDST(TF_S_Q + 3 * f + j); qd[j] = LDST(TF_S_QD + 3 * f + j); }
+#pragma unroll
+    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
+    if (MODE & (M_SIM | M_RESETS)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lam_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
+        fc_link = LDST(TF_S_FC_LINK + f);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { lam_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
+    }
+    if (!(MODE & M_TORQUE) && (MODE & (M_SIM | M_POST | M_RESETS))) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
+    }
+    if ((MODE & (M_SIM | M_POST)) && !(MODE & M_TORQUE)) {       // split path: the wrench accumulator comes from its rows
+#pragma unroll
+        for (int j = 0; j < 6; ++j) ft[j] = LDST(TF_S_FT + 6 * f + j);
+    }
+    if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
+    if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
+    else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
+    BAR();                                                      // #1: action tile in LDS, flag loads have returned
+    // ---- masked _reset_impl for this finger (trifinger_env.py:373-423, 1101-1147) ----
+    const bool rflag = (MODE & M_RESETS) && (IS_RESET || fl_reset != 0);
+    if (MODE & M_RESETS) {
+        if (rflag) {
+            if (P.dr_enable) draw_dr(P, gid, fl_count, dr);
+            if (P.robot_reset_type == TF_RESET_DEFAULT) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { q[j] = m.q_default[j]; qd[j] = 0.0f; }
+            } else if (P.robot_reset_type == TF_RESET_RANDOM) {
+                float n[20];
+#pragma unroll
+                for (int b = 0; b < 5; ++b) rng4(P, gid, fl_count, RNG_ROBOT + (uint32_t)b, &n[4 * b]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float nq = 0.0f, nv = 0.0f;
+#pragma unroll
+                    for (int jj = 0; jj < 9; ++jj) { nq = (jj == 3 * f + j) ? n[jj] : nq; nv = (jj == 3 * f + j) ? n[9 + jj] : nv; }
+                    q[j] = m.q_default[j] + P.dof_pos_stddev * (2.0f * nq - 1.0f);
+                    qd[j] = 0.0f + P.dof_vel_stddev * (2.0f * nv - 1.0f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tau[j] = 0.0f;          // the stored torque (what an action repeat re-applies)
+            lam_fc[0] = 0.0f; lam_fc[1] = 0.0f; lam_fc[2] = 0.0f; lam_fc[3] = 0.0f; fc_link = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { lam_tf[j] = 0.0f; lam_tw[j] = 0.0f; }
+        }
+    }
+    // ---- this finger's action values: clipped, zeroed by a reset (trifinger_env.py:387), written back for _action_buf ----
+    float act[AJ];
+    if (MODE & (M_ACT_IN | M_RESETS | M_TORQUE | M_POST)) {
+        const int row = cx.valid ? lane : (cx.n_valid - 1);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int col = (j < 3) ? (3 * f + j) : (9 + 3 * f + (j - 3));
+            float a = lds[row * A + col];
+            if (MODE & (M_ACT_IN | M_RESETS)) a = f_clamp(a, -P.clip_act, P.clip_act);
+            if (IS_RESET || rflag) a = 0.0f;
+            act[j] = a;
+        }
+        if (MODE & (M_ACT_IN | M_RESETS)) {
+            BAR();                                              // #2a: every lane has read its row (rows of invalid lanes alias the last one)
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int col = (j < 3) ? (3 * f + j) : (9 + 3 * f + (j - 3));
+                if (cx.valid) lds[lane * A + col] = act[j];
+            }
+            BAR();                                              // #2b
+            coop_store_tile<A>(P.action_buf, lds, cx);
+        }
+    }
+    // ---- _pre_step torque law for the three joints of this finger (trifinger_env.py:442-494) ----
+    if (MODE & M_TORQUE) {
+        float t[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int jg = 3 * f + j;
+            float at = act[j], ak = (AJ == 6) ? act[3 + (j % 3)] : 0.0f;
+            if (P.normalize_action) {
+                float lo = P.tables[TAB_ACT_LO + jg], hi = P.tables[TAB_ACT_HI + jg];
+                float off = (lo + hi) * 0.5f;
+                at = at * (hi - lo) * 0.5f + off;
+                if (AJ == 6) {
+                    float lo2 = P.tables[TAB_ACT_LO + 9 + jg], hi2 = P.tables[TAB_ACT_HI + 9 + jg];
+                    float off2 = (lo2 + hi2) * 0.5f;
+                    ak = ak * (hi2 - lo2) * 0.5f + off2;
+                }
+            }
+            float tq;
+            if (P.command_mode == TF_CMD_TORQUE) tq = at;
+            else if (P.command_mode == TF_CMD_POSITION) { tq = P.tables[TAB_KP + jg] * (at - q[j]); tq = tq - P.tables[TAB_KD + jg] * qd[j]; }
+            else { tq = ((AJ == 6) ? ak : at) * (at - q[j]); tq = tq - P.tables[TAB_KD + jg] * qd[j]; }
+            tq = f_max(f_min(tq, 0.36f), -0.36f);
+            if (P.apply_safety_damping) {
+                tq = tq - P.tables[TAB_KS + jg] * qd[j];
+                tq = f_max(f_min(tq, 0.36f), -0.36f);
+            }
+            t[j] = tq * dr[3];                                  // domain randomisation of the motor strength (1.0 when off)
+        }
+        if (!IS_RESET && P.dr_action_repeat > 0.0f) {           // build-defined action repeat: keep the previous step's torque
+            float u[4];
+            rng4(P, gid, sa.frame0, RNG_ACT_REPEAT, u);
+            const bool keep = u[0] < P.dr_action_repeat;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float prev = rflag ? 0.0f : LDST(TF_S_TAU + 3 * f + j);
+                t[j] = keep ? prev : t[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tau[j] = t[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) ft[j] = 0.0f;
+    }
+    if (MODE & (M_TORQUE | M_RESETS)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) STST(TF_S_TAU + 3 * f + j, tau[j]);
+    }
+    // =================================================================================================================
+    // physics: decimation x substeps solver substeps
+    // =================================================================================================================
+    if (MODE & M_SIM) {
+        const float h = P.hsub, inv_h = 1.0f / h;
+        const int nsub = sa.nsim * P.substeps;
+        for (int s = 0; s < nsub; ++s) {
+            const float cube_mass = m.cube_mass * dr[0];
+            const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
+            const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
+            const float mu_fc = m.mu_finger_cube * dr[2], mu_tf = m.mu_tip_floor * dr[2], mu_tw = m.mu_tip_wall * dr[2];
+            const float rest_f = m.restitution_finger * dr[5];
+            const float ws = m.warm_start;
+            const float hc = m.cube_half * dr[1];
+            // ---- F1: free motion ----
+            FK k;
+            float vq[3], Aw[3], Bw[3], Tw[3];
+            {
+                float M[6], bias[3], rhs[3], acc[3];
+                fk_setup(m, q, k);
+                finger_dynamics(m, k, qd, P.grav, M, bias);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) M[j] = M[j] * dr[4];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bias[j] = bias[j] * dr[4];
+                inv3sym(M, k.Minv);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rhs[j] = tau[j] - bias[j];
+                sym3_mul(k.Minv, rhs, acc);
+                const float damp = 1.0f - h * m.link_angular_damping;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) vq[j] = FMA(h, acc[j], qd[j]) * damp;
+                float Ab[3], Bb[3], To[3];
+                link_point<3>(k, m.cap_a, Ab);
+                link_point<3>(k, m.cap_b, Bb);
+                link_point<3>(k, m.tip_origin, To);
+                base_to_world(yw, Ab, Aw);
+                base_to_world(yw, Bb, Bw);
+                base_to_world(yw, To, Tw);
+                const int pb = L_REC(f);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { LD(pb + P_AW + j) = Aw[j]; LD(pb + P_BW + j) = Bw[j]; LD(pb + P_P2 + j) = k.p2[j]; LD(pb + P_P3 + j) = k.p3[j]; LD(pb + P_VQ + j) = vq[j]; }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) LD(pb + P_MINV + j) = k.Minv[j];
+                LD(pb + P_S1) = k.s1; LD(pb + P_C1) = k.c1;
+            }
+            BAR();                                              // S1: free motion of every role published
+            // ---- F2: contact generation (positions at the start of the substep) ----
+            float cp[3], cq[4], v[3], w[3], R[9];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { cp[j] = LD(L_POSE_A + j); v[j] = LD(L_POSE_B + j); w[j] = LD(L_POSE_B + 3 + j); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
+            quat_to_rot(cq, R);
+            // finger vs cube: the link capsule with the smallest gap holds the contact
+            float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
+            int link = 0;
+            {
+                float da[3] = {Aw[0] - cp[0], Aw[1] - cp[1], Aw[2] - cp[2]};
+                float db[3] = {Bw[0] - cp[0], Bw[1] - cp[1], Bw[2] - cp[2]};
+                float a[3], b[3];
+                mat3T_mul(R, da, a);
+                mat3T_mul(R, db, b);
+                seg_box(a, b, hc, m.cap_radius, gap, x, y, nc);
+                link = 3; radius = m.cap_radius;
+            }
+            {
+                float Ab[3], Bb[3], A2[3], B2[3];
+                link_point<2>(k, m.cap2_a, Ab);
+                link_point<2>(k, m.cap2_b, Bb);
+                base_to_world(yw, Ab, A2);
+                base_to_world(yw, Bb, B2);
+                float da[3] = {A2[0] - cp[0], A2[1] - cp[1], A2[2] - cp[2]};
+                float db[3] = {B2[0] - cp[0], B2[1] - cp[1], B2[2] - cp[2]};
+                float a[3], b[3], gx[3], gy[3], gn[3], gg;
+                mat3T_mul(R, da, a);
+                mat3T_mul(R, db, b);
+                seg_box(a, b, hc, m.cap2_radius, gg, gx, gy, gn);
+                const bool take = gg < gap;
+                link = take ? 2 : link; gap = take ? gg : gap; radius = take ? m.cap2_radius : radius;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(cp[2] > m.upper_check_z) != 0ull, 0)) {   // wave-level: practically never
+                float Ab[3], Bb[3], A1[3], B1[3];
+                link_point<1>(k, m.cap1_a, Ab);
+                link_point<1>(k, m.cap1_b, Bb);
+                base_to_world(yw, Ab, A1);
+                base_to_world(yw, Bb, B1);
+                float da[3] = {A1[0] - cp[0], A1[1] - cp[1], A1[2] - cp[2]};
+                float db[3] = {B1[0] - cp[0], B1[1] - cp[1], B1[2] - cp[2]};
+                float a[3], b[3], gx[3], gy[3], gn[3], gg;
+                mat3T_mul(R, da, a);
+                mat3T_mul(R, db, b);
+                seg_box(a, b, hc, m.cap1_radius, gg, gx, gy, gn);
+                const bool take = (cp[2] > m.upper_check_z) && (gg < gap);
+                link = take ? 1 : link; gap = take ? gg : gap; radius = take ? m.cap1_radius : radius;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+            }
+            // rows of the finger-cube contact; the contact-space record goes to the cube role
+            float fcJ[9], fc_arm[3], rec_A[6], rec_dir[9], rec_rxd[9], rec_Dinv[3], rec_bias = 0.0f, rec_lam[3];
+            int cur_link = 0;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { fcJ[j] = 0.0f; rec_dir[j] = 0.0f; rec_rxd[j] = 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) rec_A[j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { fc_arm[j] = 0.0f; rec_Dinv[j] = 0.0f; rec_lam[j] = 0.0f; }
+            if (__builtin_expect(gap < m.contact_margin, 1)) {
+                float rcv[3], xw[3], Dd[3], fcW[9];
+                mat3_mul(R, nc, &rec_dir[0]);
+                mat3_mul(R, y, rcv);
+                mat3_mul(R, x, xw);
+                tangent_basis(&rec_dir[0], &rec_dir[3], &rec_dir[6]);
+                float Pw[3] = {FMA(-radius, rec_dir[0], cp[0] + xw[0]), FMA(-radius, rec_dir[1], cp[1] + xw[1]),
+                               FMA(-radius, rec_dir[2], cp[2] + xw[2])};
+                float Pb[3];
+                world_to_base(yw, Pw, Pb);
+                cur_link = link;
+                finger_jac(yw, k, link, Pb, rec_dir, fcJ, fcW, Dd);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    cross3(rcv, &rec_dir[3 * d], &rec_rxd[3 * d]);
+                    rec_Dinv[d] = f_rcp2(FMA(dot3(&rec_rxd[3 * d], &rec_rxd[3 * d]), inv_I, Dd[d] + inv_m));
+                }
+                rec_A[0] = Dd[0]; rec_A[1] = dot3(&fcJ[0], &fcW[3]); rec_A[2] = dot3(&fcJ[0], &fcW[6]);
+                rec_A[3] = Dd[1]; rec_A[4] = dot3(&fcJ[3], &fcW[6]);
+                rec_A[5] = Dd[2];
+                if (link == 3) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) fc_arm[j] = Pw[j] - Tw[j];
+                }
+                float vn0 = dot3(&fcJ[0], vq) - (dot3(&rec_dir[0], v) + dot3(&rec_rxd[0], w));
+                rec_bias = contact_bias(m, gap, vn0, inv_h, rest_f);
+                if ((float)link == fc_link) {                   // same link as in the last substep: seed the impulses
+                    float l0 = lam_fc[0] * ws;
+                    float lim = mu_fc * l0;
+                    rec_lam[0] = l0;
+                    rec_lam[1] = f_clamp(dot3(&lam_fc[1], &rec_dir[3]) * ws, -lim, lim);
+                    rec_lam[2] = f_clamp(dot3(&lam_fc[1], &rec_dir[6]) * ws, -lim, lim);
+                }
+            }
+            // fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1)
+            TipContact tc[2];
+            {
+                float rho2 = FMA(Bw[0], Bw[0], Bw[1] * Bw[1]);
+                float inv = f_rsqrt(f_max(rho2, 1e-24f));
+                float rho = rho2 * inv;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    TipContact& c = tc[t];
+                    c.active = false;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) { c.J[j] = 0.0f; c.dir[j] = 0.0f; }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { c.Dinv[j] = 0.0f; c.lam[j] = 0.0f; c.arm[j] = 0.0f; }
+                    c.bias = 0.0f; c.mu = 0.0f;
+                    float gp_ = (t == 0) ? (Bw[2] - m.cap_radius) : ((wall_radius_at(m, Bw[2]) - rho) - m.cap_radius);
+                    const bool on = ((t == 0) || (rho > 1e-6f)) && (gp_ < m.contact_margin);
+                    if (__builtin_expect(on, t == 0)) {
+                        float n_w[3] = {0.0f, 0.0f, 1.0f};
+                        if (t == 1) { n_w[0] = -Bw[0] * inv; n_w[1] = -Bw[1] * inv; n_w[2] = 0.0f; }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) c.dir[j] = n_w[j];
+                        tangent_basis(&c.dir[0], &c.dir[3], &c.dir[6]);
+                        float Pw[3] = {FMA(-m.cap_radius, n_w[0], Bw[0]), FMA(-m.cap_radius, n_w[1], Bw[1]), FMA(-m.cap_radius, n_w[2], Bw[2])};
+                        float Pb[3], Dd[3], Wt[9];
+                        world_to_base(yw, Pw, Pb);
+                        c.active = true;
+                        c.mu = (t == 0) ? mu_tf : mu_tw;
+                        finger_jac(yw, k, 3, Pb, c.dir, c.J, Wt, Dd);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) c.Dinv[d] = f_rcp2(Dd[d]);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) c.arm[j] = Pw[j] - Tw[j];
+                        float vn0 = dot3(&c.J[0], vq);
+                        c.bias = contact_bias(m, gp_, vn0, inv_h, rest_f);
+                        const float* pl = (t == 0) ? lam_tf : lam_tw;      // zero when the contact was not there
+                        float l0 = pl[0] * ws;
+                        float lim = c.mu * l0;
+                        c.lam[0] = l0;
+                        c.lam[1] = f_clamp(pl[1] * ws, -lim, lim);
+                        c.lam[2] = f_clamp(pl[2] * ws, -lim, lim);
+                    }
+                }
+            }
+            // joint limit / velocity limit rows
+            float vlo[3], vhi[3], lim_dinv[3], lim_lam[3];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
+                vlo[jj] = f_clamp((m.q_lo[jj] - q[jj]) * inv_h, -m.qd_max, m.qd_max);
+                vhi[jj] = f_clamp((m.q_hi[jj] - q[jj]) * inv_h, -m.qd_max, m.qd_max);
+                lim_dinv[jj] = f_rcp(k.Minv[dg]);
+                lim_lam[jj] = 0.0f;
+            }
+            BAR();                                              // S2: the finger-finger pass of the cube role is done
+            // ---- velocity after the finger-finger pass, seeded impulses on the finger side, contact-point velocity ----
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vq[j] = LD(L_VQFF + 3 * f + j);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float Wd[3];
+                sym3_mul(k.Minv, &fcJ[3 * d], Wd);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], rec_lam[d], vq[j]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float Wd[3];
+                    sym3_mul(k.Minv, &tc[t].J[3 * d], Wd);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], tc[t].lam[d], vq[j]);
+                }
+            }
+            {
+                const int rb = L_REC(f);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) LD(rb + R_A + j) = rec_A[j];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { LD(rb + R_DIR + j) = rec_dir[j]; LD(rb + R_RXD + j) = rec_rxd[j]; }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    LD(rb + R_U + d) = dot3(&fcJ[3 * d], vq);
+                    LD(rb + R_DL + d) = rec_lam[d];             // seeded impulses (the cube role reads them once)
+                    LD(L_VQFF + 3 * f + d) = rec_Dinv[d];
+                }
+                LD(L_INIT + f) = rec_bias;
+            }
+            BAR();                                              // S3: records published
+            // ---- projected Gauss-Seidel: this finger's share ----
+            float Fc[3] = {0.0f, 0.0f, 0.0f};
+            for (int it = 0; it < P.iters; ++it) {
+                BAR();                                          // W1: the cube role has solved the finger-cube rows of this sweep
+                const int rb = L_REC(f);
+                float dl[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) dl[d] = LD(rb + R_DL + d);
+                if (it == P.iters - 1) {                        // impulses of the finger-cube contact after the last sweep
+                    lam_fc[0] = LD(L_INIT + f);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { lam_fc[1 + j] = LD(rb + R_A + j); Fc[j] = LD(rb + R_A + 3 + j); }
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float Wd[3];
+                    sym3_mul(k.Minv, &fcJ[3 * d], Wd);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], dl[d], vq[j]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {                   // fingertip - floor, fingertip - wall
+                    TipContact& c = tc[t];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        float vrel = dot3(&c.J[3 * d], vq);
+                        float dlt = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
+                                             : solve_tangent(c.lam[d], c.Dinv[d], vrel, c.mu * c.lam[0]);
+                        float Wd[3];
+                        sym3_mul(k.Minv, &c.J[3 * d], Wd);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], dlt, vq[j]);
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {                // joint limits + velocity limit
+                    const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
+                    const int c0 = (jj == 0) ? 0 : ((jj == 1) ? 1 : 2);
+                    const int c1 = (jj == 0) ? 1 : ((jj == 1) ? 3 : 4);
+                    const int c2 = (jj == 0) ? 2 : ((jj == 1) ? 4 : 5);
+                    float v0 = FMA(-k.Minv[dg], lim_lam[jj], vq[jj]);
+                    float tgt = f_clamp(v0, vlo[jj], vhi[jj]);
+                    float lam_new = (tgt - v0) * lim_dinv[jj];
+                    float dlj = lam_new - lim_lam[jj];
+                    lim_lam[jj] = lam_new;
+                    vq[0] = FMA(k.Minv[c0], dlj, vq[0]);
+                    vq[1] = FMA(k.Minv[c1], dlj, vq[1]);
+                    vq[2] = FMA(k.Minv[c2], dlj, vq[2]);
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) LD(rb + R_U + d) = dot3(&fcJ[3 * d], vq);
+                BAR();                                          // W2: contact-point velocities published
+            }
+            // ---- impulses kept for the next substep, fingertip wrench sensor, integration ----
+            fc_link = (float)cur_link;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { lam_tf[d] = tc[0].lam[d]; lam_tw[d] = tc[1].lam[d]; }
+            if (ASYM || !(MODE & M_POST)) {
+                if (cur_link == 3) {
+                    float T[3];
+                    cross3(fc_arm, Fc, T);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { ft[j] += Fc[j]; ft[3 + j] += T[j]; }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const TipContact& c = tc[t];
+                    if (c.active) {
+                        float F[3], T[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) F[j] = FMA(c.dir[6 + j], c.lam[2], FMA(c.dir[3 + j], c.lam[1], c.dir[j] * c.lam[0])) * inv_h;
+                        cross3(c.arm, F, T);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { ft[j] += F[j]; ft[3 + j] += T[j]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                qd[jj] = vq[jj];
+                q[jj] = f_clamp(FMA(h, vq[jj], q[jj]), m.q_lo[jj], m.q_hi[jj]);
+            }
+        }
+    }
+    // =================================================================================================================
+    // post: fingertip state, observation slots of this finger
+    // =================================================================================================================
+    if (MODE & M_POST) {
+        FK pk;
+        float tips[13];
+        fk_setup(m, q, pk);
+        tip_state(m, yw, pk, q, qd, tips);
+        float tip_prev[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j);
+        {   // NaN guard, part 1: this role's share of the finiteness test
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = acc + q[j] * 0.0f + qd[j] * 0.0f;
+            LD(L_NAN + f) = (acc == 0.0f) ? 0.0f : 1.0f;
+        }
+        BAR();                                                  // P1
+        const bool guarded = (LD(L_NAN) + LD(L_NAN + 1) + LD(L_NAN + 2) + LD(L_NAN + 3)) != 0.0f;
+        if (__builtin_expect(guarded, 0)) {                     // park the env at the default pose (it is flagged for reset)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { q[j] = m.q_default[j]; qd[j] = 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ft[j] = 0.0f;
+            fk_setup(m, q, pk);
+            tip_state(m, yw, pk, q, qd, tips);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) STST(TF_S_TIP_P + 3 * f + j, tips[j]);
+        // exchange for the rewards (cube role) and this finger's slots of the obs / states tile
+        const float co = P.clip_obs;
+        const bool nrm = P.normalize_obs != 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { LD(L_XCH + 6 * f + j) = tips[j]; LD(L_XCH + 6 * f + 3 + j) = tip_prev[j]; }
+        float* row = &lds[lane * TW];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float lo = (j == 0) ? -0.33f : ((j == 1) ? 0.0f : -2.7f), hi = (j == 0) ? 1.0f : ((j == 1) ? 1.57f : 0.0f);
+            row[3 * f + j] = emit_scaled(q[j], lo, hi, nrm, co);
+            row[9 + 3 * f + j] = emit_scaled(qd[j], -10.0f, 10.0f, nrm, co);
+        }
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int col = (j < 3) ? (3 * f + j) : (9 + 3 * f + (j - 3));
+            row[32 + col] = emit_table(P, 32 + col, opaque(act[j]), nrm, co);
+        }
+        if (ASYM) {
+#pragma unroll
+            for (int j = 0; j < 13; ++j) row[OD + 6 + 13 * f + j] = emit_scaled(tips[j], TLO(j), THI(j), nrm, co);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) row[OD + 45 + 3 * f + j] = emit_scaled(P.enable_ft ? tau[j] : 0.0f, -0.36f, 0.36f, nrm, co);
+            const float inv_n = 1.0f / (float)(P.substeps * P.control_decimation);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float wv[3] = {ft[3 * half] * inv_n, ft[3 * half + 1] * inv_n, ft[3 * half + 2] * inv_n};
+                float bv[3], lv[3];
+                dir_world_to_base(yw, wv, bv);
+                rot_link_T<3>(pk, bv, lv);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) row[OD + 54 + 6 * f + 3 * half + j] = emit_scaled(P.enable_ft ? lv[j] : 0.0f, -1.0f, 1.0f, nrm, co);
+            }
+        }
+        if (ASYM) {
+            BAR();                                              // P3: states tile complete
+            coop_store_tile<SD>(P.states, lds, cx);
+            if (P.dr_obs_noise > 0.0f) {
+                BAR();                                          // P4: states tile stored; obs noise goes on top of slots 0..24
+                float nz[28];
+#pragma unroll
+                for (int b = 0; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+#pragma unroll
+                for (int jj = 0; jj < 18; ++jj) {
+                    const bool mine = (jj == 3 * f) || (jj == 3 * f + 1) || (jj == 3 * f + 2) || (jj == 9 + 3 * f) || (jj == 10 + 3 * f) || (jj == 11 + 3 * f);
+                    if (mine) row[jj] = f_clamp(FMA(P.dr_obs_noise, 2.0f * nz[jj] - 1.0f, row[jj]), -co, co);
+                }
+                BAR();                                          // P5
+            }
+            coop_store_tile_strided<OD, SD>(P.obs, lds, cx);
+        } else {
+            if (P.dr_obs_noise > 0.0f) {
+                float nz[28];
+#pragma unroll
+                for (int b = 0; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+#pragma unroll
+                for (int jj = 0; jj < 18; ++jj) {
+                    const bool mine = (jj == 3 * f) || (jj == 3 * f + 1) || (jj == 3 * f + 2) || (jj == 9 + 3 * f) || (jj == 10 + 3 * f) || (jj == 11 + 3 * f);
+                    if (mine) row[jj] = f_clamp(FMA(P.dr_obs_noise, 2.0f * nz[jj] - 1.0f, row[jj]), -co, co);
+                }
+            }
+            BAR();                                              // P3
+            coop_store_tile<OD>(P.obs, lds, cx);
+        }
+    }
+    // ---- state rows of this finger ----
+    if (MODE & (M_RESETS | M_SIM | M_POST)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { STST(TF_S_Q + 3 * f + j, q[j]); STST(TF_S_QD + 3 * f + j, qd[j]); }
+    }
+    if (MODE & (M_RESETS | M_SIM)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, lam_fc[j]);
+        STST(TF_S_FC_LINK + f, fc_link);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { STST(TF_S_LAM_TF + 3 * f + j, lam_tf[j]); STST(TF_S_LAM_TW + 3 * f + j, lam_tw[j]); }
+    }
+    if ((MODE & (M_TORQUE | M_SIM | M_POST)) && !((MODE & M_TORQUE) && (MODE & M_POST))) {   // split path only
+#pragma unroll
+        for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, ft[j]);
+    }
+}
+
+// =====================================================================================================================
+// CUBE ROLE: cube, goal, flags and counters, rewards, termination, episode statistics
+// =====================================================================================================================
+struct LaneStats { float rew[6]; float pos_cnt, ori_cnt, succ, resets, nonfinite; };
+
+
+// Sum over the 64 lanes, valid in lane 63.  DPP only (operand swizzles of v_add_f32, no LDS round trips like
+// ds_bpermute): xor-1 / xor-2 inside the quads, rotate by 4 and 8 inside the 16-lane rows, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Fixed order, so the statistics stay deterministic.
+template <int CTRL, int ROW_MASK>
+DEV float dpp_add(float x) {
+    int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false);
+    return x + __builtin_bit_cast(float, moved);
+}
+DEV float wave_sum_lane63(float x) {
+    x = dpp_add<0xB1, 0xF>(x);      // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E, 0xF>(x);      // quad_perm [2,3,0,1]
+    x = dpp_add<0x124, 0xF>(x);     // row_ror:4
+    x = dpp_add<0x128, 0xF>(x);     // row_ror:8
+    x = dpp_add<0x142, 0xA>(x);     // row_bcast:15 -> rows 1, 3
+    x = dpp_add<0x143, 0xC>(x);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+
+// Episode statistics without a second launch (a separate 11-wave reduction kernel cost 4.5 us per step, mostly fixed
+// launch and cold-miss latency).  Lane k < 11 of every wave adds the wave's sum of statistic k to a 64-bit accumulator with
+// ONE device-scope integer atomic: the sum as signed fixed point (2^-16) in the upper 47 bits, an arrival count in the
+// lower 17.  Integer addition commutes, so the result does not depend on the arrival order (deterministic, unlike float
+// atomics), and the returned old value tells each lane whether it was the last to arrive: that lane carries the total to
+// the next level (16 shards -> 1, so that a thousand waves finishing together do not queue on one word) and finally
+// writes info[].  The atomic is issued as soon as the rewards are known and its return is consumed at the very end of
+// the kernel, behind the observation tiles: its latency is off the critical path of every wave but the last.
+#define STAT_SHARDS 16
+#define STAT_STRIDE 8                            /* uint64 per accumulator: 64 B apart */
+#define STAT_WORDS ((STAT_SHARDS * 11 + 11) * STAT_STRIDE)
+#define STAT_COUNT_BITS 17
+#define STAT_FIX 65536.0                         /* 2^16: |sum| < 2^30 = 1e9 fits the 47-bit field (4 Mi envs x |term| <= 250) */
+typedef GLOBAL_AS unsigned long long gu64;
+struct StatsTicket { unsigned long long mine, old; };
+DEV void stats_begin(const DevParams& P, const LaneStats& st, int lane, StatsTicket& tk) {
+    float vals[11];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) vals[t] = st.rew[t];
+    vals[6] = st.pos_cnt; vals[7] = st.ori_cnt; vals[8] = st.succ; vals[9] = st.resets; vals[10] = st.nonfinite;
+    float sum = 0.0f;                            // lane k < 11 ends up holding the wave's sum of statistic k
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float s = wave_sum_lane63(vals[k]);
+        const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), WAVE - 1));
+        sum = (lane == k) ? b : sum;
+    }
+    const long long fx = (long long)((double)sum * STAT_FIX);
+    tk.mine = ((unsigned long long)fx << STAT_COUNT_BITS) + 1ull;
+    tk.old = 0ull;
+    const int shard = (int)blockIdx.x & (STAT_SHARDS - 1);
+    gu64* acc = (gu64*)P.tickets;
+    if (lane < 11)
+        tk.old = __hip_atomic_fetch_add(&acc[(shard * 11 + lane) * STAT_STRIDE], tk.mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV void stats_end(const DevParams& P, int lane, const StatsTicket& tk) {
+    const unsigned long long cmask = (1ull << STAT_COUNT_BITS) - 1ull;
+    const int nw = (int)gridDim.x;
+    const int shard = (int)blockIdx.x & (STAT_SHARDS - 1);
+    const unsigned long long members = (unsigned long long)((nw - shard + STAT_SHARDS - 1) / STAT_SHARDS);
+    const unsigned long long nshards = (unsigned long long)(nw < STAT_SHARDS ? nw : STAT_SHARDS);
+    gu64* acc = (gu64*)P.tickets;
+    if (lane < 11 && (tk.old & cmask) == members - 1ull) {          // last wave of this shard for statistic `lane`
+        const unsigned long long total1 = tk.old + tk.mine;          // count field == members, sum field == shard sum
+        __hip_atomic_store(&acc[(shard * 11 + lane) * STAT_STRIDE], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long v2 = (total1 & ~cmask) + 1ull;
+        gu64* top = &acc[(STAT_SHARDS * 11 + lane) * STAT_STRIDE];
+        const unsigned long long old2 = __hip_atomic_fetch_add(top, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old2 & cmask) == nshards - 1ull) {                     // last shard: the grand total is complete
+            __hip_atomic_store(top, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long fxs = (long long)(old2 + v2) >> STAT_COUNT_BITS;
+            const float total = (float)((double)fxs / STAT_FIX);
+            const int k = lane;
+            const float o = (k < 6 || k == 8) ? total / (float)P.N : total;
+            const int slot = (k < 6) ? k : ((k == 6) ? TF_INFO_POS_COUNT : ((k == 7) ? TF_INFO_ORI_COUNT :
+                             ((k == 8) ? TF_INFO_SUCCESS_MEAN : ((k == 9) ? TF_INFO_NUM_RESETS : TF_INFO_NUM_NONFINITE))));
+            P.info[slot] = o;
+        }
+    }
+}
+
+DEV void stats_zero(LaneStats& st) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t) st.rew[t] = 0.0f;
+    st.pos_cnt = 0.0f; st.ori_cnt = 0.0f; st.succ = 0.0f; st.resets = 0.0f; st.nonfinite = 0.0f;
+}
+
+struct FingerPubRegs { float Aw[3], Bw[3], vq[3]; FK k; };
+DEV void read_pub(const float* lds, int lane, int f, FingerPubRegs& p) {
+    const int pb = L_REC(f);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { p.Aw[j] = LD(pb + P_AW + j); p.Bw[j] = LD(pb + P_BW + j); p.k.p2[j] = LD(pb + P_P2 + j); p.k.p3[j] = LD(pb + P_P3 + j); }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) p.k.Minv[j] = LD(pb + P_MINV + j);
+    p.k.s1 = LD(pb + P_S1); p.k.c1 = LD(pb + P_C1);
+    p.k.ax[0] = p.k.c1; p.k.ax[1] = 0.0f; p.k.ax[2] = -p.k.s1;
+}
+
+template <int A, bool IS_RESET, bool ASYM, int MODE>
+DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
+    const TfModel& m = P.m;
+    const int lane = cx.lane;
+    constexpr int OD = TF_OBS_DIM_BASE + A, SD = OD + TF_STATES_EXTRA;
+    constexpr int TW = ASYM ? SD : OD;
+    const uint32_t gid = (uint32_t)(P.env_id_offset + cx.i);
+    // ---- loads ----
+    float cp[3], cq[4], cv[3], cw[3], gp[3], gq[4], gw[3], dr[TF_NUM_DR];
+    float lam_cf[12], lam_cw[12], cf_face = 0.0f, cw_face = 0.0f;
+    float prev_obj[7];
+    uint8_t fl_reset = 0, fl_goal_reset = 0, fl_successes = 0;
+    int fl_steps = 0;
+    uint32_t fl_count = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { cp[j] = LDST(TF_S_CUBE_P + j); cv[j] = LDST(TF_S_CUBE_V + j); cw[j] = LDST(TF_S_CUBE_W + j); gp[j] = LDST(TF_S_GOAL_P + j); gw[j] = LDST(TF_S_GOAL_W + j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cq[j] = LDST(TF_S_CUBE_Q + j); gq[j] = LDST(TF_S_GOAL_Q + j); }
+#pragma unroll
+    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
+    if (MODE & (M_SIM | M_RESETS)) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = LDST(TF_S_LAM_CW + j); }
+        cf_face = LDST(TF_S_CF_FACE); cw_face = LDST(TF_S_CW_FACE);
+    }
+    if ((MODE & M_POST) && !(MODE & M_TORQUE)) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) prev_obj[j] = LDST(TF_S_PREV_OBJ_P + j);
+    }
+    if (MODE & (M_RESETS | M_POST | M_FINISH)) {
+        fl_reset = P.reset_buf[(unsigned)cx.i];
+        fl_goal_reset = P.goal_reset_buf[(unsigned)cx.i];
+        fl_successes = P.successes[(unsigned)cx.i];
+        fl_steps = P.steps[(unsigned)cx.i];
+        fl_count = P.reset_count[(unsigned)cx.i];
+    }
+    if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
+    else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
+    BAR();                                                      // #1
+    // flags carried in registers to the bookkeeping at the end of the step
+    bool c_reset = fl_reset != 0, c_goal_reset = fl_goal_reset != 0, c_successes = fl_successes != 0;
+    int c_steps = fl_steps;
+    float n_resets = 0.0f;
+    // ---- masked _reset_impl then _goal_reset_impl (env_base.py:370-379; trifinger_env.py:373-440) ----
+    if (MODE & M_RESETS) {
+        const bool rflag = IS_RESET || (fl_reset != 0);
+        const bool gflag = !IS_RESET && (fl_goal_reset != 0);
+        uint32_t count = fl_count;
+        if (rflag) {
+            if (P.dr_enable) draw_dr(P, gid, count, dr);
+            if (P.object_reset_type == TF_RESET_DEFAULT) {
+                cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = CUBE_MIN_HEIGHT * dr[1];
+                cq[0] = 0.0f; cq[1] = 0.0f; cq[2] = 0.0f; cq[3] = 1.0f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
+            } else if (P.object_reset_type == TF_RESET_RANDOM) {
+                float u[4];
+                rng4(P, gid, count, RNG_OBJECT, u);
+                sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, cp[0], cp[1]);
+                cp[2] = (0.065f / 2.0f) * dr[1];
+                sample_yaw_quat(u[2], cq);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
+            }
+            sample_goal(P, gid, count, gp, gq, gw);
+            count = count + 1u;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { lam_cf[j] = 0.0f; lam_cw[j] = 0.0f; }
+            cf_face = 0.0f; cw_face = 0.0f;
+            n_resets = cx.valid ? 1.0f : 0.0f;
+        }
+        if (gflag) {
+            sample_goal(P, gid, count, gp, gq, gw);
+            count = count + 1u;
+        }
+        if (cx.valid) {
+            if (rflag) { P.reset_buf[(unsigned)cx.i] = 0; P.steps[(unsigned)cx.i] = 0; P.successes[(unsigned)cx.i] = 0; }
+            if (gflag) P.goal_reset_buf[(unsigned)cx.i] = 0;
+            if (rflag || gflag) P.reset_count[(unsigned)cx.i] = count;
+        }
+        if (rflag && P.dr_enable) {
+#pragma unroll
+            for (int j = 0; j < TF_NUM_DR; ++j) STST(TF_S_DR + j, dr[j]);
+        }
+        if (rflag || gflag) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { STST(TF_S_GOAL_P + j, gp[j]); STST(TF_S_GOAL_W + j, gw[j]); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) STST(TF_S_GOAL_Q + j, gq[j]);
+        }
+        c_reset = false;                                        // cleared by the reset, or it was not set
+        c_goal_reset = IS_RESET ? (fl_goal_reset != 0) : false; // reset() leaves _goal_reset_buf alone
+        c_successes = rflag ? false : (fl_successes != 0);
+        c_steps = rflag ? 0 : fl_steps;
+    }
+    if (MODE & (M_ACT_IN | M_RESETS)) {
+        BAR();                                                  // #2a
+        BAR();                                                  // #2b
+        coop_store_tile<A>(P.action_buf, lds, cx);
+    }
+    if (MODE & M_TORQUE) {                                      // history[1] of the object (trifinger_env.py:975)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { STST(TF_S_PREV_OBJ_P + j, cp[j]); prev_obj[j] = cp[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { STST(TF_S_PREV_OBJ_Q + j, cq[j]); prev_obj[3 + j] = cq[j]; }
+    }
+    // =================================================================================================================
+    // physics
+    // =================================================================================================================
+    if (MODE & M_SIM) {
+        const float h = P.hsub, inv_h = 1.0f / h;
+        const int nsub = sa.nsim * P.substeps;
+        // the wall-corner impulses live in LDS through the substeps
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) LD(L_WALL + 12 * c + 9 + d) = lam_cw[3 * c + d];
+        }
+        for (int s = 0; s < nsub; ++s) {
+            const float cube_mass = m.cube_mass * dr[0];
+            const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
+            const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
+            const float mu_fc = m.mu_finger_cube * dr[2];
+            const float mu_cf = m.mu_cube_floor * dr[2], mu_cw = m.mu_cube_wall * dr[2], mu_ff = m.mu_finger_finger * dr[2];
+            const float rest_ff = m.restitution_ff * dr[5];
+            const float ws = m.warm_start;
+            const float hc = m.cube_half * dr[1];
+            // ---- C1: free motion of the cube, corner contacts against the arena ----
+            float v[3], w[3];
+            {
+                float dl = 1.0f - h * m.cube_linear_damping, da = 1.0f - h * m.cube_angular_damping;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    v[j] = FMA(h, P.grav[j], cv[j]) * dl;
+                    w[j] = cw[j] * da;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { LD(L_POSE_A + j) = cp[j]; LD(L_POSE_B + j) = v[j]; LD(L_POSE_B + 3 + j) = w[j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) LD(L_POSE_A + 3 + j) = cq[j];
+            float R[9];
+            quat_to_rot(cq, R);
+            float fr_[12], fDinv[12], fbias[4], flam[12];       // floor corners: arm, 1/D, bias, impulses of rows +z, +x, +y
+            {   // cube vs floor: the four corners of the face that points down most
+                int k = 0;
+                float best = f_abs(R[6]);
+                if (f_abs(R[7]) > best) { best = f_abs(R[7]); k = 1; }
+                if (f_abs(R[8]) > best) { best = f_abs(R[8]); k = 2; }
+                float rk = (k == 0) ? R[6] : ((k == 1) ? R[7] : R[8]);
+                float sk = (rk > 0.0f) ? -1.0f : 1.0f;
+                const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
+                const float keep = (face == cf_face) ? ws : 0.0f;
+                cf_face = face;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float* r = &fr_[3 * c];
+                    cube_corner(R, hc, k, sk, c, r);
+                    float gap = cp[2] + r[2];
+                    fDinv[3 * c] = 0.0f; fDinv[3 * c + 1] = 0.0f; fDinv[3 * c + 2] = 0.0f;
+                    fbias[c] = 0.0f;
+                    flam[3 * c] = 0.0f; flam[3 * c + 1] = 0.0f; flam[3 * c + 2] = 0.0f;
+                    if (__builtin_expect(gap < m.contact_margin, 1)) {
+                        fDinv[3 * c] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                        fDinv[3 * c + 1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
+                        fDinv[3 * c + 2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
+                        float vn0 = cz_vrel(r, v, w);
+                        fbias[c] = contact_bias(m, gap, vn0, inv_h, 0.0f);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) flam[3 * c + d] = lam_cf[3 * c + d] * keep;
+                    }
+                }
+            }
+            {   // cube vs boundary wall: the four corners of the face that points outward most; rows go to LDS
+                float rc2 = FMA(cp[0], cp[0], cp[1] * cp[1]);
+                float irc = f_rsqrt(f_max(rc2, 1e-24f));
+                float rho_c = rc2 * irc;
+                bool any = rho_c > 1e-6f;
+                float dx = 0.0f, dy = 0.0f;
+                if (any) { dx = cp[0] * irc; dy = cp[1] * irc; }
+                float pr[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) pr[j] = FMA(R[j], dx, R[3 + j] * dy);
+                int k = 0;
+                float best = f_abs(pr[0]);
+                if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
+                if (f_abs(pr[2]) > best) { best = f_abs(pr[2]); k = 2; }
+                float pk = (k == 0) ? pr[0] : ((k == 1) ? pr[1] : pr[2]);
+                float sk = (pk < 0.0f) ? -1.0f : 1.0f;
+                const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
+                const float keep = (face == cw_face) ? ws : 0.0f;
+                cw_face = face;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int wb = L_WALL + 12 * c;
+                    float r[3], n[2] = {0.0f, 0.0f}, Dinv[3] = {0.0f, 0.0f, 0.0f}, bias = 0.0f, lam[3] = {0.0f, 0.0f, 0.0f};
+                    cube_corner(R, hc, k, sk, c, r);
+                    float px = cp[0] + r[0], py = cp[1] + r[1], pz = cp[2] + r[2];
+                    float rho2 = FMA(px, px, py * py);
+                    float inv = f_rsqrt(f_max(rho2, 1e-24f));
+                    float rho = rho2 * inv;
+                    float gap = wall_radius_at(m, pz) - rho;
+                    if (__builtin_expect(any && gap < m.contact_margin && rho > 1e-6f, 0)) {
+                        n[0] = -px * inv; n[1] = -py * inv;
+                        float a[3], b[3];
+                        wall_arm_n(r, n, a);
+                        wall_arm_t(r, n, b);
+                        Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
+                        Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
+                        Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                        float vn0 = wn_vrel(n, a, v, w);
+                        bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) lam[d] = LD(wb + 9 + d) * keep;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { LD(wb + j) = r[j]; LD(wb + 5 + j) = Dinv[j]; LD(wb + 9 + j) = lam[j]; }
+                    LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
+                }
+            }
+            BAR();                                              // S1
+            // ---- FF: finger-finger contacts (distal capsules), solved before the sweeps on the free velocities: the pairs
+            // (0,1), (1,2), (2,0) in turn, TF_FF_ITERATIONS Gauss-Seidel iterations over the three rows of each pair ----
+            {
+                float vq_ff[9];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) vq_ff[3 * f + j] = LD(L_REC(f) + P_VQ + j);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int fa = p, fb = (p + 1) % 3;
+                    FingerPubRegs pa, pb_;
+                    read_pub(lds, lane, fa, pa);
+                    read_pub(lds, lane, fb, pb_);
+                    float Pa[3], Pb[3];
+                    seg_seg(pa.Aw, pa.Bw, pb_.Aw, pb_.Bw, Pa, Pb);
+                    float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
+                    float dist2 = dot3(dv, dv);
+                    const bool far_apart = !(dist2 > 1e-12f);
+                    float inv = f_rsqrt(f_max(dist2, 1e-12f));
+                    float dist = dist2 * inv;
+                    float gap = dist - 2.0f * m.cap_radius;
+                    const bool active = !far_apart && (gap < m.contact_margin);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(active) != 0ull, 0)) {
+                        const Yaw ya = {m.base_yaw_cos[fa], m.base_yaw_sin[fa], 0.0f, 0.0f, m.base_height};
+                        const Yaw yb = {m.base_yaw_cos[fb], m.base_yaw_sin[fb], 0.0f, 0.0f, m.base_height};
+                        float dirs[9];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) dirs[j] = dv[j] * inv;
+                        if (!active) { dirs[0] = 1.0f; dirs[1] = 0.0f; dirs[2] = 0.0f; }        // keep the dead lanes finite
+                        tangent_basis(&dirs[0], &dirs[3], &dirs[6]);
+                        float Ca[3], Cb[3], Cab[3], Cbb[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { Ca[j] = FMA(-m.cap_radius, dirs[j], Pa[j]); Cb[j] = FMA(m.cap_radius, dirs[j], Pb[j]); }
+                        world_to_base(ya, Ca, Cab);
+                        world_to_base(yb, Cb, Cbb);
+                        float Ja[9], Wa[9], Da[3], Jb[9], Wb[9], Db[3];
+                        finger_jac(ya, pa.k, 3, Cab, dirs, Ja, Wa, Da);
+                        finger_jac(yb, pb_.k, 3, Cbb, dirs, Jb, Wb, Db);
+                        float va[3] = {vq_ff[3 * fa], vq_ff[3 * fa + 1], vq_ff[3 * fa + 2]};
+                        float vb[3] = {vq_ff[3 * fb], vq_ff[3 * fb + 1], vq_ff[3 * fb + 2]};
+                        float vn0 = dot3(&Ja[0], va) - dot3(&Jb[0], vb);
+                        float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+                        float Dinv[3], lam[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) Dinv[d] = f_rcp2(f_max(Da[d] + Db[d], 1e-30f));
+#pragma unroll
+                        for (int it = 0; it < TF_FF_ITERATIONS; ++it) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                float vrel = dot3(&Ja[3 * d], va) - dot3(&Jb[3 * d], vb);
+                                float dl = (d == 0) ? solve_normal(lam[0], Dinv[0], vrel, bias) : solve_tangent(lam[d], Dinv[d], vrel, mu_ff * lam[0]);
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[3 * d + j], dl, va[j]); vb[j] = FMA(-Wb[3 * d + j], dl, vb[j]); }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            vq_ff[3 * fa + j] = active ? va[j] : vq_ff[3 * fa + j];
+                            vq_ff[3 * fb + j] = active ? vb[j] : vq_ff[3 * fb + j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) LD(L_VQFF + j) = vq_ff[j];
+            }
+            BAR();                                              // S2
+            BAR();                                              // S3: records published by the finger roles
+            // ---- seeded impulses of the finger contacts (1/D, bias and impulses stay in registers through the sweeps) ----
+            float cDinv[9], cbias[3], clam[9];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const int rb = L_REC(f);
+                cbias[f] = LD(L_INIT + f);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { cDinv[3 * f + d] = LD(L_VQFF + 3 * f + d); clam[3 * f + d] = LD(rb + R_DL + d); }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float dir[3], rxd[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { dir[j] = LD(rb + R_DIR + 3 * d + j); rxd[j] = LD(rb + R_RXD + 3 * d + j); }
+                    float sc = clam[3 * f + d] * inv_m, qq = clam[3 * f + d] * inv_I;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                cz_apply(&fr_[3 * c], flam[3 * c], inv_m, inv_I, v, w);
+                cx_apply(&fr_[3 * c], flam[3 * c + 1], inv_m, inv_I, v, w);
+                cy_apply(&fr_[3 * c], flam[3 * c + 2], inv_m, inv_I, v, w);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int wb = L_WALL + 12 * c;
+                float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
+                float a[3], b[3];
+                wall_arm_n(r, n, a);
+                wall_arm_t(r, n, b);
+                wn_apply(n, a, LD(wb + 9), inv_m, inv_I, v, w);
+                wt_apply(n, b, LD(wb + 10), inv_m, inv_I, v, w);
+                cz_apply(r, LD(wb + 11), inv_m, inv_I, v, w);
+            }
+            // ---- projected Gauss-Seidel: the cube role's share ----
+            for (int it = 0; it < P.iters; ++it) {
+                const bool last = it == P.iters - 1;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {                   // finger-cube rows in contact space
+                    const int rb = L_REC(f);
+                    float Am[6], u[3], dirs[9], rxds[9];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) Am[j] = LD(rb + R_A + j);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) u[j] = LD(rb + R_U + j);
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) { dirs[j] = LD(rb + R_DIR + j); rxds[j] = LD(rb + R_RXD + j); }
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const float* dir = &dirs[3 * d];
+                        const float* rxd = &rxds[3 * d];
+                        float vrel = u[d] - (dot3(dir, v) + dot3(rxd, w));
+                        float dl = (d == 0) ? solve_normal(clam[3 * f], cDinv[3 * f], vrel, cbias[f])
+                                            : solve_tangent(clam[3 * f + d], cDinv[3 * f + d], vrel, mu_fc * clam[3 * f]);
+                        LD(rb + R_DL + d) = dl;
+                        const int i0 = (d == 0) ? 0 : ((d == 1) ? 1 : 2), i1 = (d == 0) ? 1 : ((d == 1) ? 3 : 4), i2 = (d == 0) ? 2 : ((d == 1) ? 4 : 5);
+                        u[0] = FMA(Am[i0], dl, u[0]);
+                        u[1] = FMA(Am[i1], dl, u[1]);
+                        u[2] = FMA(Am[i2], dl, u[2]);
+                        float sc = dl * inv_m, qq = dl * inv_I;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
+                    }
+                    if (last) {                                 // what the finger role keeps: normal impulse, world friction impulse, force
+                        float ftv[3], Fc[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            ftv[j] = FMA(dirs[6 + j], clam[3 * f + 2], dirs[3 + j] * clam[3 * f + 1]);
+                            Fc[j] = FMA(dirs[j], clam[3 * f], ftv[j]) * inv_h;
+                        }
+                        LD(L_INIT + f) = clam[3 * f];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { LD(rb + R_A + j) = ftv[j]; LD(rb + R_A + 3 + j) = Fc[j]; }
+                    }
+                }
+                BAR();                                          // W1
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                   // cube - floor: rows +z (normal), +x, +y
+                    const float* r = &fr_[3 * c];
+                    float dl = solve_normal(flam[3 * c], fDinv[3 * c], cz_vrel(r, v, w), fbias[c]);
+                    cz_apply(r, dl, inv_m, inv_I, v, w);
+                    dl = solve_tangent(flam[3 * c + 1], fDinv[3 * c + 1], cx_vrel(r, v, w), mu_cf * flam[3 * c]);
+                    cx_apply(r, dl, inv_m, inv_I, v, w);
+                    dl = solve_tangent(flam[3 * c + 2], fDinv[3 * c + 2], cy_vrel(r, v, w), mu_cf * flam[3 * c]);
+                    cy_apply(r, dl, inv_m, inv_I, v, w);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                   // cube - wall: rows n (normal), t, +z
+                    const int wb = L_WALL + 12 * c;
+                    float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
+                    float Dinv[3] = {LD(wb + 5), LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
+                    float lam[3] = {LD(wb + 9), LD(wb + 10), LD(wb + 11)};
+                    float a[3], b[3];
+                    wall_arm_n(r, n, a);
+                    wall_arm_t(r, n, b);
+                    float dl = solve_normal(lam[0], Dinv[0], wn_vrel(n, a, v, w), bias);
+                    wn_apply(n, a, dl, inv_m, inv_I, v, w);
+                    dl = solve_tangent(lam[1], Dinv[1], wt_vrel(n, b, v, w), mu_cw * lam[0]);
+                    wt_apply(n, b, dl, inv_m, inv_I, v, w);
+                    dl = solve_tangent(lam[2], Dinv[2], cz_vrel(r, v, w), mu_cw * lam[0]);
+                    cz_apply(r, dl, inv_m, inv_I, v, w);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
+                }
+                BAR();                                          // W2
+            }
+            // ---- impulses kept for the next substep, integration ----
+#pragma unroll
+            for (int j = 0; j < 12; ++j) lam_cf[j] = flam[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                cv[j] = v[j]; cw[j] = w[j];
+                cp[j] = FMA(h, v[j], cp[j]);
+            }
+            quat_integrate(cq, cw, h);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) lam_cw[3 * c + d] = LD(L_WALL + 12 * c + 9 + d);
+        }
+    }
+    // =================================================================================================================
+    // post: observations of the object and the goal, rewards, termination, statistics
+    // =================================================================================================================
+    StatsTicket tk;
+    tk.mine = 0ull; tk.old = 0ull;
+    if (MODE & M_POST) {
+        LaneStats st;
+        stats_zero(st);
+        st.resets = n_resets;
+        {   // NaN guard, part 1: this role's share of the finiteness test
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = acc + cp[j] * 0.0f + cv[j] * 0.0f + cw[j] * 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = acc + cq[j] * 0.0f;
+            LD(L_NAN + 3) = (acc == 0.0f) ? 0.0f : 1.0f;
+        }
+        BAR();                                                  // P1
+        const bool guarded = (LD(L_NAN) + LD(L_NAN + 1) + LD(L_NAN + 2) + LD(L_NAN + 3)) != 0.0f;
+        if (__builtin_expect(guarded, 0)) {     // a non-finite env is flagged for reset and parked at the default pose
+            cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = CUBE_MIN_HEIGHT;
+            cq[0] = 0.0f; cq[1] = 0.0f; cq[2] = 0.0f; cq[3] = 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
+            if (cx.valid) P.reset_buf[(unsigned)cx.i] = 1;
+            c_reset = true;
+            st.nonfinite += cx.valid ? 1.0f : 0.0f;
+        }
+        const float co = P.clip_obs;
+        const bool nrm = P.normalize_obs != 0;
+        float* row = &lds[lane * TW];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { row[18 + j] = emit_scaled(cp[j], PLO(j), 0.3f, nrm, co); row[25 + j] = emit_scaled(gp[j], PLO(j), 0.3f, nrm, co); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { row[21 + j] = emit_scaled(cq[j], -1.0f, 1.0f, nrm, co); row[28 + j] = emit_scaled(gq[j], -1.0f, 1.0f, nrm, co); }
+        if (ASYM) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { row[OD + j] = emit_scaled(cv[j], -0.5f, 0.5f, nrm, co); row[OD + 3 + j] = emit_scaled(cw[j], -0.5f, 0.5f, nrm, co); }
+        }
+        auto add_noise = [&]() {
+            float nz[28];
+#pragma unroll
+            for (int b = 0; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+#pragma unroll
+            for (int jj = 18; jj < 25; ++jj) row[jj] = f_clamp(FMA(P.dr_obs_noise, 2.0f * nz[jj] - 1.0f, row[jj]), -co, co);
+        };
+        if (!ASYM && P.dr_obs_noise > 0.0f) add_noise();
+        BAR();                                                  // P3: tile complete, fingertip exchange published
+        // ---- rewards (reference rewards.py; order of trifinger_env.py:513-550), termination (:1053-1099) ----
+        if (!IS_RESET) {
+            float tips[9], tip_prev[9];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { tips[3 * f + j] = LD(L_XCH + 6 * f + j); tip_prev[3 * f + j] = LD(L_XCH + 6 * f + 3 + j); }
+            }
+            const RewardCoef& rc = sa.rc;
+            float r[6];
+            {
+                float s = 0.0f;
+                s = s + (norm3d(&tips[0], cp) - norm3d(&tip_prev[0], prev_obj));
+                s = s + (norm3d(&tips[3], cp) - norm3d(&tip_prev[3], prev_obj));
+                s = s + (norm3d(&tips[6], cp) - norm3d(&tip_prev[6], prev_obj));
+                r[0] = rc.c_reach * s;
+            }
+            {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { float vel = (tips[j] - tip_prev[j]) / rc.dt; s = s + vel * vel; }
+                r[1] = rc.c_move_pen * s;
+            }
+            float dist = norm3d(cp, gp);
+            r[2] = rc.c_dist * lgsk(dist, 50.0f);
+            float ang = quat_diff_rad(cq, gq);
+            r[3] = rc.w_rot * (rc.rot_num / (rc.rot_scale * f_abs(ang) + rc.rot_scale));
+            float ang_prev = quat_diff_rad(&prev_obj[3], gq);
+            r[4] = rc.w_rot_delta * (rc.rot_delta_sched * (f_abs(ang) - f_abs(ang_prev)));
+            r[5] = rc.w_move * (dist - norm3d(prev_obj, gp));
+            float total = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                r[t] = guarded ? 0.0f : r[t];
+                if (P.rew_active[t]) { total = total + r[t]; st.rew[t] += cx.valid ? r[t] : 0.0f; }
+            }
+            bool pos_ok = dist <= P.pos_tol;
+            bool ori_ok = ang <= P.ori_tol;
+            st.pos_cnt += (cx.valid && pos_ok) ? 1.0f : 0.0f;
+            st.ori_cnt += (cx.valid && ori_ok) ? 1.0f : 0.0f;
+            bool done;
+            if (P.task_difficulty < 4) done = pos_ok;
+            else if (P.task_difficulty == 4) done = pos_ok && ori_ok;
+            else done = ori_ok;
+            bool succ = c_successes;
+            if (P.success_activate) {
+                if (done) total = total + P.success_bonus;
+                if (cx.valid) P.goal_reset_buf[(unsigned)cx.i] = (uint8_t)done;
+                c_goal_reset = done;
+                succ = succ || done;
+            } else {
+                succ = c_goal_reset && succ;
+            }
+            c_successes = succ;
+            if (cx.valid) {
+                P.successes[(unsigned)cx.i] = (uint8_t)succ;
+                P.reward[(unsigned)cx.i] = total;
+            }
+            st.succ += (cx.valid && succ) ? 1.0f : 0.0f;
+        }
+        stats_begin(P, st, lane, tk);
+        if (ASYM) {
+            coop_store_tile<SD>(P.states, lds, cx);
+            if (P.dr_obs_noise > 0.0f) {
+                BAR();                                          // P4
+                add_noise();
+                BAR();                                          // P5
+            }
+            coop_store_tile_strided<OD, SD>(P.obs, lds, cx);
+        } else {
+            coop_store_tile<OD>(P.obs, lds, cx);
+        }
+    }
+    // ---- state rows of the cube role; the moving goal advances AFTER the step's observations and rewards used its pose
+    // (trifinger_env.py:500-559: __update_goal_movement_post comes last) ----
+    if (MODE & (M_RESETS | M_SIM | M_POST)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { STST(TF_S_CUBE_P + j, cp[j]); STST(TF_S_CUBE_V + j, cv[j]); STST(TF_S_CUBE_W + j, cw[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) STST(TF_S_CUBE_Q + j, cq[j]);
+    }
+    if (MODE & (M_RESETS | M_SIM)) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { STST(TF_S_LAM_CF + j, lam_cf[j]); STST(TF_S_LAM_CW + j, lam_cw[j]); }
+        STST(TF_S_CF_FACE, cf_face); STST(TF_S_CW_FACE, cw_face);
+    }
+    if ((MODE & M_POST) && P.goal_rotation_activate) {
+        const int nadv = ((MODE & M_SIM) ? sa.nsim : P.control_decimation) * P.substeps;
+        for (int s = 0; s < nadv; ++s) quat_integrate(gq, gw, P.hsub);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) STST(TF_S_GOAL_Q + j, gq[j]);
+    }
+    if (MODE & M_FINISH) {                                      // env_base.py:391-399
+        if (cx.valid) {
+            int sN = c_steps + 1;
+            P.steps[(unsigned)cx.i] = sN;
+            bool rb = c_reset;
+            if (P.episode_length > 0 && sN >= P.episode_length) { rb = true; P.reset_buf[(unsigned)cx.i] = 1; }
+            P.dones[(unsigned)cx.i] = (uint8_t)(rb && c_goal_reset);
+        }
+    }
+    if (MODE & M_POST) stats_end(P, lane, tk);
+}

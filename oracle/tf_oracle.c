@@ -1212,6 +1212,8 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 rc_->lam[2] = f_clamp(dot3(&pl[1], rc_->dir[2]) * ws, -lim, lim);
             }
         }
+        /* (the kernel keeps J only and forms W = M^-1 J where it is used: same operations, also for an absent contact) */
+        for (int d = 0; d < 3; ++d) sym3_mul(k->Minv, g->fcJ[d], g->fcW[d]);
         /* --- fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1) --- */
         {
             float rho2 = FMA(g->Bw[0], g->Bw[0], g->Bw[1] * g->Bw[1]);
@@ -1245,6 +1247,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 c->lam[1] = f_clamp(pl[1] * ws, -lim, lim);
                 c->lam[2] = f_clamp(pl[2] * ws, -lim, lim);
             }
+            for (int t = 0; t < 2; ++t) for (int d = 0; d < 3; ++d) sym3_mul(k->Minv, g->tc[t].J[d], g->tc[t].W[d]);
         }
         /* --- joint limit / velocity limit rows --- */
         for (int jj = 0; jj < 3; ++jj) {

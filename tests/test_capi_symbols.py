@@ -103,7 +103,7 @@ def test_create_rejects_bad_configs(oracle):
         cfg = make_config(lib, 4)
         cfg.num_envs = 0                                   # empty batch
         assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
-        cfg.num_envs = 4194304 + 1                         # above TF_MAX_ENVS (32-bit offsets into the state block)
+        cfg.num_envs = 2097152 + 1                         # above TF_MAX_ENVS (32-bit offsets into the state block)
         assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
         cfg = make_config(lib, 4); cfg.command_mode = 9
         assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_COMMAND_MODE

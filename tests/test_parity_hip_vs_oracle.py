@@ -139,12 +139,12 @@ def test_full_size_properties(hip):
 
 
 def test_maximum_size_matches_the_oracle_at_the_far_end(hip, oracle):
-    """TF_MAX_ENVS (4 Mi envs, 1.5 GB of state rows addressed with 32-bit byte offsets): the last 256 envs of the full
+    """TF_MAX_ENVS (2 Mi envs, 1.25 GB of state rows addressed with 32-bit byte offsets): the last 256 envs of the full
     population equal an oracle shard of exactly those envs (the RNG is keyed by the global env id), step by step; one
     env more is refused."""
     from leibnizgym_amd import _capi as capi
     from leibnizgym_amd.engine import TrifingerEngine, make_config
-    n, tail = 4194304, 256
+    n, tail = 2097152, 256
     kw = dict(pu.CONFIGS["d4_domain_randomization"])
     big = TrifingerEngine(make_config(hip, n, seed=9, episode_length=4, **kw), device=DEV, lib=hip)
     ref = TrifingerEngine(make_config(oracle, tail, seed=9, episode_length=4, env_id_offset=n - tail, global_num_envs=n, **kw),
