@@ -180,7 +180,8 @@ typedef struct TfModel {
     float restitution_finger;     /* finger shape vs cube / arena: average(0.8, 0)                   */
     float restitution_ff;         /* finger shape vs finger shape: 0.8                               */
     float bounce_threshold;       /* 0.5 m/s  (scripts/rlg_hydra.py:32)                              */
-    float contact_margin;         /* rows are generated for gaps below this                          */
+    float contact_margin;         /* broad phase: a slot is looked at for gaps below this            */
+    float contact_slack;          /* a slot gets rows when gap < slack + h max(0, -approach speed)    */
     float contact_offset;         /* 0.002 (scripts/rlg_hydra.py:30): restitution applies below it   */
     float erp;                    /* fraction of penetration removed per substep                     */
     float max_depenetration_velocity;

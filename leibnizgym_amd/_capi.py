@@ -75,7 +75,7 @@ class TfModel(C.Structure):
         ("mu_tip_floor", C.c_float), ("mu_cube_wall", C.c_float),
         ("mu_tip_wall", C.c_float), ("mu_finger_finger", C.c_float),
         ("restitution_finger", C.c_float), ("restitution_ff", C.c_float), ("bounce_threshold", C.c_float),
-        ("contact_margin", C.c_float), ("contact_offset", C.c_float), ("erp", C.c_float),
+        ("contact_margin", C.c_float), ("contact_slack", C.c_float), ("contact_offset", C.c_float), ("erp", C.c_float),
         ("max_depenetration_velocity", C.c_float), ("warm_start", C.c_float),
     ]
 

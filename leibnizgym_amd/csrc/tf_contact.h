@@ -18,6 +18,13 @@ DEV float solve_tangent(float& lam, float Dinv, float vrel, float lim) {
     return dl;
 }
 
+// A contact slot is LIVE (gets rows) when its gap is inside the broad margin and can close within this substep at the approach
+// speed of the free velocities, plus a slack for what other impulses may add.  Everything a dead slot would do is skipped:
+// the rows sit behind per-lane branches, so a wavefront with no live lane for a slot jumps over them.
+DEV bool contact_live(const TfModel& m, float gap, float vn0, float h) {
+    return (gap < m.contact_margin) && (gap < FMA(h, f_max(-vn0, 0.0f), m.contact_slack));
+}
+
 // base-frame position of a point given in the frame of link LINK (1..3)
 template <int LINK> DEV void link_point(const FK& k, const float local[3], float out[3]) {
     float t[3];

@@ -67,6 +67,20 @@ struct Ctx {
 #define STST(row, val) do { if (cx.valid) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), ST_RSRC(), (unsigned)cx.i * 4u, (row) * P.N * 4, 0); } while (0)
 #define BAR() __syncthreads()
 
+// Developer instrumentation (libtrifinger_hip_timing.so, tools/phase_timing.py only): lane 0 of every wavefront writes
+// s_memtime stamps to scratch[(workgroup * 4 + role) * 64 + id].
+#ifdef TF_PHASE_TIMING
+#define TF_SCR_STRIDE 256
+#define NOW() ((uint32_t)__builtin_readcyclecounter())
+#define STAMP(id) do { if (cx.lane == 0) ((gu32*)P.scratch)[((size_t)blockIdx.x * 4 + cx.role) * 64 + (id)] = NOW(); } while (0)
+#define STAMPV(id, val) do { if (cx.lane == 0) ((gu32*)P.scratch)[((size_t)blockIdx.x * 4 + cx.role) * 64 + (id)] = (uint32_t)(val); } while (0)
+#else
+#define TF_SCR_STRIDE 16
+#define NOW() 0u
+#define STAMP(id) do { } while (0)
+#define STAMPV(id, val) do { } while (0)
+#endif
+
 // ---- cooperative tile moves by the whole workgroup -----------------------------------------------------------------
 // store a [n_valid][W] tile staged in LDS as lds[env * W + j] to dst[(wave_first + env) * W + j]: dwordx4, coalesced; the tile
 // is a raw buffer of total4 * 16 bytes, so the hardware range check drops the lanes past its end
@@ -253,7 +267,7 @@ DEV void tip_state(const TfModel& m, const Yaw& y, const FK& k, const float q[3]
 struct TipContact {            // fingertip sphere against one feature of the arena: finger-only rows
     bool active;
     float J[9], Dinv[3], bias, lam[3], mu;
-    float dir[9], arm[3];
+    float arm[3];             // contact point relative to the tip-link origin (fingertip wrench sensor)
 };
 
 template <int A, bool IS_RESET, bool ASYM, int MODE>
@@ -266,33 +280,23 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     const Yaw yw = {m.base_yaw_cos[f], m.base_yaw_sin[f], m.base_half_yaw_cos[f], m.base_half_yaw_sin[f], m.base_height};
     const uint32_t gid = (uint32_t)(P.env_id_offset + cx.i);
     // ---- loads ----
-    float q[3], qd[3], tau[3], ft[6], dr[TF_NUM_DR];
-    float lam_fc[4], fc_link, lam_tf[3], lam_tw[3];
+    float q[3], qd[3], tau[3], dr[TF_NUM_DR];
     uint8_t fl_reset = 0;
     uint32_t fl_count = 0;
+    STAMP(0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { q[j] = LDST(TF_S_Q + 3 * f + j); qd[j] = LDST(TF_S_QD + 3 * f + j); }
 #pragma unroll
     for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
-    if (MODE & (M_SIM | M_RESETS)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lam_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
-        fc_link = LDST(TF_S_FC_LINK + f);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { lam_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
-    }
-    if (!(MODE & M_TORQUE) && (MODE & (M_SIM | M_POST | M_RESETS))) {
+    if (!(MODE & M_TORQUE) && (MODE & M_RESETS)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
-    }
-    if ((MODE & (M_SIM | M_POST)) && !(MODE & M_TORQUE)) {       // split path: the wrench accumulator comes from its rows
-#pragma unroll
-        for (int j = 0; j < 6; ++j) ft[j] = LDST(TF_S_FT + 6 * f + j);
     }
     if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
     if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
     BAR();                                                      // #1: action tile in LDS, flag loads have returned
+    STAMP(1);
     // ---- masked _reset_impl for this finger (trifinger_env.py:373-423, 1101-1147) ----
     const bool rflag = (MODE & M_RESETS) && (IS_RESET || fl_reset != 0);
     if (MODE & M_RESETS) {
@@ -316,9 +320,6 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) tau[j] = 0.0f;          // the stored torque (what an action repeat re-applies)
-            lam_fc[0] = 0.0f; lam_fc[1] = 0.0f; lam_fc[2] = 0.0f; lam_fc[3] = 0.0f; fc_link = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { lam_tf[j] = 0.0f; lam_tw[j] = 0.0f; }
         }
     }
     // ---- this finger's action values: clipped, zeroed by a reset (trifinger_env.py:387), written back for _action_buf ----
@@ -385,19 +386,43 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = t[j];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) ft[j] = 0.0f;
+        for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, 0.0f);      // fingertip wrench accumulator of the step
     }
     if (MODE & (M_TORQUE | M_RESETS)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) STST(TF_S_TAU + 3 * f + j, tau[j]);
     }
+    if (MODE & M_RESETS) {                                      // a reset clears the solver warm start
+        if (rflag) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, 0.0f);
+            STST(TF_S_FC_LINK + f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { STST(TF_S_LAM_TF + 3 * f + j, 0.0f); STST(TF_S_LAM_TW + 3 * f + j, 0.0f); }
+        }
+    }
     // =================================================================================================================
     // physics: decimation x substeps solver substeps
     // =================================================================================================================
+    STAMP(2);
     if (MODE & M_SIM) {
         const float h = P.hsub, inv_h = 1.0f / h;
         const int nsub = sa.nsim * P.substeps;
         for (int s = 0; s < nsub; ++s) {
+            const int sb_ = 4 + 12 * (s & 1);
+            // values that are cold through the sweeps are re-read from their state rows every substep (the rows hold
+            // what this thread stored above; L2 hits) instead of occupying registers the sweeps need
+            float dr[TF_NUM_DR], tau[3];
+#pragma unroll
+            for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
+            float lam_fc[4], fc_link, lam_tf[3], lam_tw[3];     // impulses of the last substep (issued here, used in F2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lam_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
+            fc_link = LDST(TF_S_FC_LINK + f);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { lam_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
             const float cube_mass = m.cube_mass * dr[0];
             const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
             const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
@@ -437,11 +462,13 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 for (int j = 0; j < 6; ++j) LD(pb + P_MINV + j) = k.Minv[j];
                 LD(pb + P_S1) = k.s1; LD(pb + P_C1) = k.c1;
             }
+            STAMP(sb_ + 0);
             BAR();                                              // S1: free motion of every role published
+            STAMP(sb_ + 1);
             // ---- F2: contact generation (positions at the start of the substep) ----
-            float cp[3], cq[4], v[3], w[3], R[9];
+            float cp[3], cq[4], R[9];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { cp[j] = LD(L_POSE_A + j); v[j] = LD(L_POSE_B + j); w[j] = LD(L_POSE_B + 3 + j); }
+            for (int j = 0; j < 3; ++j) cp[j] = LD(L_POSE_A + j);
 #pragma unroll
             for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
             quat_to_rot(cq, R);
@@ -501,41 +528,47 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
             for (int j = 0; j < 3; ++j) { fc_arm[j] = 0.0f; rec_Dinv[j] = 0.0f; rec_lam[j] = 0.0f; }
             if (__builtin_expect(gap < m.contact_margin, 1)) {
-                float rcv[3], xw[3], Dd[3], fcW[9];
-                mat3_mul(R, nc, &rec_dir[0]);
+                float rcv[3], xw[3], Dd[3], J[9], W[9], dir[9], rxd[9];
+                mat3_mul(R, nc, &dir[0]);
                 mat3_mul(R, y, rcv);
                 mat3_mul(R, x, xw);
-                tangent_basis(&rec_dir[0], &rec_dir[3], &rec_dir[6]);
-                float Pw[3] = {FMA(-radius, rec_dir[0], cp[0] + xw[0]), FMA(-radius, rec_dir[1], cp[1] + xw[1]),
-                               FMA(-radius, rec_dir[2], cp[2] + xw[2])};
+                tangent_basis(&dir[0], &dir[3], &dir[6]);
+                float Pw[3] = {FMA(-radius, dir[0], cp[0] + xw[0]), FMA(-radius, dir[1], cp[1] + xw[1]), FMA(-radius, dir[2], cp[2] + xw[2])};
                 float Pb[3];
                 world_to_base(yw, Pw, Pb);
-                cur_link = link;
-                finger_jac(yw, k, link, Pb, rec_dir, fcJ, fcW, Dd);
+                finger_jac(yw, k, link, Pb, dir, J, W, Dd);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    cross3(rcv, &rec_dir[3 * d], &rec_rxd[3 * d]);
-                    rec_Dinv[d] = f_rcp2(FMA(dot3(&rec_rxd[3 * d], &rec_rxd[3 * d]), inv_I, Dd[d] + inv_m));
-                }
-                rec_A[0] = Dd[0]; rec_A[1] = dot3(&fcJ[0], &fcW[3]); rec_A[2] = dot3(&fcJ[0], &fcW[6]);
-                rec_A[3] = Dd[1]; rec_A[4] = dot3(&fcJ[3], &fcW[6]);
-                rec_A[5] = Dd[2];
-                if (link == 3) {
+                for (int d = 0; d < 3; ++d) cross3(rcv, &dir[3 * d], &rxd[3 * d]);
+                float v[3], w[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) fc_arm[j] = Pw[j] - Tw[j];
-                }
-                float vn0 = dot3(&fcJ[0], vq) - (dot3(&rec_dir[0], v) + dot3(&rec_rxd[0], w));
-                rec_bias = contact_bias(m, gap, vn0, inv_h, rest_f);
-                if ((float)link == fc_link) {                   // same link as in the last substep: seed the impulses
-                    float l0 = lam_fc[0] * ws;
-                    float lim = mu_fc * l0;
-                    rec_lam[0] = l0;
-                    rec_lam[1] = f_clamp(dot3(&lam_fc[1], &rec_dir[3]) * ws, -lim, lim);
-                    rec_lam[2] = f_clamp(dot3(&lam_fc[1], &rec_dir[6]) * ws, -lim, lim);
+                for (int j = 0; j < 3; ++j) { v[j] = LD(L_POSE_B + j); w[j] = LD(L_POSE_B + 3 + j); }
+                float vn0 = dot3(&J[0], vq) - (dot3(&dir[0], v) + dot3(&rxd[0], w));
+                if (contact_live(m, gap, vn0, h)) {
+                    cur_link = link;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) { fcJ[j] = J[j]; rec_dir[j] = dir[j]; rec_rxd[j] = rxd[j]; }
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) rec_Dinv[d] = f_rcp2(FMA(dot3(&rxd[3 * d], &rxd[3 * d]), inv_I, Dd[d] + inv_m));
+                    rec_A[0] = Dd[0]; rec_A[1] = dot3(&J[0], &W[3]); rec_A[2] = dot3(&J[0], &W[6]);
+                    rec_A[3] = Dd[1]; rec_A[4] = dot3(&J[3], &W[6]);
+                    rec_A[5] = Dd[2];
+                    if (link == 3) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) fc_arm[j] = Pw[j] - Tw[j];
+                    }
+                    rec_bias = contact_bias(m, gap, vn0, inv_h, rest_f);
+                    if ((float)link == fc_link) {                   // same link as in the last substep: seed the impulses
+                        float l0 = lam_fc[0] * ws;
+                        float lim = mu_fc * l0;
+                        rec_lam[0] = l0;
+                        rec_lam[1] = f_clamp(dot3(&lam_fc[1], &dir[3]) * ws, -lim, lim);
+                        rec_lam[2] = f_clamp(dot3(&lam_fc[1], &dir[6]) * ws, -lim, lim);
+                    }
                 }
             }
             // fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1)
             TipContact tc[2];
+            float wall_n[2];                                    // inward horizontal normal at the fingertip (wrench of slot 1)
             {
                 float rho2 = FMA(Bw[0], Bw[0], Bw[1] * Bw[1]);
                 float inv = f_rsqrt(f_max(rho2, 1e-24f));
@@ -545,38 +578,41 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     TipContact& c = tc[t];
                     c.active = false;
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) { c.J[j] = 0.0f; c.dir[j] = 0.0f; }
+                    for (int j = 0; j < 9; ++j) c.J[j] = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { c.Dinv[j] = 0.0f; c.lam[j] = 0.0f; c.arm[j] = 0.0f; }
                     c.bias = 0.0f; c.mu = 0.0f;
                     float gp_ = (t == 0) ? (Bw[2] - m.cap_radius) : ((wall_radius_at(m, Bw[2]) - rho) - m.cap_radius);
                     const bool on = ((t == 0) || (rho > 1e-6f)) && (gp_ < m.contact_margin);
                     if (__builtin_expect(on, t == 0)) {
-                        float n_w[3] = {0.0f, 0.0f, 1.0f};
-                        if (t == 1) { n_w[0] = -Bw[0] * inv; n_w[1] = -Bw[1] * inv; n_w[2] = 0.0f; }
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) c.dir[j] = n_w[j];
-                        tangent_basis(&c.dir[0], &c.dir[3], &c.dir[6]);
-                        float Pw[3] = {FMA(-m.cap_radius, n_w[0], Bw[0]), FMA(-m.cap_radius, n_w[1], Bw[1]), FMA(-m.cap_radius, n_w[2], Bw[2])};
-                        float Pb[3], Dd[3], Wt[9];
+                        float dir[9] = {0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        if (t == 1) { dir[0] = -Bw[0] * inv; dir[1] = -Bw[1] * inv; dir[2] = 0.0f; }
+                        tangent_basis(&dir[0], &dir[3], &dir[6]);
+                        float Pw[3] = {FMA(-m.cap_radius, dir[0], Bw[0]), FMA(-m.cap_radius, dir[1], Bw[1]), FMA(-m.cap_radius, dir[2], Bw[2])};
+                        float Pb[3], Dd[3], Jt[9], Wt[9];
                         world_to_base(yw, Pw, Pb);
-                        c.active = true;
-                        c.mu = (t == 0) ? mu_tf : mu_tw;
-                        finger_jac(yw, k, 3, Pb, c.dir, c.J, Wt, Dd);
+                        finger_jac(yw, k, 3, Pb, dir, Jt, Wt, Dd);
+                        float vn0 = dot3(&Jt[0], vq);
+                        if (contact_live(m, gp_, vn0, h)) {
+                            c.active = true;
+                            c.mu = (t == 0) ? mu_tf : mu_tw;
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) c.Dinv[d] = f_rcp2(Dd[d]);
+                            for (int j = 0; j < 9; ++j) c.J[j] = Jt[j];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) c.arm[j] = Pw[j] - Tw[j];
-                        float vn0 = dot3(&c.J[0], vq);
-                        c.bias = contact_bias(m, gp_, vn0, inv_h, rest_f);
-                        const float* pl = (t == 0) ? lam_tf : lam_tw;      // zero when the contact was not there
-                        float l0 = pl[0] * ws;
-                        float lim = c.mu * l0;
-                        c.lam[0] = l0;
-                        c.lam[1] = f_clamp(pl[1] * ws, -lim, lim);
-                        c.lam[2] = f_clamp(pl[2] * ws, -lim, lim);
+                            for (int d = 0; d < 3; ++d) c.Dinv[d] = f_rcp2(Dd[d]);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) c.arm[j] = Pw[j] - Tw[j];
+                            c.bias = contact_bias(m, gp_, vn0, inv_h, rest_f);
+                            const float* pl = (t == 0) ? lam_tf : lam_tw;      // zero when the contact was not there
+                            float l0 = pl[0] * ws;
+                            float lim = c.mu * l0;
+                            c.lam[0] = l0;
+                            c.lam[1] = f_clamp(pl[1] * ws, -lim, lim);
+                            c.lam[2] = f_clamp(pl[2] * ws, -lim, lim);
+                        }
                     }
                 }
+                wall_n[0] = -Bw[0] * inv; wall_n[1] = -Bw[1] * inv;
             }
             // joint limit / velocity limit rows
             float vlo[3], vhi[3], lim_dinv[3], lim_lam[3];
@@ -588,25 +624,31 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 lim_dinv[jj] = f_rcp(k.Minv[dg]);
                 lim_lam[jj] = 0.0f;
             }
+            STAMP(sb_ + 2);
             BAR();                                              // S2: the finger-finger pass of the cube role is done
+            STAMP(sb_ + 3);
             // ---- velocity after the finger-finger pass, seeded impulses on the finger side, contact-point velocity ----
 #pragma unroll
             for (int j = 0; j < 3; ++j) vq[j] = LD(L_VQFF + 3 * f + j);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float Wd[3];
-                sym3_mul(k.Minv, &fcJ[3 * d], Wd);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], rec_lam[d], vq[j]);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            if (cur_link != 0) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     float Wd[3];
-                    sym3_mul(k.Minv, &tc[t].J[3 * d], Wd);
+                    sym3_mul(k.Minv, &fcJ[3 * d], Wd);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], tc[t].lam[d], vq[j]);
+                    for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], rec_lam[d], vq[j]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (tc[t].active) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        float Wd[3];
+                        sym3_mul(k.Minv, &tc[t].J[3 * d], Wd);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], tc[t].lam[d], vq[j]);
+                    }
                 }
             }
             {
@@ -623,11 +665,14 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
                 LD(L_INIT + f) = rec_bias;
             }
+            STAMP(sb_ + 4);
             BAR();                                              // S3: records published
+            STAMP(sb_ + 5);
             // ---- projected Gauss-Seidel: this finger's share ----
             float Fc[3] = {0.0f, 0.0f, 0.0f};
+            uint32_t t_wait = 0u;
             for (int it = 0; it < P.iters; ++it) {
-                BAR();                                          // W1: the cube role has solved the finger-cube rows of this sweep
+                { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W1: the cube role has solved the finger-cube rows of this sweep
                 const int rb = L_REC(f);
                 float dl[3];
 #pragma unroll
@@ -637,25 +682,29 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { lam_fc[1 + j] = LD(rb + R_A + j); Fc[j] = LD(rb + R_A + 3 + j); }
                 }
+                if (cur_link != 0) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    float Wd[3];
-                    sym3_mul(k.Minv, &fcJ[3 * d], Wd);
+                    for (int d = 0; d < 3; ++d) {
+                        float Wd[3];
+                        sym3_mul(k.Minv, &fcJ[3 * d], Wd);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], dl[d], vq[j]);
+                        for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], dl[d], vq[j]);
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {                   // fingertip - floor, fingertip - wall
                     TipContact& c = tc[t];
+                    if (c.active) {
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        float vrel = dot3(&c.J[3 * d], vq);
-                        float dlt = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
-                                             : solve_tangent(c.lam[d], c.Dinv[d], vrel, c.mu * c.lam[0]);
-                        float Wd[3];
-                        sym3_mul(k.Minv, &c.J[3 * d], Wd);
+                        for (int d = 0; d < 3; ++d) {
+                            float vrel = dot3(&c.J[3 * d], vq);
+                            float dlt = (d == 0) ? solve_normal(c.lam[0], c.Dinv[0], vrel, c.bias)
+                                                 : solve_tangent(c.lam[d], c.Dinv[d], vrel, c.mu * c.lam[0]);
+                            float Wd[3];
+                            sym3_mul(k.Minv, &c.J[3 * d], Wd);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], dlt, vq[j]);
+                            for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], dlt, vq[j]);
+                        }
                     }
                 }
 #pragma unroll
@@ -673,15 +722,24 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     vq[1] = FMA(k.Minv[c1], dlj, vq[1]);
                     vq[2] = FMA(k.Minv[c2], dlj, vq[2]);
                 }
+                if (cur_link != 0) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) LD(rb + R_U + d) = dot3(&fcJ[3 * d], vq);
-                BAR();                                          // W2: contact-point velocities published
+                    for (int d = 0; d < 3; ++d) LD(rb + R_U + d) = dot3(&fcJ[3 * d], vq);
+                }
+                { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W2: contact-point velocities published
             }
-            // ---- impulses kept for the next substep, fingertip wrench sensor, integration ----
-            fc_link = (float)cur_link;
+            STAMP(sb_ + 6);
+            STAMPV(sb_ + 8, t_wait);
+            // ---- impulses kept for the next substep (state rows), fingertip wrench sensor, integration ----
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { lam_tf[d] = tc[0].lam[d]; lam_tw[d] = tc[1].lam[d]; }
-            if (ASYM || !(MODE & M_POST)) {
+            for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, lam_fc[j]);
+            STST(TF_S_FC_LINK + f, (float)cur_link);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { STST(TF_S_LAM_TF + 3 * f + d, tc[0].lam[d]); STST(TF_S_LAM_TW + 3 * f + d, tc[1].lam[d]); }
+            if (ASYM) {
+                float ft[6];                                    // running sum of the step, kept in its state rows
+#pragma unroll
+                for (int j = 0; j < 6; ++j) ft[j] = LDST(TF_S_FT + 6 * f + j);
                 if (cur_link == 3) {
                     float T[3];
                     cross3(fc_arm, Fc, T);
@@ -692,22 +750,29 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 for (int t = 0; t < 2; ++t) {
                     const TipContact& c = tc[t];
                     if (c.active) {
+                        float dir[9] = {0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // same directions the rows were built with
+                        if (t == 1) { dir[0] = wall_n[0]; dir[1] = wall_n[1]; dir[2] = 0.0f; }
+                        tangent_basis(&dir[0], &dir[3], &dir[6]);
                         float F[3], T[3];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) F[j] = FMA(c.dir[6 + j], c.lam[2], FMA(c.dir[3 + j], c.lam[1], c.dir[j] * c.lam[0])) * inv_h;
+                        for (int j = 0; j < 3; ++j) F[j] = FMA(dir[6 + j], c.lam[2], FMA(dir[3 + j], c.lam[1], dir[j] * c.lam[0])) * inv_h;
                         cross3(c.arm, F, T);
 #pragma unroll
                         for (int j = 0; j < 3; ++j) { ft[j] += F[j]; ft[3 + j] += T[j]; }
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, ft[j]);
             }
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) {
                 qd[jj] = vq[jj];
                 q[jj] = f_clamp(FMA(h, vq[jj], q[jj]), m.q_lo[jj], m.q_hi[jj]);
             }
+            STAMP(sb_ + 7);
         }
     }
+    STAMP(30);
     // =================================================================================================================
     // post: fingertip state, observation slots of this finger
     // =================================================================================================================
@@ -716,22 +781,33 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         float tips[13];
         fk_setup(m, q, pk);
         tip_state(m, yw, pk, q, qd, tips);
-        float tip_prev[3];
+        float tip_prev[3], tau_p[3], act_p[AJ], ft[6];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j);
+        for (int j = 0; j < 3; ++j) { tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j); tau_p[j] = LDST(TF_S_TAU + 3 * f + j); }
+        if (ASYM) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ft[j] = LDST(TF_S_FT + 6 * f + j);
+        }
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {         // the last command, as _action_buf holds it (written above by this workgroup)
+            const int col = (j < 3) ? (3 * f + j) : (9 + 3 * f + (j - 3));
+            act_p[j] = P.action_buf[(size_t)cx.i * (size_t)A + (size_t)col];
+        }
         {   // NaN guard, part 1: this role's share of the finiteness test
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc = acc + q[j] * 0.0f + qd[j] * 0.0f;
             LD(L_NAN + f) = (acc == 0.0f) ? 0.0f : 1.0f;
         }
+        STAMP(31);
         BAR();                                                  // P1
+        STAMP(32);
         const bool guarded = (LD(L_NAN) + LD(L_NAN + 1) + LD(L_NAN + 2) + LD(L_NAN + 3)) != 0.0f;
         if (__builtin_expect(guarded, 0)) {                     // park the env at the default pose (it is flagged for reset)
 #pragma unroll
             for (int j = 0; j < 3; ++j) { q[j] = m.q_default[j]; qd[j] = 0.0f; }
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ft[j] = 0.0f;
+            for (int j = 0; j < 6; ++j) { ft[j] = 0.0f; STST(TF_S_FT + 6 * f + j, 0.0f); }
             fk_setup(m, q, pk);
             tip_state(m, yw, pk, q, qd, tips);
         }
@@ -752,13 +828,13 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int col = (j < 3) ? (3 * f + j) : (9 + 3 * f + (j - 3));
-            row[32 + col] = emit_table(P, 32 + col, opaque(act[j]), nrm, co);
+            row[32 + col] = emit_table(P, 32 + col, opaque(act_p[j]), nrm, co);
         }
         if (ASYM) {
 #pragma unroll
             for (int j = 0; j < 13; ++j) row[OD + 6 + 13 * f + j] = emit_scaled(tips[j], TLO(j), THI(j), nrm, co);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) row[OD + 45 + 3 * f + j] = emit_scaled(P.enable_ft ? tau[j] : 0.0f, -0.36f, 0.36f, nrm, co);
+            for (int j = 0; j < 3; ++j) row[OD + 45 + 3 * f + j] = emit_scaled(P.enable_ft ? tau_p[j] : 0.0f, -0.36f, 0.36f, nrm, co);
             const float inv_n = 1.0f / (float)(P.substeps * P.control_decimation);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -771,7 +847,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             }
         }
         if (ASYM) {
+            STAMP(33);
             BAR();                                              // P3: states tile complete
+            STAMP(34);
             coop_store_tile<SD>(P.states, lds, cx);
             if (P.dr_obs_noise > 0.0f) {
                 BAR();                                          // P4: states tile stored; obs noise goes on top of slots 0..24
@@ -806,17 +884,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) { STST(TF_S_Q + 3 * f + j, q[j]); STST(TF_S_QD + 3 * f + j, qd[j]); }
     }
-    if (MODE & (M_RESETS | M_SIM)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, lam_fc[j]);
-        STST(TF_S_FC_LINK + f, fc_link);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { STST(TF_S_LAM_TF + 3 * f + j, lam_tf[j]); STST(TF_S_LAM_TW + 3 * f + j, lam_tw[j]); }
-    }
-    if ((MODE & (M_TORQUE | M_SIM | M_POST)) && !((MODE & M_TORQUE) && (MODE & M_POST))) {   // split path only
-#pragma unroll
-        for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, ft[j]);
-    }
+    STAMP(35);
+    STAMPV(40, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID
+    STAMPV(41, __builtin_amdgcn_s_getreg((31 << 11) | 20));     // HW_REG_XCC_ID
 }
 
 // =====================================================================================================================
@@ -911,11 +981,11 @@ DEV void stats_zero(LaneStats& st) {
     st.pos_cnt = 0.0f; st.ori_cnt = 0.0f; st.succ = 0.0f; st.resets = 0.0f; st.nonfinite = 0.0f;
 }
 
-struct FingerPubRegs { float Aw[3], Bw[3], vq[3]; FK k; };
+struct FingerPubRegs { FK k; };
 DEV void read_pub(const float* lds, int lane, int f, FingerPubRegs& p) {
     const int pb = L_REC(f);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { p.Aw[j] = LD(pb + P_AW + j); p.Bw[j] = LD(pb + P_BW + j); p.k.p2[j] = LD(pb + P_P2 + j); p.k.p3[j] = LD(pb + P_P3 + j); }
+    for (int j = 0; j < 3; ++j) { p.k.p2[j] = LD(pb + P_P2 + j); p.k.p3[j] = LD(pb + P_P3 + j); }
 #pragma unroll
     for (int j = 0; j < 6; ++j) p.k.Minv[j] = LD(pb + P_MINV + j);
     p.k.s1 = LD(pb + P_S1); p.k.c1 = LD(pb + P_C1);
@@ -932,10 +1002,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     // ---- loads ----
     float cp[3], cq[4], cv[3], cw[3], gp[3], gq[4], gw[3], dr[TF_NUM_DR];
     float lam_cf[12], lam_cw[12], cf_face = 0.0f, cw_face = 0.0f;
-    float prev_obj[7];
     uint8_t fl_reset = 0, fl_goal_reset = 0, fl_successes = 0;
     int fl_steps = 0;
     uint32_t fl_count = 0;
+    STAMP(0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { cp[j] = LDST(TF_S_CUBE_P + j); cv[j] = LDST(TF_S_CUBE_V + j); cw[j] = LDST(TF_S_CUBE_W + j); gp[j] = LDST(TF_S_GOAL_P + j); gw[j] = LDST(TF_S_GOAL_W + j); }
 #pragma unroll
@@ -947,10 +1017,6 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = LDST(TF_S_LAM_CW + j); }
         cf_face = LDST(TF_S_CF_FACE); cw_face = LDST(TF_S_CW_FACE);
     }
-    if ((MODE & M_POST) && !(MODE & M_TORQUE)) {
-#pragma unroll
-        for (int j = 0; j < 7; ++j) prev_obj[j] = LDST(TF_S_PREV_OBJ_P + j);
-    }
     if (MODE & (M_RESETS | M_POST | M_FINISH)) {
         fl_reset = P.reset_buf[(unsigned)cx.i];
         fl_goal_reset = P.goal_reset_buf[(unsigned)cx.i];
@@ -961,6 +1027,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
     BAR();                                                      // #1
+    STAMP(1);
     // flags carried in registers to the bookkeeping at the end of the step
     bool c_reset = fl_reset != 0, c_goal_reset = fl_goal_reset != 0, c_successes = fl_successes != 0;
     int c_steps = fl_steps;
@@ -1024,16 +1091,22 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     }
     if (MODE & M_TORQUE) {                                      // history[1] of the object (trifinger_env.py:975)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { STST(TF_S_PREV_OBJ_P + j, cp[j]); prev_obj[j] = cp[j]; }
+        for (int j = 0; j < 3; ++j) STST(TF_S_PREV_OBJ_P + j, cp[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { STST(TF_S_PREV_OBJ_Q + j, cq[j]); prev_obj[3 + j] = cq[j]; }
+        for (int j = 0; j < 4; ++j) STST(TF_S_PREV_OBJ_Q + j, cq[j]);
     }
     // =================================================================================================================
     // physics
     // =================================================================================================================
+    STAMP(2);
     if (MODE & M_SIM) {
         const float h = P.hsub, inv_h = 1.0f / h;
         const int nsub = sa.nsim * P.substeps;
+        // The cube role carries the serial chain of the solve (every row depends on the one before it); the finger roles
+        // of the other workgroups on this SIMD only fill its issue gaps.  Without a raised priority the older finger
+        // wavefronts win the issue arbitration after every barrier and the chain waits for them (measured: the twelve
+        // register-resident floor rows of a sweep took 3.1 k cycles instead of 0.8 k).
+        __builtin_amdgcn_s_setprio(3);
         // the wall-corner impulses live in LDS through the substeps
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1041,6 +1114,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int d = 0; d < 3; ++d) LD(L_WALL + 12 * c + 9 + d) = lam_cw[3 * c + d];
         }
         for (int s = 0; s < nsub; ++s) {
+            const int sb_ = 4 + 12 * (s & 1);
+            float dr[TF_NUM_DR];                                // cold through the sweeps: re-read every substep (L2 hits)
+#pragma unroll
+            for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
             const float cube_mass = m.cube_mass * dr[0];
             const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
             const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
@@ -1063,6 +1140,88 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int j = 0; j < 3; ++j) { LD(L_POSE_A + j) = cp[j]; LD(L_POSE_B + j) = v[j]; LD(L_POSE_B + 3 + j) = w[j]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) LD(L_POSE_A + 3 + j) = cq[j];
+            STAMP(sb_ + 0);
+            BAR();                                              // S1
+            STAMP(sb_ + 1);
+            // ---- FF: finger-finger contacts (distal capsules), solved before the sweeps on the free velocities: the pairs
+            // (0,1), (1,2), (2,0) in turn, TF_FF_ITERATIONS Gauss-Seidel iterations over the three rows of each pair.  The
+            // velocities live in LDS (L_VQFF) while the pairs are visited; a pair no lane of the wavefront has within the
+            // margin is skipped (nearly always). ----
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) LD(L_VQFF + 3 * f + j) = LD(L_REC(f) + P_VQ + j);
+            }
+#pragma unroll 1
+            for (int p = 0; p < 3; ++p) {
+                const int fa = p, fb = (p == 2) ? 0 : p + 1;
+                float Pa[3], Pb[3];
+                {
+                    float Aa[3], Ba[3], Ab[3], Bb[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { Aa[j] = LD(L_REC(fa) + P_AW + j); Ba[j] = LD(L_REC(fa) + P_BW + j); Ab[j] = LD(L_REC(fb) + P_AW + j); Bb[j] = LD(L_REC(fb) + P_BW + j); }
+                    seg_seg(Aa, Ba, Ab, Bb, Pa, Pb);
+                }
+                float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
+                float dist2 = dot3(dv, dv);
+                float inv = f_rsqrt(f_max(dist2, 1e-12f));
+                float dist = dist2 * inv;
+                float gap = dist - 2.0f * m.cap_radius;
+                const bool active = (dist2 > 1e-12f) && (gap < m.contact_margin);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(active) != 0ull, 0)) {
+                    const Yaw ya = {m.base_yaw_cos[fa], m.base_yaw_sin[fa], 0.0f, 0.0f, m.base_height};
+                    const Yaw yb = {m.base_yaw_cos[fb], m.base_yaw_sin[fb], 0.0f, 0.0f, m.base_height};
+                    float dirs[9];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) dirs[j] = dv[j] * inv;
+                    if (!active) { dirs[0] = 1.0f; dirs[1] = 0.0f; dirs[2] = 0.0f; }        // keep the dead lanes finite
+                    tangent_basis(&dirs[0], &dirs[3], &dirs[6]);
+                    float Ja[9], Wa[9], Da[3], Jb[9], Wb[9], Db[3];
+                    {
+                        FingerPubRegs pa;
+                        read_pub(lds, lane, fa, pa);
+                        float Ca[3], Cab[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) Ca[j] = FMA(-m.cap_radius, dirs[j], Pa[j]);
+                        world_to_base(ya, Ca, Cab);
+                        finger_jac(ya, pa.k, 3, Cab, dirs, Ja, Wa, Da);
+                    }
+                    {
+                        FingerPubRegs pb_;
+                        read_pub(lds, lane, fb, pb_);
+                        float Cb[3], Cbb[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) Cb[j] = FMA(m.cap_radius, dirs[j], Pb[j]);
+                        world_to_base(yb, Cb, Cbb);
+                        finger_jac(yb, pb_.k, 3, Cbb, dirs, Jb, Wb, Db);
+                    }
+                    float va[3] = {LD(L_VQFF + 3 * fa), LD(L_VQFF + 3 * fa + 1), LD(L_VQFF + 3 * fa + 2)};
+                    float vb[3] = {LD(L_VQFF + 3 * fb), LD(L_VQFF + 3 * fb + 1), LD(L_VQFF + 3 * fb + 2)};
+                    const float va0[3] = {va[0], va[1], va[2]}, vb0[3] = {vb[0], vb[1], vb[2]};
+                    float vn0 = dot3(&Ja[0], va) - dot3(&Jb[0], vb);
+                    const bool live = active && contact_live(m, gap, vn0, h);
+                    float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+                    float Dinv[3], lam[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) Dinv[d] = f_rcp2(f_max(Da[d] + Db[d], 1e-30f));
+#pragma unroll 1
+                    for (int it = 0; it < TF_FF_ITERATIONS; ++it) {
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            float vrel = dot3(&Ja[3 * d], va) - dot3(&Jb[3 * d], vb);
+                            float dl = (d == 0) ? solve_normal(lam[0], Dinv[0], vrel, bias) : solve_tangent(lam[d], Dinv[d], vrel, mu_ff * lam[0]);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[3 * d + j], dl, va[j]); vb[j] = FMA(-Wb[3 * d + j], dl, vb[j]); }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        LD(L_VQFF + 3 * fa + j) = live ? va[j] : va0[j];
+                        LD(L_VQFF + 3 * fb + j) = live ? vb[j] : vb0[j];
+                    }
+                }
+            }
+            // ---- corner contacts of the cube against the arena (while the finger roles generate their contacts) ----
             float R[9];
             quat_to_rot(cq, R);
             float fr_[12], fDinv[12], fbias[4], flam[12];       // floor corners: arm, 1/D, bias, impulses of rows +z, +x, +y
@@ -1084,11 +1243,11 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     fDinv[3 * c] = 0.0f; fDinv[3 * c + 1] = 0.0f; fDinv[3 * c + 2] = 0.0f;
                     fbias[c] = 0.0f;
                     flam[3 * c] = 0.0f; flam[3 * c + 1] = 0.0f; flam[3 * c + 2] = 0.0f;
-                    if (__builtin_expect(gap < m.contact_margin, 1)) {
+                    const float vn0 = cz_vrel(r, v, w);
+                    if (__builtin_expect(contact_live(m, gap, vn0, h), 1)) {
                         fDinv[3 * c] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                         fDinv[3 * c + 1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
                         fDinv[3 * c + 2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
-                        float vn0 = cz_vrel(r, v, w);
                         fbias[c] = contact_bias(m, gap, vn0, inv_h, 0.0f);
 #pragma unroll
                         for (int d = 0; d < 3; ++d) flam[3 * c + d] = lam_cf[3 * c + d] * keep;
@@ -1125,93 +1284,31 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     float rho = rho2 * inv;
                     float gap = wall_radius_at(m, pz) - rho;
                     if (__builtin_expect(any && gap < m.contact_margin && rho > 1e-6f, 0)) {
-                        n[0] = -px * inv; n[1] = -py * inv;
+                        float nn[2] = {-px * inv, -py * inv};
                         float a[3], b[3];
-                        wall_arm_n(r, n, a);
-                        wall_arm_t(r, n, b);
-                        Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
-                        Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
-                        Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
-                        float vn0 = wn_vrel(n, a, v, w);
-                        bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
+                        wall_arm_n(r, nn, a);
+                        wall_arm_t(r, nn, b);
+                        const float vn0 = wn_vrel(nn, a, v, w);
+                        if (contact_live(m, gap, vn0, h)) {
+                            n[0] = nn[0]; n[1] = nn[1];
+                            Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
+                            Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
+                            Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                            bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) lam[d] = LD(wb + 9 + d) * keep;
+                            for (int d = 0; d < 3; ++d) lam[d] = LD(wb + 9 + d) * keep;
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { LD(wb + j) = r[j]; LD(wb + 5 + j) = Dinv[j]; LD(wb + 9 + j) = lam[j]; }
                     LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
                 }
             }
-            BAR();                                              // S1
-            // ---- FF: finger-finger contacts (distal capsules), solved before the sweeps on the free velocities: the pairs
-            // (0,1), (1,2), (2,0) in turn, TF_FF_ITERATIONS Gauss-Seidel iterations over the three rows of each pair ----
-            {
-                float vq_ff[9];
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) vq_ff[3 * f + j] = LD(L_REC(f) + P_VQ + j);
-                }
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const int fa = p, fb = (p + 1) % 3;
-                    FingerPubRegs pa, pb_;
-                    read_pub(lds, lane, fa, pa);
-                    read_pub(lds, lane, fb, pb_);
-                    float Pa[3], Pb[3];
-                    seg_seg(pa.Aw, pa.Bw, pb_.Aw, pb_.Bw, Pa, Pb);
-                    float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
-                    float dist2 = dot3(dv, dv);
-                    const bool far_apart = !(dist2 > 1e-12f);
-                    float inv = f_rsqrt(f_max(dist2, 1e-12f));
-                    float dist = dist2 * inv;
-                    float gap = dist - 2.0f * m.cap_radius;
-                    const bool active = !far_apart && (gap < m.contact_margin);
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(active) != 0ull, 0)) {
-                        const Yaw ya = {m.base_yaw_cos[fa], m.base_yaw_sin[fa], 0.0f, 0.0f, m.base_height};
-                        const Yaw yb = {m.base_yaw_cos[fb], m.base_yaw_sin[fb], 0.0f, 0.0f, m.base_height};
-                        float dirs[9];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) dirs[j] = dv[j] * inv;
-                        if (!active) { dirs[0] = 1.0f; dirs[1] = 0.0f; dirs[2] = 0.0f; }        // keep the dead lanes finite
-                        tangent_basis(&dirs[0], &dirs[3], &dirs[6]);
-                        float Ca[3], Cb[3], Cab[3], Cbb[3];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) { Ca[j] = FMA(-m.cap_radius, dirs[j], Pa[j]); Cb[j] = FMA(m.cap_radius, dirs[j], Pb[j]); }
-                        world_to_base(ya, Ca, Cab);
-                        world_to_base(yb, Cb, Cbb);
-                        float Ja[9], Wa[9], Da[3], Jb[9], Wb[9], Db[3];
-                        finger_jac(ya, pa.k, 3, Cab, dirs, Ja, Wa, Da);
-                        finger_jac(yb, pb_.k, 3, Cbb, dirs, Jb, Wb, Db);
-                        float va[3] = {vq_ff[3 * fa], vq_ff[3 * fa + 1], vq_ff[3 * fa + 2]};
-                        float vb[3] = {vq_ff[3 * fb], vq_ff[3 * fb + 1], vq_ff[3 * fb + 2]};
-                        float vn0 = dot3(&Ja[0], va) - dot3(&Jb[0], vb);
-                        float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
-                        float Dinv[3], lam[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) Dinv[d] = f_rcp2(f_max(Da[d] + Db[d], 1e-30f));
-#pragma unroll
-                        for (int it = 0; it < TF_FF_ITERATIONS; ++it) {
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) {
-                                float vrel = dot3(&Ja[3 * d], va) - dot3(&Jb[3 * d], vb);
-                                float dl = (d == 0) ? solve_normal(lam[0], Dinv[0], vrel, bias) : solve_tangent(lam[d], Dinv[d], vrel, mu_ff * lam[0]);
-#pragma unroll
-                                for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[3 * d + j], dl, va[j]); vb[j] = FMA(-Wb[3 * d + j], dl, vb[j]); }
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            vq_ff[3 * fa + j] = active ? va[j] : vq_ff[3 * fa + j];
-                            vq_ff[3 * fb + j] = active ? vb[j] : vq_ff[3 * fb + j];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 9; ++j) LD(L_VQFF + j) = vq_ff[j];
-            }
+            STAMP(sb_ + 2);
             BAR();                                              // S2
+            STAMP(sb_ + 3);
             BAR();                                              // S3: records published by the finger roles
+            STAMP(sb_ + 5);
             // ---- seeded impulses of the finger contacts (1/D, bias and impulses stay in registers through the sweeps) ----
             float cDinv[9], cbias[3], clam[9];
 #pragma unroll
@@ -1220,105 +1317,129 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 cbias[f] = LD(L_INIT + f);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) { cDinv[3 * f + d] = LD(L_VQFF + 3 * f + d); clam[3 * f + d] = LD(rb + R_DL + d); }
+                if (cDinv[3 * f] > 0.0f) {                       // a live contact has 1/D > 0
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    float dir[3], rxd[3];
+                    for (int d = 0; d < 3; ++d) {
+                        float dir[3], rxd[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { dir[j] = LD(rb + R_DIR + 3 * d + j); rxd[j] = LD(rb + R_RXD + 3 * d + j); }
-                    float sc = clam[3 * f + d] * inv_m, qq = clam[3 * f + d] * inv_I;
+                        for (int j = 0; j < 3; ++j) { dir[j] = LD(rb + R_DIR + 3 * d + j); rxd[j] = LD(rb + R_RXD + 3 * d + j); }
+                        float sc = clam[3 * f + d] * inv_m, qq = clam[3 * f + d] * inv_I;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
+                        for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
+                    }
                 }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                cz_apply(&fr_[3 * c], flam[3 * c], inv_m, inv_I, v, w);
-                cx_apply(&fr_[3 * c], flam[3 * c + 1], inv_m, inv_I, v, w);
-                cy_apply(&fr_[3 * c], flam[3 * c + 2], inv_m, inv_I, v, w);
+                if (fDinv[3 * c] > 0.0f) {
+                    cz_apply(&fr_[3 * c], flam[3 * c], inv_m, inv_I, v, w);
+                    cx_apply(&fr_[3 * c], flam[3 * c + 1], inv_m, inv_I, v, w);
+                    cy_apply(&fr_[3 * c], flam[3 * c + 2], inv_m, inv_I, v, w);
+                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int wb = L_WALL + 12 * c;
-                float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
-                float a[3], b[3];
-                wall_arm_n(r, n, a);
-                wall_arm_t(r, n, b);
-                wn_apply(n, a, LD(wb + 9), inv_m, inv_I, v, w);
-                wt_apply(n, b, LD(wb + 10), inv_m, inv_I, v, w);
-                cz_apply(r, LD(wb + 11), inv_m, inv_I, v, w);
+                if (LD(wb + 5) > 0.0f) {
+                    float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
+                    float a[3], b[3];
+                    wall_arm_n(r, n, a);
+                    wall_arm_t(r, n, b);
+                    wn_apply(n, a, LD(wb + 9), inv_m, inv_I, v, w);
+                    wt_apply(n, b, LD(wb + 10), inv_m, inv_I, v, w);
+                    cz_apply(r, LD(wb + 11), inv_m, inv_I, v, w);
+                }
             }
             // ---- projected Gauss-Seidel: the cube role's share ----
+            uint32_t t_wait = 0u, t_fc = 0u, t_floor = 0u;
+            STAMP(sb_ + 9);
             for (int it = 0; it < P.iters; ++it) {
+                const uint32_t tf0_ = NOW();
                 const bool last = it == P.iters - 1;
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {                   // finger-cube rows in contact space
                     const int rb = L_REC(f);
-                    float Am[6], u[3], dirs[9], rxds[9];
+                    float ftv[3] = {0.0f, 0.0f, 0.0f}, Fc[3] = {0.0f, 0.0f, 0.0f};
+                    if (cDinv[3 * f] > 0.0f) {
+                        float Am[6], u[3], dirs[9], rxds[9];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) Am[j] = LD(rb + R_A + j);
+                        for (int j = 0; j < 6; ++j) Am[j] = LD(rb + R_A + j);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) u[j] = LD(rb + R_U + j);
+                        for (int j = 0; j < 3; ++j) u[j] = LD(rb + R_U + j);
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) { dirs[j] = LD(rb + R_DIR + j); rxds[j] = LD(rb + R_RXD + j); }
+                        for (int j = 0; j < 9; ++j) { dirs[j] = LD(rb + R_DIR + j); rxds[j] = LD(rb + R_RXD + j); }
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const float* dir = &dirs[3 * d];
-                        const float* rxd = &rxds[3 * d];
-                        float vrel = u[d] - (dot3(dir, v) + dot3(rxd, w));
-                        float dl = (d == 0) ? solve_normal(clam[3 * f], cDinv[3 * f], vrel, cbias[f])
-                                            : solve_tangent(clam[3 * f + d], cDinv[3 * f + d], vrel, mu_fc * clam[3 * f]);
-                        LD(rb + R_DL + d) = dl;
-                        const int i0 = (d == 0) ? 0 : ((d == 1) ? 1 : 2), i1 = (d == 0) ? 1 : ((d == 1) ? 3 : 4), i2 = (d == 0) ? 2 : ((d == 1) ? 4 : 5);
-                        u[0] = FMA(Am[i0], dl, u[0]);
-                        u[1] = FMA(Am[i1], dl, u[1]);
-                        u[2] = FMA(Am[i2], dl, u[2]);
-                        float sc = dl * inv_m, qq = dl * inv_I;
+                        for (int d = 0; d < 3; ++d) {
+                            const float* dir = &dirs[3 * d];
+                            const float* rxd = &rxds[3 * d];
+                            float vrel = u[d] - (dot3(dir, v) + dot3(rxd, w));
+                            float dl = (d == 0) ? solve_normal(clam[3 * f], cDinv[3 * f], vrel, cbias[f])
+                                                : solve_tangent(clam[3 * f + d], cDinv[3 * f + d], vrel, mu_fc * clam[3 * f]);
+                            LD(rb + R_DL + d) = dl;
+                            const int i0 = (d == 0) ? 0 : ((d == 1) ? 1 : 2), i1 = (d == 0) ? 1 : ((d == 1) ? 3 : 4), i2 = (d == 0) ? 2 : ((d == 1) ? 4 : 5);
+                            u[0] = FMA(Am[i0], dl, u[0]);
+                            u[1] = FMA(Am[i1], dl, u[1]);
+                            u[2] = FMA(Am[i2], dl, u[2]);
+                            float sc = dl * inv_m, qq = dl * inv_I;
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
-                    }
-                    if (last) {                                 // what the finger role keeps: normal impulse, world friction impulse, force
-                        float ftv[3], Fc[3];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            ftv[j] = FMA(dirs[6 + j], clam[3 * f + 2], dirs[3 + j] * clam[3 * f + 1]);
-                            Fc[j] = FMA(dirs[j], clam[3 * f], ftv[j]) * inv_h;
+                            for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
                         }
+                        if (last) {                             // what the finger role keeps: world friction impulse, force
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                ftv[j] = FMA(dirs[6 + j], clam[3 * f + 2], dirs[3 + j] * clam[3 * f + 1]);
+                                Fc[j] = FMA(dirs[j], clam[3 * f], ftv[j]) * inv_h;
+                            }
+                        }
+                    }
+                    if (last) {
                         LD(L_INIT + f) = clam[3 * f];
 #pragma unroll
                         for (int j = 0; j < 3; ++j) { LD(rb + R_A + j) = ftv[j]; LD(rb + R_A + 3 + j) = Fc[j]; }
                     }
                 }
-                BAR();                                          // W1
+                t_fc += NOW() - tf0_;
+                { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W1
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                   // cube - floor: rows +z (normal), +x, +y
                     const float* r = &fr_[3 * c];
-                    float dl = solve_normal(flam[3 * c], fDinv[3 * c], cz_vrel(r, v, w), fbias[c]);
-                    cz_apply(r, dl, inv_m, inv_I, v, w);
-                    dl = solve_tangent(flam[3 * c + 1], fDinv[3 * c + 1], cx_vrel(r, v, w), mu_cf * flam[3 * c]);
-                    cx_apply(r, dl, inv_m, inv_I, v, w);
-                    dl = solve_tangent(flam[3 * c + 2], fDinv[3 * c + 2], cy_vrel(r, v, w), mu_cf * flam[3 * c]);
-                    cy_apply(r, dl, inv_m, inv_I, v, w);
+                    if (fDinv[3 * c] > 0.0f) {
+                        float dl = solve_normal(flam[3 * c], fDinv[3 * c], cz_vrel(r, v, w), fbias[c]);
+                        cz_apply(r, dl, inv_m, inv_I, v, w);
+                        dl = solve_tangent(flam[3 * c + 1], fDinv[3 * c + 1], cx_vrel(r, v, w), mu_cf * flam[3 * c]);
+                        cx_apply(r, dl, inv_m, inv_I, v, w);
+                        dl = solve_tangent(flam[3 * c + 2], fDinv[3 * c + 2], cy_vrel(r, v, w), mu_cf * flam[3 * c]);
+                        cy_apply(r, dl, inv_m, inv_I, v, w);
+                    }
                 }
+                t_floor += NOW() - tf0_;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                   // cube - wall: rows n (normal), t, +z
                     const int wb = L_WALL + 12 * c;
-                    float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
-                    float Dinv[3] = {LD(wb + 5), LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
-                    float lam[3] = {LD(wb + 9), LD(wb + 10), LD(wb + 11)};
-                    float a[3], b[3];
-                    wall_arm_n(r, n, a);
-                    wall_arm_t(r, n, b);
-                    float dl = solve_normal(lam[0], Dinv[0], wn_vrel(n, a, v, w), bias);
-                    wn_apply(n, a, dl, inv_m, inv_I, v, w);
-                    dl = solve_tangent(lam[1], Dinv[1], wt_vrel(n, b, v, w), mu_cw * lam[0]);
-                    wt_apply(n, b, dl, inv_m, inv_I, v, w);
-                    dl = solve_tangent(lam[2], Dinv[2], cz_vrel(r, v, w), mu_cw * lam[0]);
-                    cz_apply(r, dl, inv_m, inv_I, v, w);
+                    const float D0 = LD(wb + 5);
+                    if (__builtin_expect(D0 > 0.0f, 0)) {
+                        float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
+                        float Dinv[3] = {D0, LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
+                        float lam[3] = {LD(wb + 9), LD(wb + 10), LD(wb + 11)};
+                        float a[3], b[3];
+                        wall_arm_n(r, n, a);
+                        wall_arm_t(r, n, b);
+                        float dl = solve_normal(lam[0], Dinv[0], wn_vrel(n, a, v, w), bias);
+                        wn_apply(n, a, dl, inv_m, inv_I, v, w);
+                        dl = solve_tangent(lam[1], Dinv[1], wt_vrel(n, b, v, w), mu_cw * lam[0]);
+                        wt_apply(n, b, dl, inv_m, inv_I, v, w);
+                        dl = solve_tangent(lam[2], Dinv[2], cz_vrel(r, v, w), mu_cw * lam[0]);
+                        cz_apply(r, dl, inv_m, inv_I, v, w);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
+                        for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
+                    }
                 }
-                BAR();                                          // W2
+                { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W2
             }
+            STAMP(sb_ + 6);
+            STAMPV(sb_ + 8, t_wait);
+            STAMPV(sb_ + 10, t_fc);
+            STAMPV(sb_ + 11, t_floor);
             // ---- impulses kept for the next substep, integration ----
 #pragma unroll
             for (int j = 0; j < 12; ++j) lam_cf[j] = flam[j];
@@ -1328,19 +1449,35 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 cp[j] = FMA(h, v[j], cp[j]);
             }
             quat_integrate(cq, cw, h);
+            STAMP(sb_ + 7);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) lam_cw[3 * c + d] = LD(L_WALL + 12 * c + 9 + d);
         }
+        __builtin_amdgcn_s_setprio(0);
     }
+    STAMP(30);
     // =================================================================================================================
     // post: observations of the object and the goal, rewards, termination, statistics
     // =================================================================================================================
     StatsTicket tk;
     tk.mine = 0ull; tk.old = 0ull;
+    if (MODE & (M_POST | M_FINISH)) {     // the flag buffers as the reset logic left them (cold through the physics: re-read)
+        c_reset = P.reset_buf[(unsigned)cx.i] != 0;
+        c_goal_reset = P.goal_reset_buf[(unsigned)cx.i] != 0;
+        c_successes = P.successes[(unsigned)cx.i] != 0;
+        c_steps = P.steps[(unsigned)cx.i];
+    }
     if (MODE & M_POST) {
+        float gp[3], gq[4], prev_obj[7];                        // cold through the physics: re-read from their rows
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gp[j] = LDST(TF_S_GOAL_P + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gq[j] = LDST(TF_S_GOAL_Q + j);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) prev_obj[j] = LDST(TF_S_PREV_OBJ_P + j);
         LaneStats st;
         stats_zero(st);
         st.resets = n_resets;
@@ -1352,7 +1489,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int j = 0; j < 4; ++j) acc = acc + cq[j] * 0.0f;
             LD(L_NAN + 3) = (acc == 0.0f) ? 0.0f : 1.0f;
         }
+        STAMP(31);
         BAR();                                                  // P1
+        STAMP(32);
         const bool guarded = (LD(L_NAN) + LD(L_NAN + 1) + LD(L_NAN + 2) + LD(L_NAN + 3)) != 0.0f;
         if (__builtin_expect(guarded, 0)) {     // a non-finite env is flagged for reset and parked at the default pose
             cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = CUBE_MIN_HEIGHT;
@@ -1382,7 +1521,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int jj = 18; jj < 25; ++jj) row[jj] = f_clamp(FMA(P.dr_obs_noise, 2.0f * nz[jj] - 1.0f, row[jj]), -co, co);
         };
         if (!ASYM && P.dr_obs_noise > 0.0f) add_noise();
+        STAMP(33);
         BAR();                                                  // P3: tile complete, fingertip exchange published
+        STAMP(34);
         // ---- rewards (reference rewards.py; order of trifinger_env.py:513-550), termination (:1053-1099) ----
         if (!IS_RESET) {
             float tips[9], tip_prev[9];
@@ -1470,10 +1611,15 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         STST(TF_S_CF_FACE, cf_face); STST(TF_S_CW_FACE, cw_face);
     }
     if ((MODE & M_POST) && P.goal_rotation_activate) {
-        const int nadv = ((MODE & M_SIM) ? sa.nsim : P.control_decimation) * P.substeps;
-        for (int s = 0; s < nadv; ++s) quat_integrate(gq, gw, P.hsub);
+        float gq2[4], gw2[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) STST(TF_S_GOAL_Q + j, gq[j]);
+        for (int j = 0; j < 4; ++j) gq2[j] = LDST(TF_S_GOAL_Q + j);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gw2[j] = LDST(TF_S_GOAL_W + j);
+        const int nadv = ((MODE & M_SIM) ? sa.nsim : P.control_decimation) * P.substeps;
+        for (int s = 0; s < nadv; ++s) quat_integrate(gq2, gw2, P.hsub);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) STST(TF_S_GOAL_Q + j, gq2[j]);
     }
     if (MODE & M_FINISH) {                                      // env_base.py:391-399
         if (cx.valid) {
@@ -1485,4 +1631,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         }
     }
     if (MODE & M_POST) stats_end(P, lane, tk);
+    STAMP(35);
+    STAMPV(40, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID
+    STAMPV(41, __builtin_amdgcn_s_getreg((31 << 11) | 20));     // HW_REG_XCC_ID
 }

@@ -30,7 +30,7 @@
 
 #include "tf_roles.h"
 
-#define SCR_STRIDE 16
+#define SCR_STRIDE TF_SCR_STRIDE
 
 // One launch = one or more hooks of the reference step (MODE) for every env of the handle.
 template <int A, bool IS_RESET, bool ASYM, int MODE>
@@ -244,6 +244,7 @@ void tf_default_model(TfModel* m) {
     m->restitution_ff = 0.8f;
     m->bounce_threshold = 0.5f;
     m->contact_margin = 0.04f;
+    m->contact_slack = 0.005f;
     m->contact_offset = 0.002f;
     m->erp = 0.2f;
     m->warm_start = 0.9f;

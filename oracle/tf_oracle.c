@@ -385,6 +385,7 @@ void tf_default_model(TfModel* m) {
     m->restitution_ff = 0.8f;             /* avg(0.8, 0.8) */
     m->bounce_threshold = 0.5f;
     m->contact_margin = 0.04f;
+    m->contact_slack = 0.005f;
     m->contact_offset = 0.002f;
     m->erp = 0.2f;
     m->warm_start = 0.9f;
@@ -702,8 +703,9 @@ typedef struct {
 } Env;
 
 /* one cube corner against the floor or the wall.  Rows are always evaluated: an inactive contact has
- * Dinv = 0 and bias = 0, so its impulses stay exactly zero (the kernel does the same, branch-free). */
+ * (rows of a corner that is not live are skipped) */
 typedef struct {
+    int active;
     float r[3];
     float n[2];        /* wall: horizontal inward normal */
     float Dinv[3];
@@ -765,6 +767,14 @@ static float contact_bias(const TfModel* m, float gap, float vn0, float inv_h, f
     else b = f_max(m->erp * gap * inv_h, -m->max_depenetration_velocity);
     if (restitution > 0.0f && gap < m->contact_offset && vn0 < -m->bounce_threshold) b = f_min(b, restitution * vn0);
     return b;
+}
+
+/* A contact slot is LIVE (gets rows) when its gap is inside the broad margin and can close within this substep at the
+ * approach speed of the free velocities, plus a slack for what other impulses may add: gap < slack + h max(0, -vn0).
+ * Everything a dead slot would do is skipped (the kernel masks those lanes; a wavefront with no live lane for a slot
+ * skips its rows altogether). */
+static inline int contact_live(const TfModel* m, float gap, float vn0, float h) {
+    return (gap < m->contact_margin) && (gap < FMA(h, f_max(-vn0, 0.0f), m->contact_slack));
 }
 
 /* base-frame position of a point given in the frame of link 1..3 */
@@ -983,6 +993,7 @@ typedef struct {
 /* Contact-space record of one finger-cube contact, handed to the cube role (LDS in the HIP kernel): the 3x3 block
  * A = J M^-1 J^T of the finger side, the cube-side directions and arms, and the running contact-point velocity u. */
 typedef struct {
+    int active;
     float A[6];                   /* 00 01 02 11 12 22 */
     float Dinv[3], bias, lam[3];
     float dir[3][3], rxd[3][3];
@@ -1053,8 +1064,9 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             memset(c, 0, sizeof(*c));
             cube_corner(R, hc, k, sk, i, c->r);
             float gap = e->cp[2] + c->r[2];
-            if (gap < m->contact_margin) {
+            if (contact_live(m, gap, cz_vrel(c->r, v, w), h)) {
                 const float* r = c->r;
+                c->active = 1;
                 c->Dinv[0] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));   /* +z */
                 c->Dinv[1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));   /* +x */
                 c->Dinv[2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));   /* +y */
@@ -1089,12 +1101,15 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             float inv = f_rsqrt(f_max(rho2, 1e-24f));
             float rho = rho2 * inv;
             float gap = wall_radius_at(m, pz) - rho;
-            if (any && gap < m->contact_margin && rho > 1e-6f) {
+            if (!(any && gap < m->contact_margin && rho > 1e-6f)) continue;
+            c->n[0] = -px * inv; c->n[1] = -py * inv;
+            {
                 const float* r = c->r;
-                c->n[0] = -px * inv; c->n[1] = -py * inv;
                 float a[3], b[3];
                 wall_arm_n(c, a);
                 wall_arm_t(c, b);
+                if (!contact_live(m, gap, wn_vrel(c, a, v, w), h)) { c->n[0] = 0.0f; c->n[1] = 0.0f; continue; }
+                c->active = 1;
                 c->Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
                 c->Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
                 c->Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
@@ -1132,6 +1147,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         float* va = vq_ff[fa];
         float* vb = vq_ff[fb];
         float vn0 = dot3(Ja[0], va) - dot3(Jb[0], vb);
+        if (!contact_live(m, gap, vn0, h)) continue;
         float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
         float Dinv[3], lam[3] = {0.0f, 0.0f, 0.0f};
         for (int d = 0; d < 3; ++d) Dinv[d] = f_rcp2(Da[d] + Db[d]);
@@ -1181,39 +1197,41 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) { g->fcJ[d][j] = 0.0f; g->fcW[d][j] = 0.0f; }
         g->fc_arm[0] = 0.0f; g->fc_arm[1] = 0.0f; g->fc_arm[2] = 0.0f;
         if (gap < m->contact_margin) {
-            float rcv[3], xw[3], Dd[3];
-            mat3_mul(R, nc, rc_->dir[0]);
+            float rcv[3], xw[3], Dd[3], dir[3][3], rxd[3][3], J[3][3], W[3][3];
+            mat3_mul(R, nc, dir[0]);
             mat3_mul(R, y, rcv);
             mat3_mul(R, x, xw);
-            tangent_basis(rc_->dir[0], rc_->dir[1], rc_->dir[2]);
+            tangent_basis(dir[0], dir[1], dir[2]);
             /* finger-side contact point (world): axis point minus r n */
-            float Pw[3] = {FMA(-radius, rc_->dir[0][0], e->cp[0] + xw[0]), FMA(-radius, rc_->dir[0][1], e->cp[1] + xw[1]),
-                           FMA(-radius, rc_->dir[0][2], e->cp[2] + xw[2])};
+            float Pw[3] = {FMA(-radius, dir[0][0], e->cp[0] + xw[0]), FMA(-radius, dir[0][1], e->cp[1] + xw[1]),
+                           FMA(-radius, dir[0][2], e->cp[2] + xw[2])};
             float Pb[3];
             world_to_base(m, f, Pw, Pb);
-            g->fc_link = link;
-            finger_jac(m, f, k, link, Pb, rc_->dir, g->fcJ, g->fcW, Dd);
-            for (int d = 0; d < 3; ++d) {
-                cross3(rcv, rc_->dir[d], rc_->rxd[d]);
-                rc_->Dinv[d] = f_rcp2(FMA(dot3(rc_->rxd[d], rc_->rxd[d]), inv_I, Dd[d] + inv_m));
-            }
-            rc_->A[0] = Dd[0];                        rc_->A[1] = dot3(g->fcJ[0], g->fcW[1]); rc_->A[2] = dot3(g->fcJ[0], g->fcW[2]);
-            rc_->A[3] = Dd[1];                        rc_->A[4] = dot3(g->fcJ[1], g->fcW[2]);
-            rc_->A[5] = Dd[2];
-            if (link == 3) for (int i = 0; i < 3; ++i) g->fc_arm[i] = Pw[i] - g->Tw[i];
-            float vn0 = dot3(g->fcJ[0], g->vq) - (dot3(rc_->dir[0], v) + dot3(rc_->rxd[0], w));
-            rc_->bias = contact_bias(m, gap, vn0, inv_h, rest_f);
-            if ((float)link == e->fc_link[f]) {          /* same link as in the last substep: seed the impulses */
-                const float* pl = e->lam_fc[f];
-                float l0 = pl[0] * ws;
-                float lim = mu_fc * l0;
-                rc_->lam[0] = l0;
-                rc_->lam[1] = f_clamp(dot3(&pl[1], rc_->dir[1]) * ws, -lim, lim);
-                rc_->lam[2] = f_clamp(dot3(&pl[1], rc_->dir[2]) * ws, -lim, lim);
+            finger_jac(m, f, k, link, Pb, dir, J, W, Dd);
+            for (int d = 0; d < 3; ++d) cross3(rcv, dir[d], rxd[d]);
+            float vn0 = dot3(J[0], g->vq) - (dot3(dir[0], v) + dot3(rxd[0], w));
+            if (contact_live(m, gap, vn0, h)) {
+                rc_->active = 1;
+                g->fc_link = link;
+                for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) {
+                    g->fcJ[d][j] = J[d][j]; g->fcW[d][j] = W[d][j]; rc_->dir[d][j] = dir[d][j]; rc_->rxd[d][j] = rxd[d][j];
+                }
+                for (int d = 0; d < 3; ++d) rc_->Dinv[d] = f_rcp2(FMA(dot3(rxd[d], rxd[d]), inv_I, Dd[d] + inv_m));
+                rc_->A[0] = Dd[0];                        rc_->A[1] = dot3(J[0], W[1]); rc_->A[2] = dot3(J[0], W[2]);
+                rc_->A[3] = Dd[1];                        rc_->A[4] = dot3(J[1], W[2]);
+                rc_->A[5] = Dd[2];
+                if (link == 3) for (int i = 0; i < 3; ++i) g->fc_arm[i] = Pw[i] - g->Tw[i];
+                rc_->bias = contact_bias(m, gap, vn0, inv_h, rest_f);
+                if ((float)link == e->fc_link[f]) {          /* same link as in the last substep: seed the impulses */
+                    const float* pl = e->lam_fc[f];
+                    float l0 = pl[0] * ws;
+                    float lim = mu_fc * l0;
+                    rc_->lam[0] = l0;
+                    rc_->lam[1] = f_clamp(dot3(&pl[1], dir[1]) * ws, -lim, lim);
+                    rc_->lam[2] = f_clamp(dot3(&pl[1], dir[2]) * ws, -lim, lim);
+                }
             }
         }
-        /* (the kernel keeps J only and forms W = M^-1 J where it is used: same operations, also for an absent contact) */
-        for (int d = 0; d < 3; ++d) sym3_mul(k->Minv, g->fcJ[d], g->fcW[d]);
         /* --- fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1) --- */
         {
             float rho2 = FMA(g->Bw[0], g->Bw[0], g->Bw[1] * g->Bw[1]);
@@ -1225,20 +1243,21 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 float gp_ = (t == 0) ? (g->Bw[2] - m->cap_radius) : ((wall_radius_at(m, g->Bw[2]) - rho) - m->cap_radius);
                 if (t == 1 && !(rho > 1e-6f)) continue;
                 if (!(gp_ < m->contact_margin)) continue;
-                float n_w[3] = {0.0f, 0.0f, 1.0f};
-                if (t == 1) { n_w[0] = -g->Bw[0] * inv; n_w[1] = -g->Bw[1] * inv; n_w[2] = 0.0f; }
-                for (int i = 0; i < 3; ++i) c->dir[0][i] = n_w[i];
-                tangent_basis(c->dir[0], c->dir[1], c->dir[2]);
-                float Pw[3] = {FMA(-m->cap_radius, n_w[0], g->Bw[0]), FMA(-m->cap_radius, n_w[1], g->Bw[1]),
-                               FMA(-m->cap_radius, n_w[2], g->Bw[2])};
-                float Pb[3], Dd[3];
+                float dir[3][3] = {{0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+                if (t == 1) { dir[0][0] = -g->Bw[0] * inv; dir[0][1] = -g->Bw[1] * inv; dir[0][2] = 0.0f; }
+                tangent_basis(dir[0], dir[1], dir[2]);
+                float Pw[3] = {FMA(-m->cap_radius, dir[0][0], g->Bw[0]), FMA(-m->cap_radius, dir[0][1], g->Bw[1]),
+                               FMA(-m->cap_radius, dir[0][2], g->Bw[2])};
+                float Pb[3], Dd[3], J[3][3], W[3][3];
                 world_to_base(m, f, Pw, Pb);
+                finger_jac(m, f, k, 3, Pb, dir, J, W, Dd);
+                float vn0 = dot3(J[0], g->vq);
+                if (!contact_live(m, gp_, vn0, h)) continue;
                 c->active = 1;
                 c->mu = (t == 0) ? mu_tf : mu_tw;
-                finger_jac(m, f, k, 3, Pb, c->dir, c->J, c->W, Dd);
+                for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) { c->J[d][j] = J[d][j]; c->W[d][j] = W[d][j]; c->dir[d][j] = dir[d][j]; }
                 for (int d = 0; d < 3; ++d) c->Dinv[d] = f_rcp2(Dd[d]);
                 for (int i = 0; i < 3; ++i) c->arm[i] = Pw[i] - g->Tw[i];
-                float vn0 = dot3(c->J[0], g->vq);
                 c->bias = contact_bias(m, gp_, vn0, inv_h, rest_f);
                 const float* pl = (t == 0) ? e->lam_tf[f] : e->lam_tw[f];      /* zero when the contact was not there */
                 float l0 = pl[0] * ws;
@@ -1247,7 +1266,6 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 c->lam[1] = f_clamp(pl[1] * ws, -lim, lim);
                 c->lam[2] = f_clamp(pl[2] * ws, -lim, lim);
             }
-            for (int t = 0; t < 2; ++t) for (int d = 0; d < 3; ++d) sym3_mul(k->Minv, g->tc[t].J[d], g->tc[t].W[d]);
         }
         /* --- joint limit / velocity limit rows --- */
         for (int jj = 0; jj < 3; ++jj) {
@@ -1259,25 +1277,31 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         }
         /* --- velocity after the finger-finger pass, seeded impulses applied on the finger side, contact-point velocity --- */
         for (int j = 0; j < 3; ++j) g->vq[j] = vq_ff[f][j];
-        for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) g->vq[j] = FMA(g->fcW[d][j], rc_->lam[d], g->vq[j]);
-        for (int t = 0; t < 2; ++t)
+        if (rc_->active)
+            for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) g->vq[j] = FMA(g->fcW[d][j], rc_->lam[d], g->vq[j]);
+        for (int t = 0; t < 2; ++t) {
+            if (!g->tc[t].active) continue;
             for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) g->vq[j] = FMA(g->tc[t].W[d][j], g->tc[t].lam[d], g->vq[j]);
-        for (int d = 0; d < 3; ++d) rc_->u[d] = dot3(g->fcJ[d], g->vq);
+        }
+        if (rc_->active) for (int d = 0; d < 3; ++d) rc_->u[d] = dot3(g->fcJ[d], g->vq);
     }
     /* ---- seeded impulses on the cube side: finger contacts, floor corners, wall corners ---- */
     for (int f = 0; f < 3; ++f) {
         const FcRecord* c = &rec[f];
+        if (!c->active) continue;
         for (int d = 0; d < 3; ++d) {
             float sc = c->lam[d] * inv_m, q = c->lam[d] * inv_I;
             for (int j = 0; j < 3; ++j) { v[j] = FMA(-c->dir[d][j], sc, v[j]); w[j] = FMA(-c->rxd[d][j], q, w[j]); }
         }
     }
     for (int i = 0; i < 4; ++i) {
+        if (!cf[i].active) continue;
         cz_apply(cf[i].r, cf[i].lam[0], inv_m, inv_I, v, w);
         cx_apply(cf[i].r, cf[i].lam[1], inv_m, inv_I, v, w);
         cy_apply(cf[i].r, cf[i].lam[2], inv_m, inv_I, v, w);
     }
     for (int i = 0; i < 4; ++i) {
+        if (!cwl[i].active) continue;
         float a[3], b[3];
         wall_arm_n(&cwl[i], a);
         wall_arm_t(&cwl[i], b);
@@ -1290,6 +1314,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         /* cube role: finger-cube rows in contact space */
         for (int f = 0; f < 3; ++f) {
             FcRecord* c = &rec[f];
+            if (!c->active) continue;
             for (int d = 0; d < 3; ++d) {
                 float vrel = c->u[d] - (dot3(c->dir[d], v) + dot3(c->rxd[d], w));
                 float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
@@ -1308,9 +1333,10 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             FingerRole* g = &fr[f];
             FcRecord* c = &rec[f];
             float* vf = g->vq;
-            for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) vf[j] = FMA(g->fcW[d][j], c->dl[d], vf[j]);
+            if (c->active) for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) vf[j] = FMA(g->fcW[d][j], c->dl[d], vf[j]);
             for (int t = 0; t < 2; ++t) {             /* fingertip - floor, fingertip - wall */
                 TipContact* tcn = &g->tc[t];
+                if (!tcn->active) continue;
                 for (int d = 0; d < 3; ++d) {
                     float vrel = dot3(tcn->J[d], vf);
                     float dl = (d == 0) ? solve_normal(&tcn->lam[0], tcn->Dinv[0], vrel, tcn->bias)
@@ -1331,11 +1357,12 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 vf[1] = FMA(Mi[col[jj][1]], dl, vf[1]);
                 vf[2] = FMA(Mi[col[jj][2]], dl, vf[2]);
             }
-            for (int d = 0; d < 3; ++d) c->u[d] = dot3(g->fcJ[d], vf);
+            if (c->active) for (int d = 0; d < 3; ++d) c->u[d] = dot3(g->fcJ[d], vf);
         }
         /* cube role: corner rows */
         for (int i = 0; i < 4; ++i) {             /* cube - floor: rows +z (normal), +x, +y */
             CubeContact* c = &cf[i];
+            if (!c->active) continue;
             float dl = solve_normal(&c->lam[0], c->Dinv[0], cz_vrel(c->r, v, w), c->bias);
             cz_apply(c->r, dl, inv_m, inv_I, v, w);
             dl = solve_tangent(&c->lam[1], c->Dinv[1], cx_vrel(c->r, v, w), mu_cf * c->lam[0]);
@@ -1345,6 +1372,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         }
         for (int i = 0; i < 4; ++i) {             /* cube - wall: rows n (normal), t, +z */
             CubeContact* c = &cwl[i];
+            if (!c->active) continue;
             float a[3], b[3];
             wall_arm_n(c, a);
             wall_arm_t(c, b);
@@ -1370,14 +1398,14 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int i = 0; i < 3; ++i) e->lam_fc[f][1 + i] = ftv[i];
         e->fc_link[f] = (float)g->fc_link;
         for (int d = 0; d < 3; ++d) { e->lam_tf[f][d] = g->tc[0].lam[d]; e->lam_tw[f][d] = g->tc[1].lam[d]; }
-        if (g->fc_link == 3) {
+        if (cfg->asymmetric_obs && g->fc_link == 3) {
             float T[3];
             cross3(g->fc_arm, Fc, T);
             for (int i = 0; i < 3; ++i) { e->ft[6 * f + i] += Fc[i]; e->ft[6 * f + 3 + i] += T[i]; }
         }
         for (int t = 0; t < 2; ++t) {
             const TipContact* tcn = &g->tc[t];
-            if (!tcn->active) continue;
+            if (!tcn->active || !cfg->asymmetric_obs) continue;
             float F[3], T[3];
             for (int i = 0; i < 3; ++i)
                 F[i] = FMA(tcn->dir[2][i], tcn->lam[2], FMA(tcn->dir[1][i], tcn->lam[1], tcn->dir[0][i] * tcn->lam[0])) * inv_h;
@@ -1888,7 +1916,7 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
             for (int s = 0; s < nsim * c->substeps; ++s) substep(h, &e, hsub);
             post_step_env(h, i, &e, prev_obj, &rc, !is_reset, &local);
             goal_advance(h, &e, nsim * c->substeps, hsub);
-            env_store(h, i, &e, 0);      /* the wrench accumulator rows belong to the split path */
+            env_store(h, i, &e, 1);
             if (!is_reset) finish_env(h, i);
         }
 #pragma omp critical

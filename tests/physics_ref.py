@@ -29,7 +29,7 @@ CUBE_INERTIA = CUBE_MASS * 0.065 ** 2 / 6.0
 LINK_DAMP, CUBE_LIN_DAMP, CUBE_ANG_DAMP = 0.01, 0.0, 0.05
 MU = dict(fc=1.0, cf=0.55, tf=0.55, cw=1.0, tw=1.0, ff=1.0)
 REST_F, REST_FF, BOUNCE = 0.4, 0.8, 0.5
-MARGIN, OFFSET, ERP, MAX_DEPEN = 0.04, 0.002, 0.2, 1000.0
+MARGIN, SLACK, OFFSET, ERP, MAX_DEPEN = 0.04, 0.005, 0.002, 0.2, 1000.0
 Q_LO = np.array([-0.33, 0.0, -2.7])
 Q_HI = np.array([1.0, 1.57, 0.0])
 QD_MAX = 10.0
@@ -91,6 +91,11 @@ def contact_bias(gap, vn0, h, restitution):
     if restitution > 0.0 and gap < OFFSET and vn0 < -BOUNCE:
         b = min(b, restitution * vn0)
     return b
+
+
+def contact_live(gap, vn0, h):
+    """a slot gets rows when its gap can close within the substep at the free approach speed, plus a slack"""
+    return gap < MARGIN and gap < SLACK + h * max(0.0, -vn0)
 
 
 def wall_radius_at(z):
@@ -167,6 +172,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         """three rows for the 3x15 map `Jn_dofs` (velocity of body A minus body B at the contact, world) and dirs n,t1,t2"""
         Jr = [d @ Jn_dofs for d in dirs]
         vn0 = float(Jr[0] @ vref)
+        if not contact_live(gap, vn0, h):
+            return None
         n_row = Row(Jr[0], "normal", bias=contact_bias(gap, vn0, h, restitution))
         rows.append(n_row)
         rows.append(Row(Jr[1], "tangent", parent=n_row, mu=mu))
@@ -205,6 +212,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         Jm[:, 3 * fa:3 * fa + 3] = point_jacobian(fa, q[3 * fa:3 * fa + 3], 3, Pa - rad * n)
         Jm[:, 3 * fb:3 * fb + 3] = -point_jacobian(fb, q[3 * fb:3 * fb + 3], 3, Pb + rad * n)
         bias = contact_bias(gap, float(n @ Jm @ v_ff), h, REST_FF)
+        if not contact_live(gap, float(n @ Jm @ v_ff), h):
+            continue
         lam = [0.0, 0.0, 0.0]
         for _ in range(FF_ITERATIONS):
             for d, dvec in enumerate((n, t1, t2)):
@@ -246,7 +255,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
             Jm = -cube_map(rc)
             Jm[:, sl] = point_jacobian(f, qf, link, Pw)
             nr = add_contact(Jm, (n, t1, t2), gap, REST_F, MU["fc"], vfree)
-            details["fc"].append((f, link, gap, nr))
+            if nr is not None:
+                details["fc"].append((f, link, gap, nr))
         # fingertip sphere against the floor and against the boundary wall
         B = tipsphere[f]
         rad = CAPS[3][2]
@@ -263,7 +273,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
                 Jm = np.zeros((3, 15))
                 Jm[:, sl] = point_jacobian(f, qf, 3, B - rad * n)
                 nr = add_contact(Jm, (n, t1, t2), gp, REST_F, MU["tf"] if kind == "floor" else MU["tw"], vfree)
-                details["te"].append((f, kind, gp, nr))
+                if nr is not None:
+                    details["te"].append((f, kind, gp, nr))
     # ---- cube corners against the floor ----
     k = int(np.argmax(np.abs(R[2, :])))
     sk = -1.0 if R[2, k] > 0 else 1.0
@@ -278,8 +289,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         if gap < MARGIN:
             Jm = cube_map(r)
             ez, ex, ey = np.eye(3)[2], np.eye(3)[0], np.eye(3)[1]
-            add_contact(Jm, (ez, ex, ey), gap, 0.0, MU["cf"], vfree)
-            details["n_floor"] += 1
+            if add_contact(Jm, (ez, ex, ey), gap, 0.0, MU["cf"], vfree) is not None:
+                details["n_floor"] += 1
     # ---- cube corners against the boundary wall ----
     rho_c = np.hypot(cp[0], cp[1])
     if rho_c > 1e-6:
@@ -300,8 +311,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
             if gap < MARGIN and rho > 1e-6:
                 n = np.array([-P[0] / rho, -P[1] / rho, 0.0])
                 t = np.array([-n[1], n[0], 0.0])
-                add_contact(cube_map(r), (n, t, np.array([0.0, 0.0, 1.0])), gap, 0.0, MU["cw"], vfree)
-                details["n_wall"] += 1
+                if add_contact(cube_map(r), (n, t, np.array([0.0, 0.0, 1.0])), gap, 0.0, MU["cw"], vfree) is not None:
+                    details["n_wall"] += 1
     # ---- joint / velocity limit rows ----
     for j in range(9):
         Jr = np.zeros(15)

@@ -1,5 +1,5 @@
-"""Developer tool (GPU box): per-phase cycle counts of k_step from s_memtime stamps (build: make -C leibnizgym_amd/csrc
-libtrifinger_hip_timing.so; lane 0 of every wave appends a stamp at each PHASE_STAMP site)."""
+"""Developer tool (GPU box): per-phase cycle counts of the fused step from s_memtime stamps (build: make -C leibnizgym_amd/csrc
+libtrifinger_hip_timing.so; lane 0 of every wavefront writes a stamp at each STAMP site of tf_roles.h)."""
 import sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -8,32 +8,39 @@ import bench
 from leibnizgym_amd.engine import TrifingerEngine, make_config
 from leibnizgym_amd import _capi
 
-SUB = ["free motion (FK, dynamics, M^-1)", "finger contacts + rows", "cube-floor corners", "cube-wall corners",
-       "limit rows", "PGS sweeps", "wrench + integrate"]
-LABELS = (["issue all loads", "wait for loads, action via LDS", "apply_resets", "action_buf store, torque, park"]
-          + [f"sub0: {x}" for x in SUB] + [f"sub1: {x}" for x in SUB]
-          + ["(stamp 2)", "unpark, tip FK, NaN guard", "tip history, rewards, termination, statistics atomic",
-             "obs emit + store", "states emit + store", "(stamp)", "state stores, finish", "statistics ticket check / fold"])
-
 lib = _capi.TfLib(os.path.join(REPO, "leibnizgym_amd", "csrc", "libtrifinger_hip_timing.so"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-stride = int(lib.tf_scratch_floats(64))
-for asym in (True, False):
-    eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym)), device="cuda:0", lib=lib)
-    g = torch.Generator(device="cuda:0").manual_seed(1)
-    ring = [(torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1) for _ in range(8)]
-    eng.reset()
-    acc = []
-    for k in range(60):
-        eng.step(ring[k % 8])
-        if k >= 10:
-            torch.cuda.synchronize()
-            st = eng.scratch.view(torch.int32).view(-1, stride)[:, 16:16 + len(LABELS) + 1].cpu().numpy().astype(np.int64) & 0xffffffff
-            acc.append(np.diff(st, axis=1) & 0xffffffff)
-    d = np.stack(acc).astype(np.float64)           # [steps, waves, phases]
-    med = np.median(d, axis=(0, 1))
-    tot = med.sum()
-    print(f"asym={asym} N={n}: median s_memtime ticks per wave, total {tot:.0f}")
-    for lab, m in zip(LABELS, med):
-        print(f"  {lab:40s} {m:9.0f}  {100 * m / tot:5.1f} %")
-    eng.close()
+asym = True
+eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym)), device="cuda:0", lib=lib)
+g = torch.Generator(device="cuda:0").manual_seed(1)
+ring = [(torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1) for _ in range(8)]
+eng.reset()
+acc = []
+for k in range(40):
+    eng.step(ring[k % 8])
+    if k >= 10:
+        torch.cuda.synchronize()
+        st = eng.scratch.view(torch.int32).view(-1, 4, 64).cpu().numpy().astype(np.int64) & 0xffffffff
+        acc.append(st)
+S = np.stack(acc)                 # [steps, wg, role, id]
+def d(a, b, role):                # median over steps and workgroups of stamp[b] - stamp[a] for a role (0..2 fingers pooled)
+    sel = S[:, :, role, :] if role == 3 else S[:, :, 0:3, :].reshape(S.shape[0], -1, 64)
+    return np.median((sel[..., b] - sel[..., a]) & 0xffffffff)
+def v(a, role):
+    sel = S[:, :, role, :] if role == 3 else S[:, :, 0:3, :].reshape(S.shape[0], -1, 64)
+    return np.median(sel[..., a])
+print(f"N={n} asym={asym}: median s_memtime ticks; finger role | cube role")
+rows = [("loads + action tile (to #1)", 0, 1), ("resets, action_buf, torque", 1, 2)]
+for s in (0, 1):
+    b = 4 + 12 * s
+    rows += [(f"sub{s}: free motion / corners (to S1 arrive)", (2 if s == 0 else 4 + 7), b + 0), (f"sub{s}: S1 wait", b + 0, b + 1),
+             (f"sub{s}: contact generation / finger-finger pass", b + 1, b + 2), (f"sub{s}: S2 wait", b + 2, b + 3),
+             (f"sub{s}: publish record (finger) + S3", b + 3, b + 5), (f"sub{s}: sweeps incl. barriers", b + 5, b + 6),
+             (f"sub{s}: wrench / integrate", b + 6, b + 7)]
+rows += [("to post start", 4 + 12 + 7, 30), ("tip FK / nan flags", 30, 31), ("P1 wait", 31, 32), ("emit tile", 32, 33), ("P3 wait", 33, 34), ("rewards, stores, finish", 34, 35), ("TOTAL", 0, 35)]
+for lab, a, b in rows:
+    print(f"  {lab:55s} {d(a, b, 0):9.0f} | {d(a, b, 3):9.0f}")
+for s in (0, 1):
+    b = 4 + 12 * s
+    print(f"  sub{s}: barrier wait inside sweeps: finger {v(b + 8, 0):.0f} | cube {v(b + 8, 3):.0f};  cube finger-cube rows {v(b + 10, 3):.0f}; up to the end of the floor rows (incl. W1) {v(b + 11, 3):.0f}")
+eng.close()
