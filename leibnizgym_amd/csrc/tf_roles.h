@@ -19,7 +19,6 @@
 #include "tf_contact.h"
 
 #define NT 256                          // threads per workgroup
-#define TF_FF_ITERATIONS 4
 
 // kernel modes: which hooks of the reference step a launch performs (the fused step does all of them)
 enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINISH = 32 };
@@ -287,10 +286,18 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
     for (int j = 0; j < 3; ++j) { q[j] = LDST(TF_S_Q + 3 * f + j); qd[j] = LDST(TF_S_QD + 3 * f + j); }
 #pragma unroll
-    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
-    if (!(MODE & M_TORQUE) && (MODE & M_RESETS)) {
+    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = P.dr_enable ? LDST(TF_S_DR + j) : 1.0f;   // rows are read only when the feature is on
+    if (!(MODE & M_TORQUE) && (MODE & (M_RESETS | M_SIM))) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
+    }
+    float lam0_fc[4], lam0_link = 0.0f, lam0_tf[3], lam0_tw[3];  // solver warm start for the first substep
+    if (MODE & M_SIM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lam0_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
+        lam0_link = LDST(TF_S_FC_LINK + f);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { lam0_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam0_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
     }
     if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
     if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
@@ -320,6 +327,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) tau[j] = 0.0f;          // the stored torque (what an action repeat re-applies)
+            if (MODE & M_SIM) {                                 // ... and the solver warm start
+                lam0_fc[0] = 0.0f; lam0_fc[1] = 0.0f; lam0_fc[2] = 0.0f; lam0_fc[3] = 0.0f; lam0_link = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { lam0_tf[j] = 0.0f; lam0_tw[j] = 0.0f; }
+            }
         }
     }
     // ---- this finger's action values: clipped, zeroed by a reset (trifinger_env.py:387), written back for _action_buf ----
@@ -412,17 +424,38 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             const int sb_ = 4 + 12 * (s & 1);
             // values that are cold through the sweeps are re-read from their state rows every substep (the rows hold
             // what this thread stored above; L2 hits) instead of occupying registers the sweeps need
-            float dr[TF_NUM_DR], tau[3];
-#pragma unroll
-            for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
+            float drs[TF_NUM_DR], taus[3];
             float lam_fc[4], fc_link, lam_tf[3], lam_tw[3];     // impulses of the last substep (issued here, used in F2)
+            float ft_run[6];                                    // fingertip wrench accumulator of the step (its state rows)
+            if (s == 0) {                                       // first substep: what the step started with is still in registers
 #pragma unroll
-            for (int j = 0; j < 4; ++j) lam_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
-            fc_link = LDST(TF_S_FC_LINK + f);
+                for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = dr[j];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { lam_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
+                for (int j = 0; j < 3; ++j) { taus[j] = tau[j]; lam_tf[j] = lam0_tf[j]; lam_tw[j] = lam0_tw[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lam_fc[j] = lam0_fc[j];
+                fc_link = lam0_link;
+                if (ASYM) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) ft_run[j] = (MODE & M_TORQUE) ? 0.0f : LDST(TF_S_FT + 6 * f + j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = P.dr_enable ? LDST(TF_S_DR + j) : 1.0f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) taus[j] = LDST(TF_S_TAU + 3 * f + j);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lam_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
+                fc_link = LDST(TF_S_FC_LINK + f);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { lam_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
+                if (ASYM) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) ft_run[j] = LDST(TF_S_FT + 6 * f + j);
+                }
+            }
+            const float* dr = drs;
+            const float* tau = taus;
             const float cube_mass = m.cube_mass * dr[0];
             const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
             const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
@@ -466,9 +499,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             BAR();                                              // S1: free motion of every role published
             STAMP(sb_ + 1);
             // ---- F2: contact generation (positions at the start of the substep) ----
-            float cp[3], cq[4], R[9];
+            float cp[3], cq[4], R[9], cvf[3], cwf[3];             // cube pose and free velocity (their slots are reused after S1b)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) cp[j] = LD(L_POSE_A + j);
+            for (int j = 0; j < 3; ++j) { cp[j] = LD(L_POSE_A + j); cvf[j] = LD(L_POSE_B + j); cwf[j] = LD(L_POSE_B + 3 + j); }
 #pragma unroll
             for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
             quat_to_rot(cq, R);
@@ -518,15 +551,22 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
             }
-            // rows of the finger-cube contact; the contact-space record goes to the cube role
-            float fcJ[9], fc_arm[3], rec_A[6], rec_dir[9], rec_rxd[9], rec_Dinv[3], rec_bias = 0.0f, rec_lam[3];
+            STAMP(sb_ + 2);
+            BAR();                                              // S1b: the finger-finger pass of the cube role is done
+            STAMP(sb_ + 3);
+            // velocity after the finger-finger pass (the approach speeds below use the free velocity vq, as specified)
+            float vqf[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vqf[j] = LD(L_VQFF + 3 * f + j);
+            // rows of the finger-cube contact; the contact-space record goes straight to LDS for the cube role
+            const int rb = L_REC(f);
+            float fcJ[9], fc_arm[3], rec_lam[3];
             int cur_link = 0;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) { fcJ[j] = 0.0f; rec_dir[j] = 0.0f; rec_rxd[j] = 0.0f; }
+            for (int j = 0; j < 9; ++j) fcJ[j] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) rec_A[j] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { fc_arm[j] = 0.0f; rec_Dinv[j] = 0.0f; rec_lam[j] = 0.0f; }
+            for (int j = 0; j < 3; ++j) { fc_arm[j] = 0.0f; rec_lam[j] = 0.0f; }
+            bool fc_live = false;
             if (__builtin_expect(gap < m.contact_margin, 1)) {
                 float rcv[3], xw[3], Dd[3], J[9], W[9], dir[9], rxd[9];
                 mat3_mul(R, nc, &dir[0]);
@@ -539,24 +579,22 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 finger_jac(yw, k, link, Pb, dir, J, W, Dd);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) cross3(rcv, &dir[3 * d], &rxd[3 * d]);
-                float v[3], w[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) { v[j] = LD(L_POSE_B + j); w[j] = LD(L_POSE_B + 3 + j); }
-                float vn0 = dot3(&J[0], vq) - (dot3(&dir[0], v) + dot3(&rxd[0], w));
+                float vn0 = dot3(&J[0], vq) - (dot3(&dir[0], cvf) + dot3(&rxd[0], cwf));
                 if (contact_live(m, gap, vn0, h)) {
                     cur_link = link;
+                    fc_live = true;
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) { fcJ[j] = J[j]; rec_dir[j] = dir[j]; rec_rxd[j] = rxd[j]; }
+                    for (int j = 0; j < 9; ++j) { fcJ[j] = J[j]; LD(rb + R_DIR + j) = dir[j]; LD(rb + R_RXD + j) = rxd[j]; }
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) rec_Dinv[d] = f_rcp2(FMA(dot3(&rxd[3 * d], &rxd[3 * d]), inv_I, Dd[d] + inv_m));
-                    rec_A[0] = Dd[0]; rec_A[1] = dot3(&J[0], &W[3]); rec_A[2] = dot3(&J[0], &W[6]);
-                    rec_A[3] = Dd[1]; rec_A[4] = dot3(&J[3], &W[6]);
-                    rec_A[5] = Dd[2];
+                    for (int d = 0; d < 3; ++d) LD(L_VQFF + 3 * f + d) = f_rcp2(FMA(dot3(&rxd[3 * d], &rxd[3 * d]), inv_I, Dd[d] + inv_m));
+                    LD(rb + R_A + 0) = Dd[0]; LD(rb + R_A + 1) = dot3(&J[0], &W[3]); LD(rb + R_A + 2) = dot3(&J[0], &W[6]);
+                    LD(rb + R_A + 3) = Dd[1]; LD(rb + R_A + 4) = dot3(&J[3], &W[6]);
+                    LD(rb + R_A + 5) = Dd[2];
                     if (link == 3) {
 #pragma unroll
                         for (int j = 0; j < 3; ++j) fc_arm[j] = Pw[j] - Tw[j];
                     }
-                    rec_bias = contact_bias(m, gap, vn0, inv_h, rest_f);
+                    LD(L_INIT + f) = contact_bias(m, gap, vn0, inv_h, rest_f);
                     if ((float)link == fc_link) {                   // same link as in the last substep: seed the impulses
                         float l0 = lam_fc[0] * ws;
                         float lim = mu_fc * l0;
@@ -565,6 +603,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                         rec_lam[2] = f_clamp(dot3(&lam_fc[1], &dir[6]) * ws, -lim, lim);
                     }
                 }
+            }
+            if (!fc_live) {                                     // a dead slot: 1/D = 0 tells the cube role
+#pragma unroll
+                for (int d = 0; d < 3; ++d) LD(L_VQFF + 3 * f + d) = 0.0f;
+                LD(L_INIT + f) = 0.0f;
             }
             // fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1)
             TipContact tc[2];
@@ -624,12 +667,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 lim_dinv[jj] = f_rcp(k.Minv[dg]);
                 lim_lam[jj] = 0.0f;
             }
-            STAMP(sb_ + 2);
-            BAR();                                              // S2: the finger-finger pass of the cube role is done
-            STAMP(sb_ + 3);
-            // ---- velocity after the finger-finger pass, seeded impulses on the finger side, contact-point velocity ----
+            // ---- seeded impulses on the finger side, contact-point velocity ----
 #pragma unroll
-            for (int j = 0; j < 3; ++j) vq[j] = LD(L_VQFF + 3 * f + j);
+            for (int j = 0; j < 3; ++j) vq[j] = vqf[j];
             if (cur_link != 0) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
@@ -651,19 +691,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     }
                 }
             }
-            {
-                const int rb = L_REC(f);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) LD(rb + R_A + j) = rec_A[j];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) { LD(rb + R_DIR + j) = rec_dir[j]; LD(rb + R_RXD + j) = rec_rxd[j]; }
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    LD(rb + R_U + d) = dot3(&fcJ[3 * d], vq);
-                    LD(rb + R_DL + d) = rec_lam[d];             // seeded impulses (the cube role reads them once)
-                    LD(L_VQFF + 3 * f + d) = rec_Dinv[d];
-                }
-                LD(L_INIT + f) = rec_bias;
+            for (int d = 0; d < 3; ++d) {
+                LD(rb + R_U + d) = dot3(&fcJ[3 * d], vq);
+                LD(rb + R_DL + d) = rec_lam[d];                 // seeded impulses (the cube role reads them once)
             }
             STAMP(sb_ + 4);
             BAR();                                              // S3: records published
@@ -673,7 +704,6 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             uint32_t t_wait = 0u;
             for (int it = 0; it < P.iters; ++it) {
                 { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W1: the cube role has solved the finger-cube rows of this sweep
-                const int rb = L_REC(f);
                 float dl[3];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) dl[d] = LD(rb + R_DL + d);
@@ -737,9 +767,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
             for (int d = 0; d < 3; ++d) { STST(TF_S_LAM_TF + 3 * f + d, tc[0].lam[d]); STST(TF_S_LAM_TW + 3 * f + d, tc[1].lam[d]); }
             if (ASYM) {
-                float ft[6];                                    // running sum of the step, kept in its state rows
-#pragma unroll
-                for (int j = 0; j < 6; ++j) ft[j] = LDST(TF_S_FT + 6 * f + j);
+                float* ft = ft_run;
                 if (cur_link == 3) {
                     float T[3];
                     cross3(fc_arm, Fc, T);
@@ -1011,7 +1039,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) { cq[j] = LDST(TF_S_CUBE_Q + j); gq[j] = LDST(TF_S_GOAL_Q + j); }
 #pragma unroll
-    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
+    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = P.dr_enable ? LDST(TF_S_DR + j) : 1.0f;   // rows are read only when the feature is on
     if (MODE & (M_SIM | M_RESETS)) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = LDST(TF_S_LAM_CW + j); }
@@ -1115,14 +1143,15 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         }
         for (int s = 0; s < nsub; ++s) {
             const int sb_ = 4 + 12 * (s & 1);
-            float dr[TF_NUM_DR];                                // cold through the sweeps: re-read every substep (L2 hits)
+            float drs[TF_NUM_DR];                               // cold through the sweeps: re-read for every substep but the first
 #pragma unroll
-            for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = LDST(TF_S_DR + j);
+            for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (s == 0 || !P.dr_enable) ? dr[j] : LDST(TF_S_DR + j);
+            const float* dr = drs;
             const float cube_mass = m.cube_mass * dr[0];
             const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
             const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
             const float mu_fc = m.mu_finger_cube * dr[2];
-            const float mu_cf = m.mu_cube_floor * dr[2], mu_cw = m.mu_cube_wall * dr[2], mu_ff = m.mu_finger_finger * dr[2];
+            const float mu_cf = m.mu_cube_floor * dr[2], mu_cw = m.mu_cube_wall * dr[2];
             const float rest_ff = m.restitution_ff * dr[5];
             const float ws = m.warm_start;
             const float hc = m.cube_half * dr[1];
@@ -1143,10 +1172,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             STAMP(sb_ + 0);
             BAR();                                              // S1
             STAMP(sb_ + 1);
-            // ---- FF: finger-finger contacts (distal capsules), solved before the sweeps on the free velocities: the pairs
-            // (0,1), (1,2), (2,0) in turn, TF_FF_ITERATIONS Gauss-Seidel iterations over the three rows of each pair.  The
-            // velocities live in LDS (L_VQFF) while the pairs are visited; a pair no lane of the wavefront has within the
-            // margin is skipped (nearly always). ----
+            // ---- FF: finger-finger contacts (distal capsules), frictionless, resolved before the sweeps on the free
+            // velocities: the pairs (0,1), (1,2), (2,0) in turn, one normal row each.  The velocities live in LDS (L_VQFF)
+            // while the pairs are visited. ----
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
 #pragma unroll
@@ -1167,61 +1195,45 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 float inv = f_rsqrt(f_max(dist2, 1e-12f));
                 float dist = dist2 * inv;
                 float gap = dist - 2.0f * m.cap_radius;
-                const bool active = (dist2 > 1e-12f) && (gap < m.contact_margin);
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(active) != 0ull, 0)) {
-                    const Yaw ya = {m.base_yaw_cos[fa], m.base_yaw_sin[fa], 0.0f, 0.0f, m.base_height};
-                    const Yaw yb = {m.base_yaw_cos[fb], m.base_yaw_sin[fb], 0.0f, 0.0f, m.base_height};
-                    float dirs[9];
+                if ((dist2 > 1e-12f) && (gap < m.contact_margin)) {
+                    float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};       // from finger b to finger a
+                    float Ja[3], Wa[3], Jb[3], Wb[3], va[3], vb[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) dirs[j] = dv[j] * inv;
-                    if (!active) { dirs[0] = 1.0f; dirs[1] = 0.0f; dirs[2] = 0.0f; }        // keep the dead lanes finite
-                    tangent_basis(&dirs[0], &dirs[3], &dirs[6]);
-                    float Ja[9], Wa[9], Da[3], Jb[9], Wb[9], Db[3];
-                    {
-                        FingerPubRegs pa;
-                        read_pub(lds, lane, fa, pa);
-                        float Ca[3], Cab[3];
+                    for (int side = 0; side < 2; ++side) {
+                        const int ff_ = side ? fb : fa;
+                        const Yaw yy = {m.base_yaw_cos[ff_], m.base_yaw_sin[ff_], 0.0f, 0.0f, m.base_height};
+                        FingerPubRegs pp;
+                        read_pub(lds, lane, ff_, pp);
+                        float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) Ca[j] = FMA(-m.cap_radius, dirs[j], Pa[j]);
-                        world_to_base(ya, Ca, Cab);
-                        finger_jac(ya, pa.k, 3, Cab, dirs, Ja, Wa, Da);
+                        for (int j = 0; j < 3; ++j) C[j] = side ? FMA(m.cap_radius, n[j], Pb[j]) : FMA(-m.cap_radius, n[j], Pa[j]);
+                        world_to_base(yy, C, Cb_);
+                        levers(pp.k, Cb_, L1, L2, L3);
+                        dir_world_to_base(yy, n, nb);
+                        float* J = side ? Jb : Ja;
+                        float* W = side ? Wb : Wa;
+                        float* vv = side ? vb : va;
+                        J[0] = dot3(L1, nb); J[1] = dot3(L2, nb); J[2] = dot3(L3, nb);
+                        sym3_mul(pp.k.Minv, J, W);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) vv[j] = LD(L_VQFF + 3 * ff_ + j);
                     }
-                    {
-                        FingerPubRegs pb_;
-                        read_pub(lds, lane, fb, pb_);
-                        float Cb[3], Cbb[3];
+                    float vn0 = dot3(Ja, va) - dot3(Jb, vb);
+                    if (contact_live(m, gap, vn0, h)) {
+                        float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+                        float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja, Wa) + dot3(Jb, Wb)), 0.0f);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) Cb[j] = FMA(m.cap_radius, dirs[j], Pb[j]);
-                        world_to_base(yb, Cb, Cbb);
-                        finger_jac(yb, pb_.k, 3, Cbb, dirs, Jb, Wb, Db);
-                    }
-                    float va[3] = {LD(L_VQFF + 3 * fa), LD(L_VQFF + 3 * fa + 1), LD(L_VQFF + 3 * fa + 2)};
-                    float vb[3] = {LD(L_VQFF + 3 * fb), LD(L_VQFF + 3 * fb + 1), LD(L_VQFF + 3 * fb + 2)};
-                    const float va0[3] = {va[0], va[1], va[2]}, vb0[3] = {vb[0], vb[1], vb[2]};
-                    float vn0 = dot3(&Ja[0], va) - dot3(&Jb[0], vb);
-                    const bool live = active && contact_live(m, gap, vn0, h);
-                    float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
-                    float Dinv[3], lam[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) Dinv[d] = f_rcp2(f_max(Da[d] + Db[d], 1e-30f));
-#pragma unroll 1
-                    for (int it = 0; it < TF_FF_ITERATIONS; ++it) {
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            float vrel = dot3(&Ja[3 * d], va) - dot3(&Jb[3 * d], vb);
-                            float dl = (d == 0) ? solve_normal(lam[0], Dinv[0], vrel, bias) : solve_tangent(lam[d], Dinv[d], vrel, mu_ff * lam[0]);
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[3 * d + j], dl, va[j]); vb[j] = FMA(-Wb[3 * d + j], dl, vb[j]); }
+                        for (int j = 0; j < 3; ++j) {
+                            LD(L_VQFF + 3 * fa + j) = FMA(Wa[j], lam, va[j]);
+                            LD(L_VQFF + 3 * fb + j) = FMA(-Wb[j], lam, vb[j]);
                         }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        LD(L_VQFF + 3 * fa + j) = live ? va[j] : va0[j];
-                        LD(L_VQFF + 3 * fb + j) = live ? vb[j] : vb0[j];
                     }
                 }
             }
-            // ---- corner contacts of the cube against the arena (while the finger roles generate their contacts) ----
+            STAMP(sb_ + 2);
+            BAR();                                              // S1b: finger-finger pass done
+            STAMP(sb_ + 3);
+            // ---- corner contacts of the cube against the arena (while the finger roles build their rows) ----
             float R[9];
             quat_to_rot(cq, R);
             float fr_[12], fDinv[12], fbias[4], flam[12];       // floor corners: arm, 1/D, bias, impulses of rows +z, +x, +y
@@ -1304,9 +1316,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
                 }
             }
-            STAMP(sb_ + 2);
-            BAR();                                              // S2
-            STAMP(sb_ + 3);
+            STAMP(sb_ + 4);
             BAR();                                              // S3: records published by the finger roles
             STAMP(sb_ + 5);
             // ---- seeded impulses of the finger contacts (1/D, bias and impulses stay in registers through the sweeps) ----

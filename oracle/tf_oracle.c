@@ -899,8 +899,6 @@ static void cube_corner(const float R[9], float hc, int k, float sk, int idx, fl
     mat3_mul(R, y, r);
 }
 
-#define TF_FF_ITERATIONS 4
-
 /* ---- PGS row kernels (identical arithmetic in the HIP file) ---- */
 static inline float solve_normal(float* lam, float Dinv, float vrel, float bias) {
     float ln = f_max(FMA(-Dinv, vrel + bias, *lam), 0.0f);
@@ -1011,7 +1009,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     const float cube_inertia = m->cube_inertia * e->dr[0] * e->dr[1] * e->dr[1];
     const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
     const float mu_fc = m->mu_finger_cube * e->dr[2], mu_tf = m->mu_tip_floor * e->dr[2], mu_tw = m->mu_tip_wall * e->dr[2];
-    const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2], mu_ff = m->mu_finger_finger * e->dr[2];
+    const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2];
     const float rest_f = m->restitution_finger * e->dr[5], rest_ff = m->restitution_ff * e->dr[5];
     const float ws = m->warm_start;
     FingerRole fr[3];
@@ -1119,8 +1117,9 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             }
         }
     }
-    /* ---- FF: finger-finger contacts (distal capsules), solved before the sweeps on the free velocities: the pairs (0,1),
-     * (1,2), (2,0) in turn, TF_FF_ITERATIONS Gauss-Seidel iterations over the three rows of each pair; the finger contacts below measure their approach speeds on the velocities before this pass ---- */
+    /* ---- FF: finger-finger contacts (distal capsules), frictionless, resolved before the sweeps on the free velocities:
+     * the pairs (0,1), (1,2), (2,0) in turn, one normal row each (a single row is solved exactly by one projection);
+     * the finger contacts below measure their approach speeds on the velocities before this pass ---- */
     float vq_ff[3][3];
     for (int f = 0; f < 3; ++f) for (int j = 0; j < 3; ++j) vq_ff[f][j] = fr[f].vq[j];
     for (int p = 0; p < 3; ++p) {
@@ -1134,30 +1133,28 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         float dist = dist2 * inv;
         float gap = dist - 2.0f * m->cap_radius;
         if (!(gap < m->contact_margin)) continue;
-        float dirs[3][3];
-        for (int i = 0; i < 3; ++i) dirs[0][i] = dv[i] * inv;          /* from finger b to finger a */
-        tangent_basis(dirs[0], dirs[1], dirs[2]);
-        float Ca[3], Cb[3], Cab[3], Cbb[3];
-        for (int i = 0; i < 3; ++i) { Ca[i] = FMA(-m->cap_radius, dirs[0][i], Pa[i]); Cb[i] = FMA(m->cap_radius, dirs[0][i], Pb[i]); }
-        world_to_base(m, fa, Ca, Cab);
-        world_to_base(m, fb, Cb, Cbb);
-        float Ja[3][3], Wa[3][3], Da[3], Jb[3][3], Wb[3][3], Db[3];
-        finger_jac(m, fa, &fr[fa].k, 3, Cab, dirs, Ja, Wa, Da);
-        finger_jac(m, fb, &fr[fb].k, 3, Cbb, dirs, Jb, Wb, Db);
+        float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};          /* from finger b to finger a */
+        float Ja[3], Wa[3], Jb[3], Wb[3];
+        for (int side = 0; side < 2; ++side) {
+            const int ff = side ? fb : fa;
+            const FK* k = &fr[ff].k;
+            float C[3], Cb[3], L1[3], L2[3], L3[3], nb[3];
+            for (int i = 0; i < 3; ++i) C[i] = side ? FMA(m->cap_radius, n[i], Pb[i]) : FMA(-m->cap_radius, n[i], Pa[i]);
+            world_to_base(m, ff, C, Cb);
+            levers(k, Cb, L1, L2, L3);
+            dir_world_to_base(m, ff, n, nb);
+            float* J = side ? Jb : Ja;
+            float* W = side ? Wb : Wa;
+            J[0] = dot3(L1, nb); J[1] = dot3(L2, nb); J[2] = dot3(L3, nb);
+            sym3_mul(k->Minv, J, W);
+        }
         float* va = vq_ff[fa];
         float* vb = vq_ff[fb];
-        float vn0 = dot3(Ja[0], va) - dot3(Jb[0], vb);
+        float vn0 = dot3(Ja, va) - dot3(Jb, vb);
         if (!contact_live(m, gap, vn0, h)) continue;
         float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
-        float Dinv[3], lam[3] = {0.0f, 0.0f, 0.0f};
-        for (int d = 0; d < 3; ++d) Dinv[d] = f_rcp2(Da[d] + Db[d]);
-        for (int it = 0; it < TF_FF_ITERATIONS; ++it) {
-            for (int d = 0; d < 3; ++d) {
-                float vrel = dot3(Ja[d], va) - dot3(Jb[d], vb);
-                float dl = (d == 0) ? solve_normal(&lam[0], Dinv[0], vrel, bias) : solve_tangent(&lam[d], Dinv[d], vrel, mu_ff * lam[0]);
-                for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[d][j], dl, va[j]); vb[j] = FMA(-Wb[d][j], dl, vb[j]); }
-            }
-        }
+        float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja, Wa) + dot3(Jb, Wb)), 0.0f);
+        for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[j], lam, va[j]); vb[j] = FMA(-Wb[j], lam, vb[j]); }
     }
     /* ---- F2: contacts of each finger ---- */
     float cube_top_check = e->cp[2];
@@ -1449,7 +1446,7 @@ static void env_load(const struct TfHandle_* h, int i, Env* e) {
     }
     for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
     for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
-    for (int j = 0; j < TF_NUM_DR; ++j) e->dr[j] = ST(h, TF_S_DR + j, i);
+    for (int j = 0; j < TF_NUM_DR; ++j) e->dr[j] = h->cfg.dr_enable ? ST(h, TF_S_DR + j, i) : 1.0f;   /* rows are read only when the feature is on */
     for (int f = 0; f < 3; ++f) {
         for (int j = 0; j < 4; ++j) e->lam_fc[f][j] = ST(h, TF_S_LAM_FC + 4 * f + j, i);
         for (int j = 0; j < 3; ++j) { e->lam_tf[f][j] = ST(h, TF_S_LAM_TF + 3 * f + j, i); e->lam_tw[f][j] = ST(h, TF_S_LAM_TW + 3 * f + j, i); }
@@ -1470,7 +1467,7 @@ static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_
     }
     for (int j = 0; j < 4; ++j) { ST(h, TF_S_CUBE_Q + j, i) = e->cq[j]; ST(h, TF_S_GOAL_Q + j, i) = e->gq[j]; }
     if (store_ft) for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
-    for (int j = 0; j < TF_NUM_DR; ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
+    if (h->cfg.dr_enable) for (int j = 0; j < TF_NUM_DR; ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
     for (int f = 0; f < 3; ++f) {
         for (int j = 0; j < 4; ++j) ST(h, TF_S_LAM_FC + 4 * f + j, i) = e->lam_fc[f][j];
         for (int j = 0; j < 3; ++j) { ST(h, TF_S_LAM_TF + 3 * f + j, i) = e->lam_tf[f][j]; ST(h, TF_S_LAM_TW + 3 * f + j, i) = e->lam_tw[f][j]; }

@@ -194,7 +194,7 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         b3 = link_point_world(f, q[sl], 3, CAPS[3][1])
         distal.append((a3, b3))
         tipsphere.append(b3)
-    # ---- finger-finger pre-pass on the free velocities: pairs in turn, FF_ITERATIONS local Gauss-Seidel iterations each ----
+    # ---- finger-finger pre-pass on the free velocities: pairs in turn, one frictionless normal row each ----
     v_ff = vfree.copy()
     for p in range(3):
         fa, fb = p, (p + 1) % 3
@@ -211,22 +211,12 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         Jm = np.zeros((3, 15))
         Jm[:, 3 * fa:3 * fa + 3] = point_jacobian(fa, q[3 * fa:3 * fa + 3], 3, Pa - rad * n)
         Jm[:, 3 * fb:3 * fb + 3] = -point_jacobian(fb, q[3 * fb:3 * fb + 3], 3, Pb + rad * n)
-        bias = contact_bias(gap, float(n @ Jm @ v_ff), h, REST_FF)
-        if not contact_live(gap, float(n @ Jm @ v_ff), h):
+        Jr = n @ Jm
+        vn0 = float(Jr @ v_ff)
+        if not contact_live(gap, vn0, h):
             continue
-        lam = [0.0, 0.0, 0.0]
-        for _ in range(FF_ITERATIONS):
-            for d, dvec in enumerate((n, t1, t2)):
-                Jr = dvec @ Jm
-                D = Jr @ Minv @ Jr
-                vrel = Jr @ v_ff
-                if d == 0:
-                    new = max(lam[0] - (vrel + bias) / D, 0.0)
-                else:
-                    new = float(np.clip(lam[d] - vrel / D, -MU["ff"] * lam[0], MU["ff"] * lam[0]))
-                v_ff = v_ff + Minv @ Jr * (new - lam[d])
-                lam[d] = new
-        lam_n = lam[0]
+        lam_n = max(-(vn0 + contact_bias(gap, vn0, h, REST_FF)) / float(Jr @ Minv @ Jr), 0.0)     # frictionless: one row
+        v_ff = v_ff + Minv @ Jr * lam_n
         details["ff"].append((fa, fb, gap, lam_n))
     # ---- finger contacts ----
     for f in range(3):

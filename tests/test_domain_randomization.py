@@ -57,6 +57,7 @@ def test_physical_effects(oracle):
     """Motor factor scales the applied torque; friction factor scales the Coulomb deceleration."""
     cfg = make_config(oracle, 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
                       robot_reset="none", object_reset="none", episode_length=0, success={"activate": False},
+                      domain_randomization={"activate": True, "cube_mass": (1.0, 1.0), "cube_size": (1.0, 1.0), "friction": (1.0, 1.0), "motor_torque": (1.0, 1.0), "link_mass": (1.0, 1.0), "restitution": (1.0, 1.0)},      # the rows are read only when the feature is on
                       reward_terms={k: {"activate": False} for k in capi.REWARD_TERM_ORDER})
     eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
     eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3).repeat(2, 1).T)
@@ -89,6 +90,7 @@ def test_link_mass_and_restitution_effects(oracle):
     off = {k: {"activate": False} for k in capi.REWARD_TERM_ORDER}
     cfg = make_config(oracle, 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
                       robot_reset="none", object_reset="none", episode_length=0, success={"activate": False},
+                      domain_randomization={"activate": True, "cube_mass": (1.0, 1.0), "cube_size": (1.0, 1.0), "friction": (1.0, 1.0), "motor_torque": (1.0, 1.0), "link_mass": (1.0, 1.0), "restitution": (1.0, 1.0)},
                       reward_terms=off, gravity=(0.0, 0.0, 0.0))
     eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
     eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3).repeat(2, 1).T)
@@ -106,6 +108,7 @@ def test_link_mass_and_restitution_effects(oracle):
     # stays down, with factor 2 (restitution 0.8) it rebounds by about a centimetre
     cfg = make_config(oracle, 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
                       robot_reset="none", object_reset="none", episode_length=0, success={"activate": False},
+                      domain_randomization={"activate": True, "cube_mass": (1.0, 1.0), "cube_size": (1.0, 1.0), "friction": (1.0, 1.0), "motor_torque": (1.0, 1.0), "link_mass": (1.0, 1.0), "restitution": (1.0, 1.0)},
                       reward_terms=off)
     eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
     eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3).repeat(2, 1).T)
