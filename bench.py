@@ -16,8 +16,9 @@ Workload = BASELINE.json configs[2]: trifinger_difficulty_4, 65536 envs per GPU,
 defaults of scripts/rlg_hydra.py:58-118 + difficulty-4 reward schedule (:140-182), asymmetric obs on
 (the shipped resources/config/rlg/asymm.yaml default), episode_length 750.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel k_step vs the HBM roofline, as the north star
-asks; the kernel is FP32-issue bound) and `cpu_baseline` (this repo's CPU oracle on the
+Rank 0 prints ONE JSON line with `roofline` (the fused step kernel vs the HBM roofline, as the north star asks;
+what binds it is the serial chain of the contact solve; HBM traffic and issue counters are parsed
+from the newest matching profiles/r*_pmc.txt, nothing is hard-coded) and `cpu_baseline` (this repo's CPU oracle on the
 host cores - the reference's IsaacGym CPU pipeline cannot be run).
 """
 import argparse
@@ -35,18 +36,35 @@ from leibnizgym_amd.engine import TrifingerEngine, make_config  # noqa: E402
 from leibnizgym_amd import _capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# HBM bytes per k_step launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs, raw
-# counter expressions; profiles/r1_l_pmc.txt).  Only valid for the exact workload it was measured on.
-PMC_TRAFFIC = {(65536, True): (9234.968 + 57067.408) * 1024.0}
-# SQ counters of the same profile (per wave, 1024 waves): what actually bounds the kernel.  One wave per SIMD issues one
-# instruction per ~5.0-5.1 cycles whatever the instruction is (tools/microbench/valu_issue.hip, valu_pk.hip).
-PMC_ISSUE = {(65536, True): {"valu_insts_per_wave": 25591047.552 / 1024, "salu_insts_per_wave": 873000.305 / 1024,
-                             "lds_insts_per_wave": 180224.0 / 1024, "wave_cycles": 36547658.390 * 4 / 1024,
-                             "single_wave_cycles_per_inst": 5.0,
-                             "source": "rocprofv3 --pmc SQ_*, profiles/r1_l_pmc.txt; tools/microbench"}}
 FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
-BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs
+N_SIMD = 256 * 4                 # SIMDs of the chip (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32)
+VALU_CYCLES_PER_INST = 2.0       # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
+BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs (algorithmic)
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
+KERNEL_NAME = {True: "k_env<9, false, true, 63>", False: "k_env<9, false, false, 63>"}   # fused step, torque/position actions
+
+
+def load_pmc_profile(n, asym):
+    """Per-launch counters of the fused step kernel from the newest profiles/r*_pmc.txt whose header names this workload
+    (written by tools/profile_round.sh; rocprofv3 --pmc passes, raw counter expressions).  Returns (dict, path) or
+    (None, None): nothing is hard-coded here, a profile of another N / kernel is not used."""
+    import glob
+    import re
+    want = f"# workload: N={n} asym={asym} kernel={KERNEL_NAME[asym]}"
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.txt")), reverse=True):
+        text = open(path).read()
+        if want not in text:
+            continue
+        vals = {}
+        for line in text.splitlines():
+            if line.startswith(KERNEL_NAME[asym]):
+                m = re.search(r"\)\s+(\w+)\s+(\d+)\s+([0-9.eE+-]+)", line)
+                if m:
+                    vals[m.group(1)] = float(m.group(3))
+        if vals:
+            return vals, os.path.relpath(path, REPO)
+    return None, None
+
 
 D4_REWARDS = {                   # scripts/rlg_hydra.py:140-174
     "finger_move_penalty": {"activate": True, "weight": -0.1},
@@ -151,6 +169,9 @@ def main():
                     help="secondary runs only (BASELINE configs[1]: --difficulty 1 --envs 8192); the headline is 4")
     ap.add_argument("--dr", action="store_true",
                     help="secondary runs only: every domain-randomisation feature on (BASELINE configs[3]: --dr --envs 16384)")
+    ap.add_argument("--stats-every", type=int, default=0,
+                    help="all-reduce the episode statistics over the ranks every K steps on a side stream (the optional "
+                         "exchange of the north star; RCCL on a multi-GPU run); 0: off")
     ap.add_argument("--time-window", type=int, default=8,
                     help="one HIP event pair per window of W consecutive k_step launches of the timed region (an event "
                          "pair costs ~3 us of stream time: per launch it would slow the region it measures and read "
@@ -175,7 +196,10 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == max(1, args.gpus) or not distributed, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != max(1, args.gpus):
+        sys.exit(f"bench.py --gpus {args.gpus} needs {args.gpus} ranks (WORLD_SIZE={world}): launch it as "
+                 f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                 f"bench.py --gpus {args.gpus} ...`")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path in the product)"
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
@@ -198,18 +222,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    reducer = None
+    if args.stats_every > 0:
+        from leibnizgym_amd.sharding import EpisodeStatsReducer
+        if not distributed:           # single rank: a world of one, so that the same code path runs
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="gloo" if one_device else "nccl", rank=0, world_size=1)
+        reducer = EpisodeStatsReducer(eng, world * n, every=args.stats_every)
     eng.enable_kernel_timing(8192 if args.time_window > 0 else 0, max(1, args.time_window))
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         eng.step(ring[k % len(ring)])
+        if reducer is not None:
+            reducer.step()
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = eng.kernel_time_ms()
+    global_stats = reducer.result().cpu().tolist() if reducer is not None else None
+    # the same loop with the actions generated on the device inside it (2*U[0,1)-1 every step, as
+    # scripts/trifinger_random_action.py:33 does): reported beside `value`, never instead of it
+    eng.enable_kernel_timing(0)
+    gen_steps = max(1, args.steps // 4)
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(gen_steps):
+        eng.step(torch.rand(n, eng.action_dim, device=dev, generator=gen) * 2 - 1)
+    barrier()
+    elapsed_gen = time.perf_counter() - t1
     if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_gen], device=dev if not one_device else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_gen = float(t[0].item()), float(t[1].item())
 
     # sanity on what was just timed: finite state, resets happened if steps crossed an episode boundary
     assert torch.isfinite(eng.state).all(), "non-finite state after the timed region"
@@ -219,8 +265,24 @@ def main():
     kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
     bytes_per_launch = BYTES_PER_ENV_STEP[asym] * n
     achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
+    pmc, pmc_path = load_pmc_profile(n, asym) if headline else (None, None)
+    traffic = issue = None
+    if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # KiB per dispatch -> bytes
+    if pmc and "SQ_INSTS_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc:
+        issue = {
+            "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "waves_per_launch": pmc.get("SQ_WAVES"),
+            "wave_cycles_per_launch": pmc["SQ_WAVE_CYCLES"] * 4.0,              # the counter is in quad-cycles
+            # fraction of the resident wave-cycles in which a VALU instruction of that wave occupies the SIMD
+            "valu_issue_frac": pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (pmc["SQ_WAVE_CYCLES"] * 4.0),
+            "wait_frac": pmc.get("SQ_WAIT_ANY", 0.0) / pmc["SQ_WAVE_CYCLES"],
+            "source": f"rocprofv3 --pmc SQ_*, {pmc_path}",
+        }
+    clock_ghz = 2.4
+    simd_busy = (pmc["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (N_SIMD * kern_avg_s * clock_ghz * 1e9)) if (pmc and kern_n and "SQ_INSTS_VALU" in pmc) else None
+    secondary = "" if headline else " [secondary run: not the headline workload]"
     out = {
-        "metric": "env-steps/sec (whole node), trifinger_difficulty_4 @65536 envs, 1/2/4/8 GPUs",
+        "metric": "env-steps/sec (whole node), trifinger_difficulty_4 @65536 envs, 1/2/4/8 GPUs" + secondary,
         "value": value,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -232,6 +294,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "value_with_action_generation": world * n * gen_steps / elapsed_gen,
+        "action_generation": f"second timed region of {gen_steps} steps with torch.rand(N, A)*2-1 generated on the device inside the "
+                             f"loop (one extra elementwise launch per step); `value` steps a ring of 16 resident action tensors",
         "config": {
             "workload": f"trifinger_difficulty_{args.difficulty}{' + full domain randomisation' if args.dr else ''}, "
                         f"{n} envs/GPU x {world} GPU, torque mode, random actions 2*U-1, "
@@ -240,35 +305,42 @@ def main():
             "envs_per_gpu": n,
             "global_envs": world * n,
             "asymmetric_obs": asym,
-            "parallelism": f"env-shard x{world} (no data-path collective)",
+            "parallelism": f"env-shard x{world} (no data-path collective"
+                           + (f"; episode statistics all-reduced every {args.stats_every} steps on a side stream)" if reducer else ")"),
         },
         "roofline": {
             "bound": "hbm",
             "achieved": achieved_gbs,
+            "achieved_is": "algorithmic bytes per launch (SURVEY 8d: 1075 B/env-step asymmetric, 623 B symmetric; the solver's "
+                           "warm-start rows are an implementation choice and are not counted) / measured kernel time",
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
-            "traffic": PMC_TRAFFIC.get((n, asym)) if headline else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r1_l_pmc.txt" if headline and (n, asym) in PMC_TRAFFIC else None,
-            "kernel": "k_step<9,false>",
+            "traffic": traffic,
+            "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counters), {pmc_path}" if traffic else None),
+            "kernel": KERNEL_NAME[asym] if eng.action_dim == 9 else KERNEL_NAME[asym].replace("<9,", "<18,"),
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
             "kernel_timing": f"one HIP event pair on the launch stream around every window of {max(1, args.time_window)} "
-                             f"consecutive k_step launches of the timed region; kernel_avg_us = window time / launches",
+                             f"consecutive launches of the fused step kernel in the timed region; kernel_avg_us = window time / launches",
             "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP[asym],
-            "note": "north star asks for the HBM fraction; what binds is instruction issue: at <= 65536 envs the chip holds "
-                    "one wave per SIMD, a lone wave issues one instruction per ~5 cycles, and k_step's ~27 k instructions "
-                    "per wave account for ~97 % of its measured wave cycles (issue_bound; DESIGN.md section 4)",
-            "issue_bound": PMC_ISSUE.get((n, asym)) if headline else None,
+            "note": "north star asks for the HBM fraction; what binds the fused step is the serial dependency chain of the "
+                    "Gauss-Seidel solve (one chain per 64 envs, carried by the cube wavefront of each workgroup) and "
+                    "instruction issue, not bandwidth: see valu_issue and DESIGN.md section 4",
+            "valu_issue": issue,
+            "valu_issue_frac": issue["valu_issue_frac"] if issue else None,
+            "simd_valu_busy": simd_busy,
             "fp32_frac_est": (FLOP_PER_ENV_STEP * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
         },
     }
+    if global_stats is not None:
+        out["episode_stats_all_reduced"] = global_stats[:11]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(asym)
         print(json.dumps(out), flush=True)
     eng.close()
-    if distributed:
+    if distributed or reducer is not None:
         dist.destroy_process_group()
 
 

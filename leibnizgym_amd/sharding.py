@@ -51,9 +51,15 @@ class EpisodeStatsReducer:
         if self._count % self.every:
             return False
         if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream(self.engine.device))
+            # snapshot `info` on the MAIN stream: the next engine.step() (queued behind it on that stream) overwrites
+            # info[], so the read must not be left to the side stream; only the collective runs there
+            main = torch.cuda.current_stream(self.engine.device)
+            if self._work is not None:          # a previous reduction still owns `buf`
+                self._work.wait()
+                main.wait_stream(self._side)
+            torch.mul(self.engine.info, self._scale_in, out=self.buf)
+            self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                torch.mul(self.engine.info, self._scale_in, out=self.buf)
                 self._work = self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             torch.mul(self.engine.info, self._scale_in, out=self.buf)

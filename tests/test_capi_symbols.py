@@ -123,3 +123,13 @@ def test_create_rejects_bad_configs(oracle):
     assert oracle.tf_create(C.byref(make_config(oracle, 4)), C.byref(h)) == 0
     assert oracle.tf_step(h, C.c_void_p(1), None) == capi.TF_ERR_NOT_BOUND
     oracle.tf_destroy(h)
+
+
+def test_default_model_is_the_same_in_both_libraries(oracle):
+    """tf_default_model of the product and of the oracle are written twice (C++ / C): every field must agree bit for bit,
+    otherwise the parity tests would compare two different physical models (no GPU needed: a host function)."""
+    import ctypes as C
+    hip = capi.TfLib(capi.hip_library_path())
+    a, b = hip.default_model(), oracle.default_model()
+    assert bytes(C.string_at(C.addressof(a), C.sizeof(a))) == bytes(C.string_at(C.addressof(b), C.sizeof(b))), \
+        [n for n, _ in capi.TfModel._fields_ if bytes(getattr(a, n)) != bytes(getattr(b, n))]
