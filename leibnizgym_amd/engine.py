@@ -258,6 +258,8 @@ class TrifingerEngine:
     # -- hot path ---------------------------------------------------------------------------
     def step(self, action):
         """One fused control step.  `action`: contiguous float32 [N, A] tensor on the engine's device."""
+        if action.device != self.device:      # a host pointer handed to the kernel would fault the GPU
+            raise ValueError(f"action tensor lives on {action.device}, the engine on {self.device}")
         if self._is_cuda and torch.cuda.current_device() != self._dev_index:
             with torch.cuda.device(self._dev_index):
                 rc = self.lib.tf_step(self._handle, C.c_void_p(action.data_ptr()), self._stream())

@@ -26,3 +26,19 @@ def hip():
     from leibnizgym_amd import _capi
     assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
     return _capi.load_hip_library()
+
+
+BACKENDS = [pytest.param("oracle", id="oracle-cpu"), pytest.param("hip", id="hip-gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    """(library, device) for tests of the host-side layers that must hold on both sides: the CPU oracle injected through
+    the `lib=` test hook (CPU suite) and the HIP product library on cuda:0 (`-m gpu`)."""
+    if request.param == "oracle":
+        from oracle_util import load_oracle
+        return load_oracle(), "cpu"
+    import torch
+    from leibnizgym_amd import _capi
+    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    return _capi.load_hip_library(), "cuda:0"

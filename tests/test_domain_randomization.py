@@ -16,89 +16,89 @@ RANGES = {"cube_mass": (0.5, 1.5), "cube_size": (0.9, 1.1), "friction": (0.6, 1.
 NEUTRAL = {k: (1, 1) for k in RANGES}
 
 
-def test_factors_are_uniform_in_range_and_redrawn(oracle):
+def test_factors_are_uniform_in_range_and_redrawn(backend):
     n = 20000
-    cfg = make_config(oracle, n, seed=5, command_mode="torque", episode_length=3,
+    cfg = make_config(backend[0], n, seed=5, command_mode="torque", episode_length=3,
                       domain_randomization=dict(activate=True, **RANGES), success={"activate": False})
-    eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
+    eng = TrifingerEngine(cfg, device=backend[1], lib=backend[0])
     assert torch.all(eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR] == 1.0)
     eng.reset()
-    dr = eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR].numpy().copy()
+    dr = eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR].cpu().numpy().copy()
     for row, (lo, hi) in zip(dr, RANGES.values()):
         assert row.min() >= lo - 1e-6 and row.max() <= hi + 1e-6
         assert stats.kstest((row - lo) / (hi - lo), "uniform").pvalue > 1e-3
     assert abs(np.corrcoef(dr)[0, 1]) < 0.03
     # spawn height follows the size factor: cube rests at half-size * factor (after the single simulate)
-    z = eng.state[capi.S_CUBE_P + 2].numpy()
+    z = eng.state[capi.S_CUBE_P + 2].cpu().numpy()
     assert np.abs(z - 0.0325 * dr[1]).max() < 1e-3
-    act = torch.zeros(n, 9)
+    act = torch.zeros(n, 9, device=backend[1])
     for _ in range(3):
         eng.step(act)
     eng.step(act)                                  # time-out at 3 -> reset inside this step -> new draw
-    dr2 = eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR].numpy()
+    dr2 = eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR].cpu().numpy()
     assert not np.array_equal(dr, dr2) and abs(np.corrcoef(dr[0], dr2[0])[0, 1]) < 0.03
     eng.close()
 
 
-def test_off_by_default_is_bitwise_neutral(oracle):
+def test_off_by_default_is_bitwise_neutral(backend):
     kw = dict(seed=2, command_mode="torque", success={"activate": False})
-    a = TrifingerEngine(make_config(oracle, 64, **kw), device="cpu", lib=oracle)
-    b = TrifingerEngine(make_config(oracle, 64, domain_randomization=dict(activate=True, **NEUTRAL), **kw),
-                        device="cpu", lib=oracle)
+    a = TrifingerEngine(make_config(backend[0], 64, **kw), device=backend[1], lib=backend[0])
+    b = TrifingerEngine(make_config(backend[0], 64, domain_randomization=dict(activate=True, **NEUTRAL), **kw),
+                        device=backend[1], lib=backend[0])
     a.reset(), b.reset()
     g = torch.Generator().manual_seed(0)
     for _ in range(20):
-        act = torch.rand(64, 9, generator=g) * 2 - 1
+        act = (torch.rand(64, 9, generator=g) * 2 - 1).to(backend[1])
         a.step(act), b.step(act)
     assert torch.equal(a.state, b.state) and torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
 
 
-def test_physical_effects(oracle):
+def test_physical_effects(backend):
     """Motor factor scales the applied torque; friction factor scales the Coulomb deceleration."""
-    cfg = make_config(oracle, 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
+    cfg = make_config(backend[0], 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
                       robot_reset="none", object_reset="none", episode_length=0, success={"activate": False},
                       domain_randomization={"activate": True, "cube_mass": (1.0, 1.0), "cube_size": (1.0, 1.0), "friction": (1.0, 1.0), "motor_torque": (1.0, 1.0), "link_mass": (1.0, 1.0), "restitution": (1.0, 1.0)},      # the rows are read only when the feature is on
                       reward_terms={k: {"activate": False} for k in capi.REWARD_TERM_ORDER})
-    eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
-    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3).repeat(2, 1).T)
-    eng.cube[0:3] = torch.tensor([-0.05, 0.0, 0.0325])[:, None]
-    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])[:, None]
+    eng = TrifingerEngine(cfg, device=backend[1], lib=backend[0])
+    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3, device=backend[1]).repeat(2, 1).T)
+    eng.cube[0:3] = torch.tensor([-0.05, 0.0, 0.0325], device=backend[1])[:, None]
+    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=backend[1])[:, None]
     eng.cube[7] = 0.5
     eng.state[capi.S_DR + 2, 1] = 0.5          # env 1: half the friction
     eng.state[capi.S_DR + 3, 1] = 0.75         # env 1: 75 % motor strength
-    eng.step(torch.full((2, 9), 0.2))
-    tau = eng.tau.numpy()
+    eng.step(torch.full((2, 9), 0.2, device=backend[1]))
+    tau = eng.tau.cpu().numpy()
     assert np.allclose(tau[:, 0], 0.2) and np.allclose(tau[:, 1], 0.15)
-    dv = 0.5 - eng.cube[7].numpy()
+    dv = 0.5 - eng.cube[7].cpu().numpy()
     assert abs(dv[0] / 0.02 - 0.55 * 9.81) < 0.5 and abs(dv[1] / 0.02 - 0.275 * 9.81) < 0.3
     eng.close()
 
 
-def test_env_config_key(oracle):
+def test_env_config_key(backend):
     env = TrifingerEnv(config={"num_instances": 8, "command_mode": "torque",
                                "domain_randomization": {"activate": True, "cube_mass": [0.9, 1.1]}},
-                       device="cpu", verbose=False, lib=oracle)
+                       device=backend[1], verbose=False, lib=backend[0])
     env.reset()
     m = env._engine.state[capi.S_DR]
     assert (m >= 0.9).all() and (m <= 1.1).all() and m.std() > 0
     assert env.config["domain_randomization"]["friction"] == [0.7, 1.3]     # defaults merged
 
 
-def test_link_mass_and_restitution_effects(oracle):
+def test_link_mass_and_restitution_effects(backend):
     """A heavier finger accelerates less under the same torque (and its own weight scales with it: the gravity-free
     acceleration is exactly 1/factor); a larger restitution factor makes a fingertip bounce higher off the floor."""
     off = {k: {"activate": False} for k in capi.REWARD_TERM_ORDER}
-    cfg = make_config(oracle, 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
+    cfg = make_config(backend[0], 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
                       robot_reset="none", object_reset="none", episode_length=0, success={"activate": False},
                       domain_randomization={"activate": True, "cube_mass": (1.0, 1.0), "cube_size": (1.0, 1.0), "friction": (1.0, 1.0), "motor_torque": (1.0, 1.0), "link_mass": (1.0, 1.0), "restitution": (1.0, 1.0)},
                       reward_terms=off, gravity=(0.0, 0.0, 0.0))
-    eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
-    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3).repeat(2, 1).T)
-    eng.cube[0:3] = torch.tensor([0.0, 0.0, 0.0325])[:, None]
-    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])[:, None]
+    eng = TrifingerEngine(cfg, device=backend[1], lib=backend[0])
+    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3, device=backend[1]).repeat(2, 1).T)
+    eng.cube[0:3] = torch.tensor([0.0, 0.0, 0.0325], device=backend[1])[:, None]
+    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=backend[1])[:, None]
     eng.state[capi.S_DR + 4, 1] = 2.0          # env 1: links twice as heavy
-    eng.step(torch.full((2, 9), 0.05))
-    qd = eng.qd.numpy()
+    eng.step(torch.full((2, 9), 0.05, device=backend[1]))
+    qd = eng.qd.cpu().numpy()
     assert np.all(np.abs(qd[:, 0]) > 1e-3)
     # zero gravity, zero initial velocity: acceleration = M^-1 tau (the velocity-product terms start at 0), so the
     # velocity after one step scales with 1/factor up to the second-substep Coriolis terms
@@ -106,48 +106,48 @@ def test_link_mass_and_restitution_effects(oracle):
     eng.close()
     # bounce: joint 3 of finger 0 swings the tip into the floor (impact at step 4, ~1 m/s); without restitution the tip
     # stays down, with factor 2 (restitution 0.8) it rebounds by about a centimetre
-    cfg = make_config(oracle, 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
+    cfg = make_config(backend[0], 2, command_mode="torque", normalize_action=False, apply_safety_damping=False,
                       robot_reset="none", object_reset="none", episode_length=0, success={"activate": False},
                       domain_randomization={"activate": True, "cube_mass": (1.0, 1.0), "cube_size": (1.0, 1.0), "friction": (1.0, 1.0), "motor_torque": (1.0, 1.0), "link_mass": (1.0, 1.0), "restitution": (1.0, 1.0)},
                       reward_terms=off)
-    eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
-    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3).repeat(2, 1).T)
-    eng.cube[0:3] = torch.tensor([0.0, 0.12, 0.0325])[:, None]
-    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0])[:, None]
+    eng = TrifingerEngine(cfg, device=backend[1], lib=backend[0])
+    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3, device=backend[1]).repeat(2, 1).T)
+    eng.cube[0:3] = torch.tensor([0.0, 0.12, 0.0325], device=backend[1])[:, None]
+    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=backend[1])[:, None]
     eng.state[capi.S_DR + 5, 0] = 0.0
     eng.state[capi.S_DR + 5, 1] = 2.0
-    act = torch.zeros(2, 9)
+    act = torch.zeros(2, 9, device=backend[1])
     act[:, 2] = 0.36
     z = []
     for _ in range(8):
         eng.step(act)
-        z.append(eng.state[capi.S_TIP_P + 2].numpy().copy())
+        z.append(eng.state[capi.S_TIP_P + 2].cpu().numpy().copy())
     z = np.array(z)
     assert abs(z[3, 0] - z[3, 1]) < 1e-6 and z[3, 0] < 0.01          # same impact
     assert z[4:, 0].max() < 0.0085 and z[4:, 1].max() > 0.015, z     # dead contact vs rebound
     eng.close()
 
 
-def test_observation_noise(oracle):
+def test_observation_noise(backend):
     """obs slots 0..24 get a * U(-1, 1) on top of the clean value; goal, action and the states vector stay exact;
     a different frame gives a different draw; the draw does not depend on the shard layout."""
     kw = dict(seed=3, command_mode="torque", asymmetric_obs=True, task_difficulty=4, success={"activate": False})
     n, a = 4096, 0.05
-    clean = TrifingerEngine(make_config(oracle, n, domain_randomization=dict(activate=True, **NEUTRAL), **kw),
-                            device="cpu", lib=oracle)
-    noisy = TrifingerEngine(make_config(oracle, n, domain_randomization=dict(activate=True, obs_noise=a, **NEUTRAL), **kw),
-                            device="cpu", lib=oracle)
-    shard = TrifingerEngine(make_config(oracle, 1024, env_id_offset=2048, global_num_envs=n,
+    clean = TrifingerEngine(make_config(backend[0], n, domain_randomization=dict(activate=True, **NEUTRAL), **kw),
+                            device=backend[1], lib=backend[0])
+    noisy = TrifingerEngine(make_config(backend[0], n, domain_randomization=dict(activate=True, obs_noise=a, **NEUTRAL), **kw),
+                            device=backend[1], lib=backend[0])
+    shard = TrifingerEngine(make_config(backend[0], 1024, env_id_offset=2048, global_num_envs=n,
                                         domain_randomization=dict(activate=True, obs_noise=a, **NEUTRAL), **kw),
-                            device="cpu", lib=oracle)
+                            device=backend[1], lib=backend[0])
     for e in (clean, noisy, shard):
         e.reset()
     g = torch.Generator().manual_seed(0)
     prev = None
     for _ in range(3):
-        act = torch.rand(n, 9, generator=g) * 2 - 1
+        act = (torch.rand(n, 9, generator=g) * 2 - 1).to(backend[1])
         clean.step(act), noisy.step(act), shard.step(act[2048:3072])
-        d = (noisy.obs - clean.obs).numpy()
+        d = (noisy.obs - clean.obs).cpu().numpy()
         assert np.all(d[:, 25:] == 0.0) and torch.equal(noisy.states, clean.states)
         assert torch.equal(noisy.state, clean.state) and torch.equal(noisy.reward, clean.reward)
         u = d[:, :25] / a
@@ -161,21 +161,21 @@ def test_observation_noise(oracle):
         e.close()
 
 
-def test_action_repeat(oracle):
+def test_action_repeat(backend):
     """With probability p an env re-applies the torque of its previous step; the command the obs reports is unaffected;
     a reset clears the stored torque; the draw is the same whatever the shard layout."""
     n, p = 8192, 0.3
     base = dict(seed=9, command_mode="torque", normalize_action=False, apply_safety_damping=False,
                 success={"activate": False}, episode_length=0)
-    mk = lambda lib_n, **kw: TrifingerEngine(make_config(oracle, lib_n, domain_randomization=dict(   # noqa: E731
-        activate=True, action_repeat_prob=p, **NEUTRAL), **base, **kw), device="cpu", lib=oracle)
+    mk = lambda lib_n, **kw: TrifingerEngine(make_config(backend[0], lib_n, domain_randomization=dict(   # noqa: E731
+        activate=True, action_repeat_prob=p, **NEUTRAL), **base, **kw), device=backend[1], lib=backend[0])
     eng, shard = mk(n), mk(1024, env_id_offset=4096, global_num_envs=n)
     eng.reset(), shard.reset()
     prev = eng.tau.clone()
     assert torch.all(prev == 0)
     fracs = []
     for t in range(6):
-        act = torch.full((n, 9), 0.05 * (t + 1))
+        act = torch.full((n, 9), 0.05 * (t + 1), device=backend[1])
         eng.step(act), shard.step(act[4096:5120])
         tau = eng.tau
         kept = torch.all(tau == prev, dim=0)
@@ -188,10 +188,10 @@ def test_action_repeat(oracle):
     assert all(abs(f - p) < 0.02 for f in fracs), fracs
     eng.close(), shard.close()
     # p = 1 and a time-out reset: the stored torque is cleared, so the env keeps applying zero
-    e1 = TrifingerEngine(make_config(oracle, 64, domain_randomization=dict(activate=True, action_repeat_prob=1.0, **NEUTRAL),
-                                     **dict(base, episode_length=3)), device="cpu", lib=oracle)
+    e1 = TrifingerEngine(make_config(backend[0], 64, domain_randomization=dict(activate=True, action_repeat_prob=1.0, **NEUTRAL),
+                                     **dict(base, episode_length=3)), device=backend[1], lib=backend[0])
     e1.reset()
     for t in range(8):
-        e1.step(torch.full((64, 9), 0.1))
+        e1.step(torch.full((64, 9), 0.1, device=backend[1]))
         assert torch.all(e1.tau == 0)
     e1.close()

@@ -1,5 +1,6 @@
-"""Host-side API and step sequencing (T1-T3, T14, T15 and the quirk list of SURVEY.md 8a-Q), run on the CPU with
-the oracle library injected through the test hook `lib=` (the product never loads it by itself).
+"""Host-side API and step sequencing (T1-T3, T14, T15 and the quirk list of SURVEY.md 8a-Q).  Every test takes the
+`backend` fixture (tests/conftest.py): the CPU suite runs it with the oracle library injected through the test hook
+`lib=` (the product never loads it by itself), `-m gpu` runs the same test on the HIP library on cuda:0.
 
 Known answers are hand-derived from the cited reference lines; nothing here depends on the physics details.
 """
@@ -16,29 +17,29 @@ from leibnizgym_amd.utils.rlg_train import RlGamesGpuEnvAdapter
 from leibnizgym_amd.wrappers import VecTaskPython
 
 
-def make_env(oracle, **cfg):
+def make_env(backend, **cfg):
     base = {"num_instances": 4, "command_mode": "torque"}
     base.update(cfg)
-    return TrifingerEnv(config=base, device="cpu", verbose=False, lib=oracle)
+    return TrifingerEnv(config=base, device=backend[1], verbose=False, lib=backend[0])
 
 
-def test_shapes_specs_and_getters(oracle):
-    env = make_env(oracle, asymmetric_obs=True)
+def test_shapes_specs_and_getters(backend):
+    env = make_env(backend, asymmetric_obs=True)
     assert isinstance(env, IsaacEnvBase)
     assert env.get_num_instances() == 4
     assert env.get_obs_dim() == 41 and env.get_state_dim() == 113 and env.get_action_dim() == 9
     assert tuple(env.get_obs_shape()) == (4, 41) and tuple(env.get_action_shape()) == (4, 9)
     assert sum(env.obs_spec.values()) == 41 and sum(env.state_spec.values()) == 113
     assert env.config["enable_ft_sensors"] is True                       # forced by asymmetric_obs (:272-273)
-    env2 = make_env(oracle, command_mode="position_impedance")
+    env2 = make_env(backend, command_mode="position_impedance")
     assert env2.get_action_dim() == 18 and env2.get_obs_dim() == 50 and env2.get_state_dim() == 0
     # scale tables (trifinger_env.py:663-710)
     assert env._observations_scale.low.shape[0] == 41 and env._states_scale.high.shape[0] == 113
-    assert torch.equal(env._action_scale.high, torch.full((9,), 0.36))
+    assert torch.equal(env._action_scale.high.cpu(), torch.full((9,), 0.36))
 
 
-def test_reset_and_step_contract(oracle):
-    env = make_env(oracle)
+def test_reset_and_step_contract(backend):
+    env = make_env(backend)
     assert env.env_steps_count == 0
     obs = env.reset()
     assert obs.shape == (4, 41) and obs.data_ptr() != env.obs_buf.data_ptr()          # reset returns a clone
@@ -57,31 +58,31 @@ def test_reset_and_step_contract(oracle):
     assert env._steps_count_buf.tolist() == [2, 2, 2, 2]
 
 
-def test_invalid_inputs_raise_like_the_reference(oracle):
-    env = make_env(oracle)
+def test_invalid_inputs_raise_like_the_reference(backend):
+    env = make_env(backend)
     env.reset()
     with pytest.raises(ValueError, match="Invalid shape for tensor `action`"):
         env.step(torch.zeros(4, 8))
     with pytest.raises(ValueError, match="Invalid command mode"):
-        make_env(oracle, command_mode="velocity")
+        make_env(backend, command_mode="velocity")
     with pytest.raises(ValueError, match="Invalid difficulty index"):
-        make_env(oracle, task_difficulty=7)
+        make_env(backend, task_difficulty=7)
     with pytest.raises(ValueError, match="Invalid robot initial state distribution"):
-        make_env(oracle, reset_distribution={"robot_initial_state": {"type": "gaussian"}})
+        make_env(backend, reset_distribution={"robot_initial_state": {"type": "gaussian"}})
     with pytest.raises(ValueError, match="Invalid object initial state distribution"):
-        make_env(oracle, reset_distribution={"object_initial_state": {"type": "grid"}})
+        make_env(backend, reset_distribution={"object_initial_state": {"type": "grid"}})
     with pytest.raises(ValueError, match="Invalid physics engine backend"):
-        make_env(oracle, physics_engine="bullet")
+        make_env(backend, physics_engine="bullet")
     with pytest.raises(ValueError, match="Invalid physics up-axis"):
-        make_env(oracle, sim={"up_axis": "x"})
+        make_env(backend, sim={"up_axis": "x"})
     with pytest.raises(RuntimeError, match="MI355X"):
         TrifingerEnv(config={"num_instances": 2, "command_mode": "torque"}, device="cpu", verbose=False)
 
 
-def test_timeout_reset_sequencing(oracle):
+def test_timeout_reset_sequencing(backend):
     """Quirks 1-3: time-out uses steps >= episode_length after the increment; the reset happens at the START of
     the next step, before physics, and zeroes that env's action for the step (env_base.py:370-395)."""
-    env = make_env(oracle, episode_length=3, termination_conditions={"success": {"activate": False}})
+    env = make_env(backend, episode_length=3, termination_conditions={"success": {"activate": False}})
     env.reset()
     act = torch.full((4, 9), 0.5)
     for k in range(1, 4):
@@ -89,20 +90,20 @@ def test_timeout_reset_sequencing(oracle):
         assert env._steps_count_buf.tolist() == [k] * 4
         assert env._reset_buf.tolist() == [k >= 3] * 4
         assert not dones.any()                       # quirk 2: dones = reset & goal_reset, never true here
-        assert torch.equal(env.action_buf, act)
+        assert torch.equal(env.action_buf.cpu(), act)
     counts_before = env._engine.reset_count.clone()
     env.step(act)                                    # reset applied first, then one physics step
     assert env._steps_count_buf.tolist() == [1] * 4 and not env._reset_buf.any()
-    assert torch.equal(env.action_buf, torch.zeros(4, 9))      # trifinger_env.py:387
-    assert torch.equal(env.obs_buf[:, 32:41], torch.zeros(4, 9))   # normalised zero action in the observation
+    assert torch.equal(env.action_buf.cpu(), torch.zeros(4, 9))      # trifinger_env.py:387
+    assert torch.equal(env.obs_buf[:, 32:41].cpu(), torch.zeros(4, 9))   # normalised zero action in the observation
     assert (env._engine.reset_count == counts_before + 1).all()
-    q = env._dof_position
+    q = env._dof_position.cpu()
     assert (q - torch.tensor([0.0, 0.9, -1.7] * 3)).abs().max() < 0.15   # default pose + one step of sag
     assert env.dones_buf.data_ptr() == env._reset_buf.data_ptr()    # quirk: dones_buf IS the reset buffer (:281-284)
 
 
-def test_partial_reset_only_touches_flagged_envs(oracle):
-    env = make_env(oracle, episode_length=0)
+def test_partial_reset_only_touches_flagged_envs(backend):
+    env = make_env(backend, episode_length=0)
     env.reset()
     env.step(torch.zeros(4, 9))
     before = env._engine.state.clone()
@@ -117,10 +118,10 @@ def test_partial_reset_only_touches_flagged_envs(oracle):
     assert before.shape == env._engine.state.shape
 
 
-def test_success_goal_reset_and_dones(oracle):
+def test_success_goal_reset_and_dones(backend):
     """Success termination on: goal_reset_buf = hit, bonus added, successes |= hit, goal resampled next step
     (trifinger_env.py:1088-1094, 425-440); dones only when a time-out coincides with a hit."""
-    env = make_env(oracle, episode_length=2, task_difficulty=1,
+    env = make_env(backend, episode_length=2, task_difficulty=1,
                    termination_conditions={"success": {"activate": True, "bonus": 123.0, "position_tolerance": 10.0,
                                                        "orientation_tolerance": 10.0}},
                    reward_terms={k: {"activate": False} for k in
@@ -128,7 +129,7 @@ def test_success_goal_reset_and_dones(oracle):
                                   "object_rot_delta", "object_move")})
     env.reset()
     _, rew, dones, info = env.step(torch.zeros(4, 9))
-    assert torch.equal(rew, torch.full((4,), 123.0))                    # huge tolerance: every env hits
+    assert torch.equal(rew.cpu(), torch.full((4,), 123.0))                    # huge tolerance: every env hits
     assert env._goal_reset_buf.all() and env._successes.all() and not dones.any()
     assert float(info["env/average_consecutive_success"]) == 1.0
     assert float(info["env/current_position_goal/count"]) == 4.0
@@ -139,12 +140,12 @@ def test_success_goal_reset_and_dones(oracle):
     assert env._engine.reset_count.tolist() == [2] * 4                  # reset() + one goal reset
 
 
-def test_reward_schedule_follows_env_steps_count(oracle):
+def test_reward_schedule_follows_env_steps_count(backend):
     """object_rot switches on when env_steps_count >= 1e7 (difficulty-4 schedule, scripts/rlg_hydra.py:160-167)."""
     cfg = gym_config("trifinger_difficulty_4")
     cfg.update(num_instances=4, seed=1, physics_engine="physx")
     cfg["sim"]["use_gpu_pipeline"] = True
-    env = TrifingerEnv(config=cfg, device="cpu", verbose=False, lib=oracle)
+    env = TrifingerEnv(config=cfg, device=backend[1], verbose=False, lib=backend[0])
     env.reset()
     _, _, _, info = env.step(torch.zeros(4, 9))
     assert float(info["env/rewards/object_rot"]) == 0.0
@@ -156,10 +157,10 @@ def test_reward_schedule_follows_env_steps_count(oracle):
     assert env.env_steps_count == 4 * 2_500_001
 
 
-def test_control_decimation_repeats_simulate(oracle):
+def test_control_decimation_repeats_simulate(backend):
     # safety damping off: the torque of a zero action is then exactly zero, whatever the joint velocity
-    a = make_env(oracle, control_decimation=1, episode_length=0, apply_safety_damping=False)
-    b = make_env(oracle, control_decimation=5, episode_length=0, apply_safety_damping=False)   # reference tests use 5
+    a = make_env(backend, control_decimation=1, episode_length=0, apply_safety_damping=False)
+    b = make_env(backend, control_decimation=5, episode_length=0, apply_safety_damping=False)   # reference tests use 5
     a.reset(), b.reset()
     b.step(torch.zeros(4, 9))
     assert b.env_steps_count == (1 + 5) * 4
@@ -170,8 +171,8 @@ def test_control_decimation_repeats_simulate(oracle):
     assert torch.allclose(a._engine.q, b._engine.q, atol=1e-6)
 
 
-def test_vec_task_clamps_and_spaces(oracle):
-    env = make_env(oracle, asymmetric_obs=True)
+def test_vec_task_clamps_and_spaces(backend):
+    env = make_env(backend, asymmetric_obs=True)
     vec = VecTaskPython(env, rl_device="cpu", clip_obs=5.0, clip_actions=1.0)
     assert (vec.num_envs, vec.num_obs, vec.num_states, vec.num_actions) == (4, 41, 113, 9)
     assert vec.observation_space.shape == (41,) and float(vec.observation_space.high[0]) == 5.0
@@ -180,27 +181,27 @@ def test_vec_task_clamps_and_spaces(oracle):
     assert obs.abs().max() <= 5.0
     big = torch.full((4, 9), 7.0)
     obs, rew, done, info = vec.step(big)
-    assert torch.equal(env.action_buf, torch.ones(4, 9))                # clipped before the task sees it
+    assert torch.equal(env.action_buf.cpu(), torch.ones(4, 9))                # clipped before the task sees it
     assert obs.abs().max() <= 5.0 and vec.get_state().abs().max() <= 5.0
     assert "Number of observations: 41" in str(vec)
     with pytest.raises(AssertionError):
         VecTaskPython(object(), rl_device="cpu")
 
 
-def test_fused_clipping_equals_wrapper_clamps(oracle):
+def test_fused_clipping_equals_wrapper_clamps(backend):
     """The clamps fused into the native step give what the literal three-operation wrapper gives (vec_task.py:146-170),
     also when they bite: tiny bounds, actions outside +-clip_actions."""
     kw = dict(asymmetric_obs=True, command_mode="torque", num_instances=64)
     outs = []
     for fused in (True, False):
-        env = make_env(oracle, **kw)
+        env = make_env(backend, **kw)
         vec = VecTaskPython(env, rl_device="cpu", clip_obs=0.3, clip_actions=0.6, fuse_clipping=fused)
         assert vec._fused is fused
         g = torch.Generator().manual_seed(4)
         o = [vec.reset().clone()]
         for _ in range(12):
             obs, rew, done, _ = vec.step(torch.rand(64, 9, generator=g) * 4 - 2)
-            o += [obs.clone(), vec.get_state().clone(), rew.clone(), env.action_buf.clone()]
+            o += [obs.clone(), vec.get_state().clone(), rew.clone(), env.action_buf.cpu().clone()]
         outs.append(o)
         env.close()
     assert any(bool((t.abs() == 0.3).any()) for t in outs[0][1::4])      # the observation clamp did bite
@@ -208,8 +209,8 @@ def test_fused_clipping_equals_wrapper_clamps(oracle):
         assert torch.equal(a, b)
 
 
-def test_rl_games_adapter_contract(oracle):
-    env = make_env(oracle, asymmetric_obs=True)
+def test_rl_games_adapter_contract(backend):
+    env = make_env(backend, asymmetric_obs=True)
     ad = RlGamesGpuEnvAdapter("rlgpu", 4, env=VecTaskPython(env, rl_device="cpu"))
     assert ad.use_global_obs and set(ad.full_state) == {"obs", "states"}
     info = ad.get_env_info()
@@ -219,13 +220,13 @@ def test_rl_games_adapter_contract(oracle):
     assert out is first is ad.full_state                                 # the SAME dict object every call
     assert out["obs"].shape == (4, 41) and out["states"].shape == (4, 113)
     assert isinstance(extra, list) and extra[0] == [] and "env/average_consecutive_success" in extra[1]
-    sym = RlGamesGpuEnvAdapter("rlgpu", 4, env=VecTaskPython(make_env(oracle), rl_device="cpu"))
+    sym = RlGamesGpuEnvAdapter("rlgpu", 4, env=VecTaskPython(make_env(backend), rl_device="cpu"))
     assert not sym.use_global_obs and torch.is_tensor(sym.reset())
     assert ad.get_number_of_agents() == 1
 
 
-def test_dump_config_and_seed(oracle, tmp_path):
-    env = make_env(oracle)
+def test_dump_config_and_seed(backend, tmp_path):
+    env = make_env(backend)
     path = os.path.join(tmp_path, "sub", "env_config")
     env.dump_config(path)
     import yaml
@@ -238,9 +239,9 @@ def test_dump_config_and_seed(oracle, tmp_path):
     env.render(), env.close()
 
 
-def test_same_seed_same_trajectory_and_two_instances_coexist(oracle):
-    a, b = make_env(oracle, seed=11), make_env(oracle, seed=11)
-    c = make_env(oracle, seed=12)
+def test_same_seed_same_trajectory_and_two_instances_coexist(backend):
+    a, b = make_env(backend, seed=11), make_env(backend, seed=11)
+    c = make_env(backend, seed=12)
     oa, ob, oc = a.reset(), b.reset(), c.reset()
     assert torch.equal(oa, ob) and not torch.equal(oa, oc)
     g = torch.Generator().manual_seed(0)
@@ -268,7 +269,7 @@ def test_hydra_schema_loader():
         raise InvalidTaskNameError("Foo")
 
 
-def test_fingertip_history_keeps_the_pre_reset_tips_for_one_step(oracle):
+def test_fingertip_history_keeps_the_pre_reset_tips_for_one_step(backend):
     """Quirk 4 of SURVEY 8a-Q: `_reset_impl` zeroes only the OLDER fingertip history entry, which the next fill shifts out
     (trifinger_env.py:1146-1147, :974), so on the first step after a reset the fingertip terms difference against the
     PRE-reset fingertips - a spurious jump - while the object history is rewritten with the reset pose (:1183-1187) and the
@@ -280,16 +281,16 @@ def test_fingertip_history_keeps_the_pre_reset_tips_for_one_step(oracle):
     only = lambda name, **kw: {k: dict(activate=(k == name), **(kw if k == name else {})) for k in capi.REWARD_TERM_ORDER}  # noqa: E731
     for term in ("finger_move_penalty", "object_move"):
         weight = -0.1 if term == "finger_move_penalty" else -750.0
-        cfg = make_config(oracle, n, seed=6, command_mode="torque", robot_reset="random", episode_length=5,
+        cfg = make_config(backend[0], n, seed=6, command_mode="torque", robot_reset="random", episode_length=5,
                           reward_terms=only(term, weight=weight), success={"activate": False}, task_difficulty=1)
-        eng = TrifingerEngine(cfg, device="cpu", lib=oracle)
+        eng = TrifingerEngine(cfg, device=backend[1], lib=backend[0])
         eng.reset()
         g = torch.Generator().manual_seed(1)
         for t in range(7):
-            tips_before = eng.state[capi.S_TIP_P:capi.S_TIP_P + 9].T.clone().view(n, 3, 3)      # history[0] going in
+            tips_before = eng.state[capi.S_TIP_P:capi.S_TIP_P + 9].T.cpu().clone().view(n, 3, 3)      # history[0] going in
             was_flagged = eng.reset_buf.clone().bool()
-            eng.step(torch.rand(n, 9, generator=g) * 2 - 1)
-            tips_now = eng.state[capi.S_TIP_P:capi.S_TIP_P + 9].T.view(n, 3, 3)
+            eng.step((torch.rand(n, 9, generator=g) * 2 - 1).to(eng.device))
+            tips_now = eng.state[capi.S_TIP_P:capi.S_TIP_P + 9].T.cpu().reshape(n, 3, 3)
             if t != 5:
                 assert not was_flagged.any()
                 continue
@@ -297,16 +298,16 @@ def test_fingertip_history_keeps_the_pre_reset_tips_for_one_step(oracle):
             if term == "finger_move_penalty":
                 pad = lambda x: torch.cat([x, torch.zeros(n, 3, 10)], dim=-1)   # noqa: E731
                 want = rw.FingertipMovementPenalty(activate=True, weight=weight).compute(dt, pad(tips_now), pad(tips_before))
-                assert torch.allclose(eng.reward, want, rtol=1e-4, atol=1e-5)
+                assert torch.allclose(eng.reward.cpu(), want, rtol=1e-4, atol=1e-5)
                 # and it IS a jump: the pre-reset tips are far from where the freshly reset fingers are
                 assert float(eng.reward.abs().median()) > 5 * 0.1 * (0.01 / dt) ** 2
             else:
-                obj_prev = eng.state[capi.S_PREV_OBJ_P:capi.S_PREV_OBJ_P + 3].T       # the reset pose the physics started from
-                obj_now = eng.state[capi.S_CUBE_P:capi.S_CUBE_P + 3].T
-                goal = eng.state[capi.S_GOAL_P:capi.S_GOAL_P + 3].T
+                obj_prev = eng.state[capi.S_PREV_OBJ_P:capi.S_PREV_OBJ_P + 3].T.cpu()       # the reset pose the physics started from
+                obj_now = eng.state[capi.S_CUBE_P:capi.S_CUBE_P + 3].T.cpu()
+                goal = eng.state[capi.S_GOAL_P:capi.S_GOAL_P + 3].T.cpu()
                 pad13 = lambda p: torch.cat([p, torch.zeros(n, 10)], dim=-1)          # noqa: E731
                 want = rw.ObjectMoveReward(activate=True, weight=weight).compute(pad13(obj_now), pad13(obj_prev),
                                                                                  torch.cat([goal, torch.zeros(n, 4)], dim=-1))
-                assert torch.allclose(eng.reward, want, rtol=1e-4, atol=2e-4)
+                assert torch.allclose(eng.reward.cpu(), want, rtol=1e-4, atol=2e-4)
                 assert float(eng.reward.abs().max()) < 750 * 0.01     # one step of a resting cube: no jump
         eng.close()

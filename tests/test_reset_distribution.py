@@ -10,15 +10,16 @@ N = 20000
 R_MAX = 0.13870835
 
 
-def sample(lib, **kw):
-    eng = TrifingerEngine(make_config(lib, N, seed=2024, command_mode="torque", **kw), device="cpu", lib=lib)
+def sample(backend, **kw):
+    lib, device = backend
+    eng = TrifingerEngine(make_config(lib, N, seed=2024, command_mode="torque", **kw), device=device, lib=lib)
     eng.reset()
-    out = eng.state.numpy().copy(), eng
+    out = eng.state.cpu().numpy().copy(), eng
     return out
 
 
-def test_goal_pose_distributions_difficulty4(oracle):
-    st, eng = sample(oracle, task_difficulty=4)
+def test_goal_pose_distributions_difficulty4(backend):
+    st, eng = sample(backend, task_difficulty=4)
     gx, gy, gz = st[31], st[32], st[33]
     r2 = (gx * gx + gy * gy) / R_MAX ** 2
     assert stats.kstest(r2, "uniform").pvalue > 1e-3                      # radius = r_max sqrt(U)
@@ -36,8 +37,8 @@ def test_goal_pose_distributions_difficulty4(oracle):
     eng.close()
 
 
-def test_object_pose_and_independence(oracle):
-    st, eng = sample(oracle, task_difficulty=1)
+def test_object_pose_and_independence(backend):
+    st, eng = sample(backend, task_difficulty=1)
     cx, cy = st[18], st[19]
     # the cube has gone through ONE simulate since the reset (env_base.py:336): positions moved by < 1 mm
     r2 = (cx * cx + cy * cy) / R_MAX ** 2
@@ -53,14 +54,14 @@ def test_object_pose_and_independence(oracle):
     eng.close()
 
 
-def test_random_robot_reset_and_reproducibility(oracle):
+def test_random_robot_reset_and_reproducibility(backend):
     kw = dict(task_difficulty=1, robot_reset="random", dof_pos_stddev=0.05, dof_vel_stddev=0.2)
-    st, eng = sample(oracle, **kw)
+    st, eng = sample(backend, **kw)
     # q = default + stddev * U(-1, 1) before the single simulate; the step moves it by O(h * qd)
     d = st[1] - 0.9
     assert abs(d.mean()) < 0.03 and 0.02 < d.std() < 0.05                  # one 20 ms simulate of gravity sag shifts the mean
-    st2, eng2 = sample(oracle, **kw)
+    st2, eng2 = sample(backend, **kw)
     assert np.array_equal(st, st2)                                         # same seed -> same draws
     eng2.reset()                                                           # second reset: counter advanced
-    assert not np.array_equal(eng2.state.numpy()[31:38], st[31:38])
+    assert not np.array_equal(eng2.state.cpu().numpy()[31:38], st[31:38])
     eng.close(), eng2.close()
