@@ -1266,6 +1266,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     }
                 }
             }
+            bool wall_lane = false;
             {   // cube vs boundary wall: the four corners of the face that points outward most; rows go to LDS
                 float rc2 = FMA(cp[0], cp[0], cp[1] * cp[1]);
                 float irc = f_rsqrt(f_max(rc2, 1e-24f));
@@ -1285,6 +1286,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
                 const float keep = (face == cw_face) ? ws : 0.0f;
                 cw_face = face;
+                wall_lane = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int wb = L_WALL + 12 * c;
@@ -1314,8 +1316,12 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { LD(wb + j) = r[j]; LD(wb + 5 + j) = Dinv[j]; LD(wb + 9 + j) = lam[j]; }
                     LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
+                    wall_lane = wall_lane || (Dinv[0] > 0.0f);
                 }
             }
+            // wave-uniform: no lane of this wavefront has a live wall corner (the usual case) -> the sweeps skip the wall block
+            // without its four dependent LDS round trips
+            const bool wall_any = __builtin_amdgcn_ballot_w64(wall_lane) != 0ull;
             STAMP(sb_ + 4);
             BAR();                                              // S3: records published by the finger roles
             STAMP(sb_ + 5);
@@ -1347,6 +1353,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     cy_apply(&fr_[3 * c], flam[3 * c + 2], inv_m, inv_I, v, w);
                 }
             }
+            if (__builtin_expect(wall_any, 0)) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int wb = L_WALL + 12 * c;
@@ -1359,6 +1366,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     wt_apply(n, b, LD(wb + 10), inv_m, inv_I, v, w);
                     cz_apply(r, LD(wb + 11), inv_m, inv_I, v, w);
                 }
+            }
             }
             // ---- projected Gauss-Seidel: the cube role's share ----
             uint32_t t_wait = 0u, t_fc = 0u, t_floor = 0u;
@@ -1423,6 +1431,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     }
                 }
                 t_floor += NOW() - tf0_;
+                if (__builtin_expect(wall_any, 0)) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                   // cube - wall: rows n (normal), t, +z
                     const int wb = L_WALL + 12 * c;
@@ -1443,6 +1452,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
                         for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
                     }
+                }
                 }
                 { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W2
             }
