@@ -70,10 +70,47 @@ ARGS = {            # Args, scripts/rlg_hydra.py:193-233
 
 GYM_GROUP = ("trifinger_difficulty_1", "trifinger_difficulty_2", "trifinger_difficulty_3", "trifinger_difficulty_4")
 
-# resources/config/rlg/asymm.yaml of the reference, as data (the agent side is consumed by RL-Games, not by us)
-RLG_ASYMM = {"asymmetric_obs": True, "params": {"config": {"name": "trifinger", "env_name": "rlgpu",
-                                                            "minibatch_size": 8192, "steps_num": 32,
-                                                            "central_value_config": {"minibatch_size": 8192}}}}
+def _mlp_block(init_name: str, init_scale: float) -> dict:
+    return {"units": [400, 200, 100], "activation": "elu", "d2rl": False,
+            "initializer": {"name": init_name, "scale": init_scale}, "regularizer": {"name": "None"}}
+
+
+# The agent group `rlg=asymm` (reference resources/config/rlg/asymm.yaml:1-90) as data: asymmetric actor-critic for
+# RL-Games' a2c_continuous - actor on `obs`, central value network on `states`.  RL-Games consumes this tree as is
+# (`Runner.load`); the in-repo trainer (leibnizgym_amd/ppo.py) reads its hyper-parameters from the same tree
+# (`PPOConfig.from_rlg`).  YAML spells None as the string 'None' in two places; kept.
+RLG_ASYMM = {
+    "asymmetric_obs": True,
+    "params": {
+        "algo": {"name": "a2c_continuous"},
+        "model": {"name": "continuous_a2c_logstd"},
+        "network": {
+            "separate": True, "name": "actor_critic",
+            "space": {"continuous": {
+                "mu_activation": "None", "sigma_activation": "None",
+                "mu_init": {"name": "variance_scaling_initializer", "scale": 0.02},
+                "sigma_init": {"name": "const_initializer", "val": 0},
+                "fixed_sigma": True}},
+            "mlp": _mlp_block("default", 2),
+        },
+        "load_checkpoint": False, "load_path": "nn/weights.pth",
+        "config": {
+            "name": "trifinger", "env_name": "rlgpu", "ppo": True, "normalize_input": False,
+            "reward_shaper": {"scale_value": 0.01}, "normalize_advantage": True,
+            "gamma": 0.99, "tau": 0.95, "learning_rate": 3e-4, "lr_schedule": "adaptive", "lr_threshold": 0.008,
+            "score_to_win": 1000000, "max_epochs": 100000, "save_best_after": 500, "save_frequency": 100,
+            "preemption_checkpoint_freq": 500, "print_stats": True, "grad_norm": 1.0, "entropy_coef": 0.0,
+            "truncate_grads": True, "e_clip": 0.2, "steps_num": 32, "minibatch_size": 8192, "mini_epochs": 4,
+            "critic_coef": 4, "clip_value": False, "seq_len": 4, "bounds_loss_coef": 0.0001,
+            "central_value_config": {
+                "seq_length": 4, "minibatch_size": 8192, "mini_epochs": 4, "lr": 5e-4, "clip_value": False,
+                "normalize_input": False, "grad_norm": 1.0, "truncate_grads": True,
+                "network": {"name": "actor_critic", "central_value": True,
+                            "mlp": _mlp_block("variance_scaling_initializer", 2)},
+            },
+        },
+    },
+}
 
 
 def gym_config(name: str) -> dict:

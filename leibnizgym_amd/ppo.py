@@ -3,8 +3,14 @@
 Follows the agent configuration the reference ships for RL-Games (resources/config/rlg/asymm.yaml): continuous
 A2C/PPO, actor MLP [400, 200, 100] ELU on `obs`, central value MLP [400, 200, 100] ELU on `states`, state-independent
 log-std (`fixed_sigma`), horizon `steps_num` 32, 4 mini-epochs, minibatch = num_envs, gamma 0.99, GAE tau 0.95,
-lr 3e-4 adaptive on a KL threshold of 0.008, e_clip 0.2, critic_coef 4, reward scale 0.01, grad-norm 1.0,
-bounds loss 1e-4, normalised advantages.
+actor lr 3e-4 adaptive on a KL threshold of 0.008, e_clip 0.2, reward scale 0.01, grad-norm 1.0, bounds loss 1e-4,
+normalised advantages; the central value network has its OWN optimiser state (asymm.yaml:70-90): lr 5e-4 constant, its
+own gradient-norm truncation, unweighted MSE loss (RL-Games drops `critic_coef` from the actor loss when a central value
+network exists); initialisers as asymm.yaml:16-18,31-33,84-86 (`variance_scaling_initializer`: truncated normal with
+variance scale / fan_in; biases zero).  `PPOConfig.from_rlg` reads all of it from the `rlg` tree of the launcher.
+Checkpoints (`save` / `restore`: networks, optimiser moments, learning rates, frame and epoch counters), periodic and
+best-so-far saving and a deterministic `play` mode mirror what the reference gets from RL-Games (`args.checkpoint`,
+`args.play`, `save_frequency`, `save_best_after`).
 
 This is host-side training glue, NOT part of the measured hot path: networks are plain `torch.nn` (rocBLAS GEMMs).
 The update is launch-bound (two tiny MLPs, ~150 launches per minibatch, 128 minibatches per iteration), so on the GPU
@@ -40,8 +46,47 @@ class PPOConfig:
     bounds_loss_coef: float = 1e-4
     entropy_coef: float = 0.0
     normalize_advantage: bool = True
+    value_mini_epochs: int = 0        # central_value_config.mini_epochs; 0 = as mini_epochs (they must be equal: one fused pass serves both)
+    value_grad_norm: float = 1.0      # central_value_config.grad_norm
+    mu_init_scale: float = 0.02       # network.space.continuous.mu_init (variance scaling)
+    actor_init: str = "default"       # network.mlp.initializer.name
+    value_init: str = "variance_scaling_initializer"   # central_value_config.network.mlp.initializer
+    value_init_scale: float = 2.0
+    save_frequency: int = 100
+    save_best_after: int = 500
+    max_epochs: int = 100000
+    name: str = "trifinger"
     seed: int = 7
     use_graphs: bool = True           # capture the minibatch step into HIP graphs when the trainer runs on a GPU
+
+    @classmethod
+    def from_rlg(cls, rlg: dict, num_envs: int = None, **overrides):
+        """Hyper-parameters from the launcher's `rlg` tree (leibnizgym_amd/config.py:RLG_ASYMM, i.e. the reference's
+        resources/config/rlg/asymm.yaml).  `minibatch_size` is given in samples there; the trainer counts minibatches per
+        epoch: horizon * num_envs / minibatch_size."""
+        p = rlg["params"]
+        c, net = p["config"], p["network"]
+        cv = c.get("central_value_config", {})
+        kw = dict(units=list(net["mlp"]["units"]), horizon=int(c["steps_num"]), mini_epochs=int(c["mini_epochs"]),
+                  gamma=float(c["gamma"]), tau=float(c["tau"]), lr=float(c["learning_rate"]),
+                  kl_threshold=float(c["lr_threshold"]), e_clip=float(c["e_clip"]), critic_coef=float(c["critic_coef"]),
+                  reward_scale=float(c["reward_shaper"]["scale_value"]), grad_norm=float(c["grad_norm"]),
+                  bounds_loss_coef=float(c["bounds_loss_coef"]), entropy_coef=float(c["entropy_coef"]),
+                  normalize_advantage=bool(c["normalize_advantage"]),
+                  mu_init_scale=float(net["space"]["continuous"]["mu_init"].get("scale", 0.02)),
+                  actor_init=str(net["mlp"]["initializer"]["name"]),
+                  save_frequency=int(c.get("save_frequency", 100)), save_best_after=int(c.get("save_best_after", 500)),
+                  max_epochs=int(c.get("max_epochs", 100000)), name=str(c.get("name", "trifinger")),
+                  seed=int(rlg.get("seed", 7)))
+        if cv:
+            init = cv["network"]["mlp"]["initializer"]
+            kw.update(lr_value=float(cv["lr"]), value_mini_epochs=int(cv["mini_epochs"]),
+                      value_grad_norm=float(cv["grad_norm"]), value_init=str(init["name"]),
+                      value_init_scale=float(init.get("scale", 2.0)))
+        if num_envs:
+            kw["minibatches"] = max(1, kw["horizon"] * int(num_envs) // int(c["minibatch_size"]))
+        kw.update(overrides)
+        return cls(**kw)
 
 
 class _SplitKLinear(torch.autograd.Function):
@@ -85,13 +130,39 @@ def mlp(inp, units, out):
     return nn.Sequential(*layers)
 
 
+def variance_scaling_(w: torch.Tensor, scale: float) -> torch.Tensor:
+    """RL-Games' `variance_scaling_initializer` (fan_in mode): normal with variance scale / fan_in, truncated at two
+    standard deviations."""
+    std = math.sqrt(scale / w.shape[1])
+    return nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2.0 * std, b=2.0 * std)
+
+
 class ActorCritic(nn.Module):
-    def __init__(self, obs_dim, state_dim, act_dim, units):
+    def __init__(self, obs_dim, state_dim, act_dim, units, cfg: "PPOConfig" = None):
         super().__init__()
         self.actor = mlp(obs_dim, units, act_dim)
         self.critic = mlp(state_dim if state_dim > 0 else obs_dim, units, 1)
         self.log_std = nn.Parameter(torch.zeros(act_dim))          # sigma_init const 0, fixed_sigma
         self.central = state_dim > 0
+        if cfg is not None:
+            self.init_like_rl_games(cfg)
+
+    def init_like_rl_games(self, cfg: "PPOConfig"):
+        """asymm.yaml:12-18,31-33,84-86 through RL-Games' network builder: every Linear gets its MLP initialiser
+        (`default` leaves torch's) and a zero bias; the mu head gets `mu_init`."""
+        for net, kind, scale in ((self.actor, cfg.actor_init, 2.0), (self.critic, cfg.value_init if self.central else cfg.actor_init, cfg.value_init_scale)):
+            for m in net:
+                if isinstance(m, nn.Linear):
+                    if kind == "variance_scaling_initializer":
+                        variance_scaling_(m.weight.data, scale)
+                    nn.init.zeros_(m.bias)
+        variance_scaling_(self.actor[-1].weight.data, cfg.mu_init_scale)
+
+    def actor_parameters(self):
+        return list(self.actor.parameters()) + [self.log_std]
+
+    def critic_parameters(self):
+        return list(self.critic.parameters())
 
     def value(self, obs, states):
         return self.critic(states if self.central else obs).squeeze(-1)
@@ -110,19 +181,27 @@ class PPOTrainer:
 
     def __init__(self, env, obs_dim, state_dim, act_dim, cfg: PPOConfig = None, device="cuda:0", group=None):
         self.env, self.cfg, self.device, self.group = env, cfg or PPOConfig(), torch.device(device), group
-        torch.manual_seed(self.cfg.seed)
-        self.net = ActorCritic(obs_dim, state_dim, act_dim, self.cfg.units).to(self.device)
-        # fused multi-tensor Adam on the GPU: the update is launch-bound (tiny MLPs), one kernel instead of ~60
+        c = self.cfg
+        if state_dim > 0 and c.value_mini_epochs not in (0, c.mini_epochs):
+            raise ValueError("central_value_config.mini_epochs must equal mini_epochs: actor and central value network "
+                             "are updated in one fused pass over the same minibatches")
+        torch.manual_seed(c.seed)              # identical initial weights on every rank (and a broadcast below)
+        self.net = ActorCritic(obs_dim, state_dim, act_dim, c.units, c).to(self.device)
+        # fused multi-tensor Adam on the GPU: the update is launch-bound (tiny MLPs), one kernel instead of ~60.
+        # Two parameter groups = RL-Games' two optimisers: the actor's learning rate follows the KL schedule, the
+        # central value network keeps central_value_config.lr; moments are per parameter, so nothing else is shared.
         fused = self.device.type == "cuda"
-        self.graphs = fused and self.cfg.use_graphs
-        if self.graphs:                        # capturable: the step counter and the learning rate live on the device
-            self.opt = torch.optim.Adam(self.net.parameters(), lr=torch.tensor(self.cfg.lr, device=self.device), eps=1e-8,
-                                        fused=True, capturable=True)
-        else:
-            self.opt = torch.optim.Adam(self.net.parameters(), lr=self.cfg.lr, eps=1e-8, **({"fused": True} if fused else {}))
-        self.lr = self.cfg.lr
+        self.graphs = fused and c.use_graphs
+        lr_v = c.lr_value if self.net.central else c.lr
+        mk = (lambda x: torch.tensor(x, device=self.device)) if self.graphs else (lambda x: x)   # capturable: lr on the device
+        groups = [{"params": self.net.actor_parameters(), "lr": mk(c.lr)},
+                  {"params": self.net.critic_parameters(), "lr": mk(lr_v)}]
+        kw = {"fused": True, "capturable": True} if self.graphs else ({"fused": True} if fused else {})
+        self.opt = torch.optim.Adam(groups, eps=1e-8, **kw)
+        self.lr = c.lr
         self._g = None                         # captured minibatch step (built on the first update)
         self.dist_on = False
+        rank = 0
         try:
             import torch.distributed as dist
             self.dist = dist
@@ -132,8 +211,64 @@ class PPOTrainer:
         if self.dist_on:                       # identical initial weights on every rank
             for p in self.net.parameters():
                 self.dist.broadcast(p.data, src=0, group=group)
+            rank = self.dist.get_rank(group)
+        # exploration noise and minibatch order must differ between ranks (the same env index of two shards would
+        # otherwise receive the same noise sequence): re-seed with the rank after the weights are in place
+        torch.manual_seed(c.seed + 7919 * rank)
         self.last = self._unpack(env.reset())
         self.frames = 0
+        self.epoch = 0
+        self.last_info = {}
+        self.best_reward = -float("inf")
+
+    # ---- checkpoints (what RL-Games' save / restore / `args.checkpoint` give the reference launcher) ----
+    def state_dict(self):
+        return {"model": self.net.state_dict(), "optimizer": self.opt.state_dict(), "lr": self.lr, "frames": self.frames,
+                "epoch": self.epoch, "best_reward": self.best_reward, "config": dict(self.cfg.__dict__)}
+
+    def save(self, path: str):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+        torch.save(self.state_dict(), path)
+        return path
+
+    def restore(self, path: str):
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.net.load_state_dict(ck["model"])
+        if "optimizer" in ck:
+            lrs = [g["lr"] for g in self.opt.param_groups]           # keep this trainer's lr objects (device tensors when graphed)
+            self.opt.load_state_dict(ck["optimizer"])
+            for g, lr0 in zip(self.opt.param_groups, lrs):
+                new = g["lr"]
+                if torch.is_tensor(lr0):
+                    lr0.fill_(float(new))
+                    g["lr"] = lr0
+                else:
+                    g["lr"] = float(new)
+        self.lr = float(ck.get("lr", self.lr))
+        self.frames, self.epoch = int(ck.get("frames", 0)), int(ck.get("epoch", 0))
+        self.best_reward = float(ck.get("best_reward", -float("inf")))
+        self._g = None                                               # graphs hold the old optimiser state tensors
+        return ck
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=True):
+        mu, ls = self.net.dist(obs)
+        return mu if deterministic else mu + ls.exp() * torch.randn_like(mu)
+
+    @torch.no_grad()
+    def play(self, steps: int, deterministic=True):
+        """`args.play`: roll the policy without learning; returns the mean reward per step and the last info dict."""
+        obs, _ = self.last
+        total, info = 0.0, {}
+        for _ in range(steps):
+            out, r, _, extra = self.env.step(self.act(obs, deterministic))
+            obs, states = self._unpack(out)
+            total += float(r.mean())
+            if isinstance(extra, (list, tuple)) and len(extra) > 1 and isinstance(extra[1], dict):
+                info = extra[1]
+        self.last = (obs, states)
+        return total / max(steps, 1), info
 
     @staticmethod
     def _unpack(o):
@@ -162,8 +297,10 @@ class PPOTrainer:
                 buf["states"][t] = states
             buf["nlp"][t] = neglogp(a, mu, ls)
             buf["val"][t] = self.net.value(obs, states)
-            out, r, d, _ = self.env.step(a)
+            out, r, d, extra = self.env.step(a)
             obs, states = self._unpack(out)
+            if isinstance(extra, (list, tuple)) and len(extra) > 1 and isinstance(extra[1], dict):
+                self.last_info = extra[1]                   # RL-Games convention: [[], info] (direct logging from the env)
             buf["rew"][t] = r.to(dev) * c.reward_scale
             buf["done"][t] = d.to(dev).float()
         buf["val"][T] = self.net.value(obs, states)
@@ -195,7 +332,10 @@ class PPOTrainer:
         c_loss = (v - d["ret"][idx]).pow(2).mean()
         b_loss = ((mu - 1.1).clamp(min=0).pow(2) + (-1.1 - mu).clamp(min=0).pow(2)).sum(-1).mean()
         ent = (ls + 0.5 + 0.5 * math.log(2 * math.pi)).sum(-1).mean()
-        loss = a_loss + 0.5 * c.critic_coef * c_loss - c.entropy_coef * ent + c.bounds_loss_coef * b_loss
+        # with a central value network RL-Games trains it on its own unweighted MSE and drops the critic term from the
+        # actor loss; the two gradients do not overlap (separate parameters), so one backward serves both
+        v_coef = 1.0 if self.net.central else 0.5 * c.critic_coef
+        loss = a_loss + v_coef * c_loss - c.entropy_coef * ent + c.bounds_loss_coef * b_loss
         for p in self.net.parameters():
             p.grad = None
         loss.backward()
@@ -205,7 +345,11 @@ class PPOTrainer:
             acc["loss"] += loss.detach(); acc["a_loss"] += a_loss.detach(); acc["c_loss"] += c_loss.detach()
 
     def _mb_apply(self):
-        nn.utils.clip_grad_norm_(self.net.parameters(), self.cfg.grad_norm, foreach=True)
+        if self.net.central:                   # truncate_grads of each optimiser on its own network
+            nn.utils.clip_grad_norm_(self.net.actor_parameters(), self.cfg.grad_norm, foreach=True)
+            nn.utils.clip_grad_norm_(self.net.critic_parameters(), self.cfg.value_grad_norm, foreach=True)
+        else:
+            nn.utils.clip_grad_norm_(self.net.parameters(), self.cfg.grad_norm, foreach=True)
         self.opt.step()
 
     def _flatten_grads(self, out=None):
@@ -233,6 +377,8 @@ class PPOTrainer:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         state = {k: v.detach().clone() for k, v in self.net.state_dict().items()}
+        # optimiser moments restored from a checkpoint must survive the warm-up; a fresh optimiser has none yet
+        snap = {p: {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.opt.state.items()}
         with torch.cuda.stream(side):          # warm-up off the capture (allocator, lazy optimizer state), then undone
             for _ in range(3):
                 self._mb_backward(d, idx, acc)
@@ -242,10 +388,13 @@ class PPOTrainer:
                 self._mb_apply()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.net.load_state_dict(state)
-        for st in self.opt.state.values():     # the warm-up steps must not count: moments and step counter back to zero
-            for v in st.values():
+        for p, st in self.opt.state.items():   # the warm-up steps must not count: moments and step counter as before
+            for k, v in st.items():
                 if torch.is_tensor(v):
-                    v.zero_()
+                    if p in snap and k in snap[p]:
+                        v.copy_(snap[p][k])
+                    else:
+                        v.zero_()
         for v in acc.values():
             v.zero_()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -319,7 +468,7 @@ class PPOTrainer:
                 self.lr = max(self.lr / 1.5, 1e-6)
             elif kl < 0.5 * c.kl_threshold:
                 self.lr = min(self.lr * 1.5, 1e-2)
-            for g in self.opt.param_groups:
+            for g in (self.opt.param_groups[:1] if self.net.central else self.opt.param_groups):
                 if torch.is_tensor(g["lr"]):
                     g["lr"].fill_(self.lr)
                 else:
@@ -330,12 +479,26 @@ class PPOTrainer:
         stats["mean_reward"] = float(buf["rew"].mean() / c.reward_scale)
         return stats
 
-    def train(self, epochs, log=None):
+    def train(self, epochs, log=None, checkpoint_dir=None):
+        """`epochs` PPO iterations.  With `checkpoint_dir` (rank 0 only): `<name>.pth` every `save_frequency` epochs and
+        at the end, `<name>_best.pth` whenever the mean reward improves after `save_best_after` epochs."""
+        import os
         out = []
-        for e in range(epochs):
+        for _ in range(epochs):
             st = self.update(self.rollout())
-            st["epoch"], st["frames"] = e, self.frames
+            self.epoch += 1
+            st["epoch"], st["frames"] = self.epoch - 1, self.frames
             out.append(st)
             if log:
                 log(st)
+            if checkpoint_dir:
+                if self.epoch % max(self.cfg.save_frequency, 1) == 0:
+                    self.save(os.path.join(checkpoint_dir, f"{self.cfg.name}.pth"))
+                if self.epoch >= self.cfg.save_best_after and st["mean_reward"] > self.best_reward:
+                    self.best_reward = st["mean_reward"]
+                    self.save(os.path.join(checkpoint_dir, f"{self.cfg.name}_best.pth"))
+            if self.epoch >= self.cfg.max_epochs:
+                break
+        if checkpoint_dir:
+            self.save(os.path.join(checkpoint_dir, f"{self.cfg.name}.pth"))
         return out

@@ -42,6 +42,7 @@ class VecTask:
 
     # sizes ------------------------------------------------------------------------------------------
     num_envs = property(lambda self: self._task.get_num_instances())
+    rl_device = property(lambda self: self._rl_device)
     num_obs = property(lambda self: self._dims["obs"])
     num_states = property(lambda self: self._dims["state"])
     num_actions = property(lambda self: self._dims["act"])

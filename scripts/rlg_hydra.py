@@ -2,10 +2,12 @@
 """Launcher with the reference's command line (scripts/rlg_hydra.py):
 
     python scripts/rlg_hydra.py gym=trifinger_difficulty_4 args.num_envs=65536 args.headless=True
+    python scripts/rlg_hydra.py gym=trifinger_difficulty_4 args.num_envs=8192 args.play=True args.checkpoint=<run>/nn/trifinger.pth
 
-Composes the same configuration (leibnizgym_amd/config.py), then hands the env to RL-Games when `rl_games`
-is installed; without it, runs a random-action rollout (scripts/trifinger_random_action.py of the reference)
-and prints env-steps/s."""
+Composes the same configuration (leibnizgym_amd/config.py) and hands it to `run_rlg_hydra`
+(leibnizgym_amd/utils/rlg_train.py): time-stamped run directory with `agent_config.yaml` / `env_config.yaml`, the env-info
+observer, then RL-Games' `Runner` when `rl_games` is installed and the in-repo PPO runner otherwise.  `rollout=N` runs a
+random-action rollout instead (scripts/trifinger_random_action.py of the reference) and prints env-steps/s."""
 import os
 import sys
 import time
@@ -20,27 +22,28 @@ from leibnizgym_amd.utils import rlg_train  # noqa: E402
 
 
 def main(argv):
-    cfg = compose(argv)
+    rollout = None
+    rest = []
+    for a in argv:
+        if a.startswith("rollout="):
+            rollout = int(a.split("=", 1)[1])
+        else:
+            rest.append(a)
+    cfg = compose(rest)
+    if rollout is None:
+        return rlg_train.run_rlg_hydra(cfg)
     args = SimpleNamespace(**cfg["args"])
-    rlg_train.configure(cfg["gym"], args, args.logdir)
-    if rlg_train.HAVE_RL_GAMES and args.train:
-        from rl_games.torch_runner import Runner
-        runner = Runner()
-        runner.load(cfg["rlg"])
-        runner.reset()
-        runner.run(cfg["args"])
-        return
+    rlg_train.configure(cfg["gym"], args, None, cfg["rlg"])
     env = rlg_train.parse_vec_task(args, cfg["gym"])
     env.reset()
     n, a = env.num_envs, env.num_actions
-    steps = int(os.environ.get("TF_ROLLOUT_STEPS", "500"))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(rollout):
         env.step(2 * torch.rand((n, a), device="cuda:0") - 1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"rl_games not installed: random-action rollout, {n} envs x {steps} steps: {n * steps / dt:.3e} env-steps/s")
+    print(f"random-action rollout, {n} envs x {rollout} steps: {n * rollout / dt:.3e} env-steps/s")
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end PPO on the native TriFinger env (BASELINE config 5: difficulty 4, 8192 envs per GPU).
 
-    python scripts/train_ppo.py gym=trifinger_difficulty_4 args.num_envs=8192 [epochs=20]
+    python scripts/train_ppo.py gym=trifinger_difficulty_4 args.num_envs=8192 [epochs=20] [args.checkpoint=run/nn/trifinger.pth] [save_dir=run/nn]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_ppo.py ...
 
 One process per GPU; envs are sharded (no data-path collective), gradients are averaged with one fused RCCL
@@ -22,11 +22,13 @@ from leibnizgym_amd.wrappers import VecTaskPython  # noqa: E402
 
 
 def main(argv):
-    epochs = 20
+    epochs, save_dir = 20, None
     rest = []
     for a in argv:
         if a.startswith("epochs="):
             epochs = int(a.split("=", 1)[1])
+        elif a.startswith("save_dir="):
+            save_dir = a.split("=", 1)[1]
         else:
             rest.append(a)
     cfg = compose(rest)
@@ -43,8 +45,11 @@ def main(argv):
     env = TrifingerEnv(config=cfg["gym"], device=dev, verbose=False, env_id_offset=rank * n,
                        global_num_instances=world * n)
     adapter = RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device=dev))
+    # hyper-parameters from the agent tree (asymm.yaml); minibatch = envs per GPU, as update_cfg sets it
     tr = PPOTrainer(adapter, env.get_obs_dim(), env.get_state_dim(), env.get_action_dim(),
-                    PPOConfig(seed=cfg["args"]["seed"]), device=dev)
+                    PPOConfig.from_rlg(cfg["rlg"], num_envs=n), device=dev)
+    if cfg["args"]["checkpoint"]:
+        tr.restore(cfg["args"]["checkpoint"])
     t0 = time.perf_counter()
 
     def log(st):
@@ -53,7 +58,7 @@ def main(argv):
             print(f"epoch {st['epoch']:4d} frames {st['frames'] * world:10d} reward/step {st['mean_reward']:9.3f} "
                   f"kl {st['kl']:.4f} lr {st['lr']:.2e} loss {st['loss']:.4f}  {st['frames'] * world / dt:.3e} frames/s",
                   flush=True)
-    tr.train(epochs, log)
+    tr.train(epochs, log, checkpoint_dir=save_dir if rank == 0 else None)
     if world > 1:
         dist.destroy_process_group()
 

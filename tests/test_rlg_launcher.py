@@ -1,0 +1,202 @@
+"""The RL-Games drop-in: full agent parameter tree, env-info observer, run directory with its two
+configuration dumps, runner interface with checkpoint / play, the central value optimiser and the initialisers of the
+in-repo trainer.  CPU tests inject the oracle library through the launcher's env-kwargs hook."""
+import csv
+import glob
+import math
+import os
+
+import pytest
+import torch
+import yaml
+
+from leibnizgym_amd.config import compose
+from leibnizgym_amd.ppo import ActorCritic, PPOConfig, PPOTrainer
+from leibnizgym_amd.utils import rlg_train
+from leibnizgym_amd.utils.rlg_train import EnvInfoObserver, LeibnizAlgoObserver, NativeRunner, ScalarSink
+
+
+def small_cfg(tmp_path, *extra):
+    return compose(["gym=trifinger_difficulty_4", "args.num_envs=16", "args.headless=True", "args.seed=3",
+                    f"args.logdir={tmp_path}/logs", "rlg.params.config.steps_num=4", *extra])
+
+
+def test_agent_tree_is_the_full_asymm_yaml():
+    """reference resources/config/rlg/asymm.yaml:1-90 after update_cfg (scripts/rlg_hydra.py:251-286)"""
+    cfg = compose(["gym=trifinger_difficulty_4", "args.num_envs=8192", "args.checkpoint=nn/x.pth", "args.experiment_name=exp"])
+    r = cfg["rlg"]
+    p = r["params"]
+    assert r["asymmetric_obs"] is True and r["seed"] == 7
+    assert p["algo"]["name"] == "a2c_continuous" and p["model"]["name"] == "continuous_a2c_logstd"
+    net = p["network"]
+    assert net["name"] == "actor_critic" and net["separate"] is True and net["mlp"]["units"] == [400, 200, 100]
+    assert net["mlp"]["activation"] == "elu" and net["mlp"]["initializer"] == {"name": "default", "scale": 2}
+    assert net["space"]["continuous"]["mu_init"] == {"name": "variance_scaling_initializer", "scale": 0.02}
+    assert net["space"]["continuous"]["sigma_init"] == {"name": "const_initializer", "val": 0}
+    assert net["space"]["continuous"]["fixed_sigma"] is True
+    c = p["config"]
+    assert (c["gamma"], c["tau"], c["learning_rate"], c["lr_schedule"], c["lr_threshold"]) == (0.99, 0.95, 3e-4, "adaptive", 0.008)
+    assert (c["e_clip"], c["steps_num"], c["mini_epochs"], c["critic_coef"], c["grad_norm"]) == (0.2, 32, 4, 4, 1.0)
+    assert c["reward_shaper"]["scale_value"] == 0.01 and c["bounds_loss_coef"] == 0.0001 and c["env_name"] == "rlgpu"
+    assert (c["save_best_after"], c["save_frequency"], c["max_epochs"]) == (500, 100, 100000)
+    cv = c["central_value_config"]
+    assert cv["lr"] == 5e-4 and cv["mini_epochs"] == 4 and cv["network"]["central_value"] is True
+    assert cv["network"]["mlp"]["initializer"]["name"] == "variance_scaling_initializer"
+    # what update_cfg writes into the tree
+    assert c["minibatch_size"] == c["num_actors"] == cv["minibatch_size"] == 8192
+    assert p["load_checkpoint"] is True and p["load_path"] == "nn/x.pth"
+    assert c["name"] == "exp_Python_GPU_physx"
+    k = PPOConfig.from_rlg(r, num_envs=8192)
+    assert (k.lr, k.lr_value, k.horizon, k.minibatches, k.mini_epochs, k.value_mini_epochs) == (3e-4, 5e-4, 32, 32, 4, 4)
+    assert k.units == [400, 200, 100] and k.value_init == "variance_scaling_initializer" and k.seed == 7
+
+
+class FakeRunner:
+    """stands in for rl_games.torch_runner.Runner"""
+    seen = {}
+
+    def __init__(self, observer):
+        FakeRunner.seen = {"observer": observer, "calls": []}
+
+    def load(self, tree):
+        FakeRunner.seen["tree"] = tree
+        FakeRunner.seen["calls"].append("load")
+
+    def reset(self):
+        FakeRunner.seen["calls"].append("reset")
+
+    def run(self, args):
+        FakeRunner.seen["args"] = args
+        FakeRunner.seen["calls"].append("run")
+        return "ran"
+
+
+def test_run_rlg_hands_the_tree_and_the_observer_to_the_runner(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    cfg = small_cfg(tmp_path)
+    assert rlg_train.run_rlg_hydra(cfg, runner_factory=FakeRunner) == "ran"
+    seen = FakeRunner.seen
+    assert seen["calls"] == ["load", "reset", "run"] and isinstance(seen["observer"], EnvInfoObserver)
+    assert LeibnizAlgoObserver is EnvInfoObserver
+    tree = seen["tree"]
+    assert {"algo", "model", "network", "config", "load_checkpoint", "load_path"} <= set(tree["params"])
+    assert tree["params"]["config"]["num_actors"] == 16 and tree["seed"] == 3
+    assert os.path.isdir(tmp_path / "nn") and os.path.isdir(tmp_path / "runs")        # reference :222-223
+    run_dir = seen["args"]["logdir"]
+    assert os.path.dirname(run_dir.rstrip("/")) == f"{tmp_path}/logs" and os.path.isdir(run_dir)   # time-stamped sub-directory
+    dumped = yaml.safe_load(open(os.path.join(run_dir, "agent_config.yaml")))
+    assert dumped == tree
+    assert seen["args"]["train"] is True and seen["args"]["play"] is False and seen["args"]["checkpoint"] == ""
+    a = torch.rand(3)                                      # run_rlg seeded the generators with the agent seed (:236)
+    rlg_train.set_seed(tree["seed"])
+    assert torch.equal(a, torch.rand(3))
+
+
+def test_observer_logs_env_info_and_scores():
+    class W:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append((tag, float(value), step))
+    from types import SimpleNamespace
+    algo = SimpleNamespace(writer=W(), games_to_track=3, num_agents=1, ppo_device="cpu")
+    ob = EnvInfoObserver()
+    ob.after_init(algo)
+    ob.process_infos([], [])
+    ob.process_infos([[], {"env/rewards/object_dist": torch.tensor(1.5), "env/current_position_goal/count": 4.0}], [])
+    ob.after_print_stats(frame=640, epoch_num=2, total_time=1.0)
+    assert ("env/rewards/object_dist", 1.5, 640) in algo.writer.rows and ("env/current_position_goal/count", 4.0, 640) in algo.writer.rows
+    assert not any(t.startswith("scores/") for t, _, _ in algo.writer.rows)              # no finished games yet
+    ob.process_infos([{"scores": 2.0}, {"scores": 4.0}], [0, 1])                         # per-agent dicts of finished games
+    ob.after_print_stats(frame=1280, epoch_num=3, total_time=2.0)
+    assert ("scores/mean", 3.0, 1280) in algo.writer.rows and ("scores/iter", 3.0, 3) in algo.writer.rows
+    ob.after_clear_stats()
+    n = len(algo.writer.rows)
+    ob.direct_info = {}
+    ob.after_print_stats(frame=1, epoch_num=1, total_time=0.1)
+    assert len(algo.writer.rows) == n
+
+
+def _scalars(run_dir):
+    path = os.path.join(run_dir, "summaries", "scalars.csv")
+    if os.path.isfile(path):
+        return {row["tag"] for row in csv.DictReader(open(path))}
+    from tensorboard.backend.event_processing.event_accumulator import EventAccumulator
+    acc = EventAccumulator(os.path.join(run_dir, "summaries"))
+    acc.Reload()
+    return set(acc.Tags()["scalars"])
+
+
+def test_native_runner_trains_checkpoints_resumes_and_plays(oracle, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("TF_MAX_EPOCHS", "2")
+    monkeypatch.setenv("TF_PLAY_STEPS", "5")
+    stats = rlg_train.run_rlg_hydra(small_cfg(tmp_path), runner_factory=NativeRunner, lib=oracle, sim_device="cpu")
+    assert len(stats) == 2 and all(math.isfinite(s["loss"]) for s in stats)
+    run_dir = rlg_train.logdir
+    for f in ("agent_config.yaml", "env_config.yaml", "nn/trifinger.pth"):
+        assert os.path.isfile(os.path.join(run_dir, f)), f
+    env_cfg = yaml.safe_load(open(os.path.join(run_dir, "env_config.yaml")))
+    assert env_cfg["num_instances"] == 16 and env_cfg["task_difficulty"] == 4 and env_cfg["asymmetric_obs"] is True
+    tags = _scalars(run_dir)
+    assert {"env/rewards/object_dist", "env/average_consecutive_success", "losses/a_loss", "info/kl", "info/lr"} <= tags
+    # resume: the checkpoint reproduces the policy (same deterministic actions) and carries the counters and the moments
+    ck = os.path.join(run_dir, "nn", "trifinger.pth")
+    saved = torch.load(ck, weights_only=False)
+    assert saved["epoch"] == 2 and saved["frames"] == 2 * 4 * 16 and len(saved["optimizer"]["state"]) > 0
+    rlg_train.configure(small_cfg(tmp_path)["gym"], small_cfg(tmp_path)["args"], None, None, lib=oracle, sim_device="cpu")
+    vec = rlg_train.create_rlgpu_env()
+    ad = rlg_train.RlGamesGpuEnvAdapter("rlgpu", 16, env=vec)
+    fresh = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=4, minibatches=4, seed=99), device="cpu")
+    obs = torch.randn(16, 41)
+    before = fresh.act(obs)
+    fresh.restore(ck)
+    want = torch.load(ck, weights_only=False)["model"]
+    assert all(torch.equal(v, fresh.net.state_dict()[k]) for k, v in want.items())
+    assert not torch.equal(before, fresh.act(obs)) and fresh.epoch == 2
+    ref = ActorCritic(41, 113, 9, [400, 200, 100])
+    ref.load_state_dict(want)
+    assert torch.equal(ref.dist(obs)[0], fresh.act(obs))
+    st = fresh.train(1)                                    # training continues from the restored moments
+    assert st[0]["epoch"] == 2 and math.isfinite(st[0]["loss"])
+    # play through the launcher: args.play + args.checkpoint (scripts/rlg_hydra.py:275-276)
+    out = rlg_train.run_rlg_hydra(small_cfg(tmp_path, "args.play=True", f"args.checkpoint={ck}"),
+                                  runner_factory=NativeRunner, lib=oracle, sim_device="cpu")
+    assert math.isfinite(out["mean_reward"])
+    assert len(glob.glob(f"{tmp_path}/logs/*/agent_config.yaml")) >= 1
+
+
+def test_central_value_optimiser_and_initialisers(oracle):
+    """asymm.yaml:70-90: the central value network has its own learning rate (5e-4, not on the KL schedule) and gradient
+    truncation; :16-18,31-33,84-86: initialisers."""
+    from test_ppo import make
+    env, ad = make(oracle, n=16)
+    tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=4, minibatches=2, mini_epochs=2, kl_threshold=1e-9), device="cpu")
+    g = tr.opt.param_groups
+    assert len(g) == 2 and float(g[0]["lr"]) == 3e-4 and float(g[1]["lr"]) == 5e-4
+    assert sum(p.numel() for p in g[0]["params"]) == sum(p.numel() for p in tr.net.actor.parameters()) + 9
+    assert sum(p.numel() for p in g[1]["params"]) == sum(p.numel() for p in tr.net.critic.parameters())
+    critic_before = [p.detach().clone() for p in tr.net.critic.parameters()]
+    tr.train(1)
+    assert float(g[0]["lr"]) < 3e-4 and float(g[1]["lr"]) == 5e-4           # any KL > 2e-9 lowers the actor's lr only
+    assert any(not torch.equal(a, b) for a, b in zip(critic_before, tr.net.critic.parameters()))
+    with pytest.raises(ValueError, match="mini_epochs"):
+        PPOTrainer(ad, 41, 113, 9, PPOConfig(mini_epochs=4, value_mini_epochs=2), device="cpu")
+    torch.manual_seed(0)
+    net = ActorCritic(41, 113, 9, [400, 200, 100], PPOConfig())
+    lin = [m for m in list(net.actor) + list(net.critic) if isinstance(m, torch.nn.Linear)]
+    assert all(float(m.bias.abs().max()) == 0.0 for m in lin)
+    mu_w = net.actor[-1].weight
+    assert abs(float(mu_w.std()) / math.sqrt(0.02 / 100) - 0.88) < 0.08 and float(mu_w.abs().max()) <= 2 * math.sqrt(0.02 / 100) + 1e-7
+    c0 = net.critic[0].weight                                                # truncated normal, variance 2 / fan_in
+    assert abs(float(c0.std()) / math.sqrt(2 / 113) - 0.88) < 0.03 and float(c0.abs().max()) <= 2 * math.sqrt(2 / 113) + 1e-7
+    a0 = net.actor[0].weight                                                 # `default`: torch's own (uniform +- 1/sqrt(fan_in))
+    assert float(a0.abs().max()) <= 1 / math.sqrt(41) + 1e-7
+
+
+def test_scalar_sink_csv(tmp_path):
+    s = ScalarSink(str(tmp_path / "s"))
+    s.add_scalar("a/b", torch.tensor(2.5), 7)
+    s.close()
+    assert os.listdir(tmp_path / "s")

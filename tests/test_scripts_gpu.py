@@ -23,10 +23,19 @@ def test_random_action_driver(hip):
     assert "Trifinger environment creation successful." in out and "env-steps/s" in out
 
 
-def test_hydra_style_launcher(hip):
-    out = run(["scripts/rlg_hydra.py", "gym=trifinger_difficulty_4", "args.num_envs=512", "args.headless=True"],
-              env={"TF_ROLLOUT_STEPS": "40"})
-    assert "env-steps/s" in out or "rl_games" in out
+def test_hydra_style_launcher(hip, tmp_path):
+    """reference command line: train two epochs through run_rlg (run directory, config dumps, checkpoint), then
+    args.play=True args.checkpoint=... from that checkpoint; rollout=N is the random-action mode"""
+    import glob
+    base = ["scripts/rlg_hydra.py", "gym=trifinger_difficulty_4", "args.num_envs=512", "args.headless=True", f"args.logdir={tmp_path}/logs"]
+    out = run(base, env={"TF_MAX_EPOCHS": "2"})
+    assert "Saving logs at" in out and len([ln for ln in out.splitlines() if ln.startswith("epoch")]) == 2
+    runs = glob.glob(f"{tmp_path}/logs/*")
+    assert len(runs) == 1 and all(os.path.isfile(os.path.join(runs[0], f)) for f in ("agent_config.yaml", "env_config.yaml", "nn/trifinger.pth"))
+    out = run(base + ["args.play=True", f"args.checkpoint={runs[0]}/nn/trifinger.pth"], env={"TF_PLAY_STEPS": "20"})
+    assert "Restoring checkpoint" in out and "play: 20 steps" in out
+    out = run(base + ["rollout=40"])
+    assert "env-steps/s" in out
 
 
 def test_ppo_training_script(hip):
