@@ -110,6 +110,7 @@ enum {
     TF_STATE_ROWS = 149
 };
 #define TF_NUM_DR 6
+#define TF_NORM_INF (-1)      /* finger_reach_norm_p: the maximum norm */
 /* Largest num_envs of one handle: the kernels address state[TF_STATE_ROWS][num_envs] with 32-bit byte offsets
  * (149 * 2 Mi * 4 B = 1.25 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
 #define TF_MAX_ENVS 2097152
@@ -205,7 +206,8 @@ typedef struct TfConfig {
     int32_t object_reset_type;
     int32_t goal_rotation_activate; float goal_rotation_rate_magnitude;
     TfRewardTerm reward[TF_NUM_REWARD_TERMS];
-    int32_t finger_reach_norm_p;  /* only p = 2 is built (both shipped configs use 2)               */
+    int32_t finger_reach_norm_p;  /* p of torch.norm in FingerReachObjectRatePenalty (rewards.py:203-235): 1..16, or
+                                   * TF_NORM_INF for float('inf'); anything else -> TF_ERR_UNSUPPORTED            */
     float object_rot_scale;       /* ObjectRotationReward.scale  rewards.py:109                      */
     int32_t success_activate; float success_bonus, position_tolerance, orientation_tolerance;
     /* physics stepping (env_base.py:47-70, scripts/rlg_hydra.py:15-35) */

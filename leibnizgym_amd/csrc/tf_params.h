@@ -55,6 +55,7 @@ struct DevParams {
     // MDP
     int32_t command_mode, normalize_action, normalize_obs, apply_safety_damping, asymmetric_obs, enable_ft;
     int32_t task_difficulty, episode_length;
+    int32_t norm_p;                 // finger_reach_object_rate: p of the vector norm (2 in the shipped configs)
     int32_t robot_reset_type, object_reset_type, goal_rotation_activate;
     float dof_pos_stddev, dof_vel_stddev, goal_rate;
     int32_t dr_enable;

@@ -237,6 +237,26 @@ DEV float norm3d(const float a[3], const float b[3]) {
     float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     return f_sqrt(dx * dx + dy * dy + dz * dz);
 }
+// torch.norm(a - b, p) for the finger_reach_object_rate term (reference rewards.py:216-226): p = 2 is the Euclidean norm above;
+// p = 1 and the maximum norm are exact; an integer p in 3..16 takes the p-th root as exp(log(s) / p) followed by one Newton
+// step on y^p = s, which brings the polynomial exp / log (1e-7 relative) down to rounding error
+DEV float ipow(float x, int n) {
+    float t = x;
+    for (int k = 1; k < n; ++k) t = t * x;
+    return t;
+}
+DEV float norm_p3(const float a[3], const float b[3], int p) {
+    if (__builtin_expect(p == 2, 1)) return norm3d(a, b);
+    const float ax = f_abs(a[0] - b[0]), ay = f_abs(a[1] - b[1]), az = f_abs(a[2] - b[2]);
+    if (p == 1) return (ax + ay) + az;
+    if (p == TF_NORM_INF) return f_max(f_max(ax, ay), az);
+    const float s = (ipow(ax, p) + ipow(ay, p)) + ipow(az, p);
+    if (!(s > 0.0f)) return 0.0f;
+    float y = tf_exp(tf_log(s) / (float)p);
+    const float yp1 = ipow(y, p - 1);
+    y = y - (yp1 * y - s) / ((float)p * yp1);
+    return y;
+}
 
 // fingertip link state in the world frame: position, quaternion (xyzw), linear and angular velocity
 DEV void tip_state(const TfModel& m, const Yaw& y, const FK& k, const float q[3], const float qd[3], float out[13]) {
@@ -1556,9 +1576,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             float r[6];
             {
                 float s = 0.0f;
-                s = s + (norm3d(&tips[0], cp) - norm3d(&tip_prev[0], prev_obj));
-                s = s + (norm3d(&tips[3], cp) - norm3d(&tip_prev[3], prev_obj));
-                s = s + (norm3d(&tips[6], cp) - norm3d(&tip_prev[6], prev_obj));
+                s = s + (norm_p3(&tips[0], cp, P.norm_p) - norm_p3(&tip_prev[0], prev_obj, P.norm_p));
+                s = s + (norm_p3(&tips[3], cp, P.norm_p) - norm_p3(&tip_prev[3], prev_obj, P.norm_p));
+                s = s + (norm_p3(&tips[6], cp, P.norm_p) - norm_p3(&tip_prev[6], prev_obj, P.norm_p));
                 r[0] = rc.c_reach * s;
             }
             {

@@ -303,7 +303,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (cfg->object_reset_type < 0 || cfg->object_reset_type > 2) return TF_ERR_OBJECT_RESET;
     int d = cfg->task_difficulty;
     if (!(d == -1 || (d >= 1 && d <= 6))) return TF_ERR_DIFFICULTY;
-    if (cfg->finger_reach_norm_p != 2) return TF_ERR_UNSUPPORTED;
+    if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
     if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
     TfHandle_* h = new TfHandle_();
@@ -322,6 +322,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     P.command_mode = cfg->command_mode; P.normalize_action = cfg->normalize_action; P.normalize_obs = cfg->normalize_obs;
     P.apply_safety_damping = cfg->apply_safety_damping; P.asymmetric_obs = cfg->asymmetric_obs; P.enable_ft = cfg->enable_ft_sensors;
     P.task_difficulty = cfg->task_difficulty; P.episode_length = cfg->episode_length;
+    P.norm_p = cfg->finger_reach_norm_p;
     P.robot_reset_type = cfg->robot_reset_type; P.object_reset_type = cfg->object_reset_type;
     P.goal_rotation_activate = cfg->goal_rotation_activate;
     P.dr_enable = cfg->dr_enable;

@@ -11,6 +11,8 @@ import ctypes as C
 
 import torch
 
+C_NORM_INF = -1          # TF_NORM_INF of include/trifinger.h
+
 from . import _capi as capi
 
 
@@ -49,7 +51,15 @@ def fill_reward_terms(cfg, reward_terms):
         else:
             term.sched_start = 0.0
             term.sched_end = 0.0
-    cfg.finger_reach_norm_p = int(reward_terms.get("finger_reach_object_rate", {}).get("norm_p", 2))
+    norm_p = reward_terms.get("finger_reach_object_rate", {}).get("norm_p", 2)      # rewards.py:203: any p torch.norm takes
+    if isinstance(norm_p, str):
+        norm_p = float(norm_p)
+    if norm_p == float("inf"):
+        cfg.finger_reach_norm_p = C_NORM_INF
+    elif float(norm_p) == int(norm_p) and 1 <= int(norm_p) <= 16:
+        cfg.finger_reach_norm_p = int(norm_p)
+    else:
+        raise ValueError(f"finger_reach_object_rate.norm_p = {norm_p!r}: the native step builds integer p in 1..16 and inf")
     cfg.object_rot_scale = float(reward_terms.get("object_rot", {}).get("scale", 1.0))
 
 

@@ -446,7 +446,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (cfg->object_reset_type < 0 || cfg->object_reset_type > 2) return TF_ERR_OBJECT_RESET;
     int d = cfg->task_difficulty;
     if (!(d == -1 || (d >= 1 && d <= 6))) return TF_ERR_DIFFICULTY;
-    if (cfg->finger_reach_norm_p != 2) return TF_ERR_UNSUPPORTED;
+    if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
     if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
     struct TfHandle_* h = (struct TfHandle_*)calloc(1, sizeof(*h));
@@ -1688,6 +1688,25 @@ static float norm3d(const float a[3], const float b[3]) {
     float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     return sqrtf(dx * dx + dy * dy + dz * dz);
 }
+/* torch.norm(a - b, p), reference rewards.py:216-226 (FingerReachObjectRatePenalty takes any p); p = 1, 2 and the maximum
+ * norm are exact, an integer p in 3..16 takes the p-th root as exp(log(s) / p) plus one Newton step on y^p = s */
+static float ipow(float x, int n) {
+    float t = x;
+    for (int k = 1; k < n; ++k) t = t * x;
+    return t;
+}
+static float norm_p3(const float a[3], const float b[3], int p) {
+    if (p == 2) return norm3d(a, b);
+    const float ax = f_abs(a[0] - b[0]), ay = f_abs(a[1] - b[1]), az = f_abs(a[2] - b[2]);
+    if (p == 1) return (ax + ay) + az;
+    if (p == TF_NORM_INF) return f_max(f_max(ax, ay), az);
+    const float s = (ipow(ax, p) + ipow(ay, p)) + ipow(az, p);
+    if (!(s > 0.0f)) return 0.0f;
+    float y = tf_exp(tf_log(s) / (float)p);
+    const float yp1 = ipow(y, p - 1);
+    y = y - (yp1 * y - s) / ((float)p * yp1);
+    return y;
+}
 
 /* fingertip link state in the world frame: position, quaternion (xyzw), linear and angular velocity */
 static void tip_state(const TfModel* m, int f, const float q[3], const float qd[3], float out[13]) {
@@ -1806,8 +1825,8 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
     {
         float s = 0.0f;
         for (int f = 0; f < 3; ++f) {
-            float cur = norm3d(tips[f], e->cp);
-            float prv = norm3d(&tip_prev[3 * f], prev_obj);
+            float cur = norm_p3(tips[f], e->cp, c->finger_reach_norm_p);
+            float prv = norm_p3(&tip_prev[3 * f], prev_obj, c->finger_reach_norm_p);
             s = s + (cur - prv);
         }
         r[0] = rc->c_reach * s;

@@ -20,6 +20,10 @@ Fixtures written (all float32 unless noted):
   obs.npz         T5   obs[41]/states[113] assembly + scale tables
   termination.npz T8   success flags / counts / bonus for difficulty {1,4,5} x activate {T,F}
   constants.npz   T13  CuboidalObject(0.065) numbers, dimension enum values
+  finger_rewards.npz T7 the two fingertip terms (FingerReachObjectRatePenalty with norm_p in {2, 1, 3, inf},
+                       FingertipMovementPenalty) of the imported reference evaluated on fingertip positions that the
+                       native step itself produced (forward kinematics of the stored joint positions, run here through
+                       the CPU oracle): the fixture pins term(tips), the tips are whatever the engine's FK gives
 """
 import os
 import sys
@@ -443,6 +447,50 @@ def gen_constants():
              object_pose_dim=np.int64(d.ObjectPoseDim.value), object_vel_dim=np.int64(d.ObjectVelocityDim.value))
 
 
+NORM_PS = (2, 1, 3, float("inf"))
+
+
+def gen_finger_rewards():
+    """Fingertip reward terms on FK-produced tips.  The joint positions are seeded inputs; the fingertip positions are the
+    output of the native step's forward kinematics (CPU oracle here; the HIP library reproduces them bit for bit), the
+    expected values are the outputs of the imported reference classes on those fingertips."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle_util import load_oracle
+    from leibnizgym_amd import _capi as capi
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    lib = load_oracle()
+    rng = np.random.default_rng(77)
+    n = N
+    base = np.tile(np.array([0.0, 0.9, -1.7], dtype=np.float32), (n, 3))
+    q_prev = base + rng.uniform(-0.3, 0.3, (n, 9)).astype(np.float32)
+    q = q_prev + rng.uniform(-0.02, 0.02, (n, 9)).astype(np.float32)
+    obj = np.zeros((n, 13), dtype=np.float32)
+    obj[:, 0:3] = rng.uniform(-0.1, 0.1, (n, 3)); obj[:, 2] = np.abs(obj[:, 2]) + 0.0325; obj[:, 6] = 1.0
+    obj_prev = obj.copy()
+    obj_prev[:, 0:3] += rng.uniform(-0.002, 0.002, (n, 3)).astype(np.float32)
+    off = {k: {"activate": False} for k in capi.REWARD_TERM_ORDER}
+    eng = TrifingerEngine(make_config(lib, n, command_mode="torque", reward_terms=off, success={"activate": False}),
+                          device="cpu", lib=lib)
+    tips_of = {}
+    for name, qq in (("prev", q_prev), ("now", q)):
+        eng.q.copy_(torch.from_numpy(np.ascontiguousarray(qq.T)))
+        eng.post_step()
+        tips_of[name] = eng.tip_pos.T.numpy().reshape(n, 3, 3).copy()
+    eng.close()
+    tips = torch.zeros(n, 3, 13, dtype=F32); tips[:, :, 0:3] = torch.from_numpy(tips_of["now"])
+    tips_prev = torch.zeros(n, 3, 13, dtype=F32); tips_prev[:, :, 0:3] = torch.from_numpy(tips_of["prev"])
+    out = {"q": q, "q_prev": q_prev, "obj": obj, "obj_prev": obj_prev, "tips": tips_of["now"], "tips_prev": tips_of["prev"],
+           "dt": np.float32(0.02), "norm_ps": np.array(NORM_PS, dtype=np.float64),
+           "reach_weight": np.float32(-750.0), "move_weight": np.float32(-0.1)}
+    o, op = torch.from_numpy(obj), torch.from_numpy(obj_prev)
+    for k, p in enumerate(NORM_PS):
+        term = rw.FingerReachObjectRatePenalty(activate=True, weight=-750.0, norm_p=p)
+        out[f"reach_{k}"] = npf(term.compute(0.0, tips, tips_prev, o, op))
+    out["move"] = npf(rw.FingertipMovementPenalty(activate=True, weight=-0.1).compute(0.02, tips, tips_prev))
+    np.savez(os.path.join(HERE, "finger_rewards.npz"), **out)
+
+
 if __name__ == "__main__":
     gen_math()
     gen_rewards()
@@ -451,6 +499,7 @@ if __name__ == "__main__":
     gen_obs()
     gen_termination()
     gen_constants()
+    gen_finger_rewards()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

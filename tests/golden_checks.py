@@ -248,42 +248,37 @@ def check_rewards(lib, device):
 
 
 def check_finger_rewards(lib, device):
-    """T7 fingertip terms with FK-produced tips: the golden per-term values are reproduced by feeding
-    the golden (tips - tips_prev) displacement through the previous-tip history."""
-    g = golden("rewards")
-    tips, tips_prev = g["tips"][:, :, 0:3], g["tips_prev"][:, :, 0:3]
-    obj, obj_prev = g["obj"], g["obj_prev"]
-    n = obj.shape[0]
-    terms = {k: dict(v) for k, v in REWARD_CFGS["d1"].items()}
-    terms["object_dist"]["activate"] = False
-    cfg = make_config(lib, n, command_mode="torque", reward_terms=terms, dt=float(g["dt"]),
-                      success={"activate": False}, robot_reset="default")
-    eng = TrifingerEngine(cfg, device=device, lib=lib)
-    rng = np.random.default_rng(5)
-    q = np.tile(np.array([0.0, 0.9, -1.7], dtype=np.float32), (n, 3)) + rng.uniform(-0.3, 0.3, (n, 9)).astype(np.float32)
-    eng.q.copy_(T(q.T, device))
-    eng.post_step()                       # first call: leaves FK tips in the history row
-    sync(device)
-    fk_tips = eng.tip_pos.T.cpu().numpy().reshape(n, 3, 3).copy()
-    # previous tips = fk_tips - golden displacement; object placed so that tip-object offsets equal golden ones
-    disp = (tips - tips_prev).astype(np.float32)
-    prev = (fk_tips - disp).astype(np.float32)
-    eng.tip_pos.copy_(T(prev.reshape(n, 9).T, device))
-    eng.cube.copy_(T(obj.T, device))
-    eng.view(capi.S_PREV_OBJ_P, 7).copy_(T(obj_prev[:, :7].T, device))
-    eng.post_step()
-    sync(device)
-    o, op = obj[:, 0:3].astype(np.float64), obj_prev[:, 0:3].astype(np.float64)
-    cur = np.linalg.norm(fk_tips.astype(np.float64) - o[:, None, :], axis=-1)
-    prv = np.linalg.norm(prev.astype(np.float64) - op[:, None, :], axis=-1)
-    reach = -750.0 * (cur - prv).sum(-1)
-    move = -0.1 * (((fk_tips.astype(np.float64) - prev.astype(np.float64)) / 0.02) ** 2).sum((-1, -2))
-    close(eng.reward.cpu().numpy(), reach + move, atol=5e-3, rtol=5e-5, what="finger terms (formula)")
-    # finger_move_penalty depends only on the displacement -> equals the golden term up to the fp32
-    # rounding of (fk - (fk - disp)) ~ 1e-7 m, amplified by (1/dt)^2 * 2 * v
-    got_move = eng.reward.cpu().numpy().astype(np.float64) - reach
-    close(got_move, g["d1_per_term"][0, 1], atol=5e-3, rtol=5e-3, what="finger_move_penalty vs imported reference term")
-    eng.close()
+    """T7 fingertip terms against the IMPORTED reference classes (tests/golden/finger_rewards.npz): the fixture holds joint
+    positions, the fingertip positions the native FK gives for them, and the values of FingerReachObjectRatePenalty
+    (norm_p in {2, 1, 3, inf}, rewards.py:187-235) and FingertipMovementPenalty (:238-270) on those fingertips.  The test
+    replays the joint positions - previous frame, then current frame - and compares fingertips and rewards."""
+    g = golden("finger_rewards")
+    n = g["q"].shape[0]
+    for k, p in enumerate(g["norm_ps"]):
+        for active in ("reach", "move"):
+            terms = {name: {"activate": False} for name in capi.REWARD_TERM_ORDER}
+            if active == "reach":
+                terms["finger_reach_object_rate"] = {"activate": True, "weight": float(g["reach_weight"]), "norm_p": float(p)}
+            elif k == 0:
+                terms["finger_move_penalty"] = {"activate": True, "weight": float(g["move_weight"])}
+            else:
+                continue
+            cfg = make_config(lib, n, command_mode="torque", reward_terms=terms, dt=float(g["dt"]), success={"activate": False})
+            eng = TrifingerEngine(cfg, device=device, lib=lib)
+            eng.q.copy_(T(g["q_prev"].T, device))
+            eng.post_step()                                   # leaves the previous frame's fingertips in the history row
+            sync(device)
+            close(eng.tip_pos.T.cpu().numpy().reshape(n, 3, 3), g["tips_prev"], atol=1e-7, rtol=0, what="FK tips (previous frame)")
+            eng.q.copy_(T(g["q"].T, device))
+            eng.cube.copy_(T(g["obj"].T, device))
+            eng.view(capi.S_PREV_OBJ_P, 7).copy_(T(g["obj_prev"][:, :7].T, device))
+            eng.post_step()
+            sync(device)
+            close(eng.tip_pos.T.cpu().numpy().reshape(n, 3, 3), g["tips"], atol=1e-7, rtol=0, what="FK tips")
+            want = g[f"reach_{k}"] if active == "reach" else g["move"]
+            # values of order 10 built from differences of distances of order 0.1 m times 750: 2e-4 abs is fp32 rounding
+            close(eng.reward.cpu().numpy(), want, atol=3e-4, rtol=2e-5, what=f"{active} term vs imported reference, norm_p={p}")
+            eng.close()
 
 
 def check_termination(lib, device):

@@ -113,8 +113,9 @@ def test_create_rejects_bad_configs(oracle):
         assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_ROBOT_RESET
         cfg = make_config(lib, 4); cfg.object_reset_type = -1
         assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_OBJECT_RESET
-        cfg = make_config(lib, 4); cfg.finger_reach_norm_p = 1
-        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_UNSUPPORTED
+        for bad_p in (0, 17, -2):                          # built: 1..16 and TF_NORM_INF (-1)
+            cfg = make_config(lib, 4); cfg.finger_reach_norm_p = bad_p
+            assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_UNSUPPORTED
         cfg = make_config(lib, 4); cfg.api_version = 99
         assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
         assert lib.tf_step(None, None, None) == capi.TF_ERR_INVALID_ARG

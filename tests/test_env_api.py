@@ -311,3 +311,17 @@ def test_fingertip_history_keeps_the_pre_reset_tips_for_one_step(backend):
                 assert torch.allclose(eng.reward.cpu(), want, rtol=1e-4, atol=2e-4)
                 assert float(eng.reward.abs().max()) < 750 * 0.01     # one step of a resting cube: no jump
         eng.close()
+
+
+def test_finger_reach_norm_p_values(backend):
+    """FingerReachObjectRatePenalty takes any p of torch.norm (rewards.py:190-226); the native step builds the integer ones
+    up to 16 and the maximum norm, and says so for the rest."""
+    for p in (1, 2, 3, float("inf"), "inf"):
+        env = make_env(backend, reward_terms={"finger_reach_object_rate": {"activate": True, "norm_p": p}})
+        env.reset()
+        _, rew, _, _ = env.step(torch.zeros(4, 9))
+        assert torch.isfinite(rew).all()
+        env.close()
+    for p in (2.5, 0, 17):
+        with pytest.raises(ValueError, match="norm_p"):
+            make_env(backend, reward_terms={"finger_reach_object_rate": {"activate": True, "norm_p": p}})
