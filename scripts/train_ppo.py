@@ -35,12 +35,20 @@ def main(argv):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook for boxes with ONE GPU (tests/test_bench_multiproc_gpu.py): every rank on cuda:0, gradients through gloo
+    one_device = os.environ.get("TF_BENCH_SINGLE_DEVICE_TEST", "") == "1"
+    if one_device:
+        local = 0
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
     n = cfg["gym"]["num_instances"]                 # envs per GPU
     env = TrifingerEnv(config=cfg["gym"], device=dev, verbose=False, env_id_offset=rank * n,
                        global_num_instances=world * n)

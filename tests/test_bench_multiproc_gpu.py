@@ -13,15 +13,20 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_print_one_aggregate_line(hip):
+def launch(script_args, nproc=2):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, TF_BENCH_SINGLE_DEVICE_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "100", "--warmup", "5", "--envs", "8192"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port)] + script_args
     p = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    return p
+
+
+def test_two_ranks_print_one_aggregate_line(hip):
+    p = launch(["bench.py", "--gpus", "2", "--steps", "100", "--warmup", "5", "--envs", "8192"])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
@@ -31,3 +36,27 @@ def test_two_ranks_print_one_aggregate_line(hip):
     assert "cpu_baseline" not in d and d["roofline"]["kernel_launches_timed"] > 0
     for k in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
         assert k in d
+
+
+def test_two_ranks_domain_randomisation_with_the_stats_all_reduce(hip):
+    """BASELINE configs[3] per GPU (difficulty 4 + every DR feature, 16384 envs) with the optional episode-statistics
+    all-reduce every 4 steps (EpisodeStatsReducer on its side stream): the exchange the RCCL path runs on a real node."""
+    p = launch(["bench.py", "--gpus", "2", "--steps", "60", "--warmup", "5", "--envs", "16384", "--dr", "--stats-every", "4"])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 16384 and d["config"]["global_envs"] == 32768
+    st = d["episode_stats_all_reduced"]
+    assert len(st) == 11 and all(x == x for x in st)
+    assert st[2] > 0.0                                         # object_dist mean over ALL 32768 envs: a positive kernel value
+    assert 0 <= st[6] <= 32768 and 0 <= st[7] <= 32768         # goal counts are sums over both shards
+
+
+def test_two_rank_ppo_training(hip):
+    """BASELINE configs[4] shape (PPO, env shards, one fused gradient all-reduce per minibatch) with two ranks on one device:
+    both ranks train, rank 0 logs, the job ends cleanly."""
+    p = launch(["scripts/train_ppo.py", "gym=trifinger_difficulty_4", "args.num_envs=1024", "epochs=2"])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("epoch")]
+    assert len(lines) == 2 and "frames/s" in lines[-1]
+    frames = int(lines[-1].split("frames")[1].split()[0])
+    assert frames == 2 * 32 * 1024 * 2                         # epochs x horizon x envs per rank x ranks
