@@ -1189,71 +1189,8 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int j = 0; j < 3; ++j) { LD(L_POSE_A + j) = cp[j]; LD(L_POSE_B + j) = v[j]; LD(L_POSE_B + 3 + j) = w[j]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) LD(L_POSE_A + 3 + j) = cq[j];
-            STAMP(sb_ + 0);
-            BAR();                                              // S1
-            STAMP(sb_ + 1);
-            // ---- FF: finger-finger contacts (distal capsules), frictionless, resolved before the sweeps on the free
-            // velocities: the pairs (0,1), (1,2), (2,0) in turn, one normal row each.  The velocities live in LDS (L_VQFF)
-            // while the pairs are visited. ----
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) LD(L_VQFF + 3 * f + j) = LD(L_REC(f) + P_VQ + j);
-            }
-#pragma unroll 1
-            for (int p = 0; p < 3; ++p) {
-                const int fa = p, fb = (p == 2) ? 0 : p + 1;
-                float Pa[3], Pb[3];
-                {
-                    float Aa[3], Ba[3], Ab[3], Bb[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { Aa[j] = LD(L_REC(fa) + P_AW + j); Ba[j] = LD(L_REC(fa) + P_BW + j); Ab[j] = LD(L_REC(fb) + P_AW + j); Bb[j] = LD(L_REC(fb) + P_BW + j); }
-                    seg_seg(Aa, Ba, Ab, Bb, Pa, Pb);
-                }
-                float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
-                float dist2 = dot3(dv, dv);
-                float inv = f_rsqrt(f_max(dist2, 1e-12f));
-                float dist = dist2 * inv;
-                float gap = dist - 2.0f * m.cap_radius;
-                if ((dist2 > 1e-12f) && (gap < m.contact_margin)) {
-                    float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};       // from finger b to finger a
-                    float Ja[3], Wa[3], Jb[3], Wb[3], va[3], vb[3];
-#pragma unroll
-                    for (int side = 0; side < 2; ++side) {
-                        const int ff_ = side ? fb : fa;
-                        const Yaw yy = {m.base_yaw_cos[ff_], m.base_yaw_sin[ff_], 0.0f, 0.0f, m.base_height};
-                        FingerPubRegs pp;
-                        read_pub(lds, lane, ff_, pp);
-                        float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) C[j] = side ? FMA(m.cap_radius, n[j], Pb[j]) : FMA(-m.cap_radius, n[j], Pa[j]);
-                        world_to_base(yy, C, Cb_);
-                        levers(pp.k, Cb_, L1, L2, L3);
-                        dir_world_to_base(yy, n, nb);
-                        float* J = side ? Jb : Ja;
-                        float* W = side ? Wb : Wa;
-                        float* vv = side ? vb : va;
-                        J[0] = dot3(L1, nb); J[1] = dot3(L2, nb); J[2] = dot3(L3, nb);
-                        sym3_mul(pp.k.Minv, J, W);
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) vv[j] = LD(L_VQFF + 3 * ff_ + j);
-                    }
-                    float vn0 = dot3(Ja, va) - dot3(Jb, vb);
-                    if (contact_live(m, gap, vn0, h)) {
-                        float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
-                        float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja, Wa) + dot3(Jb, Wb)), 0.0f);
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            LD(L_VQFF + 3 * fa + j) = FMA(Wa[j], lam, va[j]);
-                            LD(L_VQFF + 3 * fb + j) = FMA(-Wb[j], lam, vb[j]);
-                        }
-                    }
-                }
-            }
-            STAMP(sb_ + 2);
-            BAR();                                              // S1b: finger-finger pass done
-            STAMP(sb_ + 3);
-            // ---- corner contacts of the cube against the arena (while the finger roles build their rows) ----
+            // ---- corner contacts of the cube against the arena: built BEFORE S1, in the window in which the finger roles compute their
+            // free motion and this role would only wait ----
             float R[9];
             quat_to_rot(cq, R);
             float fr_[12], fDinv[12], fbias[4], flam[12];       // floor corners: arm, 1/D, bias, impulses of rows +z, +x, +y
@@ -1342,6 +1279,70 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             // wave-uniform: no lane of this wavefront has a live wall corner (the usual case) -> the sweeps skip the wall block
             // without its four dependent LDS round trips
             const bool wall_any = __builtin_amdgcn_ballot_w64(wall_lane) != 0ull;
+            STAMP(sb_ + 0);
+            BAR();                                              // S1
+            STAMP(sb_ + 1);
+            // ---- FF: finger-finger contacts (distal capsules), frictionless, resolved before the sweeps on the free
+            // velocities: the pairs (0,1), (1,2), (2,0) in turn, one normal row each.  The velocities live in LDS (L_VQFF)
+            // while the pairs are visited. ----
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) LD(L_VQFF + 3 * f + j) = LD(L_REC(f) + P_VQ + j);
+            }
+#pragma unroll 1
+            for (int p = 0; p < 3; ++p) {
+                const int fa = p, fb = (p == 2) ? 0 : p + 1;
+                float Pa[3], Pb[3];
+                {
+                    float Aa[3], Ba[3], Ab[3], Bb[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { Aa[j] = LD(L_REC(fa) + P_AW + j); Ba[j] = LD(L_REC(fa) + P_BW + j); Ab[j] = LD(L_REC(fb) + P_AW + j); Bb[j] = LD(L_REC(fb) + P_BW + j); }
+                    seg_seg(Aa, Ba, Ab, Bb, Pa, Pb);
+                }
+                float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
+                float dist2 = dot3(dv, dv);
+                float inv = f_rsqrt(f_max(dist2, 1e-12f));
+                float dist = dist2 * inv;
+                float gap = dist - 2.0f * m.cap_radius;
+                if ((dist2 > 1e-12f) && (gap < m.contact_margin)) {
+                    float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};       // from finger b to finger a
+                    float Ja[3], Wa[3], Jb[3], Wb[3], va[3], vb[3];
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        const int ff_ = side ? fb : fa;
+                        const Yaw yy = {m.base_yaw_cos[ff_], m.base_yaw_sin[ff_], 0.0f, 0.0f, m.base_height};
+                        FingerPubRegs pp;
+                        read_pub(lds, lane, ff_, pp);
+                        float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) C[j] = side ? FMA(m.cap_radius, n[j], Pb[j]) : FMA(-m.cap_radius, n[j], Pa[j]);
+                        world_to_base(yy, C, Cb_);
+                        levers(pp.k, Cb_, L1, L2, L3);
+                        dir_world_to_base(yy, n, nb);
+                        float* J = side ? Jb : Ja;
+                        float* W = side ? Wb : Wa;
+                        float* vv = side ? vb : va;
+                        J[0] = dot3(L1, nb); J[1] = dot3(L2, nb); J[2] = dot3(L3, nb);
+                        sym3_mul(pp.k.Minv, J, W);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) vv[j] = LD(L_VQFF + 3 * ff_ + j);
+                    }
+                    float vn0 = dot3(Ja, va) - dot3(Jb, vb);
+                    if (contact_live(m, gap, vn0, h)) {
+                        float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+                        float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja, Wa) + dot3(Jb, Wb)), 0.0f);
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            LD(L_VQFF + 3 * fa + j) = FMA(Wa[j], lam, va[j]);
+                            LD(L_VQFF + 3 * fb + j) = FMA(-Wb[j], lam, vb[j]);
+                        }
+                    }
+                }
+            }
+            STAMP(sb_ + 2);
+            BAR();                                              // S1b: finger-finger pass done
+            STAMP(sb_ + 3);
             STAMP(sb_ + 4);
             BAR();                                              // S3: records published by the finger roles
             STAMP(sb_ + 5);
