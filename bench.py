@@ -41,7 +41,7 @@ N_SIMD = 256 * 4                 # SIMDs of the chip (MI355X_MICROARCH.md: 256 C
 VALU_CYCLES_PER_INST = 2.0       # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs (algorithmic)
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
-KERNEL_NAME = {True: "k_env<9, false, true, 63>", False: "k_env<9, false, false, 63>"}   # fused step, torque/position actions
+KERNEL_NAME = {True: "k_env<9, false, true, 63, false>", False: "k_env<9, false, false, 63, false>"}   # fused step, torque/position actions
 
 
 def load_pmc_profile(n, asym):

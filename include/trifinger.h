@@ -187,7 +187,24 @@ typedef struct TfModel {
     float erp;                    /* fraction of penetration removed per substep                     */
     float max_depenetration_velocity;
     float warm_start;             /* fraction of the previous substep's impulses that seeds the solver */
+    /* The object as a general box (objects/urdf/cube_multicolor_rrc_phase3.urdf, 20 x 80 x 20 mm, density 500).
+     * box == 0: the cube above (isotropic inertia, the fast path); box != 0: half extents and principal moments below,
+     * cube_mass = mass of the box, cube_inertia = the reference scalar I_ref of the inertia-scaled solve. */
+    int32_t box;
+    int32_t box_gyroscopic;       /* free motion includes -w x (I w) (PhysX leaves it out unless asked; default 1 here) */
+    float box_half[3];
+    float box_inertia[3];
+    /* task constants of the object: reference envs/trifinger/utils.py:57-131 (CuboidalObject(size)) */
+    float obj_radius_3d;          /* max(size) sqrt(3) / 2                       0.05629165 for the cube */
+    float obj_max_com_dist;       /* ARENA_RADIUS (0.195) - radius_3d            0.13870835              */
+    float obj_min_height;         /* size_z / 2                                  0.0325                  */
+    float obj_span_min_height;    /* max_height (0.1) - min_height               0.0675   (difficulty 3) */
+    float obj_span_radius;        /* max_height - radius_3d                      0.04370835 (difficulty 4, 5) */
 } TfModel;
+
+/* Fill the box fields of `m` for an object of `size` (x, y, z, metres) and `density` (kg/m^3): mass, principal moments,
+ * reference inertia, CuboidalObject constants.  A cubic size keeps box = 0 when it equals the default cube. */
+void tf_model_set_box(TfModel* m, const float size[3], float density);
 
 typedef struct TfConfig {
     int32_t api_version;          /* TF_API_VERSION */

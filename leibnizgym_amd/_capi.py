@@ -77,6 +77,9 @@ class TfModel(C.Structure):
         ("restitution_finger", C.c_float), ("restitution_ff", C.c_float), ("bounce_threshold", C.c_float),
         ("contact_margin", C.c_float), ("contact_slack", C.c_float), ("contact_offset", C.c_float), ("erp", C.c_float),
         ("max_depenetration_velocity", C.c_float), ("warm_start", C.c_float),
+        ("box", C.c_int32), ("box_gyroscopic", C.c_int32), ("box_half", C.c_float * 3), ("box_inertia", C.c_float * 3),
+        ("obj_radius_3d", C.c_float), ("obj_max_com_dist", C.c_float), ("obj_min_height", C.c_float),
+        ("obj_span_min_height", C.c_float), ("obj_span_radius", C.c_float),
     ]
 
 
@@ -119,6 +122,7 @@ SYMBOLS = {
     "tf_backend_name": (C.c_char_p, []),
     "tf_last_error_string": (C.c_char_p, []),
     "tf_default_model": (None, [C.POINTER(TfModel)]),
+    "tf_model_set_box": (None, [C.POINTER(TfModel), C.POINTER(C.c_float), C.c_float]),
     "tf_action_dim": (C.c_int, [C.c_int32]),
     "tf_scratch_floats": (C.c_int64, [C.c_int32]),
     "tf_create": (C.c_int, [C.POINTER(TfConfig), C.POINTER(_P)]),
@@ -182,6 +186,12 @@ class TfLib:
     def default_model(self):
         m = TfModel()
         self.tf_default_model(C.byref(m))
+        return m
+
+    def box_model(self, size, density):
+        """default model with the object replaced by a box of `size` (x, y, z in metres) and `density` (kg / m^3)"""
+        m = self.default_model()
+        self.tf_model_set_box(C.byref(m), (C.c_float * 3)(*[float(x) for x in size]), float(density))
         return m
 
     def last_error(self):

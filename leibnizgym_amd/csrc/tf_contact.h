@@ -54,10 +54,10 @@ DEV void finger_jac(const Yaw& y, const FK& k, int link, const float Pb[3], cons
 
 // g(s) = d . (x - clamp(x)) with x = a + s d: half the derivative of the squared distance between the segment point x(s)
 // and the box [-hc, hc]^3; monotone non-decreasing and piecewise linear in s
-DEV float seg_box_g(const float a[3], const float d[3], float s, float hc) {
+DEV float seg_box_g(const float a[3], const float d[3], float s, const float hc[3]) {
     float e[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { float x = FMA(s, d[i], a[i]); e[i] = x - f_clamp(x, -hc, hc); }
+    for (int i = 0; i < 3; ++i) { float x = FMA(s, d[i], a[i]); e[i] = x - f_clamp(x, -hc[i], hc[i]); }
     return dot3(d, e);
 }
 // Closest points between the segment a + s (b - a) and the box [-hc, hc]^3 (box frame), exact: g changes slope only where
@@ -65,7 +65,7 @@ DEV float seg_box_g(const float a[3], const float d[3], float s, float hc) {
 // breakpoint with g <= 0 and the first with g > 0 (end points included): one linear interpolation, no iteration, no
 // branches.  x on the segment, y on the box, unit direction nc from y to x, gap = |x - y| - radius.  A segment point inside
 // the box is pushed out through the nearest face.
-DEV void seg_box(const float a[3], const float b[3], float hc, float radius, float& gap_out, float x[3], float y[3], float nc[3]) {
+DEV void seg_box(const float a[3], const float b[3], const float hc[3], float radius, float& gap_out, float x[3], float y[3], float nc[3]) {
     float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     const float g0 = seg_box_g(a, d, 0.0f, hc), g1 = seg_box_g(a, d, 1.0f, hc);
     float lo = 0.0f, glo = g0, hi = 1.0f, ghi = g1;
@@ -77,7 +77,7 @@ DEV void seg_box(const float a[3], const float b[3], float hc, float radius, flo
         inv = (d[i] < 0.0f) ? -inv : inv;
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
-            const float sb = ((side ? hc : -hc) - a[i]) * inv;
+            const float sb = ((side ? hc[i] : -hc[i]) - a[i]) * inv;
             const float gb = seg_box_g(a, d, sb, hc);
             const bool valid = ok && sb > 0.0f && sb < 1.0f;
             const bool take_lo = valid && gb <= 0.0f && sb > lo;
@@ -90,7 +90,7 @@ DEV void seg_box(const float a[3], const float b[3], float hc, float radius, flo
     if (g0 > 0.0f) s = 0.0f;
     if (!(g1 > 0.0f)) s = 1.0f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
+    for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc[i], hc[i]); }
     float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
     float dist2 = dot3(ev, ev);
     if (__builtin_expect(dist2 > 1e-12f, 1)) {
@@ -100,15 +100,15 @@ DEV void seg_box(const float a[3], const float b[3], float hc, float radius, flo
         gap_out = dist - radius;
     } else {
         int bi = 0;
-        float best = f_abs(x[0]) - hc;
-        float p1 = f_abs(x[1]) - hc;
+        float best = f_abs(x[0]) - hc[0];
+        float p1 = f_abs(x[1]) - hc[1];
         if (p1 > best) { best = p1; bi = 1; }
-        float p2 = f_abs(x[2]) - hc;
+        float p2 = f_abs(x[2]) - hc[2];
         if (p2 > best) { best = p2; bi = 2; }
         float xb = (bi == 0) ? x[0] : ((bi == 1) ? x[1] : x[2]);
         float sg = (xb < 0.0f) ? -1.0f : 1.0f;
         nc[0] = (bi == 0) ? sg : 0.0f; nc[1] = (bi == 1) ? sg : 0.0f; nc[2] = (bi == 2) ? sg : 0.0f;
-        y[0] = (bi == 0) ? sg * hc : y[0]; y[1] = (bi == 1) ? sg * hc : y[1]; y[2] = (bi == 2) ? sg * hc : y[2];
+        y[0] = (bi == 0) ? sg * hc[0] : y[0]; y[1] = (bi == 1) ? sg * hc[1] : y[1]; y[2] = (bi == 2) ? sg * hc[2] : y[2];
         gap_out = best - radius;
     }
 }
@@ -140,16 +140,39 @@ DEV float wall_radius_at(const TfModel& m, float z) {
     return r;
 }
 
-DEV void cube_corner(const float R[9], float hc, int k, float sk, int idx, float r[3]) {
-    // axes a < b are the two that are not k
+DEV void cube_corner(const float R[9], const float hc[3], int k, float sk, int idx, float r[3]) {
+    // axes a < b are the two that are not k: bit 0 of idx is the sign along a, bit 1 the sign along b
     float y[3];
-    float sa = (idx & 1) ? hc : -hc;
-    float sb = (idx & 2) ? hc : -hc;
-    float fk_ = sk * hc;
-    y[0] = (k == 0) ? fk_ : sa;
-    y[1] = (k == 1) ? fk_ : ((k == 0) ? sa : sb);
-    y[2] = (k == 2) ? fk_ : sb;
+    const bool pa = (idx & 1) != 0, pb = (idx & 2) != 0;
+    y[0] = (k == 0) ? sk * hc[0] : (pa ? hc[0] : -hc[0]);
+    y[1] = (k == 1) ? sk * hc[1] : (((k == 0) ? pa : pb) ? hc[1] : -hc[1]);
+    y[2] = (k == 2) ? sk * hc[2] : (pb ? hc[2] : -hc[2]);
     mat3_mul(R, y, r);
+}
+
+// ---- general box (TfModel.box): rows with explicit arms in INERTIA-SCALED angular coordinates (oracle: same names).  With
+// S = R diag(sqrt(I_ref / I_k)) R^T the substitution w = S w^, a^ = S a keeps every row in the isotropic form with
+// inv_I = 1 / I_ref; only its arm is S (r x n) instead of r x n.
+DEV void box_arm(const float S[6], const float r[3], const float n[3], float a[3]) {
+    float c[3];
+    cross3(r, n, c);
+    sym3_mul(S, c, a);
+}
+DEV float g_vrel(const float n[3], const float a[3], const float v[3], const float w[3]) { return dot3(n, v) + dot3(a, w); }
+DEV void g_apply(const float n[3], const float a[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
+    float s = dl * inv_m, q = dl * inv_I;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { v[j] = FMA(n[j], s, v[j]); w[j] = FMA(a[j], q, w[j]); }
+}
+DEV void rot_diag_rot(const float R[9], const float s[3], float S[6]) {     // R diag(s) R^T as 00 01 02 11 12 22
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int i = (e < 3) ? 0 : ((e < 5) ? 1 : 2), j = (e < 3) ? e : ((e < 5) ? e - 2 : 2);
+        S[e] = FMA(R[3 * i + 2] * s[2], R[3 * j + 2], FMA(R[3 * i + 1] * s[1], R[3 * j + 1], (R[3 * i] * s[0]) * R[3 * j]));
+    }
+}
+DEV void box_axis(int d, float n[3]) {        // rows +z, +x, +y of a floor corner
+    n[0] = (d == 1) ? 1.0f : 0.0f; n[1] = (d == 2) ? 1.0f : 0.0f; n[2] = (d == 0) ? 1.0f : 0.0f;
 }
 
 // axis-aligned rows of a cube corner with arm r: direction +z / +x / +y.  *_vrel: relative velocity of the row, *_apply:

@@ -49,6 +49,8 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 #define L_VQFF 138                      //   9: joint velocities after the finger-finger pass; then Dinv[3] of finger f at 3 f
 #define L_INIT 147                      //   3: bias of finger f; after the last sweep the normal impulse of finger f
 #define LDS_SLOTS 150
+#define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
+#define LDS_SLOTS_BOX 156
 // post phase (aliases the above)
 #define L_XCH (MAX_STATES)              //  18: fingertip position (3) and previous fingertip position (3) of finger f at 6 f
 #define L_NAN (MAX_STATES + 18)         //   4: non-finite flag of each role
@@ -164,9 +166,7 @@ DEV void normalize_quat(const float n[4], float q[4]) {                         
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = n[i] * inv;
 }
-#define CUBE_RADIUS_3D 0.05629165f      // CuboidalObject(0.065).radius_3d, reference envs/trifinger/utils.py:122-131
-#define CUBE_MAX_COM_DIST 0.13870835f
-#define CUBE_MIN_HEIGHT 0.0325f
+// the CuboidalObject numbers of the reference (envs/trifinger/utils.py:122-131) come with the model: TfModel.obj_*
 
 DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, float gp[3], float gq[4], float gw[3]) {   // trifinger_env.py:1194-1265
     int d = P.task_difficulty;
@@ -174,11 +174,11 @@ DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, float gp[
     rng4(P, gid, count, RNG_GOAL_POS, u);
     float x = 0.0f, y = 0.0f, z;
     float quat[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-    if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, x, y);
-    if (d == -1 || d == 1) z = CUBE_MIN_HEIGHT;
-    else if (d == 2 || d == 6) z = CUBE_MIN_HEIGHT + 0.05f;
-    else if (d == 3) z = 0.0675f * u[2] + CUBE_MIN_HEIGHT;
-    else z = 0.04370835f * u[2] + CUBE_RADIUS_3D;
+    if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], P.m.obj_max_com_dist, x, y);
+    if (d == -1 || d == 1) z = P.m.obj_min_height;
+    else if (d == 2 || d == 6) z = P.m.obj_min_height + 0.05f;
+    else if (d == 3) z = P.m.obj_span_min_height * u[2] + P.m.obj_min_height;
+    else z = P.m.obj_span_radius * u[2] + P.m.obj_radius_3d;
     if (d == -1) sample_yaw_quat(u[3], quat);
     if (d == 4 || d == 5 || d == 6) {
         float v[4], n[4];
@@ -289,7 +289,7 @@ struct TipContact {            // fingertip sphere against one feature of the ar
     float arm[3];             // contact point relative to the tip-link origin (fingertip wrench sensor)
 };
 
-template <int A, bool IS_RESET, bool ASYM, int MODE>
+template <int A, bool IS_RESET, bool ASYM, int MODE, bool BOX>
 DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
     const TfModel& m = P.m;
     const int f = cx.role, lane = cx.lane;
@@ -482,7 +482,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             const float mu_fc = m.mu_finger_cube * dr[2], mu_tf = m.mu_tip_floor * dr[2], mu_tw = m.mu_tip_wall * dr[2];
             const float rest_f = m.restitution_finger * dr[5];
             const float ws = m.warm_start;
-            const float hc = m.cube_half * dr[1];
+            constexpr bool box = BOX;      // general box object: its own kernel instantiation, the cube kernels carry none of it
+            float hc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) hc[j] = (box ? m.box_half[j] : m.cube_half) * dr[1];
             // ---- F1: free motion ----
             FK k;
             float vq[3], Aw[3], Bw[3], Tw[3];
@@ -599,6 +602,17 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 finger_jac(yw, k, link, Pb, dir, J, W, Dd);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) cross3(rcv, &dir[3 * d], &rxd[3 * d]);
+                if (__builtin_expect(box, 0)) {                 // general box: inertia-scaled arms S (r x d)
+                    float S[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) S[e] = LD(L_POSE_S + e);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        float t[3];
+                        sym3_mul(S, &rxd[3 * d], t);
+                        rxd[3 * d] = t[0]; rxd[3 * d + 1] = t[1]; rxd[3 * d + 2] = t[2];
+                    }
+                }
                 float vn0 = dot3(&J[0], vq) - (dot3(&dir[0], cvf) + dot3(&rxd[0], cwf));
                 if (contact_live(m, gap, vn0, h)) {
                     cur_link = link;
@@ -1040,7 +1054,23 @@ DEV void read_pub(const float* lds, int lane, int f, FingerPubRegs& p) {
     p.k.ax[0] = p.k.c1; p.k.ax[1] = 0.0f; p.k.ax[2] = -p.k.s1;
 }
 
-template <int A, bool IS_RESET, bool ASYM, int MODE>
+// arms of the three rows of a wall corner: r x n, r x t and (box only) r x z, inertia-scaled for a box (S from LDS)
+DEV void wall_arms(bool box, const float* lds, int lane, const float r[3], const float n[2], float a[3], float b[3], float c3[3]) {
+    wall_arm_n(r, n, a);
+    wall_arm_t(r, n, b);
+    c3[0] = 0.0f; c3[1] = 0.0f; c3[2] = 0.0f;
+    if (__builtin_expect(box, 0)) {
+        float S[6], t[3], ez[3];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) S[e] = LD(L_POSE_S + e);
+        sym3_mul(S, a, t); a[0] = t[0]; a[1] = t[1]; a[2] = t[2];
+        sym3_mul(S, b, t); b[0] = t[0]; b[1] = t[1]; b[2] = t[2];
+        box_axis(0, ez);
+        box_arm(S, r, ez, c3);
+    }
+}
+
+template <int A, bool IS_RESET, bool ASYM, int MODE, bool BOX>
 DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
     const TfModel& m = P.m;
     const int lane = cx.lane;
@@ -1088,15 +1118,15 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         if (rflag) {
             if (P.dr_enable) draw_dr(P, gid, count, dr);
             if (P.object_reset_type == TF_RESET_DEFAULT) {
-                cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = CUBE_MIN_HEIGHT * dr[1];
+                cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = m.obj_min_height * dr[1];
                 cq[0] = 0.0f; cq[1] = 0.0f; cq[2] = 0.0f; cq[3] = 1.0f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
             } else if (P.object_reset_type == TF_RESET_RANDOM) {
                 float u[4];
                 rng4(P, gid, count, RNG_OBJECT, u);
-                sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, cp[0], cp[1]);
-                cp[2] = (0.065f / 2.0f) * dr[1];
+                sample_xy(u[0], u[1], m.obj_max_com_dist, cp[0], cp[1]);
+                cp[2] = m.obj_min_height * dr[1];
                 sample_yaw_quat(u[2], cq);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
@@ -1174,15 +1204,43 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             const float mu_cf = m.mu_cube_floor * dr[2], mu_cw = m.mu_cube_wall * dr[2];
             const float rest_ff = m.restitution_ff * dr[5];
             const float ws = m.warm_start;
-            const float hc = m.cube_half * dr[1];
+            constexpr bool box = BOX;      // general box object: its own kernel instantiation, the cube kernels carry none of it
+            float hc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) hc[j] = (box ? m.box_half[j] : m.cube_half) * dr[1];
             // ---- C1: free motion of the cube, corner contacts against the arena ----
             float v[3], w[3];
+            float R[9];
+            quat_to_rot(cq, R);
             {
+                float wf[3] = {cw[0], cw[1], cw[2]};
+                if (__builtin_expect(box && m.box_gyroscopic, 0)) {   // Euler's equations in the body frame, explicit
+                    float wb[3], Iw[3], tq[3];
+                    mat3T_mul(R, wf, wb);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) Iw[k] = m.box_inertia[k] * wb[k];
+                    cross3(Iw, wb, tq);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wb[k] = FMA(h, tq[k] / m.box_inertia[k], wb[k]);
+                    mat3_mul(R, wb, wf);
+                }
                 float dl = 1.0f - h * m.cube_linear_damping, da = 1.0f - h * m.cube_angular_damping;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     v[j] = FMA(h, P.grav[j], cv[j]) * dl;
-                    w[j] = cw[j] * da;
+                    w[j] = wf[j] * da;
+                }
+                if (__builtin_expect(box, 0)) {                 // from here to the integration `w` is the inertia-scaled w^ = S^-1 w
+                    float sc[3], si[3], S[6], Sinv[6], wh[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { sc[k] = f_sqrt(m.cube_inertia / m.box_inertia[k]); si[k] = 1.0f / sc[k]; }
+                    rot_diag_rot(R, sc, S);
+                    rot_diag_rot(R, si, Sinv);
+                    sym3_mul(Sinv, w, wh);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) w[j] = wh[j];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) LD(L_POSE_S + e) = S[e];
                 }
             }
 #pragma unroll
@@ -1191,14 +1249,17 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int j = 0; j < 4; ++j) LD(L_POSE_A + 3 + j) = cq[j];
             // ---- corner contacts of the cube against the arena: built BEFORE S1, in the window in which the finger roles compute their
             // free motion and this role would only wait ----
-            float R[9];
-            quat_to_rot(cq, R);
             float fr_[12], fDinv[12], fbias[4], flam[12];       // floor corners: arm, 1/D, bias, impulses of rows +z, +x, +y
             {   // cube vs floor: the four corners of the face that points down most
                 int k = 0;
-                float best = f_abs(R[6]);
-                if (f_abs(R[7]) > best) { best = f_abs(R[7]); k = 1; }
-                if (f_abs(R[8]) > best) { best = f_abs(R[8]); k = 2; }
+                float down[3] = {f_abs(R[6]), f_abs(R[7]), f_abs(R[8])};
+                if (__builtin_expect(box, 0)) {                 // the four lowest corners of a box
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) down[j] = down[j] * hc[j];
+                }
+                float best = down[0];
+                if (down[1] > best) { best = down[1]; k = 1; }
+                if (down[2] > best) { best = down[2]; k = 2; }
                 float rk = (k == 0) ? R[6] : ((k == 1) ? R[7] : R[8]);
                 float sk = (rk > 0.0f) ? -1.0f : 1.0f;
                 const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
@@ -1212,11 +1273,26 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     fDinv[3 * c] = 0.0f; fDinv[3 * c + 1] = 0.0f; fDinv[3 * c + 2] = 0.0f;
                     fbias[c] = 0.0f;
                     flam[3 * c] = 0.0f; flam[3 * c + 1] = 0.0f; flam[3 * c + 2] = 0.0f;
-                    const float vn0 = cz_vrel(r, v, w);
+                    float vn0, barm[9];
+                    if (__builtin_expect(box, 0)) {
+                        float S[6];
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) S[e] = LD(L_POSE_S + e);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) { float n[3]; box_axis(d, n); box_arm(S, r, n, &barm[3 * d]); }
+                        float n0[3];
+                        box_axis(0, n0);
+                        vn0 = g_vrel(n0, &barm[0], v, w);
+                    } else vn0 = cz_vrel(r, v, w);
                     if (__builtin_expect(contact_live(m, gap, vn0, h), 1)) {
-                        fDinv[3 * c] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
-                        fDinv[3 * c + 1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
-                        fDinv[3 * c + 2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
+                        if (__builtin_expect(box, 0)) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) fDinv[3 * c + d] = f_rcp2(FMA(dot3(&barm[3 * d], &barm[3 * d]), inv_I, inv_m));
+                        } else {
+                            fDinv[3 * c] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                            fDinv[3 * c + 1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
+                            fDinv[3 * c + 2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
+                        }
                         fbias[c] = contact_bias(m, gap, vn0, inv_h, 0.0f);
 #pragma unroll
                         for (int d = 0; d < 3; ++d) flam[3 * c + d] = lam_cf[3 * c + d] * keep;
@@ -1235,9 +1311,14 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
                 for (int j = 0; j < 3; ++j) pr[j] = FMA(R[j], dx, R[3 + j] * dy);
                 int k = 0;
-                float best = f_abs(pr[0]);
-                if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
-                if (f_abs(pr[2]) > best) { best = f_abs(pr[2]); k = 2; }
+                float out[3] = {f_abs(pr[0]), f_abs(pr[1]), f_abs(pr[2])};
+                if (__builtin_expect(box, 0)) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) out[j] = out[j] * hc[j];
+                }
+                float best = out[0];
+                if (out[1] > best) { best = out[1]; k = 1; }
+                if (out[2] > best) { best = out[2]; k = 2; }
                 float pk = (k == 0) ? pr[0] : ((k == 1) ? pr[1] : pr[2]);
                 float sk = (pk < 0.0f) ? -1.0f : 1.0f;
                 const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
@@ -1256,15 +1337,14 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     float gap = wall_radius_at(m, pz) - rho;
                     if (__builtin_expect(any && gap < m.contact_margin && rho > 1e-6f, 0)) {
                         float nn[2] = {-px * inv, -py * inv};
-                        float a[3], b[3];
-                        wall_arm_n(r, nn, a);
-                        wall_arm_t(r, nn, b);
+                        float a[3], b[3], c3[3];
+                        wall_arms(box, lds, lane, r, nn, a, b, c3);
                         const float vn0 = wn_vrel(nn, a, v, w);
                         if (contact_live(m, gap, vn0, h)) {
                             n[0] = nn[0]; n[1] = nn[1];
                             Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
                             Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
-                            Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                            Dinv[2] = box ? f_rcp2(FMA(dot3(c3, c3), inv_I, inv_m)) : f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                             bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
 #pragma unroll
                             for (int d = 0; d < 3; ++d) lam[d] = LD(wb + 9 + d) * keep;
@@ -1369,9 +1449,22 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (fDinv[3 * c] > 0.0f) {
-                    cz_apply(&fr_[3 * c], flam[3 * c], inv_m, inv_I, v, w);
-                    cx_apply(&fr_[3 * c], flam[3 * c + 1], inv_m, inv_I, v, w);
-                    cy_apply(&fr_[3 * c], flam[3 * c + 2], inv_m, inv_I, v, w);
+                    if (__builtin_expect(box, 0)) {
+                        float S[6];
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) S[e] = LD(L_POSE_S + e);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            float n[3], a[3];
+                            box_axis(d, n);
+                            box_arm(S, &fr_[3 * c], n, a);
+                            g_apply(n, a, flam[3 * c + d], inv_m, inv_I, v, w);
+                        }
+                    } else {
+                        cz_apply(&fr_[3 * c], flam[3 * c], inv_m, inv_I, v, w);
+                        cx_apply(&fr_[3 * c], flam[3 * c + 1], inv_m, inv_I, v, w);
+                        cy_apply(&fr_[3 * c], flam[3 * c + 2], inv_m, inv_I, v, w);
+                    }
                 }
             }
             if (__builtin_expect(wall_any, 0)) {
@@ -1380,12 +1473,12 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 const int wb = L_WALL + 12 * c;
                 if (LD(wb + 5) > 0.0f) {
                     float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
-                    float a[3], b[3];
-                    wall_arm_n(r, n, a);
-                    wall_arm_t(r, n, b);
+                    float a[3], b[3], c3[3];
+                    wall_arms(box, lds, lane, r, n, a, b, c3);
                     wn_apply(n, a, LD(wb + 9), inv_m, inv_I, v, w);
                     wt_apply(n, b, LD(wb + 10), inv_m, inv_I, v, w);
-                    cz_apply(r, LD(wb + 11), inv_m, inv_I, v, w);
+                    if (__builtin_expect(box, 0)) { float ez[3]; box_axis(0, ez); g_apply(ez, c3, LD(wb + 11), inv_m, inv_I, v, w); }
+                    else cz_apply(r, LD(wb + 11), inv_m, inv_I, v, w);
                 }
             }
             }
@@ -1442,6 +1535,23 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                   // cube - floor: rows +z (normal), +x, +y
                     const float* r = &fr_[3 * c];
+                    if (__builtin_expect(box, 0)) {
+                        if (fDinv[3 * c] > 0.0f) {
+                            float S[6];
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) S[e] = LD(L_POSE_S + e);
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                float n[3], a[3];
+                                box_axis(d, n);
+                                box_arm(S, r, n, a);
+                                const float vrel = g_vrel(n, a, v, w);
+                                const float dlb = (d == 0) ? solve_normal(flam[3 * c], fDinv[3 * c], vrel, fbias[c])
+                                                           : solve_tangent(flam[3 * c + d], fDinv[3 * c + d], vrel, mu_cf * flam[3 * c]);
+                                g_apply(n, a, dlb, inv_m, inv_I, v, w);
+                            }
+                        }
+                    } else
                     if (fDinv[3 * c] > 0.0f) {
                         float dl = solve_normal(flam[3 * c], fDinv[3 * c], cz_vrel(r, v, w), fbias[c]);
                         cz_apply(r, dl, inv_m, inv_I, v, w);
@@ -1461,15 +1571,21 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                         float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
                         float Dinv[3] = {D0, LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
                         float lam[3] = {LD(wb + 9), LD(wb + 10), LD(wb + 11)};
-                        float a[3], b[3];
-                        wall_arm_n(r, n, a);
-                        wall_arm_t(r, n, b);
+                        float a[3], b[3], c3[3];
+                        wall_arms(box, lds, lane, r, n, a, b, c3);
                         float dl = solve_normal(lam[0], Dinv[0], wn_vrel(n, a, v, w), bias);
                         wn_apply(n, a, dl, inv_m, inv_I, v, w);
                         dl = solve_tangent(lam[1], Dinv[1], wt_vrel(n, b, v, w), mu_cw * lam[0]);
                         wt_apply(n, b, dl, inv_m, inv_I, v, w);
-                        dl = solve_tangent(lam[2], Dinv[2], cz_vrel(r, v, w), mu_cw * lam[0]);
-                        cz_apply(r, dl, inv_m, inv_I, v, w);
+                        if (__builtin_expect(box, 0)) {
+                            float ez[3];
+                            box_axis(0, ez);
+                            dl = solve_tangent(lam[2], Dinv[2], g_vrel(ez, c3, v, w), mu_cw * lam[0]);
+                            g_apply(ez, c3, dl, inv_m, inv_I, v, w);
+                        } else {
+                            dl = solve_tangent(lam[2], Dinv[2], cz_vrel(r, v, w), mu_cw * lam[0]);
+                            cz_apply(r, dl, inv_m, inv_I, v, w);
+                        }
 #pragma unroll
                         for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
                     }
@@ -1484,6 +1600,14 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             // ---- impulses kept for the next substep, integration ----
 #pragma unroll
             for (int j = 0; j < 12; ++j) lam_cf[j] = flam[j];
+            if (__builtin_expect(box, 0)) {                     // back to the world angular velocity: w = S w^
+                float S[6], ww[3];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) S[e] = LD(L_POSE_S + e);
+                sym3_mul(S, w, ww);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w[j] = ww[j];
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 cv[j] = v[j]; cw[j] = w[j];
@@ -1535,7 +1659,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         STAMP(32);
         const bool guarded = (LD(L_NAN) + LD(L_NAN + 1) + LD(L_NAN + 2) + LD(L_NAN + 3)) != 0.0f;
         if (__builtin_expect(guarded, 0)) {     // a non-finite env is flagged for reset and parked at the default pose
-            cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = CUBE_MIN_HEIGHT;
+            cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = m.obj_min_height;
             cq[0] = 0.0f; cq[1] = 0.0f; cq[2] = 0.0f; cq[3] = 1.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }

@@ -33,9 +33,9 @@
 #define SCR_STRIDE TF_SCR_STRIDE
 
 // One launch = one or more hooks of the reference step (MODE) for every env of the handle.
-template <int A, bool IS_RESET, bool ASYM, int MODE>
+template <int A, bool IS_RESET, bool ASYM, int MODE, bool BOX>
 __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_SLOTS * WAVE];
+    __shared__ __attribute__((aligned(16))) float lds[(BOX ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
     const DevParams& P = *Pp;
     Ctx cx;
     cx.tid = (int)threadIdx.x;
@@ -47,12 +47,12 @@ __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp,
     cx.i = cx.valid ? i_raw : (P.N - 1);
     cx.n_valid = (P.N - cx.wave_first < WAVE) ? (P.N - cx.wave_first) : WAVE;
 #if defined(TF_ONLY_FINGER)      // developer builds for per-role resource analysis (make resource-usage-roles)
-    finger_role<A, IS_RESET, ASYM, MODE>(P, sa, action, lds, cx);
+    finger_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
 #elif defined(TF_ONLY_CUBE)
-    cube_role<A, IS_RESET, ASYM, MODE>(P, sa, action, lds, cx);
+    cube_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
 #else
-    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE>(P, sa, action, lds, cx);
-    else finger_role<A, IS_RESET, ASYM, MODE>(P, sa, action, lds, cx);
+    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
+    else finger_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
 #endif
 }
 
@@ -249,6 +249,38 @@ void tf_default_model(TfModel* m) {
     m->erp = 0.2f;
     m->warm_start = 0.9f;
     m->max_depenetration_velocity = 1000.0f;
+    m->box = 0;
+    m->box_gyroscopic = 1;
+    m->box_half[0] = 0.0325f; m->box_half[1] = 0.0325f; m->box_half[2] = 0.0325f;
+    m->box_inertia[0] = m->cube_inertia; m->box_inertia[1] = m->cube_inertia; m->box_inertia[2] = m->cube_inertia;
+    m->obj_radius_3d = 0.05629165f;       // CuboidalObject(0.065): reference envs/trifinger/utils.py:122-131
+    m->obj_max_com_dist = 0.13870835f;
+    m->obj_min_height = 0.0325f;
+    m->obj_span_min_height = 0.0675f;
+    m->obj_span_radius = 0.04370835f;
+}
+
+// The object as a general box: mass, principal moments about the body axes, reference inertia of the scaled solve (the mean
+// of the principal moments), CuboidalObject constants (reference envs/trifinger/utils.py:122-131, ARENA_RADIUS :54).
+void tf_model_set_box(TfModel* m, const float size[3], float density) {
+    const double sx = size[0], sy = size[1], sz = size[2];
+    const double mass = (double)density * sx * sy * sz;
+    const double I[3] = {mass * (sy * sy + sz * sz) / 12.0, mass * (sx * sx + sz * sz) / 12.0, mass * (sx * sx + sy * sy) / 12.0};
+    m->box = 1;
+    m->box_gyroscopic = 1;
+    m->box_half[0] = (float)(0.5 * sx); m->box_half[1] = (float)(0.5 * sy); m->box_half[2] = (float)(0.5 * sz);
+    for (int i = 0; i < 3; ++i) m->box_inertia[i] = (float)I[i];
+    m->cube_mass = (float)mass;
+    m->cube_inertia = (float)((I[0] + I[1] + I[2]) / 3.0);
+    m->cube_half = (float)(0.5 * sz);
+    double max_len = sx > sy ? sx : sy;
+    if (sz > max_len) max_len = sz;
+    const double radius_3d = max_len * sqrt(3.0) / 2.0;
+    m->obj_radius_3d = (float)radius_3d;
+    m->obj_max_com_dist = (float)(0.195 - radius_3d);
+    m->obj_min_height = (float)(sz / 2.0);
+    m->obj_span_min_height = (float)(0.1 - sz / 2.0);
+    m->obj_span_radius = (float)(0.1 - radius_3d);
 }
 
 // scale tables: reference trifinger_env.py:153-213 (limits) and :655-710 (concatenation order)
@@ -449,17 +481,23 @@ static inline int n_waves(const TfHandle_* h) { return (h->cfg.num_envs + WAVE -
         if (e_ != hipSuccess) return hip_fail(e_, what);           \
     } while (0)
 
-template <int MODE, bool IS_RESET>
-static void launch_env(TfHandle_* h, const float* action, hipStream_t s) {
+template <int MODE, bool IS_RESET, bool BOX>
+static void launch_env_obj(TfHandle_* h, const float* action, hipStream_t s) {
     dim3 grid(n_waves(h)), block(NT);
     const bool asym = h->cfg.asymmetric_obs != 0;
     if (h->action_dim == 9) {
-        if (asym) hipLaunchKernelGGL((k_env<9, IS_RESET, true, MODE>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<9, IS_RESET, false, MODE>), grid, block, 0, s, h->d_params, h->sa, action);
+        if (asym) hipLaunchKernelGGL((k_env<9, IS_RESET, true, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
+        else hipLaunchKernelGGL((k_env<9, IS_RESET, false, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
     } else {
-        if (asym) hipLaunchKernelGGL((k_env<18, IS_RESET, true, MODE>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE>), grid, block, 0, s, h->d_params, h->sa, action);
+        if (asym) hipLaunchKernelGGL((k_env<18, IS_RESET, true, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
+        else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
     }
+}
+// the general box object (TfModel.box) has its own instantiations: the cube kernels stay exactly what they were
+template <int MODE, bool IS_RESET>
+static void launch_env(TfHandle_* h, const float* action, hipStream_t s) {
+    if (h->cfg.model.box) launch_env_obj<MODE, IS_RESET, true>(h, action, s);
+    else launch_env_obj<MODE, IS_RESET, false>(h, action, s);
 }
 
 static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStream_t s) {

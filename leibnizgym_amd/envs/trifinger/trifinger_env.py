@@ -153,7 +153,11 @@ class TrifingerEnv(IsaacEnvBase):
             # with gymapi's default of 2.  "native.substeps" overrides it explicitly.
             substeps=int(native.get("substeps", 2)),
             solver_iterations=int(c["sim"]["physx"]["num_position_iterations"]),
-            gravity=c["sim"]["gravity"], domain_randomization=c.get("domain_randomization"))
+            gravity=c["sim"]["gravity"], domain_randomization=c.get("domain_randomization"),
+            # "native.object_size" (x, y, z in metres) / "native.object_density": a general box instead of the 65 mm cube,
+            # e.g. [0.02, 0.08, 0.02] / 500 for objects/urdf/cube_multicolor_rrc_phase3.urdf of the reference's assets
+            model=(lib.box_model(native["object_size"], native.get("object_density", 500.0))
+                   if native.get("object_size") is not None else None))
         return TrifingerEngine(cfg, device=self.device, lib=lib)
 
     def _configure_mdp_spaces(self):

@@ -390,6 +390,38 @@ void tf_default_model(TfModel* m) {
     m->erp = 0.2f;
     m->warm_start = 0.9f;
     m->max_depenetration_velocity = 1000.0f;
+    m->box = 0;
+    m->box_gyroscopic = 1;
+    m->box_half[0] = 0.0325f; m->box_half[1] = 0.0325f; m->box_half[2] = 0.0325f;
+    m->box_inertia[0] = m->cube_inertia; m->box_inertia[1] = m->cube_inertia; m->box_inertia[2] = m->cube_inertia;
+    m->obj_radius_3d = 0.05629165f;       /* CuboidalObject(0.065): reference envs/trifinger/utils.py:122-131 */
+    m->obj_max_com_dist = 0.13870835f;
+    m->obj_min_height = 0.0325f;
+    m->obj_span_min_height = 0.0675f;
+    m->obj_span_radius = 0.04370835f;
+}
+
+/* The object as a general box: mass, principal moments about the body axes, reference inertia of the scaled solve (the mean
+ * of the principal moments), CuboidalObject constants (reference envs/trifinger/utils.py:122-131, ARENA_RADIUS :54). */
+void tf_model_set_box(TfModel* m, const float size[3], float density) {
+    const double sx = size[0], sy = size[1], sz = size[2];
+    const double mass = (double)density * sx * sy * sz;
+    const double I[3] = {mass * (sy * sy + sz * sz) / 12.0, mass * (sx * sx + sz * sz) / 12.0, mass * (sx * sx + sy * sy) / 12.0};
+    m->box = 1;
+    m->box_gyroscopic = 1;
+    m->box_half[0] = (float)(0.5 * sx); m->box_half[1] = (float)(0.5 * sy); m->box_half[2] = (float)(0.5 * sz);
+    for (int i = 0; i < 3; ++i) m->box_inertia[i] = (float)I[i];
+    m->cube_mass = (float)mass;
+    m->cube_inertia = (float)((I[0] + I[1] + I[2]) / 3.0);
+    m->cube_half = (float)(0.5 * sz);
+    double max_len = sx > sy ? sx : sy;
+    if (sz > max_len) max_len = sz;
+    const double radius_3d = max_len * sqrt(3.0) / 2.0;
+    m->obj_radius_3d = (float)radius_3d;
+    m->obj_max_com_dist = (float)(0.195 - radius_3d);
+    m->obj_min_height = (float)(sz / 2.0);
+    m->obj_span_min_height = (float)(0.1 - sz / 2.0);
+    m->obj_span_radius = (float)(0.1 - radius_3d);
 }
 
 /* scale tables: trifinger_env.py:153-213 (limits), :655-710 (concatenation order) */
@@ -806,19 +838,19 @@ static void finger_jac(const TfModel* m, int f, const FK* k, int link, const flo
 
 /* g(s) = d . (x - clamp(x)) with x = a + s d: half the derivative of the squared distance between the segment point
  * x(s) and the box [-hc, hc]^3; monotone non-decreasing and piecewise linear in s */
-static inline float seg_box_g(const float a[3], const float d[3], float s, float hc) {
+static inline float seg_box_g(const float a[3], const float d[3], float s, const float hc[3]) {
     float e[3];
-    for (int i = 0; i < 3; ++i) { float x = FMA(s, d[i], a[i]); e[i] = x - f_clamp(x, -hc, hc); }
+    for (int i = 0; i < 3; ++i) { float x = FMA(s, d[i], a[i]); e[i] = x - f_clamp(x, -hc[i], hc[i]); }
     return dot3(d, e);
 }
-/* Closest points between the segment a + s (b - a) and the box [-hc, hc]^3, all in the box frame, EXACT: g changes
+/* Closest points between the segment a + s (b - a) and the box prod_i [-hc[i], hc[i]], all in the box frame, EXACT: g changes
  * slope only where a coordinate of x(s) crosses +-hc (at most six breakpoints), so the root of g lies on the straight
  * piece between the last breakpoint with g <= 0 and the first with g > 0 (end points included) and is found by one
  * linear interpolation - no iteration (4 alternating projections, the round-1 method, were off by up to 18 mm when the
  * segment runs nearly parallel to a face; tests/test_contact_lcp_reference.py caught it).  x on the segment, y on the
  * box, unit direction nc from y to x, gap = |x - y| - radius.  A segment point inside the box is pushed out through
  * the nearest face. */
-static void seg_box(const float a[3], const float b[3], float hc, float radius, float* gap_out, float x[3], float y[3],
+static void seg_box(const float a[3], const float b[3], const float hc[3], float radius, float* gap_out, float x[3], float y[3],
                     float nc[3]) {
     float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     const float g0 = seg_box_g(a, d, 0.0f, hc), g1 = seg_box_g(a, d, 1.0f, hc);
@@ -829,7 +861,7 @@ static void seg_box(const float a[3], const float b[3], float hc, float radius, 
         float inv = ok ? f_rcp(ad) : 0.0f;
         inv = (d[i] < 0.0f) ? -inv : inv;
         for (int side = 0; side < 2; ++side) {
-            const float sb = ((side ? hc : -hc) - a[i]) * inv;
+            const float sb = ((side ? hc[i] : -hc[i]) - a[i]) * inv;
             const float gb = seg_box_g(a, d, sb, hc);
             const int valid = ok && sb > 0.0f && sb < 1.0f;
             if (valid && gb <= 0.0f && sb > lo) { lo = sb; glo = gb; }
@@ -839,7 +871,7 @@ static void seg_box(const float a[3], const float b[3], float hc, float radius, 
     float s = f_clamp(FMA(-glo, (hi - lo) * f_rcp(f_max(ghi - glo, 1e-30f)), lo), lo, hi);
     if (g0 > 0.0f) s = 0.0f;
     if (!(g1 > 0.0f)) s = 1.0f;
-    for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc, hc); }
+    for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc[i], hc[i]); }
     float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
     float dist2 = dot3(ev, ev);
     if (dist2 > 1e-12f) {
@@ -849,15 +881,15 @@ static void seg_box(const float a[3], const float b[3], float hc, float radius, 
         *gap_out = dist - radius;
     } else {
         int bi = 0;
-        float best = f_abs(x[0]) - hc;
+        float best = f_abs(x[0]) - hc[0];
         for (int i = 1; i < 3; ++i) {
-            float p = f_abs(x[i]) - hc;
+            float p = f_abs(x[i]) - hc[i];
             if (p > best) { best = p; bi = i; }
         }
         nc[0] = 0.0f; nc[1] = 0.0f; nc[2] = 0.0f;
         float sg = (x[bi] < 0.0f) ? -1.0f : 1.0f;
         nc[bi] = sg;
-        y[bi] = sg * hc;
+        y[bi] = sg * hc[bi];
         *gap_out = best - radius;
     }
 }
@@ -889,15 +921,39 @@ static float wall_radius_at(const TfModel* m, float z) {
     return r;
 }
 
-static void cube_corner(const float R[9], float hc, int k, float sk, int idx, float r[3]) {
+static void cube_corner(const float R[9], const float hc[3], int k, float sk, int idx, float r[3]) {
     int a = (k + 1) % 3, b = (k + 2) % 3;
     float y[3];
     if (a > b) { int t = a; a = b; b = t; }
-    y[k] = sk * hc;
-    y[a] = (idx & 1) ? hc : -hc;
-    y[b] = (idx & 2) ? hc : -hc;
+    y[k] = sk * hc[k];
+    y[a] = (idx & 1) ? hc[a] : -hc[a];
+    y[b] = (idx & 2) ? hc[b] : -hc[b];
     mat3_mul(R, y, r);
 }
+
+/* ---- general box (TfModel.box): rows with explicit arms in INERTIA-SCALED angular coordinates.  With the principal moments
+ * I_k, a reference scalar I_ref and S = R diag(sqrt(I_ref / I_k)) R^T (symmetric), the substitution w = S w^, a^ = S a turns
+ * a . (I^-1 a) into |a^|^2 / I_ref, a . w into a^ . w^ and w += I^-1 a dl into w^ += a^ dl / I_ref: every row keeps the
+ * isotropic form with inv_I = 1 / I_ref, only its arm is S (r x n) instead of r x n. */
+static inline void box_arm(const float S[6], const float r[3], const float n[3], float a[3]) {
+    float c[3];
+    cross3(r, n, c);
+    sym3_mul(S, c, a);
+}
+static inline float g_vrel(const float n[3], const float a[3], const float v[3], const float w[3]) { return dot3(n, v) + dot3(a, w); }
+static inline void g_apply(const float n[3], const float a[3], float dl, float inv_m, float inv_I, float v[3], float w[3]) {
+    float s = dl * inv_m, q = dl * inv_I;
+    for (int j = 0; j < 3; ++j) { v[j] = FMA(n[j], s, v[j]); w[j] = FMA(a[j], q, w[j]); }
+}
+/* S = R diag(s) R^T as 00 01 02 11 12 22 */
+static void rot_diag_rot(const float R[9], const float s[3], float S[6]) {
+    static const int ij[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+    for (int e = 0; e < 6; ++e) {
+        const int i = ij[e][0], j = ij[e][1];
+        S[e] = FMA(R[3 * i + 2] * s[2], R[3 * j + 2], FMA(R[3 * i + 1] * s[1], R[3 * j + 1], (R[3 * i] * s[0]) * R[3 * j]));
+    }
+}
+static const float BOX_AXES[3][3] = {{0.0f, 0.0f, 1.0f}, {1.0f, 0.0f, 0.0f}, {0.0f, 1.0f, 0.0f}};   /* rows +z, +x, +y of a floor corner */
 
 /* ---- PGS row kernels (identical arithmetic in the HIP file) ---- */
 static inline float solve_normal(float* lam, float Dinv, float vrel, float bias) {
@@ -967,6 +1023,19 @@ static inline void wt_apply(const CubeContact* c, const float b[3], float dl, fl
     w[0] = FMA(b[0], q, w[0]); w[1] = FMA(b[1], q, w[1]); w[2] = FMA(b[2], q, w[2]);
 }
 
+/* arms of the three rows of a wall corner: r x n, r x t and (box only) r x z, inertia-scaled for a box */
+static inline void wall_arms(int box, const float S[6], const CubeContact* c, float a[3], float b[3], float c3[3]) {
+    wall_arm_n(c, a);
+    wall_arm_t(c, b);
+    c3[0] = 0.0f; c3[1] = 0.0f; c3[2] = 0.0f;
+    if (box) {
+        float t[3];
+        sym3_mul(S, a, t); a[0] = t[0]; a[1] = t[1]; a[2] = t[2];
+        sym3_mul(S, b, t); b[0] = t[0]; b[1] = t[1]; b[2] = t[2];
+        box_arm(S, c->r, BOX_AXES[0], c3);
+    }
+}
+
 /* fingertip sphere against one feature of the arena: finger-only rows */
 typedef struct {
     int active;
@@ -1012,6 +1081,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2];
     const float rest_f = m->restitution_finger * e->dr[5], rest_ff = m->restitution_ff * e->dr[5];
     const float ws = m->warm_start;
+    const int box = m->box;
     FingerRole fr[3];
     FcRecord rec[3];
     float v[3], w[3];            /* cube velocities being solved  */
@@ -1037,23 +1107,43 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         base_to_world(m, f, To, g->Tw);
     }
     /* ---- C1: free motion of the cube, corner contacts against the arena ---- */
+    float R[9];
+    quat_to_rot(e->cq, R);
+    float hc[3], S[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < 3; ++k) hc[k] = (box ? m->box_half[k] : m->cube_half) * e->dr[1];
     {
+        float wf[3] = {e->cw[0], e->cw[1], e->cw[2]};
+        if (box && m->box_gyroscopic) {      /* Euler's equations in the body frame, explicit: I dw/dt = -w x (I w) */
+            float wb[3], Iw[3], tq[3];
+            mat3T_mul(R, wf, wb);
+            for (int k = 0; k < 3; ++k) Iw[k] = m->box_inertia[k] * wb[k];
+            cross3(Iw, wb, tq);
+            for (int k = 0; k < 3; ++k) wb[k] = FMA(h, tq[k] / m->box_inertia[k], wb[k]);
+            mat3_mul(R, wb, wf);
+        }
         float dl = 1.0f - h * m->cube_linear_damping, da = 1.0f - h * m->cube_angular_damping;
         for (int i = 0; i < 3; ++i) {
             v[i] = FMA(h, cfg->gravity[i], e->cv[i]) * dl;
-            w[i] = e->cw[i] * da;
+            w[i] = wf[i] * da;
+        }
+        if (box) {                           /* from here to the integration `w` is the inertia-scaled w^ = S^-1 w */
+            float sc[3], si[3], Sinv[6], wh[3];
+            for (int k = 0; k < 3; ++k) { sc[k] = sqrtf(m->cube_inertia / m->box_inertia[k]); si[k] = 1.0f / sc[k]; }
+            rot_diag_rot(R, sc, S);
+            rot_diag_rot(R, si, Sinv);
+            sym3_mul(Sinv, w, wh);
+            for (int i = 0; i < 3; ++i) w[i] = wh[i];
         }
     }
-    float R[9];
-    quat_to_rot(e->cq, R);
-    const float hc = m->cube_half * e->dr[1];
     CubeContact cf[4], cwl[4];
     float cf_face, cw_face;
     {   /* cube vs floor: the four corners of the face that points down most */
         int k = 0;
-        float best = f_abs(R[6]);
-        if (f_abs(R[7]) > best) { best = f_abs(R[7]); k = 1; }
-        if (f_abs(R[8]) > best) { best = f_abs(R[8]); k = 2; }
+        float down[3] = {f_abs(R[6]), f_abs(R[7]), f_abs(R[8])};
+        if (box) for (int i = 0; i < 3; ++i) down[i] = down[i] * hc[i];     /* the four lowest corners of a box */
+        float best = down[0];
+        if (down[1] > best) { best = down[1]; k = 1; }
+        if (down[2] > best) { best = down[2]; k = 2; }
         float sk = (R[6 + k] > 0.0f) ? -1.0f : 1.0f;
         cf_face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
         const float keep = (cf_face == e->cf_face) ? ws : 0.0f;
@@ -1062,13 +1152,21 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             memset(c, 0, sizeof(*c));
             cube_corner(R, hc, k, sk, i, c->r);
             float gap = e->cp[2] + c->r[2];
-            if (contact_live(m, gap, cz_vrel(c->r, v, w), h)) {
+            float arm[3][3], vn0;
+            if (box) {
+                for (int d = 0; d < 3; ++d) box_arm(S, c->r, BOX_AXES[d], arm[d]);
+                vn0 = g_vrel(BOX_AXES[0], arm[0], v, w);
+            } else vn0 = cz_vrel(c->r, v, w);
+            if (contact_live(m, gap, vn0, h)) {
                 const float* r = c->r;
                 c->active = 1;
-                c->Dinv[0] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));   /* +z */
-                c->Dinv[1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));   /* +x */
-                c->Dinv[2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));   /* +y */
-                float vn0 = cz_vrel(r, v, w);
+                if (box) {
+                    for (int d = 0; d < 3; ++d) c->Dinv[d] = f_rcp2(FMA(dot3(arm[d], arm[d]), inv_I, inv_m));
+                } else {
+                    c->Dinv[0] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));   /* +z */
+                    c->Dinv[1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));   /* +x */
+                    c->Dinv[2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));   /* +y */
+                }
                 c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
                 for (int d = 0; d < 3; ++d) c->lam[d] = e->lam_cf[i][d] * keep;
             }
@@ -1084,9 +1182,11 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         float pr[3];
         for (int i = 0; i < 3; ++i) pr[i] = FMA(R[i], dx, R[3 + i] * dy);
         int k = 0;
-        float best = f_abs(pr[0]);
-        if (f_abs(pr[1]) > best) { best = f_abs(pr[1]); k = 1; }
-        if (f_abs(pr[2]) > best) { best = f_abs(pr[2]); k = 2; }
+        float out[3] = {f_abs(pr[0]), f_abs(pr[1]), f_abs(pr[2])};
+        if (box) for (int i = 0; i < 3; ++i) out[i] = out[i] * hc[i];
+        float best = out[0];
+        if (out[1] > best) { best = out[1]; k = 1; }
+        if (out[2] > best) { best = out[2]; k = 2; }
         float sk = (pr[k] < 0.0f) ? -1.0f : 1.0f;
         cw_face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
         const float keep = (cw_face == e->cw_face) ? ws : 0.0f;
@@ -1103,14 +1203,13 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             c->n[0] = -px * inv; c->n[1] = -py * inv;
             {
                 const float* r = c->r;
-                float a[3], b[3];
-                wall_arm_n(c, a);
-                wall_arm_t(c, b);
+                float a[3], b[3], c3[3];
+                wall_arms(box, S, c, a, b, c3);
                 if (!contact_live(m, gap, wn_vrel(c, a, v, w), h)) { c->n[0] = 0.0f; c->n[1] = 0.0f; continue; }
                 c->active = 1;
                 c->Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
                 c->Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
-                c->Dinv[2] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
+                c->Dinv[2] = box ? f_rcp2(FMA(dot3(c3, c3), inv_I, inv_m)) : f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                 float vn0 = wn_vrel(c, a, v, w);
                 c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
                 for (int d = 0; d < 3; ++d) c->lam[d] = e->lam_cw[i][d] * keep;
@@ -1205,7 +1304,10 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             float Pb[3];
             world_to_base(m, f, Pw, Pb);
             finger_jac(m, f, k, link, Pb, dir, J, W, Dd);
-            for (int d = 0; d < 3; ++d) cross3(rcv, dir[d], rxd[d]);
+            for (int d = 0; d < 3; ++d) {
+                cross3(rcv, dir[d], rxd[d]);
+                if (box) { float t[3]; sym3_mul(S, rxd[d], t); rxd[d][0] = t[0]; rxd[d][1] = t[1]; rxd[d][2] = t[2]; }
+            }
             float vn0 = dot3(J[0], g->vq) - (dot3(dir[0], v) + dot3(rxd[0], w));
             if (contact_live(m, gap, vn0, h)) {
                 rc_->active = 1;
@@ -1293,18 +1395,26 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     }
     for (int i = 0; i < 4; ++i) {
         if (!cf[i].active) continue;
+        if (box) {
+            for (int d = 0; d < 3; ++d) {
+                float a[3];
+                box_arm(S, cf[i].r, BOX_AXES[d], a);
+                g_apply(BOX_AXES[d], a, cf[i].lam[d], inv_m, inv_I, v, w);
+            }
+            continue;
+        }
         cz_apply(cf[i].r, cf[i].lam[0], inv_m, inv_I, v, w);
         cx_apply(cf[i].r, cf[i].lam[1], inv_m, inv_I, v, w);
         cy_apply(cf[i].r, cf[i].lam[2], inv_m, inv_I, v, w);
     }
     for (int i = 0; i < 4; ++i) {
         if (!cwl[i].active) continue;
-        float a[3], b[3];
-        wall_arm_n(&cwl[i], a);
-        wall_arm_t(&cwl[i], b);
+        float a[3], b[3], c3[3];
+        wall_arms(box, S, &cwl[i], a, b, c3);
         wn_apply(&cwl[i], a, cwl[i].lam[0], inv_m, inv_I, v, w);
         wt_apply(&cwl[i], b, cwl[i].lam[1], inv_m, inv_I, v, w);
-        cz_apply(cwl[i].r, cwl[i].lam[2], inv_m, inv_I, v, w);
+        if (box) g_apply(BOX_AXES[0], c3, cwl[i].lam[2], inv_m, inv_I, v, w);
+        else cz_apply(cwl[i].r, cwl[i].lam[2], inv_m, inv_I, v, w);
     }
     /* ---- projected Gauss-Seidel ---- */
     for (int it = 0; it < cfg->solver_iterations; ++it) {
@@ -1360,6 +1470,17 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int i = 0; i < 4; ++i) {             /* cube - floor: rows +z (normal), +x, +y */
             CubeContact* c = &cf[i];
             if (!c->active) continue;
+            if (box) {
+                for (int d = 0; d < 3; ++d) {
+                    float a[3];
+                    box_arm(S, c->r, BOX_AXES[d], a);
+                    float vrel = g_vrel(BOX_AXES[d], a, v, w);
+                    float dlb = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
+                                         : solve_tangent(&c->lam[d], c->Dinv[d], vrel, mu_cf * c->lam[0]);
+                    g_apply(BOX_AXES[d], a, dlb, inv_m, inv_I, v, w);
+                }
+                continue;
+            }
             float dl = solve_normal(&c->lam[0], c->Dinv[0], cz_vrel(c->r, v, w), c->bias);
             cz_apply(c->r, dl, inv_m, inv_I, v, w);
             dl = solve_tangent(&c->lam[1], c->Dinv[1], cx_vrel(c->r, v, w), mu_cf * c->lam[0]);
@@ -1370,15 +1491,19 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int i = 0; i < 4; ++i) {             /* cube - wall: rows n (normal), t, +z */
             CubeContact* c = &cwl[i];
             if (!c->active) continue;
-            float a[3], b[3];
-            wall_arm_n(c, a);
-            wall_arm_t(c, b);
+            float a[3], b[3], c3[3];
+            wall_arms(box, S, c, a, b, c3);
             float dl = solve_normal(&c->lam[0], c->Dinv[0], wn_vrel(c, a, v, w), c->bias);
             wn_apply(c, a, dl, inv_m, inv_I, v, w);
             dl = solve_tangent(&c->lam[1], c->Dinv[1], wt_vrel(c, b, v, w), mu_cw * c->lam[0]);
             wt_apply(c, b, dl, inv_m, inv_I, v, w);
-            dl = solve_tangent(&c->lam[2], c->Dinv[2], cz_vrel(c->r, v, w), mu_cw * c->lam[0]);
-            cz_apply(c->r, dl, inv_m, inv_I, v, w);
+            if (box) {
+                dl = solve_tangent(&c->lam[2], c->Dinv[2], g_vrel(BOX_AXES[0], c3, v, w), mu_cw * c->lam[0]);
+                g_apply(BOX_AXES[0], c3, dl, inv_m, inv_I, v, w);
+            } else {
+                dl = solve_tangent(&c->lam[2], c->Dinv[2], cz_vrel(c->r, v, w), mu_cw * c->lam[0]);
+                cz_apply(c->r, dl, inv_m, inv_I, v, w);
+            }
         }
     }
     /* ---- impulses kept for the next substep; fingertip wrench sensor: contact impulses / h, world frame, about the
@@ -1418,6 +1543,11 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         const int j = 3 * f + jj;
         e->qd[j] = fr[f].vq[jj];
         e->q[j] = f_clamp(FMA(h, fr[f].vq[jj], e->q[j]), m->q_lo[jj], m->q_hi[jj]);
+    }
+    if (box) {                               /* back to the world angular velocity: w = S w^ */
+        float ww[3];
+        sym3_mul(S, w, ww);
+        for (int i = 0; i < 3; ++i) w[i] = ww[i];
     }
     for (int i = 0; i < 3; ++i) {
         e->cv[i] = v[i]; e->cw[i] = w[i];
@@ -1518,11 +1648,11 @@ static void sample_goal(const struct TfHandle_* h, uint32_t gid, uint32_t count,
     rng4(c->seed, gid, count, RNG_GOAL_POS, u);
     float x = 0.0f, y = 0.0f, z;
     float quat[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-    if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, &x, &y);
-    if (d == -1 || d == 1) z = CUBE_MIN_HEIGHT;
-    else if (d == 2 || d == 6) z = CUBE_MIN_HEIGHT + 0.05f;
-    else if (d == 3) z = 0.0675f * u[2] + CUBE_MIN_HEIGHT;           /* (max_height - min_height) in double, then fp32 */
-    else z = 0.04370835f * u[2] + CUBE_RADIUS_3D;                    /* (max_height - radius_3d) */
+    if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], h->cfg.model.obj_max_com_dist, &x, &y);
+    if (d == -1 || d == 1) z = h->cfg.model.obj_min_height;
+    else if (d == 2 || d == 6) z = h->cfg.model.obj_min_height + 0.05f;
+    else if (d == 3) z = h->cfg.model.obj_span_min_height * u[2] + h->cfg.model.obj_min_height;           /* (max_height - min_height) in double, then fp32 */
+    else z = h->cfg.model.obj_span_radius * u[2] + h->cfg.model.obj_radius_3d;                    /* (max_height - radius_3d) */
     if (d == -1) sample_yaw_quat(u[3], quat);
     if (d == 4 || d == 5 || d == 6) {
         float v[4], n[4];
@@ -1586,14 +1716,14 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
             }
         }
         if (c->object_reset_type == TF_RESET_DEFAULT) {
-            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = CUBE_MIN_HEIGHT * e->dr[1];
+            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = h->cfg.model.obj_min_height * e->dr[1];
             e->cq[0] = 0.0f; e->cq[1] = 0.0f; e->cq[2] = 0.0f; e->cq[3] = 1.0f;
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
         } else if (c->object_reset_type == TF_RESET_RANDOM) {  /* trifinger_env.py:1169-1173 */
             float u[4];
             rng4(c->seed, gid, count, RNG_OBJECT, u);
-            sample_xy(u[0], u[1], CUBE_MAX_COM_DIST, &e->cp[0], &e->cp[1]);
-            e->cp[2] = (0.065f / 2.0f) * e->dr[1];
+            sample_xy(u[0], u[1], h->cfg.model.obj_max_com_dist, &e->cp[0], &e->cp[1]);
+            e->cp[2] = h->cfg.model.obj_min_height * e->dr[1];
             sample_yaw_quat(u[2], e->cq);
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
         }
@@ -1761,7 +1891,7 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
         for (int j = 0; j < 4; ++j) acc = acc + e->cq[j] * 0.0f;
         if (!(acc == 0.0f)) {
             for (int j = 0; j < 9; ++j) { e->q[j] = m->q_default[j % 3]; e->qd[j] = 0.0f; }
-            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = CUBE_MIN_HEIGHT;
+            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = h->cfg.model.obj_min_height;
             e->cq[0] = 0.0f; e->cq[1] = 0.0f; e->cq[2] = 0.0f; e->cq[3] = 1.0f;
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
             for (int j = 0; j < 18; ++j) e->ft[j] = 0.0f;

@@ -444,7 +444,11 @@ def gen_constants():
              arena_radius=np.float64(ref.tf_utils.ARENA_RADIUS), size=np.array(o.size, dtype=np.float64),
              state_dim=np.int64(d.StateDim.value), wrench_dim=np.int64(d.WrenchDim.value),
              num_fingers=np.int64(d.NumFingers.value), joint_dim=np.int64(d.JointPositionDim.value),
-             object_pose_dim=np.int64(d.ObjectPoseDim.value), object_vel_dim=np.int64(d.ObjectVelocityDim.value))
+             object_pose_dim=np.int64(d.ObjectPoseDim.value), object_vel_dim=np.int64(d.ObjectVelocityDim.value),
+             # the same class for the phase-3 cuboid of the reference's assets (objects/urdf/cube_multicolor_rrc_phase3.urdf)
+             **{f"phase3_{k}": np.float64(v) for k, v in (lambda c: dict(radius_3d=c.radius_3d, max_com_dist=c.max_com_distance_to_center,
+                                                                          min_height=c.min_height, max_height=c.max_height))(
+                 ref.tf_utils.CuboidalObject((0.02, 0.08, 0.02))).items()})
 
 
 NORM_PS = (2, 1, 3, float("inf"))

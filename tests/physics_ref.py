@@ -144,8 +144,17 @@ class Row:
         self.lam = 0.0
 
 
-def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_sweeps=200000):
-    """One substep of length h in fp64.  q, qd, tau: (9,), cube: (13,) [p, quat xyzw, v, w].
+def box_spec(size, density, gyroscopic=True):
+    """mass properties of a solid box of `size` (x, y, z) and `density`, written from the textbook formulas"""
+    size = np.asarray(size, dtype=np.float64)
+    mass = density * float(np.prod(size))
+    inertia = mass / 12.0 * np.array([size[1] ** 2 + size[2] ** 2, size[0] ** 2 + size[2] ** 2, size[0] ** 2 + size[1] ** 2])
+    return {"half": size / 2.0, "mass": mass, "inertia": inertia, "gyroscopic": gyroscopic}
+
+
+def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_sweeps=200000, box=None):
+    """One substep of length h in fp64.  q, qd, tau: (9,), cube: (13,) [p, quat xyzw, v, w].  `box`: a `box_spec` for a
+    general box object (full world-frame inertia tensor here - the product's inertia-scaled coordinates are not used).
     Returns (qd_new (9,), cube_v (3,), cube_w (3,), details)."""
     q, qd, cube, tau = (np.asarray(a, dtype=np.float64) for a in (q, qd, cube, tau))
     cp, cq, cv, cw = cube[0:3], cube[3:7], cube[7:10], cube[10:13]
@@ -159,12 +168,23 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         Minv[sl, sl] = Mi
         acc = Mi @ (tau[sl] - bias_forces(q[sl], qd[sl], gz))
         vfree[sl] = (qd[sl] + h * acc) * (1.0 - h * LINK_DAMP)
-    Minv[9:12, 9:12] = np.eye(3) / CUBE_MASS
-    Minv[12:15, 12:15] = np.eye(3) / CUBE_INERTIA
-    vfree[9:12] = (cv + h * np.asarray(gravity)) * (1.0 - h * CUBE_LIN_DAMP)
-    vfree[12:15] = cw * (1.0 - h * CUBE_ANG_DAMP)
     R = quat_rot(cq)
-    hc = CUBE_HALF
+    if box is None:
+        Minv[9:12, 9:12] = np.eye(3) / CUBE_MASS
+        Minv[12:15, 12:15] = np.eye(3) / CUBE_INERTIA
+        w_free = cw
+        hc = np.full(3, CUBE_HALF)
+    else:
+        Minv[9:12, 9:12] = np.eye(3) / box["mass"]
+        Minv[12:15, 12:15] = R @ np.diag(1.0 / box["inertia"]) @ R.T
+        w_free = cw
+        if box["gyroscopic"]:                       # Euler's equations, explicit step in the body frame
+            wb = R.T @ cw
+            wb = wb + h * np.cross(box["inertia"] * wb, wb) / box["inertia"]
+            w_free = R @ wb
+        hc = np.asarray(box["half"], dtype=np.float64)
+    vfree[9:12] = (cv + h * np.asarray(gravity)) * (1.0 - h * CUBE_LIN_DAMP)
+    vfree[12:15] = w_free * (1.0 - h * CUBE_ANG_DAMP)
     rows = []
     details = {"fc": [], "te": [], "ff": [], "n_floor": 0, "n_wall": 0}
 
@@ -266,14 +286,14 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
                 if nr is not None:
                     details["te"].append((f, kind, gp, nr))
     # ---- cube corners against the floor ----
-    k = int(np.argmax(np.abs(R[2, :])))
+    k = int(np.argmax(np.abs(R[2, :]) * hc))       # the face holding the four lowest corners
     sk = -1.0 if R[2, k] > 0 else 1.0
     others = [i for i in range(3) if i != k]
     for idx in range(4):
         yv = np.zeros(3)
-        yv[k] = sk * hc
-        yv[others[0]] = hc if idx & 1 else -hc
-        yv[others[1]] = hc if idx & 2 else -hc
+        yv[k] = sk * hc[k]
+        yv[others[0]] = hc[others[0]] if idx & 1 else -hc[others[0]]
+        yv[others[1]] = hc[others[1]] if idx & 2 else -hc[others[1]]
         r = R @ yv
         gap = cp[2] + r[2]
         if gap < MARGIN:
@@ -286,14 +306,14 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
     if rho_c > 1e-6:
         dvec = np.array([cp[0] / rho_c, cp[1] / rho_c, 0.0])
         pr = R.T @ dvec
-        k = int(np.argmax(np.abs(pr)))
+        k = int(np.argmax(np.abs(pr) * hc))
         sk = -1.0 if pr[k] < 0 else 1.0
         others = [i for i in range(3) if i != k]
         for idx in range(4):
             yv = np.zeros(3)
-            yv[k] = sk * hc
-            yv[others[0]] = hc if idx & 1 else -hc
-            yv[others[1]] = hc if idx & 2 else -hc
+            yv[k] = sk * hc[k]
+            yv[others[0]] = hc[others[0]] if idx & 1 else -hc[others[0]]
+            yv[others[1]] = hc[others[1]] if idx & 2 else -hc[others[1]]
             r = R @ yv
             P = cp + r
             rho = np.hypot(P[0], P[1])
