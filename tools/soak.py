@@ -11,6 +11,9 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 lib = capi.load_hip_library()
 kw = bench.workload_kwargs(True)
 kw.update(domain_randomization={"activate": True}, episode_length=300)
+box = len(sys.argv) > 3 and sys.argv[3] == "box"            # the phase-3 cuboid instead of the cube
+if box:
+    kw.update(model=lib.box_model((0.02, 0.08, 0.02), 500.0))
 eng = TrifingerEngine(make_config(lib, n, seed=11, **kw), device="cuda:0", lib=lib)
 g = torch.Generator(device="cuda:0").manual_seed(3)
 ring = [(torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1) for _ in range(32)]
@@ -24,8 +27,13 @@ for k in range(steps):
         st = eng.state
         ok = bool(torch.isfinite(st).all()) and bool(torch.isfinite(eng.obs).all()) and bool(torch.isfinite(eng.states).all())
         zmin = float(st[capi.S_CUBE_P + 2].min()); rmax = float(torch.hypot(st[capi.S_CUBE_P], st[capi.S_CUBE_P + 1]).max())
-        print(f"step {k+1}: finite={ok} cube z min {zmin:.4f} r max {rmax:.4f} |qd| max {float(st[9:18].abs().max()):.2f} "
-              f"nonfinite so far {float(nonfinite):.0f} resets {float(resets):.0f} mean reward {float(eng.reward.mean()):.3f}", flush=True)
-        assert ok and rmax < 0.25
+        zmax = float(st[capi.S_CUBE_P + 2].max()); vmax = float(st[capi.S_CUBE_V:capi.S_CUBE_V + 3].abs().max())
+        tipz = float(st[capi.S_TIP_P + 2:capi.S_TIP_P + 9:3].min())
+        if k % 10000 == 9999 or not ok:
+            print(f"step {k+1}: finite={ok} cube z [{zmin:.4f}, {zmax:.4f}] r max {rmax:.4f} |v| max {vmax:.2f} tip z min {tipz:.4f} "
+                  f"|qd| max {float(st[9:18].abs().max()):.2f} nonfinite so far {float(nonfinite):.0f} resets {float(resets):.0f} "
+                  f"mean reward {float(eng.reward.mean()):.3f}", flush=True)
+        # nothing leaves the arena, sinks through the floor or the table, or runs away
+        assert ok and rmax < 0.27 and zmin > (0.004 if box else 0.02) and zmax < 1.0 and vmax < 20.0 and tipz > -0.003, (zmin, zmax, rmax, vmax, tipz)
 torch.cuda.synchronize()
 print(f"{n} envs x {steps} steps in {time.perf_counter()-t0:.1f} s; non-finite envs caught: {float(nonfinite):.0f}")
