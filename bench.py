@@ -58,9 +58,9 @@ def load_pmc_profile(n, asym):
         vals = {}
         for line in text.splitlines():
             if line.startswith(KERNEL_NAME[asym]):
-                m = re.search(r"\)\s+(\w+)\s+(\d+)\s+([0-9.eE+-]+)", line)
-                if m:
-                    vals[m.group(1)] = float(m.group(3))
+                tok = line.split()                     # ... <counter> <n> <mean> <min> <max>; the kernel name may be cut short
+                if len(tok) >= 6 and re.fullmatch(r"[A-Z_0-9a-z]+", tok[-5]) and tok[-4].isdigit():
+                    vals[tok[-5]] = float(tok[-3])
         if vals:
             return vals, os.path.relpath(path, REPO)
     return None, None
