@@ -94,25 +94,32 @@ enum {
     TF_S_PREV_OBJ_Q = 62,/*  4 object orientation of history[1]                                   */
     TF_S_FT = 66,        /* 18 fingertip contact wrench (world frame force 3 + torque 3 per finger about
                               the tip-link origin, mean over the substeps of the step); split path only */
-    TF_S_DR = 84,        /*  6 per-env domain-randomisation scale factors drawn at reset (1.0 when DR is off):
-                              cube mass, cube size, contact friction, motor torque, finger link mass,
-                              finger contact restitution                                           */
+    TF_S_DR = 84,        /* 14 per-env domain-randomisation values drawn at reset (index list: TF_DR_* below): scale factors
+                              (1.0 when DR is off) for cube mass, cube size, contact friction, motor torque, finger link
+                              mass, finger contact restitution; offsets in metres (0.0 when off) of the robot base (x, y, z)
+                              and of the stage = table + boundary (x, y); friction factors of the robot, the object and
+                              the stage                                                                      */
     /* Warm start of the contact solver (an implementation choice, not algorithmic traffic: SURVEY 8d).  The impulses
      * of the last substep seed the next one when the contact kept its identity; a reset clears them.               */
-    TF_S_LAM_FC = 90,    /* 12 finger-cube contact of finger f at [4f..4f+3]: normal impulse, world friction impulse (3) */
-    TF_S_FC_LINK = 102,  /*  3 link that held the finger-cube contact (0 none, 1 upper, 2 middle, 3 distal)       */
-    TF_S_LAM_TF = 105,   /*  9 fingertip-floor contact of finger f at [3f..3f+2]: normal, tangent 1, tangent 2       */
-    TF_S_LAM_TW = 114,   /*  9 fingertip-boundary-wall contact of finger f, same layout                             */
-    TF_S_LAM_CF = 123,   /* 12 cube corner i against the floor at [3i..3i+2]: +z (normal), +x, +y                   */
-    TF_S_CF_FACE = 135,  /*  1 cube face whose corners those were (0 none, 1..6)                                   */
-    TF_S_LAM_CW = 136,   /* 12 cube corner i against the boundary wall at [3i..3i+2]: normal, tangent, +z          */
-    TF_S_CW_FACE = 148,  /*  1 cube face whose corners those were                                                  */
-    TF_STATE_ROWS = 149
+    TF_S_LAM_FC = 98,    /* 12 finger-cube contact of finger f at [4f..4f+3]: normal impulse, world friction impulse (3) */
+    TF_S_FC_LINK = 110,  /*  3 link that held the finger-cube contact (0 none, 1 upper, 2 middle, 3 distal)       */
+    TF_S_LAM_TF = 113,   /*  9 fingertip-floor contact of finger f at [3f..3f+2]: normal, tangent 1, tangent 2       */
+    TF_S_LAM_TW = 122,   /*  9 fingertip-boundary-wall contact of finger f, same layout                             */
+    TF_S_LAM_CF = 131,   /* 12 cube corner i against the floor at [3i..3i+2]: +z (normal), +x, +y                   */
+    TF_S_CF_FACE = 143,  /*  1 cube face whose corners those were (0 none, 1..6)                                   */
+    TF_S_LAM_CW = 144,   /* 12 cube corner i against the boundary wall at [3i..3i+2]: normal, tangent, +z          */
+    TF_S_CW_FACE = 156,  /*  1 cube face whose corners those were                                                  */
+    TF_STATE_ROWS = 157
 };
-#define TF_NUM_DR 6
+#define TF_NUM_DR 14
+enum { TF_DR_CUBE_MASS = 0, TF_DR_CUBE_SIZE = 1, TF_DR_FRICTION = 2, TF_DR_MOTOR = 3, TF_DR_LINK_MASS = 4, TF_DR_RESTITUTION = 5,
+       TF_DR_BASE_POS = 6 /* 6..8 */, TF_DR_STAGE_POS = 9 /* 9..10 */, TF_DR_FRICTION_ROBOT = 11, TF_DR_FRICTION_OBJECT = 12,
+       TF_DR_FRICTION_STAGE = 13 };
+/* value of DR slot j when the feature is off: offsets 0, factors 1 */
+#define TF_DR_NEUTRAL(j) (((j) >= TF_DR_BASE_POS && (j) < TF_DR_FRICTION_ROBOT) ? 0.0f : 1.0f)
 #define TF_NORM_INF (-1)      /* finger_reach_norm_p: the maximum norm */
 /* Largest num_envs of one handle: the kernels address state[TF_STATE_ROWS][num_envs] with 32-bit byte offsets
- * (149 * 2 Mi * 4 B = 1.25 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
+ * (157 * 2 Mi * 4 B = 1.3 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
 #define TF_MAX_ENVS 2097152
 
 #define TF_OBS_DIM_BASE 32    /* 9 + 9 + 7 + 7; the action slot (9 or 18) follows  trifinger_env.py:280-286 */
@@ -178,6 +185,7 @@ typedef struct TfModel {
     float wall_r[4], wall_z[4];
     /* materials: PhysX "average" combine of trifinger_env.py:364-365,876-878,914-915,934-936 */
     float mu_finger_cube, mu_cube_floor, mu_tip_floor, mu_cube_wall, mu_tip_wall, mu_finger_finger;
+    float mu_robot, mu_object, mu_floor, mu_stage;   /* the per-body values behind the averages (1, 1, 0.1, 1): shares of the per-body friction DR */
     float restitution_finger;     /* finger shape vs cube / arena: average(0.8, 0)                   */
     float restitution_ff;         /* finger shape vs finger shape: 0.8                               */
     float bounce_threshold;       /* 0.5 m/s  (scripts/rlg_hydra.py:32)                              */
@@ -241,6 +249,14 @@ typedef struct TfConfig {
     float dr_motor[2];
     float dr_link_mass[2];        /* one factor for the three moving links of every finger (mass and inertia)      */
     float dr_restitution[2];      /* factor on the finger contact restitution                                      */
+    /* the rest of the reference's intent list (trifinger_env.py:387-389): robot base position, stage position, friction of
+     * robot / object / stage separately.  Positions: offset ~ U[-a, a] per axis with the half-widths below (metres); the
+     * stage is the table with its boundary (object spawn and goal positions move with it).  Friction: one factor ~ U[lo, hi]
+     * per body; a contact pair's coefficient (PhysX "average" of the two bodies) is scaled by
+     * 1 + s_a (f_a - 1) + s_b (f_b - 1) with s the bodies' shares of the pair's nominal average, on top of dr_friction. */
+    float dr_base_pos[3];
+    float dr_stage_pos[2];
+    float dr_friction_robot[2], dr_friction_object[2], dr_friction_stage[2];
     /* Observation noise (the reference leaves a TODO at trifinger_env.py:979): with dr_enable and dr_obs_noise > 0
      * every step adds dr_obs_noise * U(-1, 1) to the emitted (already scaled) joint positions, joint velocities and
      * object pose of `obs` (slots 0..24); goal, last action and the privileged `states` vector stay exact.  Draws are

@@ -14,8 +14,9 @@ import os
 TF_API_VERSION = 3
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
-TF_STATE_ROWS = 149
-TF_NUM_DR = 6
+TF_STATE_ROWS = 157
+TF_NUM_DR = 14
+DR_BASE_POS, DR_STAGE_POS, DR_FRICTION_ROBOT, DR_FRICTION_OBJECT, DR_FRICTION_STAGE = 6, 9, 11, 12, 13
 
 # status codes (include/trifinger.h: TfStatus)
 TF_OK = 0
@@ -44,7 +45,7 @@ S_Q, S_QD, S_CUBE_P, S_CUBE_Q, S_CUBE_V, S_CUBE_W = 0, 9, 18, 21, 25, 28
 S_GOAL_P, S_GOAL_Q, S_GOAL_W, S_TIP_P, S_TAU = 31, 34, 38, 41, 50
 S_PREV_OBJ_P, S_PREV_OBJ_Q, S_FT, S_DR = 59, 62, 66, 84
 # warm-start rows of the contact solver
-S_LAM_FC, S_FC_LINK, S_LAM_TF, S_LAM_TW, S_LAM_CF, S_CF_FACE, S_LAM_CW, S_CW_FACE = 90, 102, 105, 114, 123, 135, 136, 148
+S_LAM_FC, S_FC_LINK, S_LAM_TF, S_LAM_TW, S_LAM_CF, S_CF_FACE, S_LAM_CW, S_CW_FACE = 98, 110, 113, 122, 131, 143, 144, 156
 
 INFO_POS_COUNT, INFO_ORI_COUNT, INFO_SUCCESS_MEAN, INFO_NUM_RESETS, INFO_NUM_NONFINITE = 6, 7, 8, 9, 10
 
@@ -74,6 +75,7 @@ class TfModel(C.Structure):
         ("mu_finger_cube", C.c_float), ("mu_cube_floor", C.c_float),
         ("mu_tip_floor", C.c_float), ("mu_cube_wall", C.c_float),
         ("mu_tip_wall", C.c_float), ("mu_finger_finger", C.c_float),
+        ("mu_robot", C.c_float), ("mu_object", C.c_float), ("mu_floor", C.c_float), ("mu_stage", C.c_float),
         ("restitution_finger", C.c_float), ("restitution_ff", C.c_float), ("bounce_threshold", C.c_float),
         ("contact_margin", C.c_float), ("contact_slack", C.c_float), ("contact_offset", C.c_float), ("erp", C.c_float),
         ("max_depenetration_velocity", C.c_float), ("warm_start", C.c_float),
@@ -103,7 +105,10 @@ class TfConfig(C.Structure):
         ("dr_enable", C.c_int32),
         ("dr_cube_mass", C.c_float * 2), ("dr_cube_size", C.c_float * 2),
         ("dr_friction", C.c_float * 2), ("dr_motor", C.c_float * 2),
-        ("dr_link_mass", C.c_float * 2), ("dr_restitution", C.c_float * 2), ("dr_obs_noise", C.c_float), ("dr_action_repeat", C.c_float),
+        ("dr_link_mass", C.c_float * 2), ("dr_restitution", C.c_float * 2),
+        ("dr_base_pos", C.c_float * 3), ("dr_stage_pos", C.c_float * 2), ("dr_friction_robot", C.c_float * 2),
+        ("dr_friction_object", C.c_float * 2), ("dr_friction_stage", C.c_float * 2),
+        ("dr_obs_noise", C.c_float), ("dr_action_repeat", C.c_float),
         ("model", TfModel),
     ]
 

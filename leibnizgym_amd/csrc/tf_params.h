@@ -60,6 +60,7 @@ struct DevParams {
     float dof_pos_stddev, dof_vel_stddev, goal_rate;
     int32_t dr_enable;
     float dr_cube_mass[2], dr_cube_size[2], dr_friction[2], dr_motor[2], dr_link_mass[2], dr_restitution[2];
+    float dr_base_pos[3], dr_stage_pos[2], dr_friction_robot[2], dr_friction_object[2], dr_friction_stage[2];
     float dr_obs_noise;      // half-width of the observation noise; 0 when off (or when dr_enable is 0)
     float dr_action_repeat;  // probability of re-applying the previous step's torque; 0 when off
     float clip_obs, clip_act; // fused wrapper clipping (tf_set_clipping); FLT_MAX when off

@@ -168,7 +168,8 @@ DEV void normalize_quat(const float n[4], float q[4]) {                         
 }
 // the CuboidalObject numbers of the reference (envs/trifinger/utils.py:122-131) come with the model: TfModel.obj_*
 
-DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, float gp[3], float gq[4], float gw[3]) {   // trifinger_env.py:1194-1265
+template <bool EXT>
+DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, const float dr[TF_NUM_DR], float gp[3], float gq[4], float gw[3]) {   // trifinger_env.py:1194-1265
     int d = P.task_difficulty;
     float u[4];
     rng4(P, gid, count, RNG_GOAL_POS, u);
@@ -199,12 +200,13 @@ DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, float gp[
     } else {
         gw[0] = 0.0f; gw[1] = 0.0f; gw[2] = 0.0f;
     }
-    gp[0] = x; gp[1] = y; gp[2] = z;
+    gp[0] = EXT ? x + dr[TF_DR_STAGE_POS] : x; gp[1] = EXT ? y + dr[TF_DR_STAGE_POS + 1] : y; gp[2] = z;      // goals move with the stage
 #pragma unroll
     for (int i = 0; i < 4; ++i) gq[i] = quat[i];
 }
 
 // per-env domain-randomisation factors drawn at a reset (build-defined): scale = lo + (hi - lo) u
+template <bool EXT>
 DEV void draw_dr(const DevParams& P, uint32_t gid, uint32_t count, float dr[TF_NUM_DR]) {
     float u[4];
     rng4(P, gid, count, RNG_DR, u);
@@ -215,6 +217,22 @@ DEV void draw_dr(const DevParams& P, uint32_t gid, uint32_t count, float dr[TF_N
     rng4(P, gid, count, RNG_DR + 1u, u);
     dr[4] = FMA(P.dr_link_mass[1] - P.dr_link_mass[0], u[0], P.dr_link_mass[0]);
     dr[5] = FMA(P.dr_restitution[1] - P.dr_restitution[0], u[1], P.dr_restitution[0]);
+    if (!EXT) return;
+    // robot base and stage positions: offset = a (2 u - 1) per axis; friction per body
+    rng4(P, gid, count, RNG_DR + 2u, u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dr[TF_DR_BASE_POS + k] = P.dr_base_pos[k] * (2.0f * u[k] - 1.0f);
+    dr[TF_DR_STAGE_POS] = P.dr_stage_pos[0] * (2.0f * u[3] - 1.0f);
+    rng4(P, gid, count, RNG_DR + 3u, u);
+    dr[TF_DR_STAGE_POS + 1] = P.dr_stage_pos[1] * (2.0f * u[0] - 1.0f);
+    dr[TF_DR_FRICTION_ROBOT] = FMA(P.dr_friction_robot[1] - P.dr_friction_robot[0], u[1], P.dr_friction_robot[0]);
+    dr[TF_DR_FRICTION_OBJECT] = FMA(P.dr_friction_object[1] - P.dr_friction_object[0], u[2], P.dr_friction_object[0]);
+    dr[TF_DR_FRICTION_STAGE] = FMA(P.dr_friction_stage[1] - P.dr_friction_stage[0], u[3], P.dr_friction_stage[0]);
+}
+// 1 + s_a (f_a - 1) + s_b (f_b - 1) with the shares s = mu / (mu_a + mu_b) of the two bodies in the pair's average
+DEV float pair_factor(float mu_a, float fa1, float mu_b, float fb1) {
+    const float inv = 1.0f / (mu_a + mu_b);
+    return FMA(mu_b * inv, fb1, FMA(mu_a * inv, fa1, 1.0f));
 }
 
 // ---- observation emission: scale_transform (reference torch_utils.py:18-36) as one FMA per slot, then the fused wrapper
@@ -289,12 +307,13 @@ struct TipContact {            // fingertip sphere against one feature of the ar
     float arm[3];             // contact point relative to the tip-link origin (fingertip wrench sensor)
 };
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, bool BOX>
+template <int A, bool IS_RESET, bool ASYM, int MODE, bool EXT>
 DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
     const TfModel& m = P.m;
     const int f = cx.role, lane = cx.lane;
     constexpr int OD = TF_OBS_DIM_BASE + A, SD = OD + TF_STATES_EXTRA;
     constexpr int TW = ASYM ? SD : OD;                 // width of the tile staged in LDS in the post phase
+    constexpr int NDR = EXT ? TF_NUM_DR : TF_DR_BASE_POS;   // the base / stage / per-body friction slots exist in the EXT kernels only
     constexpr int AJ = A / 3;                          // action values of one finger: 3, or 3 + 3 stiffnesses
     const Yaw yw = {m.base_yaw_cos[f], m.base_yaw_sin[f], m.base_half_yaw_cos[f], m.base_half_yaw_sin[f], m.base_height};
     const uint32_t gid = (uint32_t)(P.env_id_offset + cx.i);
@@ -306,7 +325,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
     for (int j = 0; j < 3; ++j) { q[j] = LDST(TF_S_Q + 3 * f + j); qd[j] = LDST(TF_S_QD + 3 * f + j); }
 #pragma unroll
-    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = P.dr_enable ? LDST(TF_S_DR + j) : 1.0f;   // rows are read only when the feature is on
+    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);   // rows are read only when the feature is on
     if (!(MODE & M_TORQUE) && (MODE & (M_RESETS | M_SIM))) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
@@ -328,7 +347,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     const bool rflag = (MODE & M_RESETS) && (IS_RESET || fl_reset != 0);
     if (MODE & M_RESETS) {
         if (rflag) {
-            if (P.dr_enable) draw_dr(P, gid, fl_count, dr);
+            if (P.dr_enable) draw_dr<EXT>(P, gid, fl_count, dr);
             if (P.robot_reset_type == TF_RESET_DEFAULT) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { q[j] = m.q_default[j]; qd[j] = 0.0f; }
@@ -461,7 +480,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = P.dr_enable ? LDST(TF_S_DR + j) : 1.0f;
+                for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) taus[j] = LDST(TF_S_TAU + 3 * f + j);
 #pragma unroll
@@ -479,10 +498,16 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             const float cube_mass = m.cube_mass * dr[0];
             const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
             const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
-            const float mu_fc = m.mu_finger_cube * dr[2], mu_tf = m.mu_tip_floor * dr[2], mu_tw = m.mu_tip_wall * dr[2];
+            // per-body friction factors, robot base and stage offsets (neutral constants when the feature is off)
+            const float fr1 = dr[TF_DR_FRICTION_ROBOT] - 1.0f, fo1 = dr[TF_DR_FRICTION_OBJECT] - 1.0f, fs1 = dr[TF_DR_FRICTION_STAGE] - 1.0f;
+            const float mu_fc = (m.mu_finger_cube * dr[2]) * (EXT ? pair_factor(m.mu_robot, fr1, m.mu_object, fo1) : 1.0f);
+            const float mu_tf = (m.mu_tip_floor * dr[2]) * (EXT ? pair_factor(m.mu_robot, fr1, m.mu_floor, fs1) : 1.0f);
+            const float mu_tw = (m.mu_tip_wall * dr[2]) * (EXT ? pair_factor(m.mu_robot, fr1, m.mu_stage, fs1) : 1.0f);
             const float rest_f = m.restitution_finger * dr[5];
+            const float boff[3] = {dr[TF_DR_BASE_POS], dr[TF_DR_BASE_POS + 1], dr[TF_DR_BASE_POS + 2]};
+            const float soff[2] = {dr[TF_DR_STAGE_POS], dr[TF_DR_STAGE_POS + 1]};
             const float ws = m.warm_start;
-            constexpr bool box = BOX;      // general box object: its own kernel instantiation, the cube kernels carry none of it
+            const bool box = EXT ? (m.box != 0) : false;      // general box object: only in the EXT kernel instantiations, the cube kernels carry none of it
             float hc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) hc[j] = (box ? m.box_half[j] : m.cube_half) * dr[1];
@@ -524,7 +549,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             // ---- F2: contact generation (positions at the start of the substep) ----
             float cp[3], cq[4], R[9], cvf[3], cwf[3];             // cube pose and free velocity (their slots are reused after S1b)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { cp[j] = LD(L_POSE_A + j); cvf[j] = LD(L_POSE_B + j); cwf[j] = LD(L_POSE_B + 3 + j); }
+            for (int j = 0; j < 3; ++j) { cp[j] = EXT ? LD(L_POSE_A + j) - boff[j] : LD(L_POSE_A + j); cvf[j] = LD(L_POSE_B + j); cwf[j] = LD(L_POSE_B + 3 + j); }   // robot frame = world - base offset
 #pragma unroll
             for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
             quat_to_rot(cq, R);
@@ -647,7 +672,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             TipContact tc[2];
             float wall_n[2];                                    // inward horizontal normal at the fingertip (wrench of slot 1)
             {
-                float rho2 = FMA(Bw[0], Bw[0], Bw[1] * Bw[1]);
+                // fingertip sphere centre in the world (z) and relative to the stage centre (x, y)
+                const float bx = EXT ? (Bw[0] + boff[0]) - soff[0] : Bw[0], by = EXT ? (Bw[1] + boff[1]) - soff[1] : Bw[1], bz = EXT ? Bw[2] + boff[2] : Bw[2];
+                float rho2 = FMA(bx, bx, by * by);
                 float inv = f_rsqrt(f_max(rho2, 1e-24f));
                 float rho = rho2 * inv;
 #pragma unroll
@@ -659,11 +686,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { c.Dinv[j] = 0.0f; c.lam[j] = 0.0f; c.arm[j] = 0.0f; }
                     c.bias = 0.0f; c.mu = 0.0f;
-                    float gp_ = (t == 0) ? (Bw[2] - m.cap_radius) : ((wall_radius_at(m, Bw[2]) - rho) - m.cap_radius);
+                    float gp_ = (t == 0) ? (bz - m.cap_radius) : ((wall_radius_at(m, bz) - rho) - m.cap_radius);
                     const bool on = ((t == 0) || (rho > 1e-6f)) && (gp_ < m.contact_margin);
                     if (__builtin_expect(on, t == 0)) {
                         float dir[9] = {0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        if (t == 1) { dir[0] = -Bw[0] * inv; dir[1] = -Bw[1] * inv; dir[2] = 0.0f; }
+                        if (t == 1) { dir[0] = -bx * inv; dir[1] = -by * inv; dir[2] = 0.0f; }
                         tangent_basis(&dir[0], &dir[3], &dir[6]);
                         float Pw[3] = {FMA(-m.cap_radius, dir[0], Bw[0]), FMA(-m.cap_radius, dir[1], Bw[1]), FMA(-m.cap_radius, dir[2], Bw[2])};
                         float Pb[3], Dd[3], Jt[9], Wt[9];
@@ -689,7 +716,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                         }
                     }
                 }
-                wall_n[0] = -Bw[0] * inv; wall_n[1] = -Bw[1] * inv;
+                wall_n[0] = -bx * inv; wall_n[1] = -by * inv;
             }
             // joint limit / velocity limit rows
             float vlo[3], vhi[3], lim_dinv[3], lim_lam[3];
@@ -843,6 +870,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         float tips[13];
         fk_setup(m, q, pk);
         tip_state(m, yw, pk, q, qd, tips);
+        float boff_p[3];                                       // robot base offset of the episode (cold through the physics: re-read)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { boff_p[j] = (EXT && P.dr_enable) ? LDST(TF_S_DR + TF_DR_BASE_POS + j) : 0.0f; if (EXT) tips[j] = tips[j] + boff_p[j]; }   // robot frame -> world
         float tip_prev[3], tau_p[3], act_p[AJ], ft[6];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j); tau_p[j] = LDST(TF_S_TAU + 3 * f + j); }
@@ -872,6 +902,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             for (int j = 0; j < 6; ++j) { ft[j] = 0.0f; STST(TF_S_FT + 6 * f + j, 0.0f); }
             fk_setup(m, q, pk);
             tip_state(m, yw, pk, q, qd, tips);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { if (EXT) tips[j] = tips[j] + boff_p[j]; }
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) STST(TF_S_TIP_P + 3 * f + j, tips[j]);
@@ -1070,12 +1102,13 @@ DEV void wall_arms(bool box, const float* lds, int lane, const float r[3], const
     }
 }
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, bool BOX>
+template <int A, bool IS_RESET, bool ASYM, int MODE, bool EXT>
 DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
     const TfModel& m = P.m;
     const int lane = cx.lane;
     constexpr int OD = TF_OBS_DIM_BASE + A, SD = OD + TF_STATES_EXTRA;
     constexpr int TW = ASYM ? SD : OD;
+    constexpr int NDR = EXT ? TF_NUM_DR : TF_DR_BASE_POS;
     const uint32_t gid = (uint32_t)(P.env_id_offset + cx.i);
     // ---- loads ----
     float cp[3], cq[4], cv[3], cw[3], gp[3], gq[4], gw[3], dr[TF_NUM_DR];
@@ -1089,7 +1122,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) { cq[j] = LDST(TF_S_CUBE_Q + j); gq[j] = LDST(TF_S_GOAL_Q + j); }
 #pragma unroll
-    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = P.dr_enable ? LDST(TF_S_DR + j) : 1.0f;   // rows are read only when the feature is on
+    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);   // rows are read only when the feature is on
     if (MODE & (M_SIM | M_RESETS)) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = LDST(TF_S_LAM_CW + j); }
@@ -1116,9 +1149,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         const bool gflag = !IS_RESET && (fl_goal_reset != 0);
         uint32_t count = fl_count;
         if (rflag) {
-            if (P.dr_enable) draw_dr(P, gid, count, dr);
+            if (P.dr_enable) draw_dr<EXT>(P, gid, count, dr);
             if (P.object_reset_type == TF_RESET_DEFAULT) {
-                cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = m.obj_min_height * dr[1];
+                cp[0] = EXT ? 0.0f + dr[TF_DR_STAGE_POS] : 0.0f; cp[1] = EXT ? 0.0f + dr[TF_DR_STAGE_POS + 1] : 0.0f; cp[2] = m.obj_min_height * dr[1];
                 cq[0] = 0.0f; cq[1] = 0.0f; cq[2] = 0.0f; cq[3] = 1.0f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
@@ -1126,12 +1159,13 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 float u[4];
                 rng4(P, gid, count, RNG_OBJECT, u);
                 sample_xy(u[0], u[1], m.obj_max_com_dist, cp[0], cp[1]);
+                if (EXT) { cp[0] = cp[0] + dr[TF_DR_STAGE_POS]; cp[1] = cp[1] + dr[TF_DR_STAGE_POS + 1]; }     // spawn relative to the stage
                 cp[2] = m.obj_min_height * dr[1];
                 sample_yaw_quat(u[2], cq);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
             }
-            sample_goal(P, gid, count, gp, gq, gw);
+            sample_goal<EXT>(P, gid, count, dr, gp, gq, gw);
             count = count + 1u;
 #pragma unroll
             for (int j = 0; j < 12; ++j) { lam_cf[j] = 0.0f; lam_cw[j] = 0.0f; }
@@ -1139,7 +1173,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             n_resets = cx.valid ? 1.0f : 0.0f;
         }
         if (gflag) {
-            sample_goal(P, gid, count, gp, gq, gw);
+            sample_goal<EXT>(P, gid, count, dr, gp, gq, gw);
             count = count + 1u;
         }
         if (cx.valid) {
@@ -1149,7 +1183,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         }
         if (rflag && P.dr_enable) {
 #pragma unroll
-            for (int j = 0; j < TF_NUM_DR; ++j) STST(TF_S_DR + j, dr[j]);
+            for (int j = 0; j < NDR; ++j) STST(TF_S_DR + j, dr[j]);
         }
         if (rflag || gflag) {
 #pragma unroll
@@ -1195,16 +1229,19 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             const int sb_ = 4 + 12 * (s & 1);
             float drs[TF_NUM_DR];                               // cold through the sweeps: re-read for every substep but the first
 #pragma unroll
-            for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (s == 0 || !P.dr_enable) ? dr[j] : LDST(TF_S_DR + j);
+            for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (j >= NDR || s == 0 || !P.dr_enable) ? dr[j] : LDST(TF_S_DR + j);
             const float* dr = drs;
             const float cube_mass = m.cube_mass * dr[0];
             const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
             const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
-            const float mu_fc = m.mu_finger_cube * dr[2];
-            const float mu_cf = m.mu_cube_floor * dr[2], mu_cw = m.mu_cube_wall * dr[2];
+            const float fr1 = dr[TF_DR_FRICTION_ROBOT] - 1.0f, fo1 = dr[TF_DR_FRICTION_OBJECT] - 1.0f, fs1 = dr[TF_DR_FRICTION_STAGE] - 1.0f;
+            const float mu_fc = (m.mu_finger_cube * dr[2]) * (EXT ? pair_factor(m.mu_robot, fr1, m.mu_object, fo1) : 1.0f);
+            const float mu_cf = (m.mu_cube_floor * dr[2]) * (EXT ? pair_factor(m.mu_object, fo1, m.mu_floor, fs1) : 1.0f);
+            const float mu_cw = (m.mu_cube_wall * dr[2]) * (EXT ? pair_factor(m.mu_object, fo1, m.mu_stage, fs1) : 1.0f);
+            const float soff[2] = {dr[TF_DR_STAGE_POS], dr[TF_DR_STAGE_POS + 1]};
             const float rest_ff = m.restitution_ff * dr[5];
             const float ws = m.warm_start;
-            constexpr bool box = BOX;      // general box object: its own kernel instantiation, the cube kernels carry none of it
+            const bool box = EXT ? (m.box != 0) : false;      // general box object: only in the EXT kernel instantiations, the cube kernels carry none of it
             float hc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) hc[j] = (box ? m.box_half[j] : m.cube_half) * dr[1];
@@ -1301,12 +1338,13 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             }
             bool wall_lane = false;
             {   // cube vs boundary wall: the four corners of the face that points outward most; rows go to LDS
-                float rc2 = FMA(cp[0], cp[0], cp[1] * cp[1]);
+                const float cx_ = EXT ? cp[0] - soff[0] : cp[0], cy_ = EXT ? cp[1] - soff[1] : cp[1];      // relative to the stage centre
+                float rc2 = FMA(cx_, cx_, cy_ * cy_);
                 float irc = f_rsqrt(f_max(rc2, 1e-24f));
                 float rho_c = rc2 * irc;
                 bool any = rho_c > 1e-6f;
                 float dx = 0.0f, dy = 0.0f;
-                if (any) { dx = cp[0] * irc; dy = cp[1] * irc; }
+                if (any) { dx = cx_ * irc; dy = cy_ * irc; }
                 float pr[3];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) pr[j] = FMA(R[j], dx, R[3 + j] * dy);
@@ -1330,7 +1368,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     const int wb = L_WALL + 12 * c;
                     float r[3], n[2] = {0.0f, 0.0f}, Dinv[3] = {0.0f, 0.0f, 0.0f}, bias = 0.0f, lam[3] = {0.0f, 0.0f, 0.0f};
                     cube_corner(R, hc, k, sk, c, r);
-                    float px = cp[0] + r[0], py = cp[1] + r[1], pz = cp[2] + r[2];
+                    float px = cx_ + r[0], py = cy_ + r[1], pz = cp[2] + r[2];
                     float rho2 = FMA(px, px, py * py);
                     float inv = f_rsqrt(f_max(rho2, 1e-24f));
                     float rho = rho2 * inv;

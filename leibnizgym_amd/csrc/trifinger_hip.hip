@@ -33,9 +33,9 @@
 #define SCR_STRIDE TF_SCR_STRIDE
 
 // One launch = one or more hooks of the reference step (MODE) for every env of the handle.
-template <int A, bool IS_RESET, bool ASYM, int MODE, bool BOX>
+template <int A, bool IS_RESET, bool ASYM, int MODE, bool EXT>
 __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
-    __shared__ __attribute__((aligned(16))) float lds[(BOX ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
+    __shared__ __attribute__((aligned(16))) float lds[(EXT ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
     const DevParams& P = *Pp;
     Ctx cx;
     cx.tid = (int)threadIdx.x;
@@ -47,12 +47,12 @@ __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp,
     cx.i = cx.valid ? i_raw : (P.N - 1);
     cx.n_valid = (P.N - cx.wave_first < WAVE) ? (P.N - cx.wave_first) : WAVE;
 #if defined(TF_ONLY_FINGER)      // developer builds for per-role resource analysis (make resource-usage-roles)
-    finger_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
+    finger_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
 #elif defined(TF_ONLY_CUBE)
-    cube_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
+    cube_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
 #else
-    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
-    else finger_role<A, IS_RESET, ASYM, MODE, BOX>(P, sa, action, lds, cx);
+    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
+    else finger_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
 #endif
 }
 
@@ -240,6 +240,7 @@ void tf_default_model(TfModel* m) {
     m->mu_cube_wall = 1.0f;
     m->mu_tip_wall = 1.0f;
     m->mu_finger_finger = 1.0f;
+    m->mu_robot = 1.0f; m->mu_object = 1.0f; m->mu_floor = 0.1f; m->mu_stage = 1.0f;   // trifinger_env.py:364-365,876-878,914-915,934-936
     m->restitution_finger = 0.4f;
     m->restitution_ff = 0.8f;
     m->bounce_threshold = 0.5f;
@@ -361,7 +362,10 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     for (int i = 0; i < 2; ++i) {
         P.dr_cube_mass[i] = cfg->dr_cube_mass[i]; P.dr_cube_size[i] = cfg->dr_cube_size[i]; P.dr_friction[i] = cfg->dr_friction[i];
         P.dr_motor[i] = cfg->dr_motor[i]; P.dr_link_mass[i] = cfg->dr_link_mass[i]; P.dr_restitution[i] = cfg->dr_restitution[i];
+        P.dr_friction_robot[i] = cfg->dr_friction_robot[i]; P.dr_friction_object[i] = cfg->dr_friction_object[i];
+        P.dr_friction_stage[i] = cfg->dr_friction_stage[i]; P.dr_stage_pos[i] = cfg->dr_stage_pos[i];
     }
+    for (int i = 0; i < 3; ++i) P.dr_base_pos[i] = cfg->dr_base_pos[i];
     P.dr_obs_noise = (cfg->dr_enable && cfg->dr_obs_noise > 0.0f) ? cfg->dr_obs_noise : 0.0f;
     P.dr_action_repeat = (cfg->dr_enable && cfg->dr_action_repeat > 0.0f) ? cfg->dr_action_repeat : 0.0f;
     P.clip_obs = 3.402823466e38f; P.clip_act = 3.402823466e38f;
@@ -481,22 +485,33 @@ static inline int n_waves(const TfHandle_* h) { return (h->cfg.num_envs + WAVE -
         if (e_ != hipSuccess) return hip_fail(e_, what);           \
     } while (0)
 
-template <int MODE, bool IS_RESET, bool BOX>
+template <int MODE, bool IS_RESET, bool EXT>
 static void launch_env_obj(TfHandle_* h, const float* action, hipStream_t s) {
     dim3 grid(n_waves(h)), block(NT);
     const bool asym = h->cfg.asymmetric_obs != 0;
     if (h->action_dim == 9) {
-        if (asym) hipLaunchKernelGGL((k_env<9, IS_RESET, true, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<9, IS_RESET, false, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
+        if (asym) hipLaunchKernelGGL((k_env<9, IS_RESET, true, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
+        else hipLaunchKernelGGL((k_env<9, IS_RESET, false, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
     } else {
-        if (asym) hipLaunchKernelGGL((k_env<18, IS_RESET, true, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE, BOX>), grid, block, 0, s, h->d_params, h->sa, action);
+        if (asym) hipLaunchKernelGGL((k_env<18, IS_RESET, true, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
+        else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
     }
 }
-// the general box object (TfModel.box) has its own instantiations: the cube kernels stay exactly what they were
+// The general box object (TfModel.box) and the extended domain randomisation (robot base / stage position, per-body friction)
+// live in their own instantiations (EXT): the kernels of the headline path stay exactly what they were - a run-time flag
+// for either cost 9 to 26 us per step through register pressure.
+static bool needs_ext(const TfConfig& c) {
+    if (c.model.box) return true;
+    if (!c.dr_enable) return false;
+    for (int i = 0; i < 3; ++i) if (c.dr_base_pos[i] > 0.0f) return true;
+    for (int i = 0; i < 2; ++i) if (c.dr_stage_pos[i] > 0.0f) return true;
+    const float* f[3] = {c.dr_friction_robot, c.dr_friction_object, c.dr_friction_stage};
+    for (int b = 0; b < 3; ++b) if (f[b][0] != 1.0f || f[b][1] != 1.0f) return true;
+    return false;
+}
 template <int MODE, bool IS_RESET>
 static void launch_env(TfHandle_* h, const float* action, hipStream_t s) {
-    if (h->cfg.model.box) launch_env_obj<MODE, IS_RESET, true>(h, action, s);
+    if (needs_ext(h->cfg)) launch_env_obj<MODE, IS_RESET, true>(h, action, s);
     else launch_env_obj<MODE, IS_RESET, false>(h, action, s);
 }
 

@@ -114,7 +114,10 @@ def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, co
     for i in range(3):
         cfg.gravity[i] = float(gravity[i])
     dr = {"activate": False, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "friction": (0.7, 1.3),
-          "motor_torque": (0.9, 1.1), "link_mass": (0.9, 1.1), "restitution": (0.5, 1.5), "obs_noise": 0.0, "action_repeat_prob": 0.0}
+          "motor_torque": (0.9, 1.1), "link_mass": (0.9, 1.1), "restitution": (0.5, 1.5), "obs_noise": 0.0, "action_repeat_prob": 0.0,
+          # the rest of the reference's intent list (trifinger_env.py:387-389); neutral unless asked for
+          "robot_base_position": (0.0, 0.0, 0.0), "stage_position": (0.0, 0.0),
+          "friction_robot": (1.0, 1.0), "friction_object": (1.0, 1.0), "friction_stage": (1.0, 1.0)}
     dr.update(domain_randomization or {})
     cfg.dr_enable = int(bool(dr["activate"]))
     if not (float(dr["obs_noise"]) >= 0.0):
@@ -123,9 +126,17 @@ def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, co
     if not (0.0 <= float(dr["action_repeat_prob"]) <= 1.0):
         raise ValueError(f"domain_randomization.action_repeat_prob: need a probability, got {dr['action_repeat_prob']}")
     cfg.dr_action_repeat = float(dr["action_repeat_prob"])
+    for name, field in (("robot_base_position", cfg.dr_base_pos), ("stage_position", cfg.dr_stage_pos)):
+        half = [float(x) for x in dr[name]]
+        if len(half) != len(field) or not all(0.0 <= x <= 0.05 for x in half):
+            raise ValueError(f"domain_randomization.{name}: need {len(field)} half-widths in [0, 0.05] m, got {dr[name]}")
+        for k, x in enumerate(half):
+            field[k] = x
     for name, field in (("cube_mass", cfg.dr_cube_mass), ("cube_size", cfg.dr_cube_size),
                         ("friction", cfg.dr_friction), ("motor_torque", cfg.dr_motor),
-                        ("link_mass", cfg.dr_link_mass), ("restitution", cfg.dr_restitution)):
+                        ("link_mass", cfg.dr_link_mass), ("restitution", cfg.dr_restitution),
+                        ("friction_robot", cfg.dr_friction_robot), ("friction_object", cfg.dr_friction_object),
+                        ("friction_stage", cfg.dr_friction_stage)):
         lo, hi = dr[name]
         if not (0.0 < float(lo) <= float(hi)):
             raise ValueError(f"domain_randomization.{name}: need 0 < lo <= hi, got {(lo, hi)}")
@@ -189,7 +200,8 @@ class TrifingerEngine:
         self.state[capi.S_CUBE_Q + 3] = 1.0     # identity quaternions (xyzw)
         self.state[capi.S_GOAL_Q + 3] = 1.0
         self.state[capi.S_PREV_OBJ_Q + 3] = 1.0
-        self.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR] = 1.0    # domain-randomisation scale factors
+        self.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR] = 1.0    # domain-randomisation scale factors ...
+        self.state[capi.S_DR + capi.DR_BASE_POS:capi.S_DR + capi.DR_FRICTION_ROBOT] = 0.0    # ... and offsets
         self.action_buf = torch.zeros((n, self.action_dim), **f32)
         self.obs = torch.zeros((n, self.obs_dim), **f32)
         self.states = torch.zeros((n, self.states_dim), **f32)

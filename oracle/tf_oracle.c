@@ -268,6 +268,7 @@ struct TfHandle_ {
     TfConfig cfg;
     TfBuffers buf;
     int bound;
+    int ext;                            /* general box or extended domain randomisation in use (the HIP library's EXT kernels) */
     int64_t frame_count;
     float clip_obs, clip_act;           /* fused wrapper clipping; FLT_MAX when off */
     int action_dim, obs_dim, states_dim;
@@ -381,6 +382,7 @@ void tf_default_model(TfModel* m) {
     m->mu_cube_wall = 1.0f;
     m->mu_tip_wall = 1.0f;
     m->mu_finger_finger = 1.0f;
+    m->mu_robot = 1.0f; m->mu_object = 1.0f; m->mu_floor = 0.1f; m->mu_stage = 1.0f;   /* trifinger_env.py:364-365,876-878,914-915,934-936 */
     m->restitution_finger = 0.4f;         /* avg(0.8, 0.0) */
     m->restitution_ff = 0.8f;             /* avg(0.8, 0.8) */
     m->bounce_threshold = 0.5f;
@@ -469,6 +471,19 @@ static void build_tables(struct TfHandle_* h) {
     }
 }
 
+/* mirrors needs_ext() of the HIP library: the base / stage offsets and per-body friction factors take part in the arithmetic
+ * only when a box object or one of those randomisations is configured (otherwise not even a + 0.0 is applied) */
+static int needs_ext(const TfConfig* c) {
+    if (c->model.box) return 1;
+    if (!c->dr_enable) return 0;
+    for (int i = 0; i < 3; ++i) if (c->dr_base_pos[i] > 0.0f) return 1;
+    for (int i = 0; i < 2; ++i) if (c->dr_stage_pos[i] > 0.0f) return 1;
+    if (c->dr_friction_robot[0] != 1.0f || c->dr_friction_robot[1] != 1.0f) return 1;
+    if (c->dr_friction_object[0] != 1.0f || c->dr_friction_object[1] != 1.0f) return 1;
+    if (c->dr_friction_stage[0] != 1.0f || c->dr_friction_stage[1] != 1.0f) return 1;
+    return 0;
+}
+
 int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (!cfg || !out) return TF_ERR_INVALID_ARG;
     if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
@@ -488,6 +503,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (h->cfg.global_num_envs <= 0) h->cfg.global_num_envs = cfg->num_envs;
     h->action_dim = tf_action_dim(cfg->command_mode);
     build_tables(h);
+    h->ext = needs_ext(&h->cfg);
     *out = h;
     return TF_OK;
 }
@@ -1067,6 +1083,12 @@ typedef struct {
     float u[3], dl[3];
 } FcRecord;
 
+/* 1 + s_a (f_a - 1) + s_b (f_b - 1) with the shares s = mu / (mu_a + mu_b) of the two bodies in the pair's average */
+static inline float pair_factor(float mu_a, float fa1, float mu_b, float fb1) {
+    const float inv = 1.0f / (mu_a + mu_b);
+    return FMA(mu_b * inv, fb1, FMA(mu_a * inv, fa1, 1.0f));
+}
+
 /* One solver substep of length h for one env.  Phases and roles: F1 free motion of each finger,
  * C1 cube free motion and corner contacts, FF finger-finger pre-pass, F2 finger contact generation, then the sweeps. */
 static void substep(const struct TfHandle_* H, Env* e, float h) {
@@ -1077,8 +1099,19 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     const float cube_mass = m->cube_mass * e->dr[0];
     const float cube_inertia = m->cube_inertia * e->dr[0] * e->dr[1] * e->dr[1];
     const float inv_m = 1.0f / cube_mass, inv_I = 1.0f / cube_inertia;
-    const float mu_fc = m->mu_finger_cube * e->dr[2], mu_tf = m->mu_tip_floor * e->dr[2], mu_tw = m->mu_tip_wall * e->dr[2];
-    const float mu_cf = m->mu_cube_floor * e->dr[2], mu_cw = m->mu_cube_wall * e->dr[2];
+    /* per-body friction factors: a pair's coefficient is scaled by 1 + s_a (f_a - 1) + s_b (f_b - 1), s = the bodies' shares */
+    const float fr1 = e->dr[TF_DR_FRICTION_ROBOT] - 1.0f, fo1 = e->dr[TF_DR_FRICTION_OBJECT] - 1.0f, fs1 = e->dr[TF_DR_FRICTION_STAGE] - 1.0f;
+    const int ext = H->ext;
+    const float mu_fc = (m->mu_finger_cube * e->dr[2]) * (ext ? pair_factor(m->mu_robot, fr1, m->mu_object, fo1) : 1.0f);
+    const float mu_tf = (m->mu_tip_floor * e->dr[2]) * (ext ? pair_factor(m->mu_robot, fr1, m->mu_floor, fs1) : 1.0f);
+    const float mu_tw = (m->mu_tip_wall * e->dr[2]) * (ext ? pair_factor(m->mu_robot, fr1, m->mu_stage, fs1) : 1.0f);
+    const float mu_cf = (m->mu_cube_floor * e->dr[2]) * (ext ? pair_factor(m->mu_object, fo1, m->mu_floor, fs1) : 1.0f);
+    const float mu_cw = (m->mu_cube_wall * e->dr[2]) * (ext ? pair_factor(m->mu_object, fo1, m->mu_stage, fs1) : 1.0f);
+    /* robot base offset: the finger roles work in the robot frame = world - offset (the cube position is shifted instead of
+     * every kinematic transform); stage offset: centre of the boundary */
+    const float* boff = &e->dr[TF_DR_BASE_POS];
+    const float* soff = &e->dr[TF_DR_STAGE_POS];
+    const float cpr[3] = {ext ? e->cp[0] - boff[0] : e->cp[0], ext ? e->cp[1] - boff[1] : e->cp[1], ext ? e->cp[2] - boff[2] : e->cp[2]};
     const float rest_f = m->restitution_finger * e->dr[5], rest_ff = m->restitution_ff * e->dr[5];
     const float ws = m->warm_start;
     const int box = m->box;
@@ -1173,12 +1206,13 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         }
     }
     {   /* cube vs boundary wall: the four corners of the face that points outward most */
-        float rc2 = FMA(e->cp[0], e->cp[0], e->cp[1] * e->cp[1]);
+        const float cx_ = ext ? e->cp[0] - soff[0] : e->cp[0], cy_ = ext ? e->cp[1] - soff[1] : e->cp[1];      /* relative to the stage centre */
+        float rc2 = FMA(cx_, cx_, cy_ * cy_);
         float irc = f_rsqrt(f_max(rc2, 1e-24f));
         float rho_c = rc2 * irc;
         int any = rho_c > 1e-6f;
         float dx = 0.0f, dy = 0.0f;
-        if (any) { dx = e->cp[0] * irc; dy = e->cp[1] * irc; }
+        if (any) { dx = cx_ * irc; dy = cy_ * irc; }
         float pr[3];
         for (int i = 0; i < 3; ++i) pr[i] = FMA(R[i], dx, R[3 + i] * dy);
         int k = 0;
@@ -1194,7 +1228,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             CubeContact* c = &cwl[i];
             memset(c, 0, sizeof(*c));
             cube_corner(R, hc, k, sk, i, c->r);
-            float px = e->cp[0] + c->r[0], py = e->cp[1] + c->r[1], pz = e->cp[2] + c->r[2];
+            float px = cx_ + c->r[0], py = cy_ + c->r[1], pz = e->cp[2] + c->r[2];
             float rho2 = FMA(px, px, py * py);
             float inv = f_rsqrt(f_max(rho2, 1e-24f));
             float rho = rho2 * inv;
@@ -1256,7 +1290,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[j], lam, va[j]); vb[j] = FMA(-Wb[j], lam, vb[j]); }
     }
     /* ---- F2: contacts of each finger ---- */
-    float cube_top_check = e->cp[2];
+    float cube_top_check = cpr[2];
     for (int f = 0; f < 3; ++f) {
         FingerRole* g = &fr[f];
         const FK* k = &g->k;
@@ -1278,8 +1312,8 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 base_to_world(m, f, Ab, Aw);
                 base_to_world(m, f, Bb, Bw);
             }
-            float da[3] = {Aw[0] - e->cp[0], Aw[1] - e->cp[1], Aw[2] - e->cp[2]};
-            float db[3] = {Bw[0] - e->cp[0], Bw[1] - e->cp[1], Bw[2] - e->cp[2]};
+            float da[3] = {Aw[0] - cpr[0], Aw[1] - cpr[1], Aw[2] - cpr[2]};
+            float db[3] = {Bw[0] - cpr[0], Bw[1] - cpr[1], Bw[2] - cpr[2]};
             float a[3], b[3], gx[3], gy[3], gn[3], gg;
             mat3T_mul(R, da, a);
             mat3T_mul(R, db, b);
@@ -1299,8 +1333,8 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             mat3_mul(R, x, xw);
             tangent_basis(dir[0], dir[1], dir[2]);
             /* finger-side contact point (world): axis point minus r n */
-            float Pw[3] = {FMA(-radius, dir[0][0], e->cp[0] + xw[0]), FMA(-radius, dir[0][1], e->cp[1] + xw[1]),
-                           FMA(-radius, dir[0][2], e->cp[2] + xw[2])};
+            float Pw[3] = {FMA(-radius, dir[0][0], cpr[0] + xw[0]), FMA(-radius, dir[0][1], cpr[1] + xw[1]),
+                           FMA(-radius, dir[0][2], cpr[2] + xw[2])};
             float Pb[3];
             world_to_base(m, f, Pw, Pb);
             finger_jac(m, f, k, link, Pb, dir, J, W, Dd);
@@ -1333,17 +1367,19 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         }
         /* --- fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1) --- */
         {
-            float rho2 = FMA(g->Bw[0], g->Bw[0], g->Bw[1] * g->Bw[1]);
+            /* fingertip sphere centre in the world (z) and relative to the stage centre (x, y) */
+            const float bx = ext ? (g->Bw[0] + boff[0]) - soff[0] : g->Bw[0], by = ext ? (g->Bw[1] + boff[1]) - soff[1] : g->Bw[1], bz = ext ? g->Bw[2] + boff[2] : g->Bw[2];
+            float rho2 = FMA(bx, bx, by * by);
             float inv = f_rsqrt(f_max(rho2, 1e-24f));
             float rho = rho2 * inv;
             for (int t = 0; t < 2; ++t) {
                 TipContact* c = &g->tc[t];
                 memset(c, 0, sizeof(*c));
-                float gp_ = (t == 0) ? (g->Bw[2] - m->cap_radius) : ((wall_radius_at(m, g->Bw[2]) - rho) - m->cap_radius);
+                float gp_ = (t == 0) ? (bz - m->cap_radius) : ((wall_radius_at(m, bz) - rho) - m->cap_radius);
                 if (t == 1 && !(rho > 1e-6f)) continue;
                 if (!(gp_ < m->contact_margin)) continue;
                 float dir[3][3] = {{0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-                if (t == 1) { dir[0][0] = -g->Bw[0] * inv; dir[0][1] = -g->Bw[1] * inv; dir[0][2] = 0.0f; }
+                if (t == 1) { dir[0][0] = -bx * inv; dir[0][1] = -by * inv; dir[0][2] = 0.0f; }
                 tangent_basis(dir[0], dir[1], dir[2]);
                 float Pw[3] = {FMA(-m->cap_radius, dir[0][0], g->Bw[0]), FMA(-m->cap_radius, dir[0][1], g->Bw[1]),
                                FMA(-m->cap_radius, dir[0][2], g->Bw[2])};
@@ -1576,7 +1612,7 @@ static void env_load(const struct TfHandle_* h, int i, Env* e) {
     }
     for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
     for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
-    for (int j = 0; j < TF_NUM_DR; ++j) e->dr[j] = h->cfg.dr_enable ? ST(h, TF_S_DR + j, i) : 1.0f;   /* rows are read only when the feature is on */
+    for (int j = 0; j < TF_NUM_DR; ++j) e->dr[j] = (h->cfg.dr_enable && (h->ext || j < TF_DR_BASE_POS)) ? ST(h, TF_S_DR + j, i) : TF_DR_NEUTRAL(j);   /* rows are read only when the feature is on */
     for (int f = 0; f < 3; ++f) {
         for (int j = 0; j < 4; ++j) e->lam_fc[f][j] = ST(h, TF_S_LAM_FC + 4 * f + j, i);
         for (int j = 0; j < 3; ++j) { e->lam_tf[f][j] = ST(h, TF_S_LAM_TF + 3 * f + j, i); e->lam_tw[f][j] = ST(h, TF_S_LAM_TW + 3 * f + j, i); }
@@ -1597,7 +1633,7 @@ static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_
     }
     for (int j = 0; j < 4; ++j) { ST(h, TF_S_CUBE_Q + j, i) = e->cq[j]; ST(h, TF_S_GOAL_Q + j, i) = e->gq[j]; }
     if (store_ft) for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
-    if (h->cfg.dr_enable) for (int j = 0; j < TF_NUM_DR; ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
+    if (h->cfg.dr_enable) for (int j = 0; j < (h->ext ? TF_NUM_DR : TF_DR_BASE_POS); ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
     for (int f = 0; f < 3; ++f) {
         for (int j = 0; j < 4; ++j) ST(h, TF_S_LAM_FC + 4 * f + j, i) = e->lam_fc[f][j];
         for (int j = 0; j < 3; ++j) { ST(h, TF_S_LAM_TF + 3 * f + j, i) = e->lam_tf[f][j]; ST(h, TF_S_LAM_TW + 3 * f + j, i) = e->lam_tw[f][j]; }
@@ -1672,7 +1708,7 @@ static void sample_goal(const struct TfHandle_* h, uint32_t gid, uint32_t count,
     } else {
         e->gw[0] = 0.0f; e->gw[1] = 0.0f; e->gw[2] = 0.0f;
     }
-    e->gp[0] = x; e->gp[1] = y; e->gp[2] = z;
+    e->gp[0] = h->ext ? x + e->dr[TF_DR_STAGE_POS] : x; e->gp[1] = h->ext ? y + e->dr[TF_DR_STAGE_POS + 1] : y; e->gp[2] = z;   /* goals move with the stage */
     for (int i = 0; i < 4; ++i) e->gq[i] = quat[i];
 }
 
@@ -1704,6 +1740,17 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
             rng4(c->seed, gid, count, RNG_DR + 1u, u);
             e->dr[4] = FMA(c->dr_link_mass[1] - c->dr_link_mass[0], u[0], c->dr_link_mass[0]);
             e->dr[5] = FMA(c->dr_restitution[1] - c->dr_restitution[0], u[1], c->dr_restitution[0]);
+            /* robot base and stage positions: offset = a (2 u - 1) per axis; friction per body */
+            if (h->ext) {
+            rng4(c->seed, gid, count, RNG_DR + 2u, u);
+            for (int k = 0; k < 3; ++k) e->dr[TF_DR_BASE_POS + k] = c->dr_base_pos[k] * (2.0f * u[k] - 1.0f);
+            e->dr[TF_DR_STAGE_POS] = c->dr_stage_pos[0] * (2.0f * u[3] - 1.0f);
+            rng4(c->seed, gid, count, RNG_DR + 3u, u);
+            e->dr[TF_DR_STAGE_POS + 1] = c->dr_stage_pos[1] * (2.0f * u[0] - 1.0f);
+            e->dr[TF_DR_FRICTION_ROBOT] = FMA(c->dr_friction_robot[1] - c->dr_friction_robot[0], u[1], c->dr_friction_robot[0]);
+            e->dr[TF_DR_FRICTION_OBJECT] = FMA(c->dr_friction_object[1] - c->dr_friction_object[0], u[2], c->dr_friction_object[0]);
+            e->dr[TF_DR_FRICTION_STAGE] = FMA(c->dr_friction_stage[1] - c->dr_friction_stage[0], u[3], c->dr_friction_stage[0]);
+            }
         }
         if (c->robot_reset_type == TF_RESET_DEFAULT) {
             for (int j = 0; j < 9; ++j) { e->q[j] = m->q_default[j % 3]; e->qd[j] = 0.0f; }
@@ -1716,13 +1763,14 @@ static int apply_resets(const struct TfHandle_* h, int i, Env* e, int force_all)
             }
         }
         if (c->object_reset_type == TF_RESET_DEFAULT) {
-            e->cp[0] = 0.0f; e->cp[1] = 0.0f; e->cp[2] = h->cfg.model.obj_min_height * e->dr[1];
+            e->cp[0] = h->ext ? 0.0f + e->dr[TF_DR_STAGE_POS] : 0.0f; e->cp[1] = h->ext ? 0.0f + e->dr[TF_DR_STAGE_POS + 1] : 0.0f; e->cp[2] = h->cfg.model.obj_min_height * e->dr[1];
             e->cq[0] = 0.0f; e->cq[1] = 0.0f; e->cq[2] = 0.0f; e->cq[3] = 1.0f;
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
         } else if (c->object_reset_type == TF_RESET_RANDOM) {  /* trifinger_env.py:1169-1173 */
             float u[4];
             rng4(c->seed, gid, count, RNG_OBJECT, u);
             sample_xy(u[0], u[1], h->cfg.model.obj_max_com_dist, &e->cp[0], &e->cp[1]);
+            if (h->ext) { e->cp[0] = e->cp[0] + e->dr[TF_DR_STAGE_POS]; e->cp[1] = e->cp[1] + e->dr[TF_DR_STAGE_POS + 1]; }   /* spawn relative to the stage */
             e->cp[2] = h->cfg.model.obj_min_height * e->dr[1];
             sample_yaw_quat(u[2], e->cq);
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
@@ -1880,7 +1928,10 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
     const TfModel* m = &c->model;
     int A = h->action_dim, OD = h->obs_dim, SD = h->states_dim;
     float tips[3][13];
-    for (int f = 0; f < 3; ++f) tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
+    for (int f = 0; f < 3; ++f) {
+        tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
+        if (h->ext) for (int j = 0; j < 3; ++j) tips[f][j] = tips[f][j] + e->dr[TF_DR_BASE_POS + j];     /* robot frame -> world */
+    }
     /* NaN guard: a non-finite env is flagged for reset and parked at the default pose; its reward terms of this step
      * (they involve the histories that were non-finite) are zero, so neither the learner nor the logged means see it */
     int guarded = 0;
@@ -1895,7 +1946,10 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
             e->cq[0] = 0.0f; e->cq[1] = 0.0f; e->cq[2] = 0.0f; e->cq[3] = 1.0f;
             for (int k = 0; k < 3; ++k) { e->cv[k] = 0.0f; e->cw[k] = 0.0f; }
             for (int j = 0; j < 18; ++j) e->ft[j] = 0.0f;
-            for (int f = 0; f < 3; ++f) tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
+            for (int f = 0; f < 3; ++f) {
+                tip_state(m, f, &e->q[3 * f], &e->qd[3 * f], tips[f]);
+                if (h->ext) for (int j = 0; j < 3; ++j) tips[f][j] = tips[f][j] + e->dr[TF_DR_BASE_POS + j];
+            }
             h->buf.reset_buf[i] = 1;
             st->nonfinite += 1.0;
             guarded = 1;

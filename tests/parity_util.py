@@ -46,6 +46,17 @@ CONFIGS = {
                                                           "action_repeat_prob": 0.2},
                                     success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.02,
                                              "orientation_tolerance": 0.25}),
+    # the rest of the intent list: robot base / stage offsets, friction per body (the EXT kernels of the HIP library)
+    "d4_domain_randomization_extended": dict(command_mode="torque", task_difficulty=4, asymmetric_obs=True,
+                                             reward_terms=D4_REWARDS,
+                                             domain_randomization={"activate": True, "cube_mass": (0.5, 1.5),
+                                                                   "cube_size": (0.85, 1.1), "friction": (0.5, 1.4),
+                                                                   "robot_base_position": (0.01, 0.02, 0.004),
+                                                                   "stage_position": (0.02, 0.015),
+                                                                   "friction_robot": (0.7, 1.3), "friction_object": (0.5, 1.5),
+                                                                   "friction_stage": (0.6, 1.4), "obs_noise": 0.01},
+                                             success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.02,
+                                                      "orientation_tolerance": 0.25}),
     # everything else: impedance actions (A=18), random robot reset, moving goal, difficulty 3, decimation 2, and the
     # wrapper clipping fused into the step with bounds tight enough to bite (tf_set_clipping)
     "impedance_random_moving": dict(_clipping=(0.8, 0.7), command_mode="position_impedance", task_difficulty=3, asymmetric_obs=True,

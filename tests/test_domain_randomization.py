@@ -4,6 +4,7 @@ U[lo, hi] (cube mass, cube size, contact friction, motor torque, finger link mas
 stream tags 9 and 10; observation noise (the TODO at trifinger_env.py:979) is a per-step uniform perturbation of the
 emitted obs slots 0..24, keyed by the frame count."""
 import numpy as np
+import pytest
 import torch
 from scipy import stats
 
@@ -21,9 +22,11 @@ def test_factors_are_uniform_in_range_and_redrawn(backend):
     cfg = make_config(backend[0], n, seed=5, command_mode="torque", episode_length=3,
                       domain_randomization=dict(activate=True, **RANGES), success={"activate": False})
     eng = TrifingerEngine(cfg, device=backend[1], lib=backend[0])
-    assert torch.all(eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR] == 1.0)
+    neutral = eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR, 0].cpu().numpy()
+    assert np.all(neutral[:6] == 1.0) and np.all(neutral[6:11] == 0.0) and np.all(neutral[11:] == 1.0)   # factors 1, offsets 0
     eng.reset()
     dr = eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR].cpu().numpy().copy()
+    assert np.array_equal(dr[6:], np.broadcast_to(neutral[6:, None], dr[6:].shape))    # the extended slots were not asked for
     for row, (lo, hi) in zip(dr, RANGES.values()):
         assert row.min() >= lo - 1e-6 and row.max() <= hi + 1e-6
         assert stats.kstest((row - lo) / (hi - lo), "uniform").pvalue > 1e-3
@@ -195,3 +198,86 @@ def test_action_repeat(backend):
         e1.step(torch.full((64, 9), 0.1, device=backend[1]))
         assert torch.all(e1.tau == 0)
     e1.close()
+
+
+EXTENDED = dict(robot_base_position=(0.01, 0.02, 0.005), stage_position=(0.015, 0.01), friction_robot=(0.8, 1.2),
+                friction_object=(0.5, 1.5), friction_stage=(0.7, 1.3))
+
+
+def test_extended_slots_are_drawn_in_range_and_shift_spawn_and_goal(backend):
+    """The rest of the reference's intent list (trifinger_env.py:387-389): robot base position, stage position, friction per
+    body.  Offsets ~ U[-a, a] per axis, factors ~ U[lo, hi]; object spawn and goal positions move with the stage."""
+    n = 20000
+    kw = dict(seed=11, command_mode="torque", task_difficulty=1, success={"activate": False})
+    eng = TrifingerEngine(make_config(backend[0], n, domain_randomization=dict(activate=True, **NEUTRAL, **EXTENDED), **kw),
+                          device=backend[1], lib=backend[0])
+    ref = TrifingerEngine(make_config(backend[0], n, domain_randomization=dict(activate=True, **NEUTRAL), **kw),
+                          device=backend[1], lib=backend[0])
+    eng.reset(), ref.reset()
+    dr = eng.state[capi.S_DR:capi.S_DR + capi.TF_NUM_DR].cpu().numpy()
+    half = list(EXTENDED["robot_base_position"]) + list(EXTENDED["stage_position"])
+    for k, a in enumerate(half):
+        row = dr[capi.DR_BASE_POS + k]
+        assert np.abs(row).max() <= a + 1e-7 and stats.kstest((row + a) / (2 * a), "uniform").pvalue > 1e-3
+    for k, name in enumerate(("friction_robot", "friction_object", "friction_stage")):
+        lo, hi = EXTENDED[name]
+        row = dr[capi.DR_FRICTION_ROBOT + k]
+        assert row.min() >= lo - 1e-6 and row.max() <= hi + 1e-6 and stats.kstest((row - lo) / (hi - lo), "uniform").pvalue > 1e-3
+    assert abs(np.corrcoef(dr[6:])[0, 1:]).max() < 0.03
+    # same seed, same draws of the spawn and goal samplers: positions differ exactly by the stage offset
+    a, b = eng.state.cpu().numpy(), ref.state.cpu().numpy()
+    for j in range(2):
+        assert np.abs((a[capi.S_GOAL_P + j] - b[capi.S_GOAL_P + j]) - dr[capi.DR_STAGE_POS + j]).max() < 1e-6
+        assert np.abs((a[capi.S_CUBE_P + j] - b[capi.S_CUBE_P + j]) - dr[capi.DR_STAGE_POS + j]).max() < 2e-3   # one simulate later
+    assert np.array_equal(a[capi.S_GOAL_P + 2], b[capi.S_GOAL_P + 2])
+    # the fingertips in the world are displaced by the base offset (same joint state up to the one simulate)
+    for j in range(3):
+        d = np.abs((a[capi.S_TIP_P + j] - b[capi.S_TIP_P + j]) - dr[capi.DR_BASE_POS + j])
+        assert np.quantile(d, 0.9) < 1e-6 and d.max() < 5e-3       # cubes spawned next to a finger touch it differently in the one simulate
+    eng.close(), ref.close()
+
+
+def test_extended_randomisation_physical_effects(backend):
+    """stage offset moves the boundary; the object friction factor changes the cube's sliding friction by its share of the
+    pair's average (object 1.0, floor 0.1: 10/11 of the coefficient is the object's)."""
+    lib, dev = backend
+    off = {k: {"activate": False} for k in capi.REWARD_TERM_ORDER}
+    dr_on = dict(activate=True, **NEUTRAL, stage_position=(0.03, 0.03), friction_object=(0.5, 1.5))
+    cfg = make_config(lib, 3, command_mode="torque", normalize_action=False, apply_safety_damping=False, robot_reset="none",
+                      object_reset="none", episode_length=0, success={"activate": False}, reward_terms=off,
+                      domain_randomization=dr_on)
+    eng = TrifingerEngine(cfg, device=dev, lib=lib)
+    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3, device=dev).repeat(3, 1).T)
+    eng.cube[0:3] = torch.tensor([0.0, 0.0, 0.0325], device=dev)[:, None]
+    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)[:, None]
+    eng.cube[7] = 0.5                                      # sliding along +x at 0.5 m/s
+    eng.state[capi.S_DR + capi.DR_FRICTION_OBJECT, 1] = 0.5
+    eng.state[capi.S_DR + capi.DR_FRICTION_OBJECT, 2] = 1.5
+    eng.step(torch.zeros(3, 9, device=dev))
+    dv = 0.5 - eng.cube[7].cpu().numpy()
+    mu = 0.55 * (1 + (1.0 / 1.1) * (np.array([1.0, 0.5, 1.5]) - 1))
+    assert np.abs(dv / 0.02 - mu * 9.81).max() < 0.35, (dv / 0.02, mu * 9.81)
+    eng.close()
+    # a cube pushed outward stops at the boundary of the SHIFTED stage
+    eng = TrifingerEngine(cfg, device=dev, lib=lib)
+    eng.q.copy_(torch.tensor([0.0, 0.9, -1.7] * 3, device=dev).repeat(3, 1).T)
+    eng.cube[0:3] = torch.tensor([0.12, 0.0, 0.0325], device=dev)[:, None]
+    eng.cube[3:7] = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)[:, None]
+    eng.cube[7] = 1.5
+    eng.state[capi.S_DR + capi.DR_STAGE_POS, 1] = 0.03     # env 1: boundary centre 3 cm further along +x
+    eng.state[capi.S_DR + capi.DR_STAGE_POS, 2] = -0.03
+    for _ in range(60):
+        eng.step(torch.zeros(3, 9, device=dev))
+    x = eng.cube[0].cpu().numpy()
+    assert abs((x[1] - x[0]) - 0.03) < 3e-3 and abs((x[2] - x[0]) + 0.03) < 3e-3, x
+    assert abs(x[0] - (np.sqrt(0.192 ** 2 - 0.0325 ** 2) - 0.0325)) < 1e-2    # the two leading corners on the cylinder of radius 0.192
+    eng.close()
+
+
+def test_extended_randomisation_validation(backend):
+    with pytest.raises(ValueError, match="robot_base_position"):
+        make_config(backend[0], 4, domain_randomization=dict(activate=True, robot_base_position=(0.1, 0.0, 0.0)))
+    with pytest.raises(ValueError, match="stage_position"):
+        make_config(backend[0], 4, domain_randomization=dict(activate=True, stage_position=(0.01,)))
+    with pytest.raises(ValueError, match="friction_object"):
+        make_config(backend[0], 4, domain_randomization=dict(activate=True, friction_object=(0.0, 1.0)))
