@@ -325,3 +325,20 @@ def test_finger_reach_norm_p_values(backend):
     for p in (2.5, 0, 17):
         with pytest.raises(ValueError, match="norm_p"):
             make_env(backend, reward_terms={"finger_reach_object_rate": {"activate": True, "norm_p": p}})
+
+
+def test_native_solver_option(backend):
+    """`native.solver`: 'pgs' (default: 2 sub-steps x num_position_iterations sweeps) or 'tgs' (num_position_iterations
+    sub-steps of one sweep, PhysX's temporal Gauss-Seidel that `sim.physx.solver_type = 1` asks for, env_base.py:62-63)."""
+    a = make_env(backend, native={"solver": "tgs"}, sim={"physx": {"num_position_iterations": 8}})
+    b = make_env(backend, sim={"physx": {"num_position_iterations": 8}})
+    assert (a._engine.cfg.substeps, a._engine.cfg.solver_iterations) == (8, 1)
+    assert (b._engine.cfg.substeps, b._engine.cfg.solver_iterations) == (2, 8)
+    a.reset(), b.reset()
+    for _ in range(30):
+        a.step(torch.zeros(4, 9)), b.step(torch.zeros(4, 9))
+    za, zb = a._engine.cube[2].cpu(), b._engine.cube[2].cpu()
+    assert (za - 0.0325).abs().max() < 1e-3 and (zb - 0.0325).abs().max() < 1e-3       # the cube rests on the table either way
+    assert torch.isfinite(a.obs_buf).all() and torch.isfinite(a._engine.state).all()     # (undriven fingers sag onto some cubes)
+    with pytest.raises(ValueError, match="native.solver"):
+        make_env(backend, native={"solver": "jacobi"})
