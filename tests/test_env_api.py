@@ -342,3 +342,27 @@ def test_native_solver_option(backend):
     assert torch.isfinite(a.obs_buf).all() and torch.isfinite(a._engine.state).all()     # (undriven fingers sag onto some cubes)
     with pytest.raises(ValueError, match="native.solver"):
         make_env(backend, native={"solver": "jacobi"})
+
+
+def test_moving_goal_is_observed_before_it_advances(backend):
+    """goal_movement.rotation: observations, rewards and termination of step t use the goal pose the step STARTED with;
+    `__update_goal_movement_post` refreshes the pose buffer from the rotated goal actor only afterwards
+    (trifinger_env.py:500-559, 1278-1284).  The goal actor turns by |w| dt per step about its angular velocity."""
+    from leibnizgym_amd import _capi as capi
+    env = make_env(backend, num_instances=64, task_difficulty=4, normalize_obs=False, episode_length=0,
+                   goal_movement={"rotation": {"activate": True, "rate_magnitude": 0.5}})
+    env.reset()
+    eng = env._engine
+    gq0 = eng.state[capi.S_GOAL_Q:capi.S_GOAL_Q + 4].T.clone()
+    gw = eng.state[capi.S_GOAL_W:capi.S_GOAL_W + 3].T.clone()
+    assert gw.norm(dim=1).min() > 1e-3                                  # every goal does rotate
+    obs, _, _, _ = env.step(torch.zeros(64, 9))
+    assert torch.equal(obs[:, 28:32], gq0)                              # observed: the pose the step started with
+    gq1 = eng.state[capi.S_GOAL_Q:capi.S_GOAL_Q + 4].T.clone()
+    chord = (gq1.double() - gq0.double()).norm(dim=1)                   # |q1 - q0| = 2 sin(angle / 4) for unit quaternions
+    angle = 4.0 * torch.asin(0.5 * chord)
+    assert torch.allclose(angle, gw.double().norm(dim=1) * 0.02, atol=2e-5, rtol=1e-3)      # advanced afterwards by |w| dt
+    assert torch.allclose(gq1.norm(dim=1), torch.ones(64, device=gq1.device), atol=1e-6)
+    obs2, _, _, _ = env.step(torch.zeros(64, 9))
+    assert torch.equal(obs2[:, 28:32], gq1)
+    assert torch.equal(env._object_goal_poses_buf[:, 3:7], eng.state[capi.S_GOAL_Q:capi.S_GOAL_Q + 4].T)   # buffer = refreshed pose
