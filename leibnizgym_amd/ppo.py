@@ -21,6 +21,7 @@ with ONE all-reduce of a flat buffer per minibatch (`torch.distributed`, backend
 box, gloo in the CPU tests) - ~1 MB, latency-bound, so a single fused collective is the right shape.
 """
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List
 
@@ -58,6 +59,7 @@ class PPOConfig:
     name: str = "trifinger"
     seed: int = 7
     use_graphs: bool = True           # capture the minibatch step into HIP graphs when the trainer runs on a GPU
+    fused_kernels: bool = True        # hand-written HIP kernels for the objective and the ELU / bias backward (GPU only)
 
     @classmethod
     def from_rlg(cls, rlg: dict, num_envs: int = None, **overrides):
@@ -121,13 +123,35 @@ class SplitKLinear(nn.Linear):
         return super().forward(x)
 
 
+class MLP(nn.Sequential):
+    """[Linear, ELU] x len(units) + Linear.  On the GPU with gradients enabled every (Linear, ELU) pair runs as one autograd
+    node whose backward fuses the ELU derivative with the bias gradient in a hand-written kernel
+    (leibnizgym_amd/ppo_kernels.py); module layout and state-dict keys are those of the plain Sequential."""
+    fused = True
+
+    def forward(self, x):
+        if not (MLP.fused and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled()):
+            return super().forward(x)
+        from .ppo_kernels import linear_elu
+        mods = list(self)
+        k = 0
+        while k < len(mods):
+            if k + 1 < len(mods) and isinstance(mods[k], nn.Linear) and isinstance(mods[k + 1], nn.ELU):
+                x = linear_elu(x, mods[k].weight, mods[k].bias)
+                k += 2
+            else:
+                x = mods[k](x)
+                k += 1
+        return x
+
+
 def mlp(inp, units, out):
     layers, last = [], inp
     for u in units:
         layers += [SplitKLinear(last, u), nn.ELU()]
         last = u
     layers.append(SplitKLinear(last, out))
-    return nn.Sequential(*layers)
+    return MLP(*layers)
 
 
 def variance_scaling_(w: torch.Tensor, scale: float) -> torch.Tensor:
@@ -199,6 +223,7 @@ class PPOTrainer:
         kw = {"fused": True, "capturable": True} if self.graphs else ({"fused": True} if fused else {})
         self.opt = torch.optim.Adam(groups, eps=1e-8, **kw)
         self.lr = c.lr
+        self.fused_loss = fused and c.fused_kernels        # hand-written objective kernel (GPU only)
         self._g = None                         # captured minibatch step (built on the first update)
         self.dist_on = False
         rank = 0
@@ -323,6 +348,8 @@ class PPOTrainer:
         sums of the logged quantities in `acc` (device tensors, no host sync)"""
         c = self.cfg
         obs = d["obs"][idx]
+        if self.fused_loss:
+            return self._mb_backward_fused(d, idx, acc, obs)
         mu, ls = self.net.dist(obs)
         nlp = neglogp(d["act"][idx], mu, ls)
         ratio = (d["old_nlp"][idx] - nlp).exp()
@@ -343,6 +370,27 @@ class PPOTrainer:
             kl = (0.5 * ((mu - d["old_mu"][idx]) / ls.exp()).pow(2)).sum(-1).mean()
             acc["kl"] += kl
             acc["loss"] += loss.detach(); acc["a_loss"] += a_loss.detach(); acc["c_loss"] += c_loss.detach()
+
+    def _mb_backward_fused(self, d, idx, acc, obs):
+        """the same step with the objective and its gradients in ONE hand-written launch (ppo_kernels.fused_ppo_loss); the
+        statistics accumulate on the device in `acc["_fused"]` = (loss, a_loss, c_loss, kl)"""
+        from .ppo_kernels import fused_ppo_loss
+        c = self.cfg
+        mu = self.net.actor(obs)
+        v = self.net.value(obs, d["states"][idx] if d["states"] is not None else None)
+        v_coef = 1.0 if self.net.central else 0.5 * c.critic_coef
+        loss = fused_ppo_loss(mu, self.net.log_std, v, d["act"][idx], d["old_nlp"][idx], d["adv"][idx], d["ret"][idx],
+                              d["old_mu"][idx], acc["_fused"], c.e_clip, v_coef, c.entropy_coef, c.bounds_loss_coef)
+        for p in self.net.parameters():
+            p.grad = None
+        loss.backward()
+
+    @staticmethod
+    def _new_acc(dev):
+        """running sums of the logged quantities, device side: views of ONE buffer (loss, a_loss, c_loss, kl), which is also
+        what the fused objective kernel accumulates into"""
+        buf = torch.zeros(4, device=dev)
+        return {"loss": buf[0], "a_loss": buf[1], "c_loss": buf[2], "kl": buf[3], "_fused": buf}
 
     def _mb_apply(self):
         if self.net.central:                   # truncate_grads of each optimiser on its own network
@@ -407,7 +455,7 @@ class PPOTrainer:
                 self._unflatten_grads(flat)
             self._mb_apply()
         # the two captures above executed nothing; parameters and accumulators are untouched
-        self._g = dict(a=ga, b=gb, idx=idx, flat=flat, d=d, acc=acc, mb=mb)
+        self._g = dict(a=ga, b=gb, idx=idx, flat=flat, d=d, acc=acc, mb=mb, side=side)
 
     def update(self, buf):
         c = self.cfg
@@ -424,7 +472,7 @@ class PPOTrainer:
         if self.graphs:
             if self._g is None or self._g["mb"] != mb or self._g["d"]["obs"].shape != src["obs"].shape:
                 d = {k: (v.clone() if v is not None else None) for k, v in src.items()}
-                acc = {k: torch.zeros((), device=dev) for k in ("kl", "loss", "a_loss", "c_loss")}
+                acc = self._new_acc(dev)
                 self._capture(d, mb, acc)
             d, acc = self._g["d"], self._g["acc"]
             for k, v in src.items():           # the graphs read the rollout from fixed addresses
@@ -432,7 +480,7 @@ class PPOTrainer:
                     d[k].copy_(v)
         else:
             d = src
-            acc = {k: torch.zeros((), device=dev) for k in ("kl", "loss", "a_loss", "c_loss")}
+            acc = self._new_acc(dev)
         for v in acc.values():
             v.zero_()
         stats = {"kl": 0.0}
@@ -449,6 +497,14 @@ class PPOTrainer:
                     if self.dist_on:
                         self._exchange(g["flat"])
                     g["b"].replay()
+                    # Bounded run-ahead WITH a drained stream.  The host queues graph launches far faster than the device retires
+                    # them (a whole mini-epoch: 32 x [index copy, graph A, graph B]).  On this ROCm stack, more than 16 launches
+                    # of the same graph executables queued behind one another without a stream synchronisation in between went
+                    # wrong: gradients came back zero or garbage for whole epochs, differently from run to run.  A stream
+                    # synchronisation every <= 16 steps made every run exact and repeatable; waiting on an event recorded 8 to
+                    # 16 steps earlier (same depth in flight, stream never drained) did not.  Every 8 steps costs < 2 %.
+                    if nmb % 8 == 7:
+                        torch.cuda.current_stream(dev).synchronize()
                 else:
                     self._mb_backward(d, perm[s:s + mb], acc)
                     if self.dist_on:

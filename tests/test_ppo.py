@@ -127,3 +127,26 @@ def test_split_k_linear_matches_linear():
     x2 = torch.randn(100, 41, requires_grad=True)
     _SplitKLinear.apply(x2, w, b).sum().backward()
     assert x2.grad.shape == (100, 41)
+
+
+@pytest.mark.gpu
+def test_graph_mode_stays_exact_over_many_queued_steps(hip):
+    """BASELINE configs[4] shape (8192 envs, 32 minibatches x 4 mini-epochs of the full asymm.yaml settings), five epochs: the
+    graph-replayed update follows the eager one.  Regression test of the run-ahead hazard documented in PPOTrainer.update -
+    with a whole mini-epoch of graph launches queued behind one another the gradients went to zero / garbage from the fourth
+    epoch on and the adaptive learning rate ran away."""
+    from leibnizgym_amd.config import compose
+
+    def run(use_graphs):
+        cfg = compose(["gym=trifinger_difficulty_4", "args.num_envs=8192", "args.headless=True"])
+        env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False)
+        ad = RlGamesGpuEnvAdapter("rlgpu", 8192, env=VecTaskPython(env, rl_device="cuda:0"))
+        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig.from_rlg(cfg["rlg"], num_envs=8192, use_graphs=use_graphs), device="cuda:0")
+        st = tr.train(5)
+        env.close()
+        return st
+    eager, graph = run(False), run(True)
+    for a, b in zip(eager, graph):
+        assert a["lr"] == b["lr"], (a["lr"], b["lr"])
+        assert abs(a["kl"] - b["kl"]) < 0.1 * a["kl"] and abs(a["c_loss"] - b["c_loss"]) < 0.05 * a["c_loss"] + 1e-4, (a, b)
+    assert 0.004 < graph[-1]["kl"] < 0.02
