@@ -59,7 +59,7 @@ class PPOConfig:
     name: str = "trifinger"
     seed: int = 7
     use_graphs: bool = True           # capture the minibatch step into HIP graphs when the trainer runs on a GPU
-    fused_kernels: bool = True        # hand-written HIP kernels for the objective and the ELU / bias backward (GPU only)
+    fused_kernels: bool = True        # hand-written HIP kernel for the objective, forward and backward in one launch (GPU only)
 
     @classmethod
     def from_rlg(cls, rlg: dict, num_envs: int = None, **overrides):
@@ -123,35 +123,13 @@ class SplitKLinear(nn.Linear):
         return super().forward(x)
 
 
-class MLP(nn.Sequential):
-    """[Linear, ELU] x len(units) + Linear.  On the GPU with gradients enabled every (Linear, ELU) pair runs as one autograd
-    node whose backward fuses the ELU derivative with the bias gradient in a hand-written kernel
-    (leibnizgym_amd/ppo_kernels.py); module layout and state-dict keys are those of the plain Sequential."""
-    fused = True
-
-    def forward(self, x):
-        if not (MLP.fused and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled()):
-            return super().forward(x)
-        from .ppo_kernels import linear_elu
-        mods = list(self)
-        k = 0
-        while k < len(mods):
-            if k + 1 < len(mods) and isinstance(mods[k], nn.Linear) and isinstance(mods[k + 1], nn.ELU):
-                x = linear_elu(x, mods[k].weight, mods[k].bias)
-                k += 2
-            else:
-                x = mods[k](x)
-                k += 1
-        return x
-
-
 def mlp(inp, units, out):
     layers, last = [], inp
     for u in units:
         layers += [SplitKLinear(last, u), nn.ELU()]
         last = u
     layers.append(SplitKLinear(last, out))
-    return MLP(*layers)
+    return nn.Sequential(*layers)
 
 
 def variance_scaling_(w: torch.Tensor, scale: float) -> torch.Tensor:

@@ -1,6 +1,5 @@
 """The trainer's hand-written HIP kernels (leibnizgym_amd/csrc/ppo_kernels.hip) against a plain PyTorch fp32 reference of the
-same operations: the fused PPO objective (value and every gradient), the fused ELU-derivative + bias-gradient backward, and the
-trainer as a whole with and without them."""
+same operations: the fused PPO objective (value and every gradient) and the trainer as a whole with and without it."""
 import ctypes as C
 import math
 import os
@@ -16,7 +15,7 @@ def test_ppo_library_loads_and_exports_its_symbols():
     from __graft_entry__ import build          # noqa: F401  (the driver builds first; here the file must simply exist)
     assert os.path.isfile(pk.library_path()), "run `make -C leibnizgym_amd/csrc` (python __graft_entry__.py)"
     lib = C.CDLL(pk.library_path())
-    for name in ("tfp_api_version", "tfp_ppo_loss", "tfp_elu_bwd_bias", "tfp_col_sum"):
+    for name in ("tfp_api_version", "tfp_ppo_loss"):
         assert hasattr(lib, name), name
     assert lib.tfp_api_version() == 1
 
@@ -65,28 +64,11 @@ def test_fused_objective_matches_torch_fp32(hip, B, A, ent_coef):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,N", [(8192, 41, 400), (8192, 400, 200), (1000, 113, 100), (64, 7, 5)])
-def test_linear_elu_matches_torch_fp32(hip, M, K, N):
-    dev = "cuda:0"
-    g = torch.Generator(device=dev).manual_seed(M + K + N)
-    x0, w0, b0 = (torch.randn(*s, device=dev, generator=g) * sc for s, sc in (((M, K), 1.0), ((N, K), K ** -0.5), ((N,), 0.1)))
-    gy = torch.randn(M, N, device=dev, generator=g)
-    out = []
-    for fused in (False, True):
-        x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
-        y = pk.linear_elu(x, w, b) if fused else torch.nn.functional.elu(torch.nn.functional.linear(x, w, b))
-        y.backward(gy)
-        out.append((y.detach(), x.grad, w.grad, b.grad))
-    for a, b in zip(*out):
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(a.abs().max()))
-
-
-@pytest.mark.gpu
 def test_trainer_with_and_without_the_kernels(hip):
     """two PPO epochs on the HIP env, eager mode: the hand-written kernels take the same optimisation steps as plain torch"""
     from leibnizgym_amd.config import gym_config
     from leibnizgym_amd.envs import TrifingerEnv
-    from leibnizgym_amd.ppo import MLP, PPOTrainer
+    from leibnizgym_amd.ppo import PPOTrainer
     from leibnizgym_amd.utils.rlg_train import RlGamesGpuEnvAdapter
     from leibnizgym_amd.wrappers import VecTaskPython
 
@@ -95,14 +77,10 @@ def test_trainer_with_and_without_the_kernels(hip):
         cfg.update(num_instances=256, seed=1, physics_engine="physx", asymmetric_obs=True, episode_length=20)
         env = TrifingerEnv(config=cfg, device="cuda:0", verbose=False)
         ad = RlGamesGpuEnvAdapter("rlgpu", 256, env=VecTaskPython(env, rl_device="cuda:0"))
-        MLP.fused = fused
-        try:
-            tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2, use_graphs=False, fused_kernels=fused),
-                            device="cuda:0")
-            torch.manual_seed(11)
-            stats = tr.train(2)
-        finally:
-            MLP.fused = True
+        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2, use_graphs=False, fused_kernels=fused),
+                        device="cuda:0")
+        torch.manual_seed(11)
+        stats = tr.train(2)
         return [p.detach().clone() for p in tr.net.parameters()], stats
     plain, s0 = run(False)
     fused, s1 = run(True)
