@@ -204,7 +204,8 @@ class TfLib:
 
 
 def hip_library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_hip.so")
+    # TF_HIP_LIB: developer override (compiler-flag experiments build variants next to the product library)
+    return os.environ.get("TF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_hip.so")
 
 
 _HIP_LIB = None
