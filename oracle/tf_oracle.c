@@ -12,9 +12,13 @@
  *     importing the reference's own functions (tests/golden/make_golden.py).
  *   - physics (reference arithmetic NOT visible: it lives in the closed-source IsaacGym/PhysX binary,
  *     "NVIDIA IsaacGym Preview Release 2", README.md:17, not under /root/reference, no version pin):
- *     PARITY UNPINNED.  The algorithm below is this build's own spec (DESIGN.md section "Physics spec"),
- *     written from the URDF numbers and the solver settings the reference asks for, and is checked
- *     against analytic known answers (tests/test_physics_analytic.py), not against IsaacGym.
+ *     PARITY WITH ISAACGYM UNPINNED.  The algorithm below is this build's own spec (DESIGN.md section "Physics spec"),
+ *     written from the URDF numbers and the solver settings the reference asks for.  The spec itself is pinned
+ *     independently of this file: free motion against an fp64 Lagrangian model of the URDF chain
+ *     (tests/test_physics_analytic.py), the contact solve against an fp64 restatement that shares no code with this
+ *     file and iterates to a fixed point (tests/physics_ref.py, tests/test_contact_lcp_reference.py: 200 random contact
+ *     configurations; tests/test_box_object.py: 60 with a general box and the full inertia tensor), and known-answer
+ *     scenarios (tests/test_contact_scenarios.py: pinch-and-lift, impact, restitution, link / finger / wall contacts).
  *
  * Arithmetic contract shared with the HIP kernels: fp32, IEEE add/mul/div/sqrt only, no FMA contraction
  * (-ffp-contract=off on both sides), own polynomial sin/cos/exp/asin/log, fixed evaluation order.  The

@@ -12,7 +12,6 @@ from leibnizgym_amd.ppo import PPOConfig, neglogp
 
 
 def test_ppo_library_loads_and_exports_its_symbols():
-    from __graft_entry__ import build          # noqa: F401  (the driver builds first; here the file must simply exist)
     assert os.path.isfile(pk.library_path()), "run `make -C leibnizgym_amd/csrc` (python __graft_entry__.py)"
     lib = C.CDLL(pk.library_path())
     for name in ("tfp_api_version", "tfp_ppo_loss"):
