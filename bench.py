@@ -252,10 +252,17 @@ def main():
         eng.step(torch.rand(n, eng.action_dim, device=dev, generator=gen) * 2 - 1)
     barrier()
     elapsed_gen = time.perf_counter() - t1
+    # ... and with the action source fused into the step itself (tf_step_random: Philox draws inside the launch)
+    barrier()
+    t2 = time.perf_counter()
+    for k in range(gen_steps):
+        eng.step_random()
+    barrier()
+    elapsed_fused = time.perf_counter() - t2
     if distributed:
-        t = torch.tensor([elapsed, elapsed_gen], device=dev if not one_device else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_gen, elapsed_fused], device=dev if not one_device else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_gen = float(t[0].item()), float(t[1].item())
+        elapsed, elapsed_gen, elapsed_fused = float(t[0].item()), float(t[1].item()), float(t[2].item())
 
     # sanity on what was just timed: finite state, resets happened if steps crossed an episode boundary
     assert torch.isfinite(eng.state).all(), "non-finite state after the timed region"
@@ -294,9 +301,12 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "value_with_action_generation": world * n * gen_steps / elapsed_gen,
-        "action_generation": f"second timed region of {gen_steps} steps with torch.rand(N, A)*2-1 generated on the device inside the "
-                             f"loop (one extra elementwise launch per step); `value` steps a ring of 16 resident action tensors",
+        "value_with_action_generation": world * n * gen_steps / elapsed_fused,
+        "value_with_torch_action_generation": world * n * gen_steps / elapsed_gen,
+        "action_generation": f"`value` steps a ring of 16 resident action tensors; `value_with_action_generation`: timed region of "
+                             f"{gen_steps} steps of tf_step_random, the step with the action source fused in (every env draws 2*U-1 "
+                             f"with Philox inside the launch); `value_with_torch_action_generation`: the same number of steps with "
+                             f"torch.rand(N, A)*2-1 generated on the device inside the loop (three extra elementwise launches per step)",
         "config": {
             "workload": f"trifinger_difficulty_{args.difficulty}{' + full domain randomisation' if args.dr else ''}, "
                         f"{n} envs/GPU x {world} GPU, torque mode, random actions 2*U-1, "

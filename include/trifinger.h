@@ -309,6 +309,11 @@ int tf_set_frame_count(tf_handle h, int64_t frames);
 
 /* The hot path: one control step for every env of the handle, fused, on `stream` (hipStream_t). */
 int tf_step(tf_handle h, const float* action /* [N][A] row-major, device */, void* stream);
+/* The same step with the action SOURCE fused in: every env draws its own action 2 U[0,1) - 1 per dimension inside the launch
+ * (Philox4x32-10 keyed by (seed, global env id, frame count, stream tag): reproducible, invariant to the sharding), exactly what
+ * the reference's demo driver feeds the env (scripts/trifinger_random_action.py:33: 2 * torch.rand(...) - 1) and what the
+ * BASELINE workload specifies ("random actions 2*U-1").  `action_buf` reports the drawn (clipped) actions as usual. */
+int tf_step_random(tf_handle h, void* stream);
 /* IsaacEnvBase.reset: reset every env, zero action, ONE simulate, fill obs/states. */
 int tf_reset(tf_handle h, void* stream);
 

@@ -138,6 +138,7 @@ SYMBOLS = {
     "tf_frame_count": (C.c_int64, [_P]),
     "tf_set_frame_count": (C.c_int, [_P, C.c_int64]),
     "tf_step": (C.c_int, [_P, _P, _P]),
+    "tf_step_random": (C.c_int, [_P, C.c_void_p]),
     "tf_reset": (C.c_int, [_P, _P]),
     "tf_enable_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "tf_set_kernel_timing_window": (C.c_int, [_P, C.c_int32]),

@@ -21,8 +21,9 @@
 #define NT 256                          // threads per workgroup
 
 // kernel modes: which hooks of the reference step a launch performs (the fused step does all of them)
-enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINISH = 32 };
+enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINISH = 32, M_ACT_RAND = 64 /* with M_ACT_IN: the action tile is drawn in the launch */ };
 #define M_FUSED_STEP (M_ACT_IN | M_RESETS | M_TORQUE | M_SIM | M_POST | M_FINISH)
+#define M_FUSED_STEP_RAND (M_FUSED_STEP | M_ACT_RAND)
 #define M_FUSED_RESET (M_RESETS | M_TORQUE | M_SIM | M_POST)
 
 // ---- LDS map: float slots of 64 lanes each, lds[slot * 64 + lane] --------------------------------------------------
@@ -144,6 +145,24 @@ DEV void coop_load_tile(const float* __restrict__ src, float* lds, const Ctx& cx
     for (int k = 0; k < ITER; ++k) {
         const unsigned idx = (unsigned)cx.tid + (unsigned)(NT * k);
         if (idx < (unsigned)(WAVE * A)) lds[idx] = t[k];
+    }
+}
+
+// the [n_valid][A] action tile drawn in place: lds[env * A + c] = 2 u - 1 with u = word (c % 4) of the Philox block
+// (global env id, frame count of the step, RNG_ACTION + c / 4).  One block of four values per thread and pass.
+template <int A>
+DEV void draw_action_tile(const DevParams& P, const StepArgs& sa, float* lds, const Ctx& cx) {
+    constexpr int NB = (A + 3) / 4;                   // Philox blocks per env
+    for (int t = cx.tid; t < WAVE * NB; t += NT) {
+        const int e = t / NB, b = t - e * NB;
+        const int ge = cx.wave_first + ((e < cx.n_valid) ? e : (cx.n_valid - 1));
+        float u[4];
+        rng4(P, (uint32_t)(P.env_id_offset + ge), sa.frame0, RNG_ACTION + (uint32_t)b, u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * b + k;
+            if (c < A) lds[e * A + c] = 2.0f * u[k] - 1.0f;
+        }
     }
 }
 
@@ -339,7 +358,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         for (int j = 0; j < 3; ++j) { lam0_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam0_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
     }
     if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
-    if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
+    if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
+    else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
     BAR();                                                      // #1: action tile in LDS, flag loads have returned
     STAMP(1);
@@ -1135,7 +1155,8 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         fl_steps = P.steps[(unsigned)cx.i];
         fl_count = P.reset_count[(unsigned)cx.i];
     }
-    if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
+    if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
+    else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
     BAR();                                                      // #1
     STAMP(1);

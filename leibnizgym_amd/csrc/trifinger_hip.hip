@@ -515,7 +515,7 @@ static void launch_env(TfHandle_* h, const float* action, hipStream_t s) {
     else launch_env_obj<MODE, IS_RESET, false>(h, action, s);
 }
 
-static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStream_t s) {
+static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStream_t s, bool random_actions = false) {
     const int nsim = is_reset ? 1 : h->cfg.control_decimation;
     h->frame_count += nsim;
     h->sa.nsim = nsim;
@@ -528,6 +528,7 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     const bool timing = !is_reset && h->ev && h->ev_used < h->ev_cap;
     if (timing && h->ev_phase == 0) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], s));      // window opens
     if (is_reset) launch_env<M_FUSED_RESET, true>(h, action, s);
+    else if (random_actions) launch_env<M_FUSED_STEP_RAND, false>(h, nullptr, s);
     else launch_env<M_FUSED_STEP, false>(h, action, s);
     LAUNCH_CHECK("k_env");
     if (timing) {
@@ -546,6 +547,10 @@ int tf_step(tf_handle h, const float* action, void* stream) {
     CHECK_HANDLE(h)
     if (!action) return TF_ERR_INVALID_ARG;
     return launch_step(h, action, false, (hipStream_t)stream);
+}
+int tf_step_random(tf_handle h, void* stream) {
+    CHECK_HANDLE(h)
+    return launch_step(h, nullptr, false, (hipStream_t)stream, true);
 }
 int tf_reset(tf_handle h, void* stream) {
     CHECK_HANDLE(h)

@@ -278,6 +278,17 @@ class TrifingerEngine:
         check(self.lib, self.lib.tf_set_gravity(self._handle, arr), "tf_set_gravity")
 
     # -- hot path ---------------------------------------------------------------------------
+    def step_random(self):
+        """One fused control step with the action source fused in: every env draws 2 U[0,1) - 1 per action dimension inside the
+        launch (what scripts/trifinger_random_action.py feeds the env); `action_buf` holds what was drawn."""
+        if self._is_cuda and torch.cuda.current_device() != self._dev_index:
+            with torch.cuda.device(self._dev_index):
+                rc = self.lib.tf_step_random(self._handle, self._stream())
+        else:
+            rc = self.lib.tf_step_random(self._handle, self._stream())
+        if rc:
+            check(self.lib, rc, "tf_step_random")
+
     def step(self, action):
         """One fused control step.  `action`: contiguous float32 [N, A] tensor on the engine's device."""
         if action.device != self.device:      # a host pointer handed to the kernel would fault the GPU

@@ -193,7 +193,8 @@ static inline float u01(uint32_t x) { return (float)(x >> 8) * 5.960464477539062
 
 /* RNG stream tags (counter word 2) */
 enum { RNG_OBJECT = 0, RNG_GOAL_POS = 1, RNG_GOAL_QUAT = 2, RNG_GOAL_ANGVEL = 3, RNG_ROBOT = 4, RNG_DR = 9 /* and 10 */,
-       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */, RNG_ACT_REPEAT = 24 /* counter = frame count */ };
+       RNG_OBS_NOISE = 16 /* .. 22, counter = frame count instead of reset count */, RNG_ACT_REPEAT = 24 /* counter = frame count */,
+       RNG_ACTION = 32 /* .. 36: fused action source, counter = frame count */ };
 
 static void rng4(uint64_t seed, uint32_t env_gid, uint32_t count, uint32_t tag, float u[4]) {
     uint32_t r[4];
@@ -2083,10 +2084,11 @@ static void stats_add(Stats* a, const Stats* b) {
 }
 
 /* fused step / reset */
-static int run_step(tf_handle h, const float* action, int is_reset) {
+/* action == NULL && random_actions: every env draws its action 2 u - 1 (tf_step_random) */
+static int run_step(tf_handle h, const float* action, int is_reset, int random_actions) {
     if (!h) return TF_ERR_INVALID_ARG;
     if (!h->bound) return TF_ERR_NOT_BOUND;
-    if (!is_reset && !action) return TF_ERR_INVALID_ARG;
+    if (!is_reset && !action && !random_actions) return TF_ERR_INVALID_ARG;
     const TfConfig* c = &h->cfg;
     int N = c->num_envs, A = h->action_dim;
     int nsim = is_reset ? 1 : c->control_decimation;
@@ -2106,6 +2108,13 @@ static int run_step(tf_handle h, const float* action, int is_reset) {
             env_load(h, i, &e);
             float* abuf = &h->buf.action_buf[(size_t)i * (size_t)A];
             if (is_reset) { for (int j = 0; j < A; ++j) abuf[j] = 0.0f; }   /* env_base.py:332-334 acts on the buffer */
+            else if (random_actions) {
+                for (int b = 0; b < (A + 3) / 4; ++b) {
+                    float u[4];
+                    rng4(c->seed, (uint32_t)(c->env_id_offset + i), (uint32_t)(h->frame_count - nsim), RNG_ACTION + (uint32_t)b, u);
+                    for (int k = 0; k < 4 && 4 * b + k < A; ++k) abuf[4 * b + k] = f_clamp(2.0f * u[k] - 1.0f, -h->clip_act, h->clip_act);
+                }
+            }
             else { for (int j = 0; j < A; ++j) abuf[j] = f_clamp(action[(size_t)i * (size_t)A + j], -h->clip_act, h->clip_act); }
             if (apply_resets(h, i, &e, is_reset)) {
                 for (int j = 0; j < A; ++j) abuf[j] = 0.0f;                  /* trifinger_env.py:387 */
@@ -2152,11 +2161,18 @@ int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {
 int tf_step(tf_handle h, const float* action, void* stream) {
     (void)stream;
     double t0 = (h && h->timing_on) ? now_ms() : 0.0;
-    int rc = run_step(h, action, 0);
+    int rc = run_step(h, action, 0, 0);
     if (h && h->timing_on) { h->timed_ms += now_ms() - t0; h->timed_launches += 1; }
     return rc;
 }
-int tf_reset(tf_handle h, void* stream) { (void)stream; return run_step(h, NULL, 1); }
+int tf_step_random(tf_handle h, void* stream) {
+    (void)stream;
+    double t0 = (h && h->timing_on) ? now_ms() : 0.0;
+    int rc = run_step(h, NULL, 0, 1);
+    if (h && h->timing_on) { h->timed_ms += now_ms() - t0; h->timed_launches += 1; }
+    return rc;
+}
+int tf_reset(tf_handle h, void* stream) { (void)stream; return run_step(h, NULL, 1, 0); }
 
 /* ---- split path ---- */
 int tf_apply_resets(tf_handle h, void* stream) {

@@ -366,3 +366,39 @@ def test_moving_goal_is_observed_before_it_advances(backend):
     obs2, _, _, _ = env.step(torch.zeros(64, 9))
     assert torch.equal(obs2[:, 28:32], gq1)
     assert torch.equal(env._object_goal_poses_buf[:, 3:7], eng.state[capi.S_GOAL_Q:capi.S_GOAL_Q + 4].T)   # buffer = refreshed pose
+
+
+def test_fused_random_action_source(backend):
+    """tf_step_random: the step with the reference demo driver's action source (2 * rand - 1, scripts/trifinger_random_action.py:33)
+    fused in.  The draws are uniform in [-1, 1), differ between envs, dimensions and steps, do not depend on the shard layout, and
+    the step is otherwise the ordinary one: stepping with the reported actions gives the same state bit for bit."""
+    from leibnizgym_amd import _capi as capi
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    from scipy import stats
+    lib, dev = backend
+    kw = dict(seed=4, command_mode="torque", asymmetric_obs=True, task_difficulty=4, success={"activate": False})
+    n = 4096
+    a = TrifingerEngine(make_config(lib, n, **kw), device=dev, lib=lib)
+    b = TrifingerEngine(make_config(lib, n, **kw), device=dev, lib=lib)
+    shard = TrifingerEngine(make_config(lib, 1024, env_id_offset=1024, global_num_envs=n, **kw), device=dev, lib=lib)
+    for e in (a, b, shard):
+        e.reset()
+    prev = None
+    for _ in range(3):
+        a.step_random(), shard.step_random()
+        act = a.action_buf.clone()
+        b.step(act)                                                        # the ordinary step with the same actions
+        assert torch.equal(a.state, b.state) and torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
+        assert torch.equal(shard.action_buf, act[1024:2048]) and torch.equal(shard.state, a.state[:, 1024:2048])
+        u = (act.cpu().numpy() + 1) / 2
+        assert u.min() >= 0 and u.max() < 1 and stats.kstest(u.ravel(), "uniform").pvalue > 1e-3
+        assert abs(np.corrcoef(u[:, 0], u[:, 5])[0, 1]) < 0.06 and abs(np.corrcoef(u[:-1, 3], u[1:, 3])[0, 1]) < 0.06
+        assert prev is None or not np.array_equal(prev, u)
+        prev = u
+    for e in (a, b, shard):
+        e.close()
+    imp = TrifingerEngine(make_config(lib, 64, seed=1, command_mode="position_impedance"), device=dev, lib=lib)   # 18 dimensions
+    imp.reset()
+    imp.step_random()
+    assert imp.action_buf.shape == (64, 18) and imp.action_buf.abs().max() <= 1 and imp.action_buf[:, 17].std() > 0.3
+    imp.close()
