@@ -247,3 +247,17 @@ def test_box_rollout_bit_exact(hip, oracle):
         want = pu.rollout(oracle, "cpu", 600, 90, cfg_name, extra=dict(model=oracle.box_model(PHASE3, DENSITY)))
         for t, (a, b) in enumerate(zip(got, want)):
             pu.assert_bit_equal(a, b, f"box {cfg_name} step {t}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 65])
+def test_ext_kernels_ragged_sizes(hip, oracle, n):
+    """the EXT kernel instantiations (box object + extended domain randomisation together) on a single env and on a ragged
+    last workgroup, split path included: bit for bit"""
+    extra = dict(model=None, domain_randomization={"activate": True, "cube_mass": (0.8, 1.2), "cube_size": (0.9, 1.1), "friction": (0.7, 1.3),
+                                                   "robot_base_position": (0.01, 0.01, 0.003), "stage_position": (0.01, 0.02),
+                                                   "friction_robot": (0.8, 1.2), "friction_object": (0.6, 1.4), "friction_stage": (0.7, 1.3)})
+    got = pu.rollout(hip, "cuda:0", n, 60, "d4_torque_asym", episode_length=25, extra=dict(extra, model=hip.box_model(PHASE3, DENSITY)))
+    want = pu.rollout(oracle, "cpu", n, 60, "d4_torque_asym", episode_length=25, extra=dict(extra, model=oracle.box_model(PHASE3, DENSITY)))
+    for t, (a, b) in enumerate(zip(got, want)):
+        pu.assert_bit_equal(a, b, f"EXT n={n} step {t}")
