@@ -114,6 +114,48 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, 
     }
 }
 
+// ---- gradient-norm truncation + Adam over FLAT buffers, two parameter groups (actor | central value network) ------------------
+// torch's fused multi-tensor Adam and clip_grad_norm_ take ~110 us per step for these 32 small tensors (two 38 us launches for
+// the two groups plus the norm / scale launches); over one flat buffer of 264 k floats the same arithmetic is two 5 us launches.
+// Group 0 = elements [0, n0), group 1 = [n0, n1).  k_grad_sqnorms also advances the step counter (kernel boundary = ordering).
+__global__ void __launch_bounds__(256) k_grad_sqnorms(const float* __restrict__ g, int n0, int n1, float* __restrict__ sq, float* __restrict__ step) {
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += gridDim.x * blockDim.x) {
+        const float x = g[i];
+        if (i < n0) a0 += x * x; else a1 += x * x;
+    }
+    __shared__ float red[4][2];
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int q = threadIdx.x;
+        const float t = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+        if (t != 0.0f) atomicAdd(&sq[q], t);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) step[0] += 1.0f;
+}
+// torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (||g|| + 1e-6)) per group; then torch.optim.Adam (no weight decay, no
+// amsgrad): m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2, p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int n0, int n1, const float* __restrict__ sq,
+                                                   const float* __restrict__ step, const float* __restrict__ lr, float max0, float max1,
+                                                   float b1, float b2, float eps) {
+    const float t = step[0];
+    const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
+    const float c0 = fminf(max0 / (sqrtf(sq[0]) + 1e-6f), 1.0f), c1 = fminf(max1 / (sqrtf(sq[1]) + 1e-6f), 1.0f);
+    const float s0 = lr[0] / bc1, s1 = lr[1] / bc1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += gridDim.x * blockDim.x) {
+        const bool g0 = i < n0;
+        const float gi = g[i] * (g0 ? c0 : c1);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= (g0 ? s0 : s1) * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
 extern "C" {
 
 int tfp_api_version(void) { return 1; }
@@ -137,6 +179,18 @@ int tfp_ppo_loss(const float* mu, const float* log_std, const float* act, const 
     else
         hipLaunchKernelGGL((k_ppo_loss<18>), grid, block, 0, s, mu, log_std, act, old_nlp, adv, old_mu, v, ret, B, e_clip, v_coef, ent_coef,
                            bounds_coef, d_mu, d_v, d_logstd, loss_out, stats);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// One optimisation step over flat buffers: sq [2] is scratch (zeroed here), step [1] and lr [2] live on the device (graph capture).
+int tfp_clip_adam(float* p, const float* g, float* m, float* v, int32_t n0, int32_t n1, float* sq, float* step, const float* lr,
+                  float max_norm0, float max_norm1, float beta1, float beta2, float eps, void* stream) {
+    if (n1 <= 0 || n0 < 0 || n0 > n1) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sq, 0, 2 * sizeof(float), s) != hipSuccess) return -2;
+    const int blocks = (n1 + 256 * 4 - 1) / (256 * 4);
+    hipLaunchKernelGGL(k_grad_sqnorms, dim3(blocks), dim3(256), 0, s, g, n0, n1, sq, step);
+    hipLaunchKernelGGL(k_clip_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, n0, n1, sq, step, lr, max_norm0, max_norm1, beta1, beta2, eps);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -215,6 +215,14 @@ class PPOTrainer:
             for p in self.net.parameters():
                 self.dist.broadcast(p.data, src=0, group=group)
             rank = self.dist.get_rank(group)
+        # GPU + fused kernels: truncation + Adam of both groups as two hand-written launches over one flat buffer
+        self.flat_opt = None
+        if fused and c.fused_kernels:
+            from .ppo_kernels import FlatClipAdam
+            if self.net.central:
+                self.flat_opt = FlatClipAdam(self.net.actor_parameters(), self.net.critic_parameters(), c.lr, lr_v, c.grad_norm, c.value_grad_norm)
+            else:
+                self.flat_opt = FlatClipAdam(list(self.net.parameters()), [], c.lr, c.lr, c.grad_norm, c.grad_norm)
         # exploration noise and minibatch order must differ between ranks (the same env index of two shards would
         # otherwise receive the same noise sequence): re-seed with the rank after the weights are in place
         torch.manual_seed(c.seed + 7919 * rank)
@@ -226,7 +234,7 @@ class PPOTrainer:
 
     # ---- checkpoints (what RL-Games' save / restore / `args.checkpoint` give the reference launcher) ----
     def state_dict(self):
-        return {"model": self.net.state_dict(), "optimizer": self.opt.state_dict(), "lr": self.lr, "frames": self.frames,
+        return {"model": self.net.state_dict(), "optimizer": (self.flat_opt or self.opt).state_dict(), "lr": self.lr, "frames": self.frames,
                 "epoch": self.epoch, "best_reward": self.best_reward, "config": dict(self.cfg.__dict__)}
 
     def save(self, path: str):
@@ -237,8 +245,21 @@ class PPOTrainer:
 
     def restore(self, path: str):
         ck = torch.load(path, map_location=self.device, weights_only=False)
-        self.net.load_state_dict(ck["model"])
-        if "optimizer" in ck:
+        with torch.no_grad():                                        # in place: the parameters may be views of a flat buffer
+            for k, v in self.net.state_dict().items():
+                v.copy_(ck["model"][k])
+        if "optimizer" in ck and self.flat_opt is not None:
+            if ck["optimizer"].get("kind") == "flat_clip_adam":
+                self.flat_opt.load_state_dict(ck["optimizer"])
+            else:                                                    # a checkpoint of the torch optimiser: moments per parameter
+                st = ck["optimizer"]["state"]
+                for name, buf in (("exp_avg", self.flat_opt.m), ("exp_avg_sq", self.flat_opt.v)):
+                    buf.copy_(torch.cat([st[i][name].reshape(-1).to(buf.device) for i in range(len(self.flat_opt.params))]))
+                self.flat_opt.step_count.fill_(float(st[0]["step"]))
+            self.flat_opt.set_lr(0, float(ck.get("lr", self.lr)))
+        elif "optimizer" in ck and ck["optimizer"].get("kind") == "flat_clip_adam":
+            pass                                                     # flat moments into the torch optimiser: weights only
+        elif "optimizer" in ck:
             lrs = [g["lr"] for g in self.opt.param_groups]           # keep this trainer's lr objects (device tensors when graphed)
             self.opt.load_state_dict(ck["optimizer"])
             for g, lr0 in zip(self.opt.param_groups, lrs):
@@ -370,7 +391,10 @@ class PPOTrainer:
         buf = torch.zeros(4, device=dev)
         return {"loss": buf[0], "a_loss": buf[1], "c_loss": buf[2], "kl": buf[3], "_fused": buf}
 
-    def _mb_apply(self):
+    def _mb_apply(self, gathered=False):
+        if self.flat_opt is not None:
+            self.flat_opt.step(gathered)
+            return
         if self.net.central:                   # truncate_grads of each optimiser on its own network
             nn.utils.clip_grad_norm_(self.net.actor_parameters(), self.cfg.grad_norm, foreach=True)
             nn.utils.clip_grad_norm_(self.net.critic_parameters(), self.cfg.value_grad_norm, foreach=True)
@@ -379,10 +403,14 @@ class PPOTrainer:
         self.opt.step()
 
     def _flatten_grads(self, out=None):
+        if self.flat_opt is not None:
+            return self.flat_opt.gather_grads()
         grads = [p.grad for p in self.net.parameters()]
         return torch.cat([g.reshape(-1) for g in grads], out=out)
 
     def _unflatten_grads(self, flat):
+        if self.flat_opt is not None:
+            return                                 # the optimiser reads the flat buffer itself
         off = 0
         for p in self.net.parameters():
             p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
@@ -399,21 +427,24 @@ class PPOTrainer:
         dev = self.device
         idx = torch.zeros(mb, dtype=torch.long, device=dev)
         nflat = sum(p.numel() for p in self.net.parameters())
-        flat = torch.zeros(nflat, device=dev)
+        flat = self.flat_opt.flat_g if self.flat_opt is not None else torch.zeros(nflat, device=dev)   # what the ranks exchange
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         state = {k: v.detach().clone() for k, v in self.net.state_dict().items()}
         # optimiser moments restored from a checkpoint must survive the warm-up; a fresh optimiser has none yet
         snap = {p: {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.opt.state.items()}
+        fsnap = self.flat_opt.snapshot() if self.flat_opt is not None else None
         with torch.cuda.stream(side):          # warm-up off the capture (allocator, lazy optimizer state), then undone
             for _ in range(3):
                 self._mb_backward(d, idx, acc)
                 if self.dist_on:
                     self._flatten_grads(out=flat)
                     self._unflatten_grads(flat)
-                self._mb_apply()
+                self._mb_apply(gathered=self.dist_on)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.net.load_state_dict(state)
+        if fsnap is not None:
+            self.flat_opt.restore_snapshot(fsnap)
         for p, st in self.opt.state.items():   # the warm-up steps must not count: moments and step counter as before
             for k, v in st.items():
                 if torch.is_tensor(v):
@@ -431,7 +462,7 @@ class PPOTrainer:
         with torch.cuda.graph(gb, pool=ga.pool()):
             if self.dist_on:
                 self._unflatten_grads(flat)
-            self._mb_apply()
+            self._mb_apply(gathered=self.dist_on)
         # the two captures above executed nothing; parameters and accumulators are untouched
         self._g = dict(a=ga, b=gb, idx=idx, flat=flat, d=d, acc=acc, mb=mb, side=side)
 
@@ -489,7 +520,7 @@ class PPOTrainer:
                         fl = self._flatten_grads()
                         self._exchange(fl)
                         self._unflatten_grads(fl)
-                    self._mb_apply()
+                    self._mb_apply(gathered=self.dist_on)
                 nmb += 1
             count += nmb
             kl = acc["kl"] / max(nmb, 1)
@@ -502,6 +533,10 @@ class PPOTrainer:
                 self.lr = max(self.lr / 1.5, 1e-6)
             elif kl < 0.5 * c.kl_threshold:
                 self.lr = min(self.lr * 1.5, 1e-2)
+            if self.flat_opt is not None:
+                self.flat_opt.set_lr(0, self.lr)
+                if not self.net.central:
+                    self.flat_opt.set_lr(1, self.lr)
             for g in (self.opt.param_groups[:1] if self.net.central else self.opt.param_groups):
                 if torch.is_tensor(g["lr"]):
                     g["lr"].fill_(self.lr)

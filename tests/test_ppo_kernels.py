@@ -87,3 +87,37 @@ def test_trainer_with_and_without_the_kernels(hip):
         assert torch.allclose(a, b, atol=3e-5, rtol=1e-3)
     for k in ("loss", "a_loss", "c_loss", "kl"):
         assert abs(s0[-1][k] - s1[-1][k]) < 1e-3 * max(1.0, abs(s0[-1][k])), (k, s0[-1][k], s1[-1][k])
+
+
+@pytest.mark.gpu
+def test_flat_clip_adam_matches_torch(hip):
+    """gradient-norm truncation per group + Adam over the flat buffer == clip_grad_norm_ + torch.optim.Adam, 25 steps with
+    gradients that exercise both the truncated and the untruncated case and two different learning rates"""
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    shapes0, shapes1 = [(400, 41), (400,), (9, 100), (9,)], [(400, 113), (400,), (1, 100), (1,)]
+    init = [torch.randn(*s, device=dev) * 0.1 for s in shapes0 + shapes1]
+    a = [torch.nn.Parameter(t.clone()) for t in init]
+    b = [torch.nn.Parameter(t.clone()) for t in init]
+    ref = torch.optim.Adam([{"params": a[:4], "lr": 3e-4}, {"params": a[4:], "lr": 5e-4}], eps=1e-8)
+    flat = pk.FlatClipAdam(b[:4], b[4:], 3e-4, 5e-4, 1.0, 0.5)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))                      # re-pointing keeps the values
+    for step in range(25):
+        scale = 10.0 if step % 3 == 0 else 0.01                              # norm far above / below the thresholds
+        grads = [torch.randn_like(p) * scale for p in a]
+        for p, q, g in zip(a, b, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        if step == 10:
+            for grp in ref.param_groups[:1]:
+                grp["lr"] = 6.75e-4
+            flat.set_lr(0, 6.75e-4)
+        torch.nn.utils.clip_grad_norm_(a[:4], 1.0)
+        torch.nn.utils.clip_grad_norm_(a[4:], 0.5)
+        ref.step()
+        flat.step()
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-7), float((x - y).abs().max())
+    sd = flat.state_dict()
+    flat2 = pk.FlatClipAdam([torch.nn.Parameter(t.clone()) for t in init[:4]], [torch.nn.Parameter(t.clone()) for t in init[4:]], 1.0, 1.0, 1.0, 0.5)
+    flat2.load_state_dict(sd)
+    assert torch.equal(flat2.m, flat.m) and float(flat2.step_count) == 25.0 and torch.equal(flat2.lr, flat.lr)
