@@ -16,6 +16,7 @@
 //   loss    = a_loss + v_coef c_loss - ent_coef ent + bounds_coef b_loss
 //   kl      = mean_i sum_a 0.5 ((mu_ia - old_mu_ia) / sigma_a)^2          (statistic only)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #define MAX_A 18
@@ -194,4 +195,280 @@ int tfp_clip_adam(float* p, const float* g, float* m, float* v, int32_t n0, int3
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+}  // extern "C"
+
+// =====================================================================================================================
+// fp32 MFMA GEMMs for the two small MLPs (41/113 -> 400 -> 200 -> 100 -> 9/1, batch 8192)
+// =====================================================================================================================
+// rocBLAS picks 256x128 macro tiles for these shapes: [8192 x 400] x [400 x 200] becomes 64 workgroups on a 256-CU chip (19 TF/s),
+// and the activation derivative / bias gradient are launches and passes over memory of their own.  Here every product is
+//     C[i, j] = sum_k opA(i, k) * opB(j, k)
+// on 64 x 64 block tiles (4 wavefronts, one 32 x 32 v_mfma_f32_32x32x2_f32 accumulator each: exact fp32, an fmaf chain), K tiles of
+// 32.  Both operands sit in LDS as [row][k] with a pitch of 36 floats: a lane reads FOUR consecutive k of its row with one
+// ds_read_b128 (lanes 0-31: k0..k0+3, lanes 32-63: k0+4..k0+7) and feeds them to four MFMAs - the order in which the k of a tile are
+// summed is free as long as both operands use the same one - so a K tile costs 8 LDS reads per 16 MFMAs.  The pitch makes any 16 rows
+// that differ mod 16 hit disjoint bank windows (36 r mod 64 = 4 (9 r mod 16)), which covers the lane groups of ds_read_b128 and of
+// ds_write_b128.  An operand is staged from memory in one of two ways:
+//   k-contiguous (x, dY, W of the forward): lane -> (row 16 w + (l & 15), k (l >> 4) * 8 .. +7): two dwordx4 loads (K % 4 == 0)
+//   k-major      (W of dX, both operands of dW): lane -> (column t & 63, k (t >> 6) * 8 .. +7): eight coalesced dword loads
+// and written with two ds_write_b128; the next K tile is prefetched into registers while the current one is multiplied.
+//   forward   y  = act(x W^T + b):        A = x  [M, K] k-contiguous, B = W [N, K] k-contiguous; bias and ELU fused into the store
+//   dX        dx = dZ W:                  A = dY [M, K] k-contiguous (dZ = dY * elu'(Y) formed in the load), B = W [K, N] k-major
+//   dW, db    [dW | db] = dZ^T [x | 1]:   A = dY [rows, N1] k-major (same fusion), B = x [rows, N2] k-major with a column of ones
+//                                         appended; split over row chunks (blockIdx.z), the partial products summed by k_sum_partials
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GT 64            // block tile (rows and columns)
+#define GK 32            // K tile
+#define GP 36            // LDS row pitch in floats
+
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.0f ? 1.0f : y + 1.0f; }   // elu'(z) in terms of y = elu(z)
+
+// this thread's 8 values of the K tile starting at k0: operand P (leading dimension ld, `rows` valid rows / columns, first one r0)
+//   KMAJ: P[k * ld + r]; else P[r * ld + k];  VEC (k-contiguous only): ld % 4 == 0, kend % 4 == 0 -> dwordx4
+//   ONES (k-major only): column `rows - 1` is a column of ones that P does not hold (ld = rows - 1)
+// Every load is unconditional (addresses clamped into the matrix, the value discarded by stage_fix): the loads of GD tiles stay in
+// flight behind one another and the compiler's vmcnt bookkeeping stays exact.
+template <bool KMAJ, bool VEC, bool ONES>
+__device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, int rows, int r0, int k0, int kend, int tid, float (&v)[8]) {
+    if (KMAJ) {
+        const int real = ONES ? rows - 1 : rows;
+        const int r = min(r0 + (tid & 63), real - 1), kb = k0 + (tid >> 6) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = P[(size_t)min(kb + c, kend - 1) * ld + r];
+    } else {
+        const int r = min(r0 + 16 * (tid >> 6) + (tid & 15), rows - 1), kb = k0 + ((tid & 63) >> 4) * 8;
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 x = *(const f32x4*)(P + (size_t)r * ld + min(kb + 4 * q, kend - 4));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[4 * q + c] = x[c];
+            }
+        } else {                                                    // lane -> (k = t & 31, rows (t >> 5) + 8 c): 128 contiguous bytes per half-wave
+            const int k = min(k0 + (tid & 31), kend - 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = P[(size_t)min(r0 + (tid >> 5) + 8 * c, rows - 1) * ld + k];
+        }
+    }
+}
+
+// what the clamped loads fetched outside the matrix becomes zero (or the column of ones); DZ: v *= elu'(y)
+template <bool KMAJ, bool VEC, bool DZ, bool ONES>
+__device__ __forceinline__ void stage_fix(int rows, int r0, int k0, int kend, int tid, float (&v)[8], const float (&y)[8]) {
+    if (!KMAJ && !VEC) {
+        const bool ink = k0 + (tid & 31) < kend;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float x = v[c];
+            if (DZ) x *= elu_grad_from_out(y[c]);
+            v[c] = (ink && r0 + (tid >> 5) + 8 * c < rows) ? x : 0.0f;
+        }
+        return;
+    }
+    const int real = ONES ? rows - 1 : rows;
+    const int r = KMAJ ? r0 + (tid & 63) : r0 + 16 * (tid >> 6) + (tid & 15);
+    const int kb = k0 + (KMAJ ? (tid >> 6) : ((tid & 63) >> 4)) * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x = v[c];
+        if (DZ) x *= elu_grad_from_out(y[c]);
+        const bool ink = kb + c < kend;
+        x = (ink && r < real) ? x : ((ONES && ink && r == real) ? 1.0f : 0.0f);
+        v[c] = x;
+    }
+}
+
+template <bool KMAJ, bool VEC>
+__device__ __forceinline__ void stage_store(float* S, int tid, const float (&v)[8]) {
+    if (!KMAJ && !VEC) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) S[((tid >> 5) + 8 * c) * GP + (tid & 31)] = v[c];
+        return;
+    }
+    const int row = KMAJ ? (tid & 63) : 16 * (tid >> 6) + (tid & 15);
+    const int kq = KMAJ ? (tid >> 6) * 8 : ((tid & 63) >> 4) * 8;
+    f32x4* d = (f32x4*)(S + row * GP + kq);
+    d[0] = f32x4{v[0], v[1], v[2], v[3]};
+    d[1] = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+#ifndef GEMM_DBG
+#define GEMM_DBG 0        // developer builds: 1 = no MFMAs, 2 = no loads inside the loop (tools/gemm_kernels_bench.py)
+#endif
+#ifndef GEMM_SCHED
+#define GEMM_SCHED 1
+#endif
+#define GD 3             // K tiles in flight per workgroup (register ring)
+
+// ACT: 0 none, 1 ELU (with bias; forward only), -1 no bias.  SPLIT: the K range is cut into chunks of `chunk`, blockIdx.z takes one and
+// writes its own [M, N] slab of C.
+template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
+__global__ void __launch_bounds__(256) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                              const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk) {
+    __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];   // [buffer][operand]: tile t is multiplied out of buffer t & 1 while
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;    // tile t + 1 is written into the other one: one barrier per tile
+    const int wr = wave >> 1, wc = wave & 1;
+    // Workgroups are handed to the 8 XCDs round-robin in launch order; each XCD has its own L2.  The workgroups that share operand rows
+    // (the column blocks of one row block; for the split form: every tile of one row chunk) are renumbered onto ONE XCD.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+        const int L = bx + nx * (by + ny * bz), xcd = L & 7, idx = L >> 3;
+        if (SPLIT) {
+            if ((nz & 7) == 0) { const int w = nx * ny, in = idx % w; bz = (idx / w) * 8 + xcd; by = in / nx; bx = in - by * nx; }
+        } else if ((ny & 7) == 0) { by = (idx / nx) * 8 + xcd; bx = idx % nx; }
+    }
+    const int r0 = by * GT, c0 = bx * GT;
+    int kbeg = 0, kend = K;
+    if (SPLIT) { kbeg = bz * chunk; kend = min(kbeg + chunk, K); C += (size_t)bz * (size_t)M * (size_t)N; }
+    const bool live = r0 + wr * 32 < M && c0 + wc * 32 < N;       // wave-uniform: a tile wholly outside the matrix is not multiplied
+    const int ntiles = (kend - kbeg + GK - 1) / GK;
+    float ra[GD][8], rb[GD][8], ry[DZ ? GD : 1][8];
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < GD; ++d) {                                  // tiles past the end are re-reads of the last one, never used
+        const int k0 = kbeg + min(d, ntiles - 1) * GK;
+        stage_load<AK, AVEC, false>(A, lda, M, r0, k0, kend, tid, ra[d]);
+        if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, k0, kend, tid, ry[DZ ? d : 0]);
+        stage_load<BK, BVEC, ONES>(B, ldb, N, c0, k0, kend, tid, rb[d]);
+        __builtin_amdgcn_sched_barrier(0);                          // keep the slots' loads in slot order: vmcnt waits count on it
+    }
+    const int aoff = (wr * 32 + (lane & 31)) * GP + 4 * (lane >> 5), boff = (wc * 32 + (lane & 31)) * GP + 4 * (lane >> 5);
+    // tile 0 -> buffer 0; its register slot takes tile GD
+    stage_fix<AK, AVEC, DZ, false>(M, r0, kbeg, kend, tid, ra[0], ry[0]);
+    stage_fix<BK, BVEC, false, ONES>(N, c0, kbeg, kend, tid, rb[0], rb[0]);
+    stage_store<AK, AVEC>(S[0][0], tid, ra[0]);
+    stage_store<BK, BVEC>(S[0][1], tid, rb[0]);
+    {
+        const int kn = kbeg + min(GD, ntiles - 1) * GK;
+        stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[0]);
+        if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[0]);
+        stage_load<BK, BVEC, ONES>(B, ldb, N, c0, kn, kend, tid, rb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    // One K tile: LDS reads of tile t, then - in the shadow of its 16 MFMAs - tile t + 1 goes from its register slot into the other LDS
+    // buffer and the slot's next loads are issued.  The MFMAs are unconditional (a wavefront whose tile lies outside the matrix
+    // multiplies zeros and stores nothing) so that the whole body is one basic block the scheduler can interleave.
+    auto body = [&](auto dc, int t) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        constexpr int dn = (d + 1) % GD;                             // register slot of tile t + 1
+        f32x4 a[GK / 8], b[GK / 8];
+#pragma unroll
+        for (int ks = 0; ks < GK / 8; ++ks) {
+            a[ks] = *(const f32x4*)(S[cur][0] + aoff + 8 * ks);
+            b[ks] = *(const f32x4*)(S[cur][1] + boff + 8 * ks);
+        }
+        const int k1 = kbeg + (t + 1) * GK;
+        stage_fix<AK, AVEC, DZ, false>(M, r0, k1, kend, tid, ra[dn], ry[DZ ? dn : 0]);
+        stage_fix<BK, BVEC, false, ONES>(N, c0, k1, kend, tid, rb[dn], rb[dn]);
+        stage_store<AK, AVEC>(S[cur ^ 1][0], tid, ra[dn]);
+        stage_store<BK, BVEC>(S[cur ^ 1][1], tid, rb[dn]);
+        if (GEMM_DBG != 2) {
+            const int kn = kbeg + min(t + 1 + GD, ntiles - 1) * GK;
+            stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[dn]);
+            if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[DZ ? dn : 0]);
+            stage_load<BK, BVEC, ONES>(B, ldb, N, c0, kn, kend, tid, rb[dn]);
+        }
+        if (GEMM_DBG != 1) {
+#pragma unroll
+            for (int ks = 0; ks < GK / 8; ++ks) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][s], b[ks][s], acc, 0, 0, 0);
+            }
+        }
+#if GEMM_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (GK / 8), 0);       // the LDS reads of this tile first
+#pragma unroll
+        for (int i = 0; i < 2 * GK / 4; ++i) {                              // then per MFMA a share of everything else
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+#endif
+        __syncthreads();
+        cur ^= 1;
+    };
+    int t = 0;
+    for (; t + GD <= ntiles; t += GD) {
+        body(std::integral_constant<int, 0>{}, t);
+        body(std::integral_constant<int, 1>{}, t + 1);
+        body(std::integral_constant<int, 2>{}, t + 2);
+    }
+    if (t < ntiles) {
+        body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
+    }
+    // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int col = c0 + wc * 32 + (lane & 31);
+    if (live && col < N) {
+        const float bv = (ACT >= 0 && bias) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = r0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (row < M) {
+                float v = acc[reg] + bv;
+                if (ACT == 1) v = v > 0.0f ? v : expm1f(v);          // ELU, alpha = 1
+                C[(size_t)row * N + col] = v;
+            }
+        }
+    }
+}
+
+// gw[N1, N2] and gb[N1] from `splits` slabs of [N1, N2 + 1] (fixed summation order: deterministic)
+__global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int splits,
+                                                      int N1, int N2) {
+    const int i = blockIdx.x * 256 + threadIdx.x, tot = N1 * (N2 + 1);
+    if (i >= tot) return;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int z = 0; z < splits; ++z) s += part[(size_t)z * tot + i];
+    const int r = i / (N2 + 1), c = i - r * (N2 + 1);
+    if (c < N2) gw[(size_t)r * N2 + c] = s; else gb[r] = s;
+}
+
+extern "C" {
+// C[M,N] = act(A[M,K] . W[N,K]^T + bias); act: 0 none, 1 ELU
+int tfp_linear_fwd(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return -1;
+    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (K & 3) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0;
+#define FWD(V, ACT_) hipLaunchKernelGGL((k_gemm<false, false, V, V, ACT_, false, false, false>), grid, block, 0, s, A, W, bias, nullptr, C, M, N, K, K, K, 0)
+    if (vec) { if (act) FWD(true, 1); else FWD(true, 0); }
+    else { if (act) FWD(false, 1); else FWD(false, 0); }
+#undef FWD
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// C[M,N] = dZ[M,K] . B[K,N] with dZ = A (Y == NULL) or A * elu'(Y)
+int tfp_gemm_nn(const float* A, const float* Y, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return -1;
+    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (K & 3) == 0 && (((uintptr_t)A | (uintptr_t)Y) & 15) == 0;
+#define NN(V, DZ_) hipLaunchKernelGGL((k_gemm<false, true, V, false, -1, DZ_, false, false>), grid, block, 0, s, A, B, nullptr, Y, C, M, N, K, K, N, 0)
+    if (vec) { if (Y) NN(true, true); else NN(true, false); }
+    else { if (Y) NN(false, true); else NN(false, false); }
+#undef NN
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// gw[N1, N2] = dZ^T B, gb[N1] = column sums of dZ, for dZ[rows, N1] = A or A * elu'(Y), B[rows, N2]; `part` is scratch for
+// ceil(rows / chunk) slabs of [N1, N2 + 1] floats
+int tfp_gemm_tn_bias(const float* A, const float* Y, const float* B, float* part, float* gw, float* gb, int32_t rows, int32_t N1, int32_t N2,
+                     int32_t chunk, void* stream) {
+    if (rows <= 0 || N1 <= 0 || N2 <= 0 || chunk <= 0 || (chunk % GK) != 0) return -1;
+    const int splits = (rows + chunk - 1) / chunk;
+    dim3 grid((N2 + 1 + GT - 1) / GT, (N1 + GT - 1) / GT, splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (Y) hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, true, true, true>), grid, block, 0, s, A, B, nullptr, Y, part, N1, N2 + 1, rows, N1, N2, chunk);
+    else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk);
+    const int tot = N1 * (N2 + 1);
+    hipLaunchKernelGGL(k_sum_partials, dim3((tot + 255) / 256), block, 0, s, part, gw, gb, splits, N1, N2);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 }  // extern "C"

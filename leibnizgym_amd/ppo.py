@@ -123,13 +123,38 @@ class SplitKLinear(nn.Linear):
         return super().forward(x)
 
 
+class FusedMLP(nn.Sequential):
+    """Linear / ELU stack (same modules and state-dict keys as the nn.Sequential it is).  With `mfma` set (the trainer does it on a
+    GPU when `fused_kernels` is on) every layer runs on the hand-written fp32 MFMA kernels of csrc/ppo_kernels.hip: bias and ELU
+    fused into the forward product, the ELU derivative formed in the operand loads of the two backward products, the bias gradient
+    as an extra column of the weight-gradient product."""
+    mfma = False
+
+    def forward(self, x):
+        if not (self.mfma and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+            return super().forward(x)
+        from .ppo_kernels import mfma_linear
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                act = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ELU)
+                x = mfma_linear(x, m.weight, m.bias, 1 if act else 0, getattr(m, "_grad_out", None) if torch.is_grad_enabled() else None)
+                i += 2 if act else 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 def mlp(inp, units, out):
     layers, last = [], inp
     for u in units:
         layers += [SplitKLinear(last, u), nn.ELU()]
         last = u
     layers.append(SplitKLinear(last, out))
-    return nn.Sequential(*layers)
+    return FusedMLP(*layers)
 
 
 def variance_scaling_(w: torch.Tensor, scale: float) -> torch.Tensor:
@@ -202,6 +227,7 @@ class PPOTrainer:
         self.opt = torch.optim.Adam(groups, eps=1e-8, **kw)
         self.lr = c.lr
         self.fused_loss = fused and c.fused_kernels        # hand-written objective kernel (GPU only)
+        self.net.actor.mfma = self.net.critic.mfma = bool(fused and c.fused_kernels)   # ... and the MFMA linear layers
         self._g = None                         # captured minibatch step (built on the first update)
         self.dist_on = False
         rank = 0
@@ -223,6 +249,10 @@ class PPOTrainer:
                 self.flat_opt = FlatClipAdam(self.net.actor_parameters(), self.net.critic_parameters(), c.lr, lr_v, c.grad_norm, c.value_grad_norm)
             else:
                 self.flat_opt = FlatClipAdam(list(self.net.parameters()), [], c.lr, c.lr, c.grad_norm, c.grad_norm)
+            for net in (self.net.actor, self.net.critic):      # the MFMA layers write dW / db straight into the flat gradient buffer
+                for m in net:
+                    if isinstance(m, nn.Linear):
+                        m._grad_out = (self.flat_opt.grad_view(m.weight), self.flat_opt.grad_view(m.bias))
         # exploration noise and minibatch order must differ between ranks (the same env index of two shards would
         # otherwise receive the same noise sequence): re-seed with the rank after the weights are in place
         torch.manual_seed(c.seed + 7919 * rank)

@@ -17,6 +17,8 @@ _F = C.POINTER(C.c_float)
 
 
 def library_path():
+    if os.environ.get("TFP_HIP_LIB"):                     # developer override (kernel experiments); never set by the package
+        return os.environ["TFP_HIP_LIB"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_ppo.so")
 
 
@@ -32,6 +34,12 @@ def load():
         lib.tfp_ppo_loss.argtypes = [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 6
         lib.tfp_clip_adam.restype = C.c_int
         lib.tfp_clip_adam.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32] + [C.c_void_p] * 3 + [C.c_float] * 5 + [C.c_void_p]
+        lib.tfp_linear_fwd.restype = C.c_int
+        lib.tfp_linear_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
+        lib.tfp_gemm_nn.restype = C.c_int
+        lib.tfp_gemm_nn.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
+        lib.tfp_gemm_tn_bias.restype = C.c_int
+        lib.tfp_gemm_tn_bias.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p]
         _LIB = lib
     return _LIB
 
@@ -84,13 +92,23 @@ class FlatClipAdam:
     def __init__(self, group0, group1, lr0, lr1, max_norm0, max_norm1, betas=(0.9, 0.999), eps=1e-8):
         params = list(group0) + list(group1)
         dev = params[0].device
-        self.params, self.n0 = params, sum(p.numel() for p in group0)
-        self.n1 = self.n0 + sum(p.numel() for p in group1)
-        self.flat_p = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
-        off = 0
-        for p in params:                                   # parameters become views of the flat buffer
-            p.data = self.flat_p[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.params = params
+        # every parameter starts on a 16-byte boundary of the flat buffer (the forward GEMM reads weight rows with dwordx4 loads); the
+        # padding floats are zero, receive zero gradients and are never read by the networks
+        al = lambda n: (n + 3) & ~3  # noqa: E731
+        self.offsets, off = [], 0
+        for k, p in enumerate(params):
+            if k == len(list(group0)):
+                self.n0 = off
+            self.offsets.append(off)
+            off += al(p.numel())
+        if not list(group1):
+            self.n0 = off
+        self.n1 = off
+        self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p, o in zip(params, self.offsets):             # parameters become views of the flat buffer
+            self.flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[o:o + p.numel()].view_as(p)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.m, self.v = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
         self.step_count = torch.zeros(1, device=dev)
@@ -101,8 +119,22 @@ class FlatClipAdam:
     def set_lr(self, group, value):
         self.lr[group] = float(value)
 
+    def grad_view(self, p):
+        """the slot of parameter `p` in the flat gradient buffer, shaped like `p` (the MFMA linear layers write their weight and bias
+        gradients straight into it)"""
+        k = next(i for i, q in enumerate(self.params) if q is p)
+        return self.flat_g[self.offsets[k]:self.offsets[k] + p.numel()].view_as(p)
+
     def gather_grads(self):
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat_g)
+        """gradients that autograd left in `.grad` -> their slots (one multi-tensor copy); the layers that wrote their slots
+        themselves have `.grad` None"""
+        dst, src = [], []
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is not None:
+                dst.append(self.flat_g[o:o + p.numel()])
+                src.append(p.grad.reshape(-1))
+        if dst:
+            torch._foreach_copy_(dst, src)
         return self.flat_g
 
     def step(self, gathered=False):
@@ -125,3 +157,71 @@ class FlatClipAdam:
         if sd.get("kind") != "flat_clip_adam" or sd["m"].numel() != self.m.numel():
             raise ValueError("optimizer state of another kind / size")
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count.copy_(sd["step"]); self.lr.copy_(sd["lr"])
+
+
+# ---- fp32 MFMA GEMMs of the two MLPs (csrc/ppo_kernels.hip: k_gemm) --------------------------------------------------------------
+def linear_fwd(x, w, b, act):
+    """act(x @ w.T + b) for contiguous float32 x [M, K], w [N, K], b [N]; act: 0 none, 1 ELU"""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _chk(load().tfp_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, int(act), _stream(x)), "tfp_linear_fwd")
+    return y
+
+
+def gemm_nn(a, b, y=None):
+    """(a * elu'(y)) @ b  (y: the ELU output the gradient a belongs to, or None)"""
+    M, K = a.shape
+    N = b.shape[1]
+    c = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _chk(load().tfp_gemm_nn(a.data_ptr(), y.data_ptr() if y is not None else None, b.data_ptr(), c.data_ptr(), M, N, K, _stream(a)), "tfp_gemm_nn")
+    return c
+
+
+def gemm_tn_bias(a, b, y=None, chunk=256, out=None):
+    """dz = a * elu'(y) (or a); returns (dz.T @ b, dz.sum(0)): products of [b | 1] over row chunks (one workgroup set per chunk),
+    then their sum in a fixed order - the bias gradient is the extra column"""
+    rows, N1 = a.shape
+    N2 = b.shape[1]
+    splits = (rows + chunk - 1) // chunk
+    part = torch.empty(splits * N1 * (N2 + 1), device=a.device, dtype=torch.float32)
+    if out is not None:
+        gw, gb = out
+    else:
+        gw = torch.empty(N1, N2, device=a.device, dtype=torch.float32)
+        gb = torch.empty(N1, device=a.device, dtype=torch.float32)
+    _chk(load().tfp_gemm_tn_bias(a.data_ptr(), y.data_ptr() if y is not None else None, b.data_ptr(), part.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                 rows, N1, N2, chunk, _stream(a)), "tfp_gemm_tn_bias")
+    return gw, gb
+
+
+class _MfmaLinear(torch.autograd.Function):
+    """act(x W^T + b) with every matrix product on the hand-written fp32 MFMA kernels: forward with bias and ELU fused into the
+    store; backward with the ELU derivative formed in the operand loads and the bias gradient as an extra column of the weight
+    gradient product - three launches (+ one reduction of the batch chunks) where the eager form takes nine.  With `grad_out` =
+    (dW buffer, db buffer) the parameter gradients are WRITTEN there (not accumulated, not returned to autograd): the trainer
+    passes the parameters' slots of its flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, grad_out):
+        x = x.contiguous()
+        y = linear_fwd(x, w, b, act)
+        ctx.act, ctx.grad_out = act, grad_out
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        yy = y if ctx.act else None
+        gx = gemm_nn(gy, w, yy) if ctx.needs_input_grad[0] else None
+        if ctx.grad_out is not None:
+            gemm_tn_bias(gy, x, yy, out=ctx.grad_out)
+            return gx, None, None, None, None
+        gw, gb = gemm_tn_bias(gy, x, yy)
+        return gx, gw, gb, None, None
+
+
+def mfma_linear(x, w, b, act, grad_out=None):
+    return _MfmaLinear.apply(x, w, b, int(act), grad_out)

@@ -14,7 +14,7 @@ from leibnizgym_amd.ppo import PPOConfig, neglogp
 def test_ppo_library_loads_and_exports_its_symbols():
     assert os.path.isfile(pk.library_path()), "run `make -C leibnizgym_amd/csrc` (python __graft_entry__.py)"
     lib = C.CDLL(pk.library_path())
-    for name in ("tfp_api_version", "tfp_ppo_loss"):
+    for name in ("tfp_api_version", "tfp_ppo_loss", "tfp_clip_adam", "tfp_linear_fwd", "tfp_gemm_nn", "tfp_gemm_tn_bias"):
         assert hasattr(lib, name), name
     assert lib.tfp_api_version() == 1
 
@@ -121,3 +121,33 @@ def test_flat_clip_adam_matches_torch(hip):
     flat2 = pk.FlatClipAdam([torch.nn.Parameter(t.clone()) for t in init[:4]], [torch.nn.Parameter(t.clone()) for t in init[4:]], 1.0, 1.0, 1.0, 0.5)
     flat2.load_state_dict(sd)
     assert torch.equal(flat2.m, flat.m) and float(flat2.step_count) == 25.0 and torch.equal(flat2.lr, flat.lr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,act", [(8192, 41, 400, 1), (8192, 400, 200, 1), (8192, 100, 9, 0), (1000, 113, 400, 1), (777, 200, 100, 1),
+                                      (65, 100, 1, 0), (64, 32, 64, 1), (3, 5, 7, 1)])
+def test_mfma_linear_matches_torch_fp32(hip, M, K, N, act):
+    """The fp32 MFMA linear layer (forward with bias + ELU fused; backward with the ELU derivative in the operand loads and the bias
+    gradient as the extra column) against torch's linear / elu / autograd in fp32 - MLP shapes of the trainer, ragged sizes, sizes
+    below one tile; with and without the gradients written into caller buffers."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(M + K + N)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+    x0, w0, b0, gy = r(M, K), r(N, K) * K ** -0.5, r(N), r(M, N)
+    ref = [t.clone().requires_grad_(True) for t in (x0, w0, b0)]
+    y_ref = torch.nn.functional.linear(*ref)
+    y_ref = torch.nn.functional.elu(y_ref) if act else y_ref
+    y_ref.backward(gy)
+    close = lambda a, b: torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.detach().abs().max()) + 1e-6)   # noqa: E731
+    for buffers in (False, True):
+        x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+        out = (torch.full((N, K), 7.0, device=dev), torch.full((N,), 7.0, device=dev)) if buffers else None
+        y = pk.mfma_linear(x, w, b, act, out)
+        y.backward(gy)
+        assert close(y, y_ref) and close(x.grad, ref[0].grad)
+        gw, gb = out if buffers else (w.grad, b.grad)
+        if buffers:
+            assert w.grad is None and b.grad is None
+        assert close(gw, ref[1].grad) and close(gb, ref[2].grad)
+    with torch.no_grad():                                                        # inference path of the rollout
+        assert close(pk.mfma_linear(x0, w0, b0, act), y_ref)
