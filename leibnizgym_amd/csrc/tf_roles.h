@@ -350,6 +350,14 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
     }
     float lam0_fc[4], lam0_link = 0.0f, lam0_tf[3], lam0_tw[3];  // solver warm start for the first substep
+    if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
+    if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
+    else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
+    else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
+    BAR();                                                      // #1: action tile in LDS, flag loads have returned
+    STAMP(1);
+    // The warm-start rows are first needed when the contact rows are built, a free-motion phase later: issued here, behind the
+    // barrier, they stay out of the load burst every workgroup of the launch starts with.
     if (MODE & M_SIM) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) lam0_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
@@ -357,12 +365,6 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) { lam0_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam0_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
     }
-    if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
-    if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
-    else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
-    else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
-    BAR();                                                      // #1: action tile in LDS, flag loads have returned
-    STAMP(1);
     // ---- masked _reset_impl for this finger (trifinger_env.py:373-423, 1101-1147) ----
     const bool rflag = (MODE & M_RESETS) && (IS_RESET || fl_reset != 0);
     if (MODE & M_RESETS) {
@@ -456,8 +458,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = t[j];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, 0.0f);      // fingertip wrench accumulator of the step
+        if (!(MODE & M_SIM) || !ASYM) {                         // fingertip wrench accumulator of the step: a launch that also simulates
+#pragma unroll                                                  // starts from zero in registers and stores after its first substep
+            for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, 0.0f);
+        }
     }
     if (MODE & (M_TORQUE | M_RESETS)) {
 #pragma unroll
@@ -1143,11 +1147,6 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     for (int j = 0; j < 4; ++j) { cq[j] = LDST(TF_S_CUBE_Q + j); gq[j] = LDST(TF_S_GOAL_Q + j); }
 #pragma unroll
     for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);   // rows are read only when the feature is on
-    if (MODE & (M_SIM | M_RESETS)) {
-#pragma unroll
-        for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = LDST(TF_S_LAM_CW + j); }
-        cf_face = LDST(TF_S_CF_FACE); cw_face = LDST(TF_S_CW_FACE);
-    }
     if (MODE & (M_RESETS | M_POST | M_FINISH)) {
         fl_reset = P.reset_buf[(unsigned)cx.i];
         fl_goal_reset = P.goal_reset_buf[(unsigned)cx.i];
@@ -1160,6 +1159,11 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
     BAR();                                                      // #1
     STAMP(1);
+    if (MODE & (M_SIM | M_RESETS)) {                            // warm-start rows: behind the barrier, out of the launch's first load burst
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = LDST(TF_S_LAM_CW + j); }
+        cf_face = LDST(TF_S_CF_FACE); cw_face = LDST(TF_S_CW_FACE);
+    }
     // flags carried in registers to the bookkeeping at the end of the step
     bool c_reset = fl_reset != 0, c_goal_reset = fl_goal_reset != 0, c_successes = fl_successes != 0;
     int c_steps = fl_steps;
