@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3         # vector FP32 peak, for the secondary figure
 N_SIMD = 256 * 4                 # SIMDs of the chip (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32)
 VALU_CYCLES_PER_INST = 2.0       # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
+TF_OBS_BASE, TF_STATES_EXTRA = 32, 72     # include/trifinger.h: obs = 32 + A values, states = obs + 72
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs (algorithmic)
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
 KERNEL_NAME = {True: "k_env<9, false, true, 63, false>", False: "k_env<9, false, false, 63, false>"}   # fused step, torque/position actions
@@ -63,6 +64,29 @@ def load_pmc_profile(n, asym):
                     vals[tok[-5]] = float(tok[-3])
         if vals:
             return vals, os.path.relpath(path, REPO)
+    return None, None
+
+
+def load_pmc_calibration():
+    """Correction factors (true bytes / counter) for FETCH_SIZE / WRITE_SIZE in the access patterns of the fused step, from the
+    newest profiles/r*_pmc_calibration.txt (tools/pmc_calibrate.sh: kernels with known byte counts under the same two rocprofv3
+    passes; MI355X_MICROARCH.md asks for exactly this where an access pattern is not the calibrated 16-B/lane stream)."""
+    import glob
+    KIB_ROWS, KIB_TILE = 64 * 65536 * 4 / 1024.0, 65536 * 113 * 4 / 1024.0
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_calibration.txt")), reverse=True):
+        got = {}
+        for line in open(path):
+            tok = line.split()
+            if line.startswith("cal_") and len(tok) >= 6 and tok[-5] in ("FETCH_SIZE", "WRITE_SIZE"):
+                got[(tok[0].split("(")[0], tok[-5])] = float(tok[-3])
+        try:
+            return {"fetch_rows_read_only": KIB_ROWS / got[("cal_read_rows", "FETCH_SIZE")],       # rows only read: the counter shows half
+                    "fetch_rows_in_place": KIB_ROWS / got[("cal_rw_rows", "FETCH_SIZE")],         # rows read and rewritten in place
+                    "write_rows_in_place": KIB_ROWS / got[("cal_rw_rows", "WRITE_SIZE")],         # ... their stores are counted twice
+                    "write_rows_fresh": KIB_ROWS / got[("cal_write_rows", "WRITE_SIZE")],
+                    "write_tile": KIB_TILE / got[("cal_write_tile", "WRITE_SIZE")]}, os.path.relpath(path, REPO)
+        except KeyError:
+            continue
     return None, None
 
 
@@ -273,9 +297,26 @@ def main():
     bytes_per_launch = BYTES_PER_ENV_STEP[asym] * n
     achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
     pmc, pmc_path = load_pmc_profile(n, asym) if headline else (None, None)
-    traffic = issue = None
+    traffic = traffic_raw = issue = None
+    traffic_how = None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-        traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0          # KiB per dispatch -> bytes
+        traffic_raw = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0      # KiB per dispatch -> bytes
+        cal, cal_path = load_pmc_calibration()
+        if cal:
+            # write-only API tensors of a launch (obs, states, action_buf as tiles; 1.0 in the calibration) vs state rows that the
+            # step reads and rewrites in place (their stores are tallied twice, their loads once)
+            tile = n * 4.0 * (TF_OBS_BASE + eng.action_dim + ((TF_OBS_BASE + eng.action_dim + TF_STATES_EXTRA) if asym else 0) + eng.action_dim)
+            w_raw = pmc["WRITE_SIZE"] * 1024.0
+            w_true = tile * cal["write_tile"] + max(0.0, w_raw - tile) * cal["write_rows_in_place"]
+            traffic = pmc["FETCH_SIZE"] * 1024.0 * cal["fetch_rows_in_place"] + w_true
+            traffic_how = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), {pmc_path}, corrected with the factors measured on "
+                           f"known byte counts in this kernel's access patterns ({cal_path}): stores of rows rewritten in place x{cal['write_rows_in_place']:.3f} "
+                           f"(the counter tallies them twice), tile stores x{cal['write_tile']:.3f} ({tile / 1e6:.1f} MB per launch: obs, states, action_buf), "
+                           f"loads of those rows x{cal['fetch_rows_in_place']:.3f}; the read-only rows (action 36 B, goal 40 B per env) may be "
+                           f"under-counted by up to half (x{cal['fetch_rows_read_only']:.2f} for a pure read stream); traffic_raw = the two counters as printed")
+        else:
+            traffic = traffic_raw
+            traffic_how = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counters), {pmc_path}"
     if pmc and "SQ_INSTS_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc:
         issue = {
             "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "waves_per_launch": pmc.get("SQ_WAVES"),
@@ -327,7 +368,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counters), {pmc_path}" if traffic else None),
+            "traffic_raw": traffic_raw,
+            "traffic_source": traffic_how,
             "kernel": KERNEL_NAME[asym] if eng.action_dim == 9 else KERNEL_NAME[asym].replace("<9,", "<18,"),
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,

@@ -47,6 +47,14 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 #define L_POSE_A 23                     //   7: cp[3], cq[4]
 #define L_POSE_B 53                     //   6: v*[3], w*[3]
 #define L_WALL 90                       //  48: corner c at 12 c: r[3], n[2], Dinv[3], bias, lam[3]
+// between two substeps: what finger f keeps for the next one, in the first slots of its own record (20 of the 23 slots below L_POSE_A)
+#define L_PARK(f) L_REC(f)
+#define PK_FC 0                         //   4
+#define PK_LINK 4
+#define PK_TF 5                         //   3
+#define PK_TW 8                         //   3
+#define PK_TAU 11                       //   3
+#define PK_FT 14                        //   6
 #define L_VQFF 138                      //   9: joint velocities after the finger-finger pass; then Dinv[3] of finger f at 3 f
 #define L_INIT 147                      //   3: bias of finger f; after the last sweep the normal impulse of finger f
 #define LDS_SLOTS 150
@@ -485,8 +493,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         const int nsub = sa.nsim * P.substeps;
         for (int s = 0; s < nsub; ++s) {
             const int sb_ = 4 + 12 * (s & 1);
-            // values that are cold through the sweeps are re-read from their state rows every substep (the rows hold
-            // what this thread stored above; L2 hits) instead of occupying registers the sweeps need
+            // Values that are cold through the sweeps (torque, last substep's impulses, wrench accumulator) do not occupy registers the
+            // sweeps need: between two substeps of a launch they are parked in the first slots of this finger's own record in LDS
+            // (L_PARK: dead from the last sweep of a substep until the finger publishes its free motion in the next one; nobody else
+            // writes slots 0..22 of a record in that window); the state rows are read at the first substep and written at the last.
             float drs[TF_NUM_DR], taus[3];
             float lam_fc[4], fc_link, lam_tf[3], lam_tw[3];     // impulses of the last substep (issued here, used in F2)
             float ft_run[6];                                    // fingertip wrench accumulator of the step (its state rows)
@@ -506,15 +516,15 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                 for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) taus[j] = LDST(TF_S_TAU + 3 * f + j);
+                for (int j = 0; j < 3; ++j) taus[j] = LD(L_PARK(f) + PK_TAU + j);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lam_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
-                fc_link = LDST(TF_S_FC_LINK + f);
+                for (int j = 0; j < 4; ++j) lam_fc[j] = LD(L_PARK(f) + PK_FC + j);
+                fc_link = LD(L_PARK(f) + PK_LINK);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { lam_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
+                for (int j = 0; j < 3; ++j) { lam_tf[j] = LD(L_PARK(f) + PK_TF + j); lam_tw[j] = LD(L_PARK(f) + PK_TW + j); }
                 if (ASYM) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) ft_run[j] = LDST(TF_S_FT + 6 * f + j);
+                    for (int j = 0; j < 6; ++j) ft_run[j] = LD(L_PARK(f) + PK_FT + j);
                 }
             }
             const float* dr = drs;
@@ -846,11 +856,20 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             STAMP(sb_ + 6);
             STAMPV(sb_ + 8, t_wait);
             // ---- impulses kept for the next substep (state rows), fingertip wrench sensor, integration ----
+            const bool last_sub = s == nsub - 1;                // wave-uniform: state rows after the last substep, LDS parking otherwise
+            if (last_sub) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, lam_fc[j]);
-            STST(TF_S_FC_LINK + f, (float)cur_link);
+                for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, lam_fc[j]);
+                STST(TF_S_FC_LINK + f, (float)cur_link);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { STST(TF_S_LAM_TF + 3 * f + d, tc[0].lam[d]); STST(TF_S_LAM_TW + 3 * f + d, tc[1].lam[d]); }
+                for (int d = 0; d < 3; ++d) { STST(TF_S_LAM_TF + 3 * f + d, tc[0].lam[d]); STST(TF_S_LAM_TW + 3 * f + d, tc[1].lam[d]); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) LD(L_PARK(f) + PK_FC + j) = lam_fc[j];
+                LD(L_PARK(f) + PK_LINK) = (float)cur_link;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { LD(L_PARK(f) + PK_TF + d) = tc[0].lam[d]; LD(L_PARK(f) + PK_TW + d) = tc[1].lam[d]; LD(L_PARK(f) + PK_TAU + d) = tau[d]; }
+            }
             if (ASYM) {
                 float* ft = ft_run;
                 if (cur_link == 3) {
@@ -874,8 +893,13 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                         for (int j = 0; j < 3; ++j) { ft[j] += F[j]; ft[3 + j] += T[j]; }
                     }
                 }
+                if (last_sub) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, ft[j]);
+                    for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, ft[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) LD(L_PARK(f) + PK_FT + j) = ft[j];
+                }
             }
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) {
