@@ -237,11 +237,11 @@ __device__ __forceinline__ void stage_load(const float* __restrict__ P, int ld, 
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = P[(size_t)min(kb + c, kend - 1) * ld + r];
     } else {
-        const int r = min(r0 + 16 * (tid >> 6) + (tid & 15), rows - 1), kb = k0 + ((tid & 63) >> 4) * 8;
-        if (VEC) {
-#pragma unroll
+        if (VEC) {                                                  // lane -> (rows t >> 3 and (t >> 3) + 32, k (t & 7) * 4 .. +3): 8 lanes read
+#pragma unroll                                                      // one whole 128-byte line of a row - a wave-load touches 8 lines, all of each
             for (int q = 0; q < 2; ++q) {
-                const f32x4 x = *(const f32x4*)(P + (size_t)r * ld + min(kb + 4 * q, kend - 4));
+                const int r = min(r0 + (tid >> 3) + 32 * q, rows - 1);
+                const f32x4 x = *(const f32x4*)(P + (size_t)r * ld + min(k0 + (tid & 7) * 4, kend - 4));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[4 * q + c] = x[c];
             }
@@ -266,9 +266,23 @@ __device__ __forceinline__ void stage_fix(int rows, int r0, int k0, int kend, in
         }
         return;
     }
+    if (!KMAJ) {                                                    // VEC: value 4 q + c belongs to row (t >> 3) + 32 q, k (t & 7) * 4 + c
+        const int kb = k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool inr = r0 + (tid >> 3) + 32 * q < rows;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x = v[4 * q + c];
+                if (DZ) x *= elu_grad_from_out(y[4 * q + c]);
+                v[4 * q + c] = (inr && kb + c < kend) ? x : 0.0f;
+            }
+        }
+        return;
+    }
     const int real = ONES ? rows - 1 : rows;
-    const int r = KMAJ ? r0 + (tid & 63) : r0 + 16 * (tid >> 6) + (tid & 15);
-    const int kb = k0 + (KMAJ ? (tid >> 6) : ((tid & 63) >> 4)) * 8;
+    const int r = r0 + (tid & 63);
+    const int kb = k0 + (tid >> 6) * 8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x = v[c];
@@ -286,9 +300,12 @@ __device__ __forceinline__ void stage_store(float* S, int tid, const float (&v)[
         for (int c = 0; c < 8; ++c) S[((tid >> 5) + 8 * c) * GP + (tid & 31)] = v[c];
         return;
     }
-    const int row = KMAJ ? (tid & 63) : 16 * (tid >> 6) + (tid & 15);
-    const int kq = KMAJ ? (tid >> 6) * 8 : ((tid & 63) >> 4) * 8;
-    f32x4* d = (f32x4*)(S + row * GP + kq);
+    if (!KMAJ) {                                                    // VEC: 8 consecutive lanes write the 128 contiguous bytes of one LDS row
+        *(f32x4*)(S + (tid >> 3) * GP + (tid & 7) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(S + ((tid >> 3) + 32) * GP + (tid & 7) * 4) = f32x4{v[4], v[5], v[6], v[7]};
+        return;
+    }
+    f32x4* d = (f32x4*)(S + (tid & 63) * GP + (tid >> 6) * 8);
     d[0] = f32x4{v[0], v[1], v[2], v[3]};
     d[1] = f32x4{v[4], v[5], v[6], v[7]};
 }
@@ -299,16 +316,37 @@ __device__ __forceinline__ void stage_store(float* S, int tid, const float (&v)[
 #ifndef GEMM_SCHED
 #define GEMM_SCHED 1
 #endif
-#define GD 3             // K tiles in flight per workgroup (register ring)
+#ifndef GD
+#define GD 3             // K tiles in flight per workgroup (register ring of the producer wavefronts)
+#endif
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, F, I + 1>(static_cast<F&&>(f)); }
+}
 
 // ACT: 0 none, 1 ELU (with bias; forward only), -1 no bias.  SPLIT: the K range is cut into chunks of `chunk`, blockIdx.z takes one and
 // writes its own [M, N] slab of C.
+#ifdef GEMM_TIMING
+__device__ unsigned g_dbg[8 * 8];
+__device__ unsigned long long g_wg[2048 * 2];     // [workgroup][start, end] in s_memrealtime ticks (100 MHz)                  // developer build: [wave][0 total, 1 barrier wait, 2 work] cycles of workgroup 0's waves
+#define TNOW() ((unsigned)__builtin_readcyclecounter())
+#define TBAR() do { const unsigned t0_ = TNOW(); __syncthreads(); t_bar += TNOW() - t0_; } while (0)
+#else
+#define TNOW() 0u
+#define TBAR() __syncthreads()
+#endif
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
-__global__ void __launch_bounds__(256) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+__global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                               const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk) {
-    __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];   // [buffer][operand]: tile t is multiplied out of buffer t & 1 while
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;    // tile t + 1 is written into the other one: one barrier per tile
-    const int wr = wave >> 1, wc = wave & 1;
+    // Role-specialised wavefronts: waves 0-3 multiply (one 32 x 32 accumulator each: LDS reads and MFMAs, nothing else), waves 4-7 stage
+    // (global loads, the fix-ups, LDS writes).  A SIMD hosts one of each per workgroup, so the staging instructions of the producers issue
+    // in the shadow of the consumers' MFMAs instead of between them; tile t is multiplied out of LDS buffer t & 1 while tile t + 1 is
+    // written into the other one, one workgroup barrier per tile.
+    __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];   // [buffer][operand]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave >= 4;
+    const int tid = threadIdx.x & 255;                               // index inside the role
+    const int wr = (wave & 3) >> 1, wc = wave & 1;
     // Workgroups are handed to the 8 XCDs round-robin in launch order; each XCD has its own L2.  The workgroups that share operand rows
     // (the column blocks of one row block; for the split form: every tile of one row chunk) are renumbered onto ONE XCD.
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -322,88 +360,85 @@ __global__ void __launch_bounds__(256) k_gemm(const float* __restrict__ A, const
     const int r0 = by * GT, c0 = bx * GT;
     int kbeg = 0, kend = K;
     if (SPLIT) { kbeg = bz * chunk; kend = min(kbeg + chunk, K); C += (size_t)bz * (size_t)M * (size_t)N; }
-    const bool live = r0 + wr * 32 < M && c0 + wc * 32 < N;       // wave-uniform: a tile wholly outside the matrix is not multiplied
     const int ntiles = (kend - kbeg + GK - 1) / GK;
-    float ra[GD][8], rb[GD][8], ry[DZ ? GD : 1][8];
+    unsigned t_bar = 0u; const unsigned t_start = TNOW(); (void)t_bar; (void)t_start;
+#ifdef GEMM_TIMING
+    const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && wg_lin < 2048) g_wg[2 * wg_lin] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (producer) {
+        float ra[GD][8], rb[GD][8], ry[DZ ? GD : 1][8];
+#pragma unroll
+        for (int d = 0; d < GD; ++d) {                              // tiles past the end are re-reads of the last one, never used
+            const int k0 = kbeg + min(d, ntiles - 1) * GK;
+            stage_load<AK, AVEC, false>(A, lda, M, r0, k0, kend, tid, ra[d]);
+            if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, k0, kend, tid, ry[DZ ? d : 0]);
+            stage_load<BK, BVEC, ONES>(B, ldb, N, c0, k0, kend, tid, rb[d]);
+            __builtin_amdgcn_sched_barrier(0);                      // keep the slots' loads in slot order: vmcnt waits count on it
+        }
+        // stage(slot d, tile t): registers -> LDS buffer t & 1, then the slot takes tile t + GD (in flight through GD multiplications)
+        auto stage = [&](auto dc, int t) __attribute__((always_inline)) {
+            constexpr int d = decltype(dc)::value;
+            const int k0 = kbeg + t * GK;
+            stage_fix<AK, AVEC, DZ, false>(M, r0, k0, kend, tid, ra[d], ry[DZ ? d : 0]);
+            stage_fix<BK, BVEC, false, ONES>(N, c0, k0, kend, tid, rb[d], rb[d]);
+            stage_store<AK, AVEC>(S[t & 1][0], tid, ra[d]);
+            stage_store<BK, BVEC>(S[t & 1][1], tid, rb[d]);
+            const int kn = kbeg + min(t + GD, ntiles - 1) * GK;
+            stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[d]);
+            if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[DZ ? d : 0]);
+            stage_load<BK, BVEC, ONES>(B, ldb, N, c0, kn, kend, tid, rb[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage(std::integral_constant<int, 0>{}, 0);
+        TBAR();                                            // tile 0 staged
+        // iteration t (consumers multiply tile t): stage tile t + 1 from slot (t + 1) % GD, then the barrier that ends the iteration
+        int t = 0;
+        for (; t + GD <= ntiles; t += GD) {                         // branch-free body, GD iterations per trip: a tile past the end stages zeros
+            static_for<GD>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                stage(std::integral_constant<int, (i + 1) % GD>{}, t + 1 + i);
+                TBAR();
+            });
+        }
+        static_for<GD - 1>([&](auto ic) __attribute__((always_inline)) {   // the remaining ntiles % GD iterations
+            constexpr int i = decltype(ic)::value;
+            if (t + i < ntiles) {
+                stage(std::integral_constant<int, (i + 1) % GD>{}, t + 1 + i);
+                TBAR();
+            }
+        });
+#ifdef GEMM_TIMING
+        if (blockIdx.x == 1 && blockIdx.y == 8 && lane == 0) { g_dbg[wave * 8] = TNOW() - t_start; g_dbg[wave * 8 + 1] = t_bar; }
+#endif
+        return;
+    }
+    // ---- consumers ----
+    const bool live = r0 + wr * 32 < M && c0 + wc * 32 < N;       // wave-uniform: a tile wholly outside the matrix is not multiplied
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll
-    for (int d = 0; d < GD; ++d) {                                  // tiles past the end are re-reads of the last one, never used
-        const int k0 = kbeg + min(d, ntiles - 1) * GK;
-        stage_load<AK, AVEC, false>(A, lda, M, r0, k0, kend, tid, ra[d]);
-        if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, k0, kend, tid, ry[DZ ? d : 0]);
-        stage_load<BK, BVEC, ONES>(B, ldb, N, c0, k0, kend, tid, rb[d]);
-        __builtin_amdgcn_sched_barrier(0);                          // keep the slots' loads in slot order: vmcnt waits count on it
-    }
     const int aoff = (wr * 32 + (lane & 31)) * GP + 4 * (lane >> 5), boff = (wc * 32 + (lane & 31)) * GP + 4 * (lane >> 5);
-    // tile 0 -> buffer 0; its register slot takes tile GD
-    stage_fix<AK, AVEC, DZ, false>(M, r0, kbeg, kend, tid, ra[0], ry[0]);
-    stage_fix<BK, BVEC, false, ONES>(N, c0, kbeg, kend, tid, rb[0], rb[0]);
-    stage_store<AK, AVEC>(S[0][0], tid, ra[0]);
-    stage_store<BK, BVEC>(S[0][1], tid, rb[0]);
-    {
-        const int kn = kbeg + min(GD, ntiles - 1) * GK;
-        stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[0]);
-        if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[0]);
-        stage_load<BK, BVEC, ONES>(B, ldb, N, c0, kn, kend, tid, rb[0]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    // One K tile: LDS reads of tile t, then - in the shadow of its 16 MFMAs - tile t + 1 goes from its register slot into the other LDS
-    // buffer and the slot's next loads are issued.  The MFMAs are unconditional (a wavefront whose tile lies outside the matrix
-    // multiplies zeros and stores nothing) so that the whole body is one basic block the scheduler can interleave.
-    auto body = [&](auto dc, int t) __attribute__((always_inline)) {
-        constexpr int d = decltype(dc)::value;
-        constexpr int dn = (d + 1) % GD;                             // register slot of tile t + 1
-        f32x4 a[GK / 8], b[GK / 8];
+    TBAR();                                                // tile 0 staged
+    for (int t = 0; t < ntiles; ++t) {
+        if (GEMM_DBG != 1 && live) {
+            f32x4 a[GK / 8], b[GK / 8];
 #pragma unroll
-        for (int ks = 0; ks < GK / 8; ++ks) {
-            a[ks] = *(const f32x4*)(S[cur][0] + aoff + 8 * ks);
-            b[ks] = *(const f32x4*)(S[cur][1] + boff + 8 * ks);
-        }
-        const int k1 = kbeg + (t + 1) * GK;
-        stage_fix<AK, AVEC, DZ, false>(M, r0, k1, kend, tid, ra[dn], ry[DZ ? dn : 0]);
-        stage_fix<BK, BVEC, false, ONES>(N, c0, k1, kend, tid, rb[dn], rb[dn]);
-        stage_store<AK, AVEC>(S[cur ^ 1][0], tid, ra[dn]);
-        stage_store<BK, BVEC>(S[cur ^ 1][1], tid, rb[dn]);
-        if (GEMM_DBG != 2) {
-            const int kn = kbeg + min(t + 1 + GD, ntiles - 1) * GK;
-            stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[dn]);
-            if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[DZ ? dn : 0]);
-            stage_load<BK, BVEC, ONES>(B, ldb, N, c0, kn, kend, tid, rb[dn]);
-        }
-        if (GEMM_DBG != 1) {
+            for (int ks = 0; ks < GK / 8; ++ks) {
+                a[ks] = *(const f32x4*)(S[t & 1][0] + aoff + 8 * ks);
+                b[ks] = *(const f32x4*)(S[t & 1][1] + boff + 8 * ks);
+            }
 #pragma unroll
             for (int ks = 0; ks < GK / 8; ++ks) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][s], b[ks][s], acc, 0, 0, 0);
             }
         }
-#if GEMM_SCHED
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (GK / 8), 0);       // the LDS reads of this tile first
-#pragma unroll
-        for (int i = 0; i < 2 * GK / 4; ++i) {                              // then per MFMA a share of everything else
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        }
+        TBAR();
+    }
+#ifdef GEMM_TIMING
+    if (blockIdx.x == 1 && blockIdx.y == 8 && lane == 0) { g_dbg[wave * 8] = TNOW() - t_start; g_dbg[wave * 8 + 1] = t_bar; g_dbg[wave * 8 + 2] = (unsigned)ntiles; }
 #endif
-        __syncthreads();
-        cur ^= 1;
-    };
-    int t = 0;
-    for (; t + GD <= ntiles; t += GD) {
-        body(std::integral_constant<int, 0>{}, t);
-        body(std::integral_constant<int, 1>{}, t + 1);
-        body(std::integral_constant<int, 2>{}, t + 2);
-    }
-    if (t < ntiles) {
-        body(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntiles) body(std::integral_constant<int, 1>{}, t + 1);
-    }
     // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int col = c0 + wc * 32 + (lane & 31);
     if (live && col < N) {
@@ -418,6 +453,9 @@ __global__ void __launch_bounds__(256) k_gemm(const float* __restrict__ A, const
             }
         }
     }
+#ifdef GEMM_TIMING
+    if (threadIdx.x == 0 && wg_lin < 2048) g_wg[2 * wg_lin + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // gw[N1, N2] and gb[N1] from `splits` slabs of [N1, N2 + 1] (fixed summation order: deterministic)
@@ -436,7 +474,7 @@ extern "C" {
 // C[M,N] = act(A[M,K] . W[N,K]^T + bias); act: 0 none, 1 ELU
 int tfp_linear_fwd(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return -1;
-    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(256);
+    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (K & 3) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0;
 #define FWD(V, ACT_) hipLaunchKernelGGL((k_gemm<false, false, V, V, ACT_, false, false, false>), grid, block, 0, s, A, W, bias, nullptr, C, M, N, K, K, K, 0)
@@ -448,7 +486,7 @@ int tfp_linear_fwd(const float* A, const float* W, const float* bias, float* C, 
 // C[M,N] = dZ[M,K] . B[K,N] with dZ = A (Y == NULL) or A * elu'(Y)
 int tfp_gemm_nn(const float* A, const float* Y, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return -1;
-    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(256);
+    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (K & 3) == 0 && (((uintptr_t)A | (uintptr_t)Y) & 15) == 0;
 #define NN(V, DZ_) hipLaunchKernelGGL((k_gemm<false, true, V, false, -1, DZ_, false, false>), grid, block, 0, s, A, B, nullptr, Y, C, M, N, K, K, N, 0)
@@ -463,12 +501,16 @@ int tfp_gemm_tn_bias(const float* A, const float* Y, const float* B, float* part
                      int32_t chunk, void* stream) {
     if (rows <= 0 || N1 <= 0 || N2 <= 0 || chunk <= 0 || (chunk % GK) != 0) return -1;
     const int splits = (rows + chunk - 1) / chunk;
-    dim3 grid((N2 + 1 + GT - 1) / GT, (N1 + GT - 1) / GT, splits), block(256);
+    dim3 grid((N2 + 1 + GT - 1) / GT, (N1 + GT - 1) / GT, splits), block(512);
     hipStream_t s = (hipStream_t)stream;
     if (Y) hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, true, true, true>), grid, block, 0, s, A, B, nullptr, Y, part, N1, N2 + 1, rows, N1, N2, chunk);
     else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk);
     const int tot = N1 * (N2 + 1);
-    hipLaunchKernelGGL(k_sum_partials, dim3((tot + 255) / 256), block, 0, s, part, gw, gb, splits, N1, N2);
+    hipLaunchKernelGGL(k_sum_partials, dim3((tot + 255) / 256), dim3(256), 0, s, part, gw, gb, splits, N1, N2);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+#ifdef GEMM_TIMING
+int tfp_debug_read_wg(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg), sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : -3; }
+int tfp_debug_read(unsigned* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned) * 64) == hipSuccess ? 0 : -3; }
+#endif
 }  // extern "C"
