@@ -316,6 +316,9 @@ __device__ __forceinline__ void stage_store(float* S, int tid, const float (&v)[
 #ifndef GEMM_SCHED
 #define GEMM_SCHED 1
 #endif
+#ifndef GEMM_PRIO
+#define GEMM_PRIO 3      // issue priority of the producer wavefronts (the consumers' MFMAs fill what is left)
+#endif
 #ifndef GD
 #define GD 3             // K tiles in flight per workgroup (register ring of the producer wavefronts)
 #endif
@@ -367,6 +370,7 @@ __global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const
     if (threadIdx.x == 0 && wg_lin < 2048) g_wg[2 * wg_lin] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (producer) {
+        __builtin_amdgcn_s_setprio(GEMM_PRIO);                      // staging instructions go first whenever they are ready: they are few, the
         float ra[GD][8], rb[GD][8], ry[DZ ? GD : 1][8];
 #pragma unroll
         for (int d = 0; d < GD; ++d) {                              // tiles past the end are re-reads of the last one, never used
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const
             const int kn = kbeg + min(t + GD, ntiles - 1) * GK;
             stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[d]);
             if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[DZ ? d : 0]);
-            stage_load<BK, BVEC, ONES>(B, ldb, N, c0, kn, kend, tid, rb[d]);
+            stage_load<BK, BVEC, ONES>(B, ldb, N, c0, GEMM_DBG == 3 ? kbeg : kn, kend, tid, rb[d]);   // (3: developer build, B re-read from L1)
             __builtin_amdgcn_sched_barrier(0);
         };
         stage(std::integral_constant<int, 0>{}, 0);
@@ -425,6 +429,7 @@ __global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const
             f32x4 a[GK / 8], b[GK / 8];
 #pragma unroll
             for (int ks = 0; ks < GK / 8; ++ks) {
+                if (GEMM_DBG == 4) { a[ks] = f32x4{1.0f, 2.0f, 3.0f, (float)t}; b[ks] = f32x4{0.5f, (float)lane, 1.5f, 2.5f}; continue; }   // developer build: no LDS reads
                 a[ks] = *(const f32x4*)(S[t & 1][0] + aoff + 8 * ks);
                 b[ks] = *(const f32x4*)(S[t & 1][1] + boff + 8 * ks);
             }
