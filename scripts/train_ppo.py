@@ -59,13 +59,17 @@ def main(argv):
     if cfg["args"]["checkpoint"]:
         tr.restore(cfg["args"]["checkpoint"])
     t0 = time.perf_counter()
+    marks = []                                      # (time, frames) after every epoch: the steady rate excludes graph capture and warm-up
 
     def log(st):
         if rank == 0:
-            dt = time.perf_counter() - t0
+            now = time.perf_counter()
+            marks.append((now, st["frames"] * world))
+            back = marks[max(0, len(marks) - 11)]
+            steady = (marks[-1][1] - back[1]) / max(now - back[0], 1e-9) if len(marks) > 1 else 0.0
             print(f"epoch {st['epoch']:4d} frames {st['frames'] * world:10d} reward/step {st['mean_reward']:9.3f} "
-                  f"kl {st['kl']:.4f} lr {st['lr']:.2e} loss {st['loss']:.4f}  {st['frames'] * world / dt:.3e} frames/s",
-                  flush=True)
+                  f"kl {st['kl']:.4f} lr {st['lr']:.2e} loss {st['loss']:.4f}  {st['frames'] * world / (now - t0):.3e} frames/s "
+                  f"since start, {steady:.3e} over the last {min(len(marks) - 1, 10)} epochs", flush=True)
     tr.train(epochs, log, checkpoint_dir=save_dir if rank == 0 else None)
     if world > 1:
         dist.destroy_process_group()

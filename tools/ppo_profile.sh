@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=${1:-rX}
 O=gpurun_out
 CMD="python3 scripts/train_ppo.py gym=trifinger_difficulty_4 args.num_envs=8192"
-$CMD epochs=24 2>&1 | grep -v amdgpu.ids > $O/${T}_ppo_rate.txt
+$CMD epochs=40 2>&1 | grep -v amdgpu.ids > $O/${T}_ppo_rate.txt
 tail -4 $O/${T}_ppo_rate.txt
 rocprofv3 --kernel-trace --stats -d $O/prof_ppo -o r -- $CMD epochs=8 > /dev/null 2>&1
 { echo "# command: rocprofv3 --kernel-trace --stats -- $CMD epochs=8"
