@@ -519,3 +519,78 @@ int tfp_debug_read_wg(unsigned long long* out) { return hipMemcpyFromSymbol(out,
 int tfp_debug_read(unsigned* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned) * 64) == hipSuccess ? 0 : -3; }
 #endif
 }  // extern "C"
+
+// ---- one launch for the minibatch gather: dst_k[i, :] = src_k[idx[i], :] for up to 8 row-major float arrays of different widths ----
+struct GatherArgs { const float* src[8]; float* dst[8]; int width[8]; int first[8]; int n; };   // first[k]: first column of array k in the concatenation
+__global__ void __launch_bounds__(256) k_gather_rows(GatherArgs ga, const long long* __restrict__ idx, int rows, int total_width) {
+    // one thread per (row, column of the concatenated row): consecutive lanes read consecutive floats of a source row
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)rows * total_width) return;
+    const int r = (int)(e / total_width), c = (int)(e - (long long)r * total_width);
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) k = (j < ga.n && c >= ga.first[j]) ? j : k;
+    const int cc = c - ga.first[k];
+    ga.dst[k][(size_t)r * ga.width[k] + cc] = ga.src[k][(size_t)idx[r] * ga.width[k] + cc];
+}
+
+// ---- one launch for the chunk sums of every layer of a backward pass ----
+struct SumArgs { const float* part[8]; float* gw[8]; float* gb[8]; int splits[8]; int n1[8]; int n2[8]; int first[9]; int n; };
+__global__ void __launch_bounds__(256) k_sum_partials_multi(SumArgs sa) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= sa.first[sa.n]) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) k = (j < sa.n && e >= sa.first[j]) ? j : k;
+    const int i = e - sa.first[k], N2 = sa.n2[k], tot = sa.n1[k] * (N2 + 1);
+    const float* part = sa.part[k];
+    float s = 0.0f;
+#pragma unroll 8
+    for (int z = 0; z < sa.splits[k]; ++z) s += part[(size_t)z * tot + i];
+    const int r = i / (N2 + 1), c = i - r * (N2 + 1);
+    if (c < N2) sa.gw[k][(size_t)r * N2 + c] = s; else sa.gb[k][r] = s;
+}
+
+extern "C" {
+// dst[k][i, :] = src[k][idx[i], :], k < n <= 8 (float rows of widths[k]); idx: int64 [rows]
+int tfp_gather_rows(const void* const* src, void* const* dst, const int32_t* widths, int32_t n, const void* idx, int32_t rows, void* stream) {
+    if (n <= 0 || n > 8 || rows <= 0) return -1;
+    GatherArgs ga;
+    int tw = 0;
+    for (int k = 0; k < 8; ++k) {
+        ga.src[k] = k < n ? (const float*)src[k] : nullptr; ga.dst[k] = k < n ? (float*)dst[k] : nullptr;
+        ga.width[k] = k < n ? widths[k] : 0; ga.first[k] = tw;
+        if (k < n) { if (widths[k] <= 0) return -1; tw += widths[k]; }
+    }
+    ga.n = n;
+    const long long total = (long long)rows * tw;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ga, (const long long*)idx, rows, tw);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// the products of tfp_gemm_tn_partials summed for n <= 8 layers in one launch (fixed order over the chunks: deterministic)
+int tfp_sum_partials_multi(const void* const* part, void* const* gw, void* const* gb, const int32_t* splits, const int32_t* n1, const int32_t* n2,
+                           int32_t n, void* stream) {
+    if (n <= 0 || n > 8) return -1;
+    SumArgs sa;
+    int tot = 0;
+    for (int k = 0; k < 8; ++k) {
+        sa.part[k] = k < n ? (const float*)part[k] : nullptr; sa.gw[k] = k < n ? (float*)gw[k] : nullptr; sa.gb[k] = k < n ? (float*)gb[k] : nullptr;
+        sa.splits[k] = k < n ? splits[k] : 0; sa.n1[k] = k < n ? n1[k] : 0; sa.n2[k] = k < n ? n2[k] : 0; sa.first[k] = tot;
+        if (k < n) tot += n1[k] * (n2[k] + 1);
+    }
+    for (int k = n; k < 9; ++k) sa.first[k] = tot;
+    sa.n = n;
+    hipLaunchKernelGGL(k_sum_partials_multi, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, sa);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// the weight / bias gradient products only (chunk slabs in `part`); the caller sums them (tfp_sum_partials_multi)
+int tfp_gemm_tn_partials(const float* A, const float* Y, const float* B, float* part, int32_t rows, int32_t N1, int32_t N2, int32_t chunk, void* stream) {
+    if (rows <= 0 || N1 <= 0 || N2 <= 0 || chunk <= 0 || (chunk % GK) != 0) return -1;
+    const int splits = (rows + chunk - 1) / chunk;
+    dim3 grid((N2 + 1 + GT - 1) / GT, (N1 + GT - 1) / GT, splits), block(512);
+    hipStream_t s = (hipStream_t)stream;
+    if (Y) hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, true, true, true>), grid, block, 0, s, A, B, nullptr, Y, part, N1, N2 + 1, rows, N1, N2, chunk);
+    else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+}  // extern "C"

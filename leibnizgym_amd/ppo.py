@@ -376,9 +376,9 @@ class PPOTrainer:
         """gather the minibatch, forward, losses, backward; returns nothing - gradients sit in p.grad, the running
         sums of the logged quantities in `acc` (device tensors, no host sync)"""
         c = self.cfg
-        obs = d["obs"][idx]
         if self.fused_loss:
-            return self._mb_backward_fused(d, idx, acc, obs)
+            return self._mb_backward_fused(d, idx, acc, None)
+        obs = d["obs"][idx]
         mu, ls = self.net.dist(obs)
         nlp = neglogp(d["act"][idx], mu, ls)
         ratio = (d["old_nlp"][idx] - nlp).exp()
@@ -401,18 +401,26 @@ class PPOTrainer:
             acc["loss"] += loss.detach(); acc["a_loss"] += a_loss.detach(); acc["c_loss"] += c_loss.detach()
 
     def _mb_backward_fused(self, d, idx, acc, obs):
-        """the same step with the objective and its gradients in ONE hand-written launch (ppo_kernels.fused_ppo_loss); the
-        statistics accumulate on the device in `acc["_fused"]` = (loss, a_loss, c_loss, kl)"""
-        from .ppo_kernels import fused_ppo_loss
+        """the same step on the hand-written kernels: one gather launch for the seven minibatch arrays, the MFMA layers, the objective
+        and its gradients in ONE launch (ppo_kernels.ppo_loss_and_grads), the backward pass started at the network outputs with those
+        gradients (no loss node), the chunk sums of all weight gradients in one launch; the statistics accumulate on the device in
+        `acc["_fused"]` = (loss, a_loss, c_loss, kl)"""
+        from . import ppo_kernels as pk
         c = self.cfg
-        mu = self.net.actor(obs)
-        v = self.net.value(obs, d["states"][idx] if d["states"] is not None else None)
-        v_coef = 1.0 if self.net.central else 0.5 * c.critic_coef
-        loss = fused_ppo_loss(mu, self.net.log_std, v, d["act"][idx], d["old_nlp"][idx], d["adv"][idx], d["ret"][idx],
-                              d["old_mu"][idx], acc["_fused"], c.e_clip, v_coef, c.entropy_coef, c.bounds_loss_coef)
+        srcs = [d["obs"], d["act"], d["old_nlp"], d["adv"], d["ret"], d["old_mu"]] + ([d["states"]] if d["states"] is not None else [])
+        g = pk.gather_rows(srcs, idx)
+        obs, act, old_nlp, adv, ret, old_mu = g[:6]
+        states = g[6] if d["states"] is not None else None
         for p in self.net.parameters():
             p.grad = None
-        loss.backward()
+        mu = self.net.actor(obs)
+        v = self.net.value(obs, states)
+        v_coef = 1.0 if self.net.central else 0.5 * c.critic_coef
+        _, d_mu, d_v, d_ls = pk.ppo_loss_and_grads(mu, self.net.log_std, v, act, old_nlp, adv, ret, old_mu, acc["_fused"], c.e_clip, v_coef,
+                                                   c.entropy_coef, c.bounds_loss_coef)
+        torch.autograd.backward((mu, v), (d_mu, d_v))
+        self.net.log_std.grad = d_ls
+        pk.flush_partial_sums()
 
     @staticmethod
     def _new_acc(dev):

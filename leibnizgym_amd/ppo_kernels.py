@@ -40,6 +40,12 @@ def load():
         lib.tfp_gemm_nn.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
         lib.tfp_gemm_tn_bias.restype = C.c_int
         lib.tfp_gemm_tn_bias.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p]
+        lib.tfp_gemm_tn_partials.restype = C.c_int
+        lib.tfp_gemm_tn_partials.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
+        lib.tfp_sum_partials_multi.restype = C.c_int
+        lib.tfp_sum_partials_multi.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]
+        lib.tfp_gather_rows.restype = C.c_int
+        lib.tfp_gather_rows.argtypes = [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = lib
     return _LIB
 
@@ -73,6 +79,21 @@ class _FusedPPOLoss(torch.autograd.Function):
     def backward(ctx, g):
         d_mu, d_v, d_ls = ctx.saved_tensors
         return d_mu * g, d_ls * g, d_v * g, None, None, None, None, None, None, None, None, None, None
+
+
+def ppo_loss_and_grads(mu, log_std, v, act, old_nlp, adv, ret, old_mu, stats, e_clip, v_coef, ent_coef, bounds_coef):
+    """(loss, d loss / d mu, d loss / d v, d loss / d log_std) straight from the kernel - for a caller that starts the backward pass at
+    the network outputs itself (`torch.autograd.backward((mu, v), (d_mu, d_v))`), without a loss node multiplying them by one"""
+    lib = load()
+    mu, v = mu.contiguous(), v.contiguous()
+    B, A = mu.shape
+    d_mu, d_v = torch.empty_like(mu), torch.empty_like(v)
+    out = torch.empty(A + 1, device=mu.device, dtype=torch.float32)
+    d_ls, loss = out[:A], out[A]
+    _chk(lib.tfp_ppo_loss(mu.data_ptr(), log_std.data_ptr(), act.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(), old_mu.data_ptr(),
+                          v.data_ptr(), ret.data_ptr(), B, A, float(e_clip), float(v_coef), float(ent_coef), float(bounds_coef),
+                          d_mu.data_ptr(), d_v.data_ptr(), d_ls.data_ptr(), loss.data_ptr(), stats.data_ptr(), _stream(mu)), "tfp_ppo_loss")
+    return loss, d_mu, d_v, d_ls
 
 
 def fused_ppo_loss(mu, log_std, v, act, old_nlp, adv, ret, old_mu, stats, e_clip, v_coef, ent_coef, bounds_coef):
@@ -178,7 +199,36 @@ def gemm_nn(a, b, y=None):
     return c
 
 
-def gemm_tn_bias(a, b, y=None, chunk=256, out=None):
+_PENDING_SUMS = []        # (part, gw, gb, splits, N1, N2) of the layers whose chunk products wait for flush_partial_sums()
+
+
+def flush_partial_sums():
+    """the chunk sums of every layer queued by `gemm_tn_bias(..., defer=True)` since the last call, in ONE launch per eight layers
+    (the trainer calls it once after the backward pass: eight launches become one)"""
+    global _PENDING_SUMS
+    pend, _PENDING_SUMS = _PENDING_SUMS, []
+    for i in range(0, len(pend), 8):
+        grp = pend[i:i + 8]
+        n = len(grp)
+        vp = lambda k: (C.c_void_p * n)(*[g[k].data_ptr() for g in grp])     # noqa: E731
+        ip = lambda k: (C.c_int32 * n)(*[g[k] for g in grp])                 # noqa: E731
+        _chk(load().tfp_sum_partials_multi(vp(0), vp(1), vp(2), ip(3), ip(4), ip(5), n, _stream(grp[0][0])), "tfp_sum_partials_multi")
+
+
+def gather_rows(srcs, idx, outs=None):
+    """[s[idx] for s in srcs] for up to 8 row-major float32 arrays (1-D arrays count as width 1) in ONE launch"""
+    assert 0 < len(srcs) <= 8 and idx.dtype == torch.long and idx.is_contiguous()
+    rows = idx.numel()
+    widths = [int(s[0].numel()) for s in srcs]
+    if outs is None:
+        outs = [torch.empty((rows,) + tuple(s.shape[1:]), device=s.device, dtype=torch.float32) for s in srcs]
+    n = len(srcs)
+    _chk(load().tfp_gather_rows((C.c_void_p * n)(*[s.data_ptr() for s in srcs]), (C.c_void_p * n)(*[o.data_ptr() for o in outs]),
+                                (C.c_int32 * n)(*widths), n, idx.data_ptr(), rows, _stream(idx)), "tfp_gather_rows")
+    return outs
+
+
+def gemm_tn_bias(a, b, y=None, chunk=256, out=None, defer=False):
     """dz = a * elu'(y) (or a); returns (dz.T @ b, dz.sum(0)): products of [b | 1] over row chunks (one workgroup set per chunk),
     then their sum in a fixed order - the bias gradient is the extra column"""
     rows, N1 = a.shape
@@ -190,6 +240,11 @@ def gemm_tn_bias(a, b, y=None, chunk=256, out=None):
     else:
         gw = torch.empty(N1, N2, device=a.device, dtype=torch.float32)
         gb = torch.empty(N1, device=a.device, dtype=torch.float32)
+    if defer:                                             # products now, the chunk sums with the other layers' in flush_partial_sums()
+        _chk(load().tfp_gemm_tn_partials(a.data_ptr(), y.data_ptr() if y is not None else None, b.data_ptr(), part.data_ptr(), rows, N1, N2, chunk,
+                                         _stream(a)), "tfp_gemm_tn_partials")
+        _PENDING_SUMS.append((part, gw, gb, splits, N1, N2))
+        return gw, gb
     _chk(load().tfp_gemm_tn_bias(a.data_ptr(), y.data_ptr() if y is not None else None, b.data_ptr(), part.data_ptr(), gw.data_ptr(), gb.data_ptr(),
                                  rows, N1, N2, chunk, _stream(a)), "tfp_gemm_tn_bias")
     return gw, gb
@@ -199,8 +254,9 @@ class _MfmaLinear(torch.autograd.Function):
     """act(x W^T + b) with every matrix product on the hand-written fp32 MFMA kernels: forward with bias and ELU fused into the
     store; backward with the ELU derivative formed in the operand loads and the bias gradient as an extra column of the weight
     gradient product - three launches (+ one reduction of the batch chunks) where the eager form takes nine.  With `grad_out` =
-    (dW buffer, db buffer) the parameter gradients are WRITTEN there (not accumulated, not returned to autograd): the trainer
-    passes the parameters' slots of its flat gradient buffer."""
+    (dW buffer, db buffer) the parameter gradients are WRITTEN there (not accumulated, not returned to autograd) - complete only
+    after `flush_partial_sums()`, which sums the row chunks of every such layer of the backward pass in one launch: the trainer
+    passes the parameters' slots of its flat gradient buffer and flushes once per minibatch step."""
 
     @staticmethod
     def forward(ctx, x, w, b, act, grad_out):
@@ -216,8 +272,8 @@ class _MfmaLinear(torch.autograd.Function):
         gy = gy.contiguous()
         yy = y if ctx.act else None
         gx = gemm_nn(gy, w, yy) if ctx.needs_input_grad[0] else None
-        if ctx.grad_out is not None:
-            gemm_tn_bias(gy, x, yy, out=ctx.grad_out)
+        if ctx.grad_out is not None:                      # the trainer's path: sums deferred to one launch after the backward pass
+            gemm_tn_bias(gy, x, yy, out=ctx.grad_out, defer=True)
             return gx, None, None, None, None
         gw, gb = gemm_tn_bias(gy, x, yy)
         return gx, gw, gb, None, None

@@ -14,7 +14,8 @@ from leibnizgym_amd.ppo import PPOConfig, neglogp
 def test_ppo_library_loads_and_exports_its_symbols():
     assert os.path.isfile(pk.library_path()), "run `make -C leibnizgym_amd/csrc` (python __graft_entry__.py)"
     lib = C.CDLL(pk.library_path())
-    for name in ("tfp_api_version", "tfp_ppo_loss", "tfp_clip_adam", "tfp_linear_fwd", "tfp_gemm_nn", "tfp_gemm_tn_bias"):
+    for name in ("tfp_api_version", "tfp_ppo_loss", "tfp_clip_adam", "tfp_linear_fwd", "tfp_gemm_nn", "tfp_gemm_tn_bias", "tfp_gemm_tn_partials",
+                 "tfp_sum_partials_multi", "tfp_gather_rows"):
         assert hasattr(lib, name), name
     assert lib.tfp_api_version() == 1
 
@@ -144,6 +145,7 @@ def test_mfma_linear_matches_torch_fp32(hip, M, K, N, act):
         out = (torch.full((N, K), 7.0, device=dev), torch.full((N,), 7.0, device=dev)) if buffers else None
         y = pk.mfma_linear(x, w, b, act, out)
         y.backward(gy)
+        pk.flush_partial_sums()                                                  # caller buffers: the chunk sums are one deferred launch
         assert close(y, y_ref) and close(x.grad, ref[0].grad)
         gw, gb = out if buffers else (w.grad, b.grad)
         if buffers:
@@ -151,3 +153,22 @@ def test_mfma_linear_matches_torch_fp32(hip, M, K, N, act):
         assert close(gw, ref[1].grad) and close(gb, ref[2].grad)
     with torch.no_grad():                                                        # inference path of the rollout
         assert close(pk.mfma_linear(x0, w0, b0, act), y_ref)
+
+
+@pytest.mark.gpu
+def test_gather_rows_and_deferred_chunk_sums(hip):
+    """The one-launch minibatch gather equals indexing; weight / bias gradients whose chunk sums are deferred to one launch for several
+    layers equal the ones summed per layer (bit for bit: same products, same summation order)."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(5)
+    srcs = [torch.randn(5000, w, device=dev, generator=g) for w in (41, 9, 113)] + [torch.randn(5000, device=dev, generator=g) for _ in range(3)]
+    idx = torch.randperm(5000, device=dev, generator=g)[:1777].contiguous()
+    for got, src in zip(pk.gather_rows(srcs, idx), srcs):
+        assert torch.equal(got, src[idx])
+    layers = [(torch.randn(2048, n1, device=dev, generator=g), torch.randn(2048, n2, device=dev, generator=g), torch.rand(2048, n1, device=dev, generator=g) - 0.3)
+              for n1, n2 in ((400, 41), (200, 400), (9, 100), (1, 100))]
+    direct = [pk.gemm_tn_bias(a, b, y) for a, b, y in layers]
+    deferred = [pk.gemm_tn_bias(a, b, y, defer=True) for a, b, y in layers]
+    pk.flush_partial_sums()
+    for (gw0, gb0), (gw1, gb1) in zip(direct, deferred):
+        assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
