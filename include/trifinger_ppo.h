@@ -1,0 +1,60 @@
+/* C ABI of the trainer kernels (leibnizgym_amd/csrc/libtrifinger_ppo.so, built from csrc/ppo_kernels.hip for gfx950).
+ *
+ * These entry points are what the in-repo PPO (leibnizgym_amd/ppo.py; SURVEY.md section 8f-1, BASELINE.json configs[4]) runs its
+ * minibatch step on when RL-Games is not installed.  They replace, for the asymmetric actor-critic of the reference's
+ * resources/config/rlg/asymm.yaml:2-90 (MLP [400, 200, 100] ELU on obs 41 / states 113, fixed sigma, central value network), the
+ * PyTorch operators RL-Games' a2c_continuous agent launches per minibatch: the Linear / ELU layers forwards and backwards
+ * (asymm.yaml:12-33, 70-90), the clipped-surrogate / value / bounds objective (asymm.yaml:38-68: e_clip, critic_coef, bounds_loss_coef,
+ * entropy_coef), gradient truncation (grad_norm, truncate_grads) and Adam (learning_rate, central_value_config.lr).
+ * Plain pointers and sizes; every pointer is DEVICE memory (float32, contiguous, row-major) unless stated; `stream` is a hipStream_t
+ * (NULL = the default stream).  Return value: 0 on success, -1 invalid argument, -2 / -3 a HIP call or launch failed.
+ * The Python binding is leibnizgym_amd/ppo_kernels.py (ctypes); tests/test_ppo_kernels.py holds every entry point against a plain
+ * PyTorch fp32 reference of the same operation.  Arithmetic: fp32 throughout; the matrix products run on v_mfma_f32_32x32x2_f32
+ * (fp32 inputs, fp32 accumulation). */
+#ifndef TRIFINGER_PPO_H
+#define TRIFINGER_PPO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int tfp_api_version(void);                                     /* 1 */
+
+/* The whole PPO objective of one minibatch, value and gradients, in one launch (B samples, A = 9 or 18 actions):
+ *   loss = a_loss + v_coef c_loss - ent_coef entropy + bounds_coef b_loss   (formulas: csrc/ppo_kernels.hip header)
+ * Outputs: d_mu [B, A], d_v [B], d_logstd [A], loss_out [1]; stats [4] += (loss, a_loss, c_loss, kl). */
+int tfp_ppo_loss(const float* mu, const float* log_std, const float* act, const float* old_nlp, const float* adv, const float* old_mu,
+                 const float* v, const float* ret, int32_t B, int32_t A, float e_clip, float v_coef, float ent_coef, float bounds_coef,
+                 float* d_mu, float* d_v, float* d_logstd, float* loss_out, float* stats, void* stream);
+
+/* Gradient-norm truncation + Adam for two parameter groups over one flat buffer: group 0 = [0, n0), group 1 = [n0, n1).
+ * sq [2] scratch, step [1] step counter (device), lr [2] learning rates (device). */
+int tfp_clip_adam(float* p, const float* g, float* m, float* v, int32_t n0, int32_t n1, float* sq, float* step, const float* lr,
+                  float max_norm0, float max_norm1, float beta1, float beta2, float eps, void* stream);
+
+/* C[M, N] = act(A[M, K] . W[N, K]^T + bias[N]); act: 0 none, 1 ELU (torch.nn.Linear followed by torch.nn.ELU) */
+int tfp_linear_fwd(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+
+/* Input gradient: C[M, N] = dZ[M, K] . B[K, N], dZ = A, or A * elu'(Y) when Y (the layer's ELU output, [M, K]) is not NULL */
+int tfp_gemm_nn(const float* A, const float* Y, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
+
+/* Weight and bias gradient: gw[N1, N2] = dZ^T B, gb[N1] = column sums of dZ, for dZ[rows, N1] (as above), B[rows, N2].
+ * `part` is scratch for ceil(rows / chunk) slabs of N1 * (N2 + 1) floats; chunk must be a multiple of 32.  The sum over the row
+ * chunks runs in a fixed order (deterministic). */
+int tfp_gemm_tn_bias(const float* A, const float* Y, const float* B, float* part, float* gw, float* gb, int32_t rows, int32_t N1, int32_t N2,
+                     int32_t chunk, void* stream);
+/* ... the chunk products only; tfp_sum_partials_multi then sums the slabs of up to 8 layers in one launch
+ * (host arrays of n device pointers / sizes) */
+int tfp_gemm_tn_partials(const float* A, const float* Y, const float* B, float* part, int32_t rows, int32_t N1, int32_t N2, int32_t chunk,
+                         void* stream);
+int tfp_sum_partials_multi(const void* const* part, void* const* gw, void* const* gb, const int32_t* splits, const int32_t* n1,
+                           const int32_t* n2, int32_t n, void* stream);
+
+/* Minibatch gather: dst[k][i, :] = src[k][idx[i], :] for n <= 8 float arrays of widths[k] columns (host arrays of n device pointers);
+ * idx: int64 [rows] on the device */
+int tfp_gather_rows(const void* const* src, void* const* dst, const int32_t* widths, int32_t n, const void* idx, int32_t rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
