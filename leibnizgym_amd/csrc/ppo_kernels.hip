@@ -162,17 +162,22 @@ extern "C" {
 int tfp_api_version(void) { return 1; }
 
 // d_logstd [A] and loss_out [1] are zeroed here (on the stream); stats [4] (loss, a_loss, c_loss, kl) ACCUMULATE across calls.
+}  // extern "C"
+// Small buffers are cleared by a kernel, not by hipMemsetAsync: inside a captured HIP graph the memset / memcpy NODES of this ROCm stack
+// proved unsafe (pointer-like garbage appeared in a 40-byte pool tensor between the graph that wrote it and the graph that read it; see
+// DESIGN.md section 8) - the trainer's graphs consist of kernel nodes only.
+__global__ void k_zero_f32(float* __restrict__ a, int na, float* __restrict__ b, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = 0.0f;
+    if (b && i < nb) b[i] = 0.0f;
+}
+extern "C" {
 int tfp_ppo_loss(const float* mu, const float* log_std, const float* act, const float* old_nlp, const float* adv, const float* old_mu,
                  const float* v, const float* ret, int32_t B, int32_t A, float e_clip, float v_coef, float ent_coef, float bounds_coef,
                  float* d_mu, float* d_v, float* d_logstd, float* loss_out, float* stats, void* stream) {
     if (B <= 0 || (A != 9 && A != 18)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (loss_out == d_logstd + A) {                              // one buffer [A + 1]: one fill
-        if (hipMemsetAsync(d_logstd, 0, sizeof(float) * (A + 1), s) != hipSuccess) return -2;
-    } else {
-        if (hipMemsetAsync(d_logstd, 0, sizeof(float) * A, s) != hipSuccess) return -2;
-        if (hipMemsetAsync(loss_out, 0, sizeof(float), s) != hipSuccess) return -2;
-    }
+    hipLaunchKernelGGL(k_zero_f32, dim3(1), dim3(64), 0, s, d_logstd, A, loss_out, 1);
     dim3 grid((B + 255) / 256), block(256);
     if (A == 9)
         hipLaunchKernelGGL((k_ppo_loss<9>), grid, block, 0, s, mu, log_std, act, old_nlp, adv, old_mu, v, ret, B, e_clip, v_coef, ent_coef,
@@ -188,7 +193,7 @@ int tfp_clip_adam(float* p, const float* g, float* m, float* v, int32_t n0, int3
                   float max_norm0, float max_norm1, float beta1, float beta2, float eps, void* stream) {
     if (n1 <= 0 || n0 < 0 || n0 > n1) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sq, 0, 2 * sizeof(float), s) != hipSuccess) return -2;
+    hipLaunchKernelGGL(k_zero_f32, dim3(1), dim3(64), 0, s, sq, 2, (float*)nullptr, 0);
     const int blocks = (n1 + 256 * 4 - 1) / (256 * 4);
     hipLaunchKernelGGL(k_grad_sqnorms, dim3(blocks), dim3(256), 0, s, g, n0, n1, sq, step);
     hipLaunchKernelGGL(k_clip_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, n0, n1, sq, step, lr, max_norm0, max_norm1, beta1, beta2, eps);

@@ -403,8 +403,9 @@ class PPOTrainer:
     def _mb_backward_fused(self, d, idx, acc, obs):
         """the same step on the hand-written kernels: one gather launch for the seven minibatch arrays, the MFMA layers, the objective
         and its gradients in ONE launch (ppo_kernels.ppo_loss_and_grads), the backward pass started at the network outputs with those
-        gradients (no loss node), the chunk sums of all weight gradients in one launch; the statistics accumulate on the device in
-        `acc["_fused"]` = (loss, a_loss, c_loss, kl)"""
+        gradients (no loss node), the chunk sums of all weight gradients in one launch.  Every parameter gradient lands in its slot of
+        the flat gradient buffer directly (the log-std gradient too), so that the optimiser's graph reads nothing but that buffer; the
+        statistics accumulate on the device in `acc["_fused"]` = (loss, a_loss, c_loss, kl)"""
         from . import ppo_kernels as pk
         c = self.cfg
         srcs = [d["obs"], d["act"], d["old_nlp"], d["adv"], d["ret"], d["old_mu"]] + ([d["states"]] if d["states"] is not None else [])
@@ -416,10 +417,9 @@ class PPOTrainer:
         mu = self.net.actor(obs)
         v = self.net.value(obs, states)
         v_coef = 1.0 if self.net.central else 0.5 * c.critic_coef
-        _, d_mu, d_v, d_ls = pk.ppo_loss_and_grads(mu, self.net.log_std, v, act, old_nlp, adv, ret, old_mu, acc["_fused"], c.e_clip, v_coef,
-                                                   c.entropy_coef, c.bounds_loss_coef)
+        _, d_mu, d_v, _ = pk.ppo_loss_and_grads(mu, self.net.log_std, v, act, old_nlp, adv, ret, old_mu, acc["_fused"], c.e_clip, v_coef,
+                                                c.entropy_coef, c.bounds_loss_coef, d_ls_out=self.flat_opt.grad_view(self.net.log_std))
         torch.autograd.backward((mu, v), (d_mu, d_v))
-        self.net.log_std.grad = d_ls
         pk.flush_partial_sums()
 
     @staticmethod
@@ -544,12 +544,14 @@ class PPOTrainer:
                     if self.dist_on:
                         self._exchange(g["flat"])
                     g["b"].replay()
-                    # Bounded run-ahead WITH a drained stream.  The host queues graph launches far faster than the device retires
-                    # them (a whole mini-epoch: 32 x [index copy, graph A, graph B]).  On this ROCm stack, more than 16 launches
-                    # of the same graph executables queued behind one another without a stream synchronisation in between went
-                    # wrong: gradients came back zero or garbage for whole epochs, differently from run to run.  A stream
-                    # synchronisation every <= 16 steps made every run exact and repeatable; waiting on an event recorded 8 to
-                    # 16 steps earlier (same depth in flight, stream never drained) did not.  Every 8 steps costs < 2 %.
+                    # Both graphs consist of KERNEL nodes only.  With hipMemsetAsync / small device-to-device copies captured as memset /
+                    # memcpy nodes (the zeroing of the 40-byte gradient buffer of the objective kernel, of the two squared norms, the
+                    # copy of the log-std gradient into the flat buffer) the replayed update went wrong on this ROCm 7.2 stack, from run
+                    # to run differently: pointer-like garbage appeared in the 40-byte tensor between the graph that wrote it and the
+                    # graph that read it, the gradient norm became inf, the actor froze and the adaptive learning rate ran to its
+                    # ceiling.  Round 2 first met it as "more than 16 graph launches queued" and drained the stream every 8 steps, which
+                    # only moved the odds; with kernel-only graphs 25 of 25 runs are exact with and without the drain.  The drain stays
+                    # as a cheap bound on the host's run-ahead (no measurable cost).
                     if nmb % 8 == 7:
                         torch.cuda.current_stream(dev).synchronize()
                 else:

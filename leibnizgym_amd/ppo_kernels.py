@@ -81,7 +81,7 @@ class _FusedPPOLoss(torch.autograd.Function):
         return d_mu * g, d_ls * g, d_v * g, None, None, None, None, None, None, None, None, None, None
 
 
-def ppo_loss_and_grads(mu, log_std, v, act, old_nlp, adv, ret, old_mu, stats, e_clip, v_coef, ent_coef, bounds_coef):
+def ppo_loss_and_grads(mu, log_std, v, act, old_nlp, adv, ret, old_mu, stats, e_clip, v_coef, ent_coef, bounds_coef, d_ls_out=None):
     """(loss, d loss / d mu, d loss / d v, d loss / d log_std) straight from the kernel - for a caller that starts the backward pass at
     the network outputs itself (`torch.autograd.backward((mu, v), (d_mu, d_v))`), without a loss node multiplying them by one"""
     lib = load()
@@ -89,7 +89,7 @@ def ppo_loss_and_grads(mu, log_std, v, act, old_nlp, adv, ret, old_mu, stats, e_
     B, A = mu.shape
     d_mu, d_v = torch.empty_like(mu), torch.empty_like(v)
     out = torch.empty(A + 1, device=mu.device, dtype=torch.float32)
-    d_ls, loss = out[:A], out[A]
+    d_ls, loss = (out[:A] if d_ls_out is None else d_ls_out), out[A]      # d_ls_out: e.g. the parameter's slot of a flat gradient buffer
     _chk(lib.tfp_ppo_loss(mu.data_ptr(), log_std.data_ptr(), act.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(), old_mu.data_ptr(),
                           v.data_ptr(), ret.data_ptr(), B, A, float(e_clip), float(v_coef), float(ent_coef), float(bounds_coef),
                           d_mu.data_ptr(), d_v.data_ptr(), d_ls.data_ptr(), loss.data_ptr(), stats.data_ptr(), _stream(mu)), "tfp_ppo_loss")
