@@ -12,10 +12,12 @@ Checkpoints (`save` / `restore`: networks, optimiser moments, learning rates, fr
 best-so-far saving and a deterministic `play` mode mirror what the reference gets from RL-Games (`args.checkpoint`,
 `args.play`, `save_frequency`, `save_best_after`).
 
-This is host-side training glue, NOT part of the measured hot path: networks are plain `torch.nn` (rocBLAS GEMMs).
-The update is launch-bound (two tiny MLPs, ~150 launches per minibatch, 128 minibatches per iteration), so on the GPU
-one minibatch step is captured once into two HIP graphs (gather + forward + backward + gradient flattening | clip +
-fused Adam) and replayed; the gradient all-reduce sits between the two replays, outside the capture.
+This is host-side training glue, NOT part of the measured hot path.  On a GPU the minibatch step runs on the hand-written kernels of
+csrc/ppo_kernels.hip (leibnizgym_amd/ppo_kernels.py): one gather launch, the Linear / ELU layers on fp32 MFMA, the objective with all
+its gradients in one launch, the chunk sums of the weight gradients in one launch, truncation + Adam over one flat buffer - about 30
+launches per step, launched eagerly.  `use_graphs=True` replays the step as two HIP graphs instead (gather + forward + backward | clip +
+Adam; the gradient all-reduce sits between the two replays, outside the capture); it is off by default, see PPOConfig.use_graphs.
+On the CPU (tests) and with `fused_kernels=False` the same step is plain torch.
 Data parallelism: every rank owns an env shard (leibnizgym_amd.sharding) and its own rollout; gradients are averaged
 with ONE all-reduce of a flat buffer per minibatch (`torch.distributed`, backend nccl = RCCL over xGMI on the GPU
 box, gloo in the CPU tests) - ~1 MB, latency-bound, so a single fused collective is the right shape.
@@ -58,7 +60,9 @@ class PPOConfig:
     max_epochs: int = 100000
     name: str = "trifinger"
     seed: int = 7
-    use_graphs: bool = True           # capture the minibatch step into HIP graphs when the trainer runs on a GPU
+    use_graphs: bool = False          # replay the minibatch step as two HIP graphs.  Off by default: with the hand-written kernels a step is
+                                      # ~30 launches and the host stays ahead of the GPU without graphs (3.9e6 vs 4.0e6 frames/s), while graph
+                                      # replay on this ROCm 7.2 stack was found unreliable twice
     fused_kernels: bool = True        # hand-written HIP kernel for the objective, forward and backward in one launch (GPU only)
 
     @classmethod

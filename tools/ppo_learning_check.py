@@ -1,6 +1,6 @@
 """Developer tool (GPU box): train the in-repo PPO on difficulty 1 (cube to a goal position on the table) and then roll the
 deterministic policy, reporting what the cube physically does - distance to the goal, speeds, heights - so that a learning
-curve cannot hide an exploit of the contact model.   python tools/ppo_learning_check.py [epochs] [num_envs]"""
+curve cannot hide an exploit of the contact model.   python tools/ppo_learning_check.py [epochs] [num_envs] [seed] [fused|plain] [graphs|nographs]"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -14,10 +14,13 @@ from leibnizgym_amd.wrappers import VecTaskPython
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+fused = (sys.argv[4] != "plain") if len(sys.argv) > 4 else True
+graphs = (sys.argv[5] == "graphs") if len(sys.argv) > 5 else False
 cfg = compose(["gym=trifinger_difficulty_1", f"args.num_envs={n}", "args.headless=True"])
 env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False)
 tr = PPOTrainer(RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device="cuda:0")), env.get_obs_dim(), env.get_state_dim(),
-                env.get_action_dim(), PPOConfig.from_rlg(cfg["rlg"], num_envs=n), device="cuda:0")
+                env.get_action_dim(), PPOConfig.from_rlg(cfg["rlg"], num_envs=n, seed=seed, fused_kernels=fused, use_graphs=graphs), device="cuda:0")
 t0 = time.perf_counter()
 for st in tr.train(epochs):
     if st["epoch"] % 10 == 9:
