@@ -451,8 +451,27 @@ __global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const
 #endif
     // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int col = c0 + wc * 32 + (lane & 31);
-    if (live && col < N) {
-        const float bv = (ACT >= 0 && bias) ? bias[col] : 0.0f;
+    const float bv = (ACT >= 0 && bias && col < N) ? bias[col] : 0.0f;
+    if (!SPLIT && (N & 3) == 0) {
+        // The 64 x 64 tile leaves through LDS as dwordx4 stores (a wave instruction = 4 rows x 256 contiguous bytes) instead of 16 dword
+        // stores per lane of 128-byte pieces: the tail of these short kernels is bound by store ISSUE (the producers have exited; the
+        // K loop's last barrier lies behind every LDS read, so the staging buffers are free).  N % 4 == 0 keeps the rows 16-byte aligned.
+        float* T = &S[0][0][0];                                     // [64][GTP]: 17 KB of the 36 KB
+        constexpr int GTP = GT + 4;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            float v = acc[reg] + bv;
+            if (ACT == 1) v = v > 0.0f ? v : expm1f(v);              // ELU, alpha = 1
+            T[(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * GTP + wc * 32 + (lane & 31)] = live ? v : 0.0f;
+        }
+        __syncthreads();                                            // the four consumer wavefronts (the producers are gone)
+        const int t = threadIdx.x;                                  // 0 .. 255
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = (t >> 4) + 16 * it, cc = (t & 15) * 4;
+            if (r0 + rr < M && c0 + cc < N) *(f32x4*)(C + (size_t)(r0 + rr) * N + c0 + cc) = *(const f32x4*)(T + rr * GTP + cc);
+        }
+    } else if (live && col < N) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = r0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
