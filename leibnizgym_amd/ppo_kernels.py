@@ -281,3 +281,26 @@ class _MfmaLinear(torch.autograd.Function):
 
 def mfma_linear(x, w, b, act, grad_out=None):
     return _MfmaLinear.apply(x, w, b, int(act), grad_out)
+
+
+# ---- the two MLPs without autograd: forward keeps the layer outputs, backward walks them in reverse --------------------------------
+def mlp_forward(x, layers):
+    """`layers`: [(weight, bias, act, grad_out)] in order.  Returns the list of layer outputs (the last one is the network output);
+    the inputs of the layers are `x` and the outputs before them."""
+    ys = []
+    for w, b, act, _ in layers:
+        x = linear_fwd(x, w, b, act)
+        ys.append(x)
+    return ys
+
+
+def mlp_backward(x, ys, gy, layers):
+    """gradients of every layer's weight and bias into its `grad_out` buffers (chunk sums deferred: call flush_partial_sums() after the
+    last network), given the gradient `gy` of the network output; the input gradient of the first layer is not formed"""
+    for k in range(len(layers) - 1, -1, -1):
+        w, _, act, grad_out = layers[k]
+        inp = ys[k - 1] if k > 0 else x
+        yy = ys[k] if act else None
+        gemm_tn_bias(gy, inp, yy, out=grad_out, defer=True)
+        if k > 0:
+            gy = gemm_nn(gy, w, yy)
