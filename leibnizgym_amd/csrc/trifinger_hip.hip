@@ -37,6 +37,15 @@ template <int A, bool IS_RESET, bool ASYM, int MODE, bool EXT>
 __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
     __shared__ __attribute__((aligned(16))) float lds[(EXT ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
     const DevParams& P = *Pp;
+    {   // Warm the scalar cache with the parameter block (one dword per 64-byte line) BEFORE the state loads of every workgroup of the
+        // launch saturate the L2: the model constants the free motion needs then come out of the constant cache instead of queueing
+        // behind that burst.
+        const unsigned* pw = reinterpret_cast<const unsigned*>(Pp);
+        unsigned touch = 0u;
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(DevParams) / 64u; ++k) touch |= pw[16u * k];
+        asm volatile("" ::"s"(touch));
+    }
     Ctx cx;
     cx.tid = (int)threadIdx.x;
     cx.lane = (int)threadIdx.x & (WAVE - 1);
