@@ -42,23 +42,23 @@ VALU_CYCLES_PER_INST = 2.0       # a wave64 VALU instruction occupies a SIMD-32 
 TF_OBS_BASE, TF_STATES_EXTRA = 32, 72     # include/trifinger.h: obs = 32 + A values, states = obs + 72
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs (algorithmic)
 FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
-KERNEL_NAME = {True: "k_env<9, false, true, 63, false>", False: "k_env<9, false, false, 63, false>"}   # fused step, torque/position actions
 
 
-def load_pmc_profile(n, asym):
+def load_pmc_profile(n, asym, ext=False):
     """Per-launch counters of the fused step kernel from the newest profiles/r*_pmc.txt whose header names this workload
     (written by tools/profile_round.sh; rocprofv3 --pmc passes, raw counter expressions).  Returns (dict, path) or
     (None, None): nothing is hard-coded here, a profile of another N / kernel is not used."""
     import glob
     import re
-    want = f"# workload: N={n} asym={asym} kernel={KERNEL_NAME[asym]}"
+    kname = kernel_name(asym, 9, ext)
+    want = f"# workload: N={n} asym={asym} kernel={kname}"
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.txt")), reverse=True):
         text = open(path).read()
         if want not in text:
             continue
         vals = {}
         for line in text.splitlines():
-            if line.startswith(KERNEL_NAME[asym]):
+            if line.startswith(kname):
                 tok = line.split()                     # ... <counter> <n> <mean> <min> <max>; the kernel name may be cut short
                 if len(tok) >= 6 and re.fullmatch(r"[A-Z_0-9a-z]+", tok[-5]) and tok[-4].isdigit():
                     vals[tok[-5]] = float(tok[-3])
@@ -111,9 +111,18 @@ D1_REWARDS = {                   # scripts/rlg_hydra.py:83-109
     "object_rot_delta": {"activate": False, "weight": -250},
     "object_move": {"activate": False, "weight": -750},
 }
+# EVERY domain-randomisation feature of the build (BASELINE configs[3] "full domain randomisation"): the six scale factors,
+# observation noise, action repeat AND the rest of the reference's intent list (trifinger_env.py:385-393): robot base / stage
+# position offsets and per-body friction - the latter select the EXT kernel instantiation k_env<..., true>.
 FULL_DR = {"activate": True, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "friction": (0.7, 1.3),
            "motor_torque": (0.9, 1.1), "link_mass": (0.9, 1.1), "restitution": (0.5, 1.5), "obs_noise": 0.02,
-           "action_repeat_prob": 0.1}
+           "action_repeat_prob": 0.1, "robot_base_position": (0.005, 0.005, 0.003), "stage_position": (0.005, 0.005),
+           "friction_robot": (0.8, 1.2), "friction_object": (0.8, 1.2), "friction_stage": (0.8, 1.2)}
+
+
+def kernel_name(asym, action_dim=9, ext=False):
+    """rocprofv3's name of the fused-step instantiation a workload launches (EXT: extended DR or the box object)."""
+    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, 63, {'true' if ext else 'false'}>"
 
 
 def workload_kwargs(asym, difficulty=4, dr=False):
@@ -193,6 +202,9 @@ def main():
                     help="secondary runs only (BASELINE configs[1]: --difficulty 1 --envs 8192); the headline is 4")
     ap.add_argument("--dr", action="store_true",
                     help="secondary runs only: every domain-randomisation feature on (BASELINE configs[3]: --dr --envs 16384)")
+    ap.add_argument("--box", action="store_true",
+                    help="secondary runs only: the phase-3 cuboid (20 x 80 x 20 mm, density 500) instead of the cube - the EXT "
+                         "kernel instantiation with the inertia-scaled solve")
     ap.add_argument("--stats-every", type=int, default=0,
                     help="all-reduce the episode statistics over the ranks every K steps on a side stream (the optional "
                          "exchange of the north star; RCCL on a multi-GPU run); 0: off")
@@ -230,9 +242,10 @@ def main():
 
     asym = not args.symmetric
     n = args.envs
-    headline = args.difficulty == 4 and not args.dr
+    headline = args.difficulty == 4 and not args.dr and not args.box
     lib = _capi.load_hip_library()
     cfg = make_config(lib, n, seed=7, env_id_offset=rank * n, global_num_envs=world * n,
+                      model=lib.box_model((0.02, 0.08, 0.02), 500.0) if args.box else None,
                       **workload_kwargs(asym, args.difficulty, args.dr))
     eng = TrifingerEngine(cfg, device=dev, lib=lib)
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -296,7 +309,8 @@ def main():
     kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
     bytes_per_launch = BYTES_PER_ENV_STEP[asym] * n
     achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
-    pmc, pmc_path = load_pmc_profile(n, asym) if headline else (None, None)
+    ext = bool(args.dr or args.box)               # extended DR / box object -> the EXT instantiation of the fused step
+    pmc, pmc_path = load_pmc_profile(n, asym, ext) if (headline or ext) else (None, None)
     traffic = traffic_raw = issue = None
     traffic_how = None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -349,10 +363,10 @@ def main():
                              f"with Philox inside the launch); `value_with_torch_action_generation`: the same number of steps with "
                              f"torch.rand(N, A)*2-1 generated on the device inside the loop (three extra elementwise launches per step)",
         "config": {
-            "workload": f"trifinger_difficulty_{args.difficulty}{' + full domain randomisation' if args.dr else ''}, "
+            "workload": f"trifinger_difficulty_{args.difficulty}{' + full domain randomisation' if args.dr else ''}{' + phase-3 cuboid object' if args.box else ''}, "
                         f"{n} envs/GPU x {world} GPU, torque mode, random actions 2*U-1, "
                         f"asymmetric_obs={asym}, episode_length 750, dt 0.02, 2 substeps, 8 solver iterations, "
-                        f"control_decimation 1 (BASELINE.json configs[{2 if (args.difficulty == 4 and not args.dr) else (3 if args.dr else 1)}])",
+                        f"control_decimation 1 (BASELINE.json configs[{2 if headline else (3 if args.dr else 1)}]{'' if not args.box else ' with the object swapped'})",
             "envs_per_gpu": n,
             "global_envs": world * n,
             "asymmetric_obs": asym,
@@ -370,7 +384,7 @@ def main():
             "traffic": traffic,
             "traffic_raw": traffic_raw,
             "traffic_source": traffic_how,
-            "kernel": KERNEL_NAME[asym] if eng.action_dim == 9 else KERNEL_NAME[asym].replace("<9,", "<18,"),
+            "kernel": kernel_name(asym, eng.action_dim, ext),
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
             "kernel_timing": f"one HIP event pair on the launch stream around every window of {max(1, args.time_window)} "

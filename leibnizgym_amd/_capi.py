@@ -205,8 +205,8 @@ class TfLib:
 
 
 def hip_library_path():
-    # TF_HIP_LIB: developer override (compiler-flag experiments build variants next to the product library)
-    return os.environ.get("TF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_hip.so")
+    """the in-tree product library; nothing (no environment variable, no search path) redirects it"""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_hip.so")
 
 
 _HIP_LIB = None
@@ -216,5 +216,8 @@ def load_hip_library():
     """Load the HIP product library (cached).  Fails loudly when it has not been built."""
     global _HIP_LIB
     if _HIP_LIB is None:
-        _HIP_LIB = TfLib(hip_library_path())
+        lib = TfLib(hip_library_path())
+        if lib.backend != "hip-gfx950":       # the product path runs the HIP kernels or nothing
+            raise TfLibraryError(f"{lib.path} reports backend `{lib.backend}`, not the gfx950 HIP build of csrc/trifinger_hip.hip")
+        _HIP_LIB = lib
     return _HIP_LIB

@@ -420,6 +420,10 @@ __global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const
 #ifdef GEMM_TIMING
         if (blockIdx.x == 1 && blockIdx.y == 8 && lane == 0) { g_dbg[wave * 8] = TNOW() - t_start; g_dbg[wave * 8 + 1] = t_bar; }
 #endif
+        // the consumers' epilogue has one more workgroup barrier (tile through LDS): the producers arrive at it too before they leave,
+        // so that every wavefront of the workgroup executes the same number of barriers (no reliance on how the hardware treats
+        // wavefronts that have already ended)
+        if (!SPLIT && (N & 3) == 0) __syncthreads();
         return;
     }
     // ---- consumers ----
@@ -454,7 +458,7 @@ __global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const
     const float bv = (ACT >= 0 && bias && col < N) ? bias[col] : 0.0f;
     if (!SPLIT && (N & 3) == 0) {
         // The 64 x 64 tile leaves through LDS as dwordx4 stores (a wave instruction = 4 rows x 256 contiguous bytes) instead of 16 dword
-        // stores per lane of 128-byte pieces: the tail of these short kernels is bound by store ISSUE (the producers have exited; the
+        // stores per lane of 128-byte pieces: the tail of these short kernels is bound by store ISSUE (the producers have staged their last tile; the
         // K loop's last barrier lies behind every LDS read, so the staging buffers are free).  N % 4 == 0 keeps the rows 16-byte aligned.
         float* T = &S[0][0][0];                                     // [64][GTP]: 17 KB of the 36 KB
         constexpr int GTP = GT + 4;
@@ -464,7 +468,7 @@ __global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const
             if (ACT == 1) v = v > 0.0f ? v : expm1f(v);              // ELU, alpha = 1
             T[(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * GTP + wc * 32 + (lane & 31)] = live ? v : 0.0f;
         }
-        __syncthreads();                                            // the four consumer wavefronts (the producers are gone)
+        __syncthreads();                                            // all eight wavefronts (the producers arrive from their own exit path)
         const int t = threadIdx.x;                                  // 0 .. 255
 #pragma unroll
         for (int it = 0; it < 4; ++it) {

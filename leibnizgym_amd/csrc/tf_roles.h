@@ -295,12 +295,14 @@ DEV float norm_p3(const float a[3], const float b[3], int p) {
     const float ax = f_abs(a[0] - b[0]), ay = f_abs(a[1] - b[1]), az = f_abs(a[2] - b[2]);
     if (p == 1) return (ax + ay) + az;
     if (p == TF_NORM_INF) return f_max(f_max(ax, ay), az);
-    const float s = (ipow(ax, p) + ipow(ay, p)) + ipow(az, p);
-    if (!(s > 0.0f)) return 0.0f;
+    // the largest component is taken out first: d^p of a 4 mm distance underflows fp32 from p = 10 on
+    const float mx = f_max(f_max(ax, ay), az);
+    if (!(mx > 0.0f)) return 0.0f;
+    const float s = (ipow(ax / mx, p) + ipow(ay / mx, p)) + ipow(az / mx, p);      // in [1, 3]
     float y = tf_exp(tf_log(s) / (float)p);
     const float yp1 = ipow(y, p - 1);
     y = y - (yp1 * y - s) / ((float)p * yp1);
-    return y;
+    return mx * y;
 }
 
 // fingertip link state in the world frame: position, quaternion (xyzw), linear and angular velocity

@@ -276,6 +276,18 @@ void tf_model_set_box(TfModel* m, const float size[3], float density) {
     const double sx = size[0], sy = size[1], sz = size[2];
     const double mass = (double)density * sx * sy * sz;
     const double I[3] = {mass * (sy * sy + sz * sz) / 12.0, mass * (sx * sx + sz * sz) / 12.0, mass * (sx * sx + sy * sy) / 12.0};
+    {   /* the default cube (65 mm, 291.3 kg/m^3) asked for as a "box" stays the cube: box = 0, headline kernels, isotropic arithmetic */
+        TfModel d;
+        tf_default_model(&d);
+        if ((float)(0.5 * sx) == d.cube_half && (float)(0.5 * sy) == d.cube_half && (float)(0.5 * sz) == d.cube_half && fabs(mass - (double)d.cube_mass) <= 1e-6 * (double)d.cube_mass) {     /* size and density arrive as floats */
+            m->box = 0; m->box_gyroscopic = d.box_gyroscopic;
+            for (int i = 0; i < 3; ++i) { m->box_half[i] = d.box_half[i]; m->box_inertia[i] = d.box_inertia[i]; }
+            m->cube_half = d.cube_half; m->cube_mass = d.cube_mass; m->cube_inertia = d.cube_inertia;
+            m->obj_radius_3d = d.obj_radius_3d; m->obj_max_com_dist = d.obj_max_com_dist; m->obj_min_height = d.obj_min_height;
+            m->obj_span_min_height = d.obj_span_min_height; m->obj_span_radius = d.obj_span_radius;
+            return;
+        }
+    }
     m->box = 1;
     m->box_gyroscopic = 1;
     m->box_half[0] = (float)(0.5 * sx); m->box_half[1] = (float)(0.5 * sy); m->box_half[2] = (float)(0.5 * sz);

@@ -215,8 +215,11 @@ class TrifingerEngine:
         self.info = torch.zeros((capi.TF_NUM_INFO,), **f32)
         self.scratch = torch.zeros((int(lib.tf_scratch_floats(n)),), **f32)
         self._is_cuda = dev.type == "cuda"
+        self._dev_type = dev.type
+        self._dev_index = None
         if self._is_cuda:
             self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+            self.device = torch.device("cuda", self._dev_index)      # 'cuda' -> 'cuda:k': what tensors on it report
         self._handle = C.c_void_p()
         with self._on_device():          # the library allocates its parameter block on the CURRENT HIP device
             check(lib, lib.tf_create(C.byref(cfg), C.byref(self._handle)), "tf_create")
@@ -291,7 +294,8 @@ class TrifingerEngine:
 
     def step(self, action):
         """One fused control step.  `action`: contiguous float32 [N, A] tensor on the engine's device."""
-        if action.device != self.device:      # a host pointer handed to the kernel would fault the GPU
+        ad = action.device                    # a host pointer handed to the kernel would fault the GPU
+        if ad.type != self._dev_type or (self._is_cuda and ad.index != self._dev_index):
             raise ValueError(f"action tensor lives on {action.device}, the engine on {self.device}")
         if self._is_cuda and torch.cuda.current_device() != self._dev_index:
             with torch.cuda.device(self._dev_index):

@@ -15,8 +15,8 @@ best-so-far saving and a deterministic `play` mode mirror what the reference get
 This is host-side training glue, NOT part of the measured hot path.  On a GPU the minibatch step runs on the hand-written kernels of
 csrc/ppo_kernels.hip (leibnizgym_amd/ppo_kernels.py): one gather launch, the Linear / ELU layers on fp32 MFMA, the objective with all
 its gradients in one launch, the chunk sums of the weight gradients in one launch, truncation + Adam over one flat buffer - about 30
-launches per step, launched eagerly.  `use_graphs=True` replays the step as two HIP graphs instead (gather + forward + backward | clip +
-Adam; the gradient all-reduce sits between the two replays, outside the capture); it is off by default, see PPOConfig.use_graphs.
+launches per step, launched eagerly (a HIP-graph replay of the step existed in round 2; it was slower than eager launches and its
+learning curves were never explained, so it was removed in round 3 - DESIGN.md section 8).
 On the CPU (tests) and with `fused_kernels=False` the same step is plain torch.
 Data parallelism: every rank owns an env shard (leibnizgym_amd.sharding) and its own rollout; gradients are averaged
 with ONE all-reduce of a flat buffer per minibatch (`torch.distributed`, backend nccl = RCCL over xGMI on the GPU
@@ -60,9 +60,6 @@ class PPOConfig:
     max_epochs: int = 100000
     name: str = "trifinger"
     seed: int = 7
-    use_graphs: bool = False          # replay the minibatch step as two HIP graphs.  Off by default: with the hand-written kernels a step is
-                                      # ~30 launches and the host stays ahead of the GPU without graphs (3.9e6 vs 4.0e6 frames/s), while graph
-                                      # replay on this ROCm 7.2 stack was found unreliable twice
     fused_kernels: bool = True        # hand-written HIP kernel for the objective, forward and backward in one launch (GPU only)
 
     @classmethod
@@ -231,17 +228,14 @@ class PPOTrainer:
         # Two parameter groups = RL-Games' two optimisers: the actor's learning rate follows the KL schedule, the
         # central value network keeps central_value_config.lr; moments are per parameter, so nothing else is shared.
         fused = self.device.type == "cuda"
-        self.graphs = fused and c.use_graphs
         lr_v = c.lr_value if self.net.central else c.lr
-        mk = (lambda x: torch.tensor(x, device=self.device)) if self.graphs else (lambda x: x)   # capturable: lr on the device
-        groups = [{"params": self.net.actor_parameters(), "lr": mk(c.lr)},
-                  {"params": self.net.critic_parameters(), "lr": mk(lr_v)}]
-        kw = {"fused": True, "capturable": True} if self.graphs else ({"fused": True} if fused else {})
+        groups = [{"params": self.net.actor_parameters(), "lr": c.lr},
+                  {"params": self.net.critic_parameters(), "lr": lr_v}]
+        kw = {"fused": True} if fused else {}
         self.opt = torch.optim.Adam(groups, eps=1e-8, **kw)
         self.lr = c.lr
         self.fused_loss = fused and c.fused_kernels        # hand-written objective kernel (GPU only)
         self.net.actor.mfma = self.net.critic.mfma = bool(fused and c.fused_kernels)   # ... and the MFMA linear layers
-        self._g = None                         # captured minibatch step (built on the first update)
         self.dist_on = False
         rank = 0
         try:
@@ -276,8 +270,83 @@ class PPOTrainer:
         self.best_reward = -float("inf")
 
     # ---- checkpoints (what RL-Games' save / restore / `args.checkpoint` give the reference launcher) ----
+    def _optimizer_state(self):
+        """Adam state in ONE format whichever optimiser runs (the flat hand-written one on a GPU, torch's otherwise): first and
+        second moments per parameter NAME, the step counter, the two learning rates - so that a checkpoint written by one path
+        restores into the other (CPU <-> GPU, fused_kernels on <-> off)."""
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        m, v, step = {}, {}, 0.0
+        if self.flat_opt is not None:
+            fo = self.flat_opt
+            for p, o in zip(fo.params, fo.offsets):
+                m[names[id(p)]] = fo.m[o:o + p.numel()].view_as(p).clone()
+                v[names[id(p)]] = fo.v[o:o + p.numel()].view_as(p).clone()
+            step = float(fo.step_count.item())
+            lrs = [float(x) for x in fo.lr.tolist()]
+        else:
+            for g in self.opt.param_groups:
+                for p in g["params"]:
+                    st = self.opt.state.get(p, {})
+                    m[names[id(p)]] = st["exp_avg"].detach().clone() if "exp_avg" in st else torch.zeros_like(p)
+                    v[names[id(p)]] = st["exp_avg_sq"].detach().clone() if "exp_avg_sq" in st else torch.zeros_like(p)
+                    step = max(step, float(st["step"]) if "step" in st else 0.0)
+            lrs = [float(g["lr"]) for g in self.opt.param_groups]
+        return {"kind": "adam_per_parameter", "exp_avg": m, "exp_avg_sq": v, "step": step, "lrs": lrs}
+
+    def _load_optimizer_state(self, sd, lr):
+        """inverse of `_optimizer_state`; also reads the two formats round-2 checkpoints hold (the flat buffers of FlatClipAdam with
+        their 16-byte padding per parameter, torch.optim.Adam's own state dict)"""
+        named = dict(self.net.named_parameters())
+        kind = sd.get("kind")
+        if kind == "adam_per_parameter":
+            m, v, step, lrs = sd["exp_avg"], sd["exp_avg_sq"], float(sd["step"]), list(sd.get("lrs", []))
+        elif kind == "flat_clip_adam":                               # round 2, GPU path: parameters padded to 4 floats each
+            order = self.net.actor_parameters() + self.net.critic_parameters() if self.net.central else list(self.net.parameters())
+            names = {id(p): n for n, p in named.items()}
+            m, v, off = {}, {}, 0
+            for p in order:
+                m[names[id(p)]] = sd["m"][off:off + p.numel()].view_as(p)
+                v[names[id(p)]] = sd["v"][off:off + p.numel()].view_as(p)
+                off += (p.numel() + 3) & ~3
+            if off != sd["m"].numel():
+                raise ValueError("optimizer state of another network size")
+            step, lrs = float(sd["step"].item()), [float(x) for x in sd["lr"].tolist()]
+        else:                                                        # torch.optim.Adam.state_dict(): moments per parameter index
+            order = [p for g in self.opt.param_groups for p in g["params"]]
+            names = {id(p): n for n, p in named.items()}
+            st = sd["state"]
+            m = {names[id(p)]: st[i]["exp_avg"] for i, p in enumerate(order) if i in st}
+            v = {names[id(p)]: st[i]["exp_avg_sq"] for i, p in enumerate(order) if i in st}
+            step = max([float(x["step"]) for x in st.values()] or [0.0])
+            lrs = [float(g["lr"]) for g in sd["param_groups"]]
+        lr_actor = float(lr) if lr is not None else (lrs[0] if lrs else self.lr)
+        lr_value = lrs[1] if len(lrs) > 1 else None
+        if self.flat_opt is not None:
+            fo = self.flat_opt
+            names = {id(p): n for n, p in named.items()}
+            fo.m.zero_(); fo.v.zero_()
+            for p, o in zip(fo.params, fo.offsets):                  # every moment into its own (padded) slot
+                n = names[id(p)]
+                if n in m:
+                    fo.m[o:o + p.numel()].copy_(m[n].reshape(-1).to(fo.m.device))
+                    fo.v[o:o + p.numel()].copy_(v[n].reshape(-1).to(fo.v.device))
+            fo.step_count.fill_(step)
+            fo.set_lr(0, lr_actor)
+            if lr_value is not None:
+                fo.set_lr(1, lr_value if self.net.central else lr_actor)
+        else:
+            fused = self.device.type == "cuda"
+            for gi, g in enumerate(self.opt.param_groups):
+                for p in g["params"]:
+                    n = next(k for k, q in named.items() if q is p)
+                    self.opt.state[p] = {
+                        "step": torch.tensor(step, dtype=torch.float32, device=p.device if fused else "cpu"),
+                        "exp_avg": (m[n].to(p.device).clone().view_as(p) if n in m else torch.zeros_like(p)),
+                        "exp_avg_sq": (v[n].to(p.device).clone().view_as(p) if n in v else torch.zeros_like(p))}
+                g["lr"] = lr_actor if (gi == 0 or not self.net.central) else (lr_value if lr_value is not None else g["lr"])
+
     def state_dict(self):
-        return {"model": self.net.state_dict(), "optimizer": (self.flat_opt or self.opt).state_dict(), "lr": self.lr, "frames": self.frames,
+        return {"model": self.net.state_dict(), "optimizer": self._optimizer_state(), "lr": self.lr, "frames": self.frames,
                 "epoch": self.epoch, "best_reward": self.best_reward, "config": dict(self.cfg.__dict__)}
 
     def save(self, path: str):
@@ -288,34 +357,20 @@ class PPOTrainer:
 
     def restore(self, path: str):
         ck = torch.load(path, map_location=self.device, weights_only=False)
+        if "optimizer" in ck:                                        # validate before anything is overwritten
+            sd = ck["optimizer"]
+            if sd.get("kind") == "flat_clip_adam":
+                order = self.net.actor_parameters() + self.net.critic_parameters() if self.net.central else list(self.net.parameters())
+                if sum((p.numel() + 3) & ~3 for p in order) != sd["m"].numel():
+                    raise ValueError("checkpoint optimizer state belongs to a network of another size")
         with torch.no_grad():                                        # in place: the parameters may be views of a flat buffer
             for k, v in self.net.state_dict().items():
                 v.copy_(ck["model"][k])
-        if "optimizer" in ck and self.flat_opt is not None:
-            if ck["optimizer"].get("kind") == "flat_clip_adam":
-                self.flat_opt.load_state_dict(ck["optimizer"])
-            else:                                                    # a checkpoint of the torch optimiser: moments per parameter
-                st = ck["optimizer"]["state"]
-                for name, buf in (("exp_avg", self.flat_opt.m), ("exp_avg_sq", self.flat_opt.v)):
-                    buf.copy_(torch.cat([st[i][name].reshape(-1).to(buf.device) for i in range(len(self.flat_opt.params))]))
-                self.flat_opt.step_count.fill_(float(st[0]["step"]))
-            self.flat_opt.set_lr(0, float(ck.get("lr", self.lr)))
-        elif "optimizer" in ck and ck["optimizer"].get("kind") == "flat_clip_adam":
-            pass                                                     # flat moments into the torch optimiser: weights only
-        elif "optimizer" in ck:
-            lrs = [g["lr"] for g in self.opt.param_groups]           # keep this trainer's lr objects (device tensors when graphed)
-            self.opt.load_state_dict(ck["optimizer"])
-            for g, lr0 in zip(self.opt.param_groups, lrs):
-                new = g["lr"]
-                if torch.is_tensor(lr0):
-                    lr0.fill_(float(new))
-                    g["lr"] = lr0
-                else:
-                    g["lr"] = float(new)
+            if "optimizer" in ck:
+                self._load_optimizer_state(ck["optimizer"], ck.get("lr"))
         self.lr = float(ck.get("lr", self.lr))
         self.frames, self.epoch = int(ck.get("frames", 0)), int(ck.get("epoch", 0))
         self.best_reward = float(ck.get("best_reward", -float("inf")))
-        self._g = None                                               # graphs hold the old optimiser state tensors
         return ck
 
     @torch.no_grad()
@@ -417,7 +472,7 @@ class PPOTrainer:
         """the same step on the hand-written kernels: one gather launch for the seven minibatch arrays, the MFMA layers, the objective
         and its gradients in ONE launch (ppo_kernels.ppo_loss_and_grads), the backward pass started at the network outputs with those
         gradients (no loss node), the chunk sums of all weight gradients in one launch.  Every parameter gradient lands in its slot of
-        the flat gradient buffer directly (the log-std gradient too), so that the optimiser's graph reads nothing but that buffer; the
+        the flat gradient buffer directly (the log-std gradient too), so that the optimiser reads nothing but that buffer; the
         statistics accumulate on the device in `acc["_fused"]` = (loss, a_loss, c_loss, kl)"""
         from . import ppo_kernels as pk
         c = self.cfg
@@ -438,9 +493,12 @@ class PPOTrainer:
             v_coef = 1.0 if self.net.central else 0.5 * c.critic_coef
             _, d_mu, d_v, _ = pk.ppo_loss_and_grads(mu, self.net.log_std, v, act, old_nlp, adv, ret, old_mu, acc["_fused"], c.e_clip, v_coef,
                                                     c.entropy_coef, c.bounds_loss_coef, d_ls_out=self.flat_opt.grad_view(self.net.log_std))
-            pk.mlp_backward(obs, ya, d_mu, la)
-            pk.mlp_backward(xc, yc, d_v.unsqueeze(-1), lc)
-            pk.flush_partial_sums()
+            try:
+                pk.mlp_backward(obs, ya, d_mu, la)
+                pk.mlp_backward(xc, yc, d_v.unsqueeze(-1), lc)
+                pk.flush_partial_sums()
+            finally:
+                pk.discard_partial_sums()                  # nothing stale survives a launch that raised
 
     @staticmethod
     def _new_acc(dev):
@@ -478,52 +536,6 @@ class PPOTrainer:
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         flat /= self.dist.get_world_size(self.group)
 
-    def _capture(self, d, mb, acc):
-        """Capture the minibatch step once: graph A = gather + forward + backward (+ flat gradient buffer when the ranks
-        exchange gradients), graph B = (unflatten +) clip + Adam.  Static inputs: the flat rollout buffers `d`, the index
-        tensor, the statistics accumulators."""
-        dev = self.device
-        idx = torch.zeros(mb, dtype=torch.long, device=dev)
-        nflat = sum(p.numel() for p in self.net.parameters())
-        flat = self.flat_opt.flat_g if self.flat_opt is not None else torch.zeros(nflat, device=dev)   # what the ranks exchange
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        state = {k: v.detach().clone() for k, v in self.net.state_dict().items()}
-        # optimiser moments restored from a checkpoint must survive the warm-up; a fresh optimiser has none yet
-        snap = {p: {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.opt.state.items()}
-        fsnap = self.flat_opt.snapshot() if self.flat_opt is not None else None
-        with torch.cuda.stream(side):          # warm-up off the capture (allocator, lazy optimizer state), then undone
-            for _ in range(3):
-                self._mb_backward(d, idx, acc)
-                if self.dist_on:
-                    self._flatten_grads(out=flat)
-                    self._unflatten_grads(flat)
-                self._mb_apply(gathered=self.dist_on)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self.net.load_state_dict(state)
-        if fsnap is not None:
-            self.flat_opt.restore_snapshot(fsnap)
-        for p, st in self.opt.state.items():   # the warm-up steps must not count: moments and step counter as before
-            for k, v in st.items():
-                if torch.is_tensor(v):
-                    if p in snap and k in snap[p]:
-                        v.copy_(snap[p][k])
-                    else:
-                        v.zero_()
-        for v in acc.values():
-            v.zero_()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            self._mb_backward(d, idx, acc)
-            if self.dist_on:
-                self._flatten_grads(out=flat)
-        with torch.cuda.graph(gb, pool=ga.pool()):
-            if self.dist_on:
-                self._unflatten_grads(flat)
-            self._mb_apply(gathered=self.dist_on)
-        # the two captures above executed nothing; parameters and accumulators are untouched
-        self._g = dict(a=ga, b=gb, idx=idx, flat=flat, d=d, acc=acc, mb=mb, side=side)
-
     def update(self, buf):
         c = self.cfg
         T, n = buf["nlp"].shape
@@ -536,18 +548,8 @@ class PPOTrainer:
         total = T * n
         mb = max(1, total // c.minibatches)
         dev = src["obs"].device
-        if self.graphs:
-            if self._g is None or self._g["mb"] != mb or self._g["d"]["obs"].shape != src["obs"].shape:
-                d = {k: (v.clone() if v is not None else None) for k, v in src.items()}
-                acc = self._new_acc(dev)
-                self._capture(d, mb, acc)
-            d, acc = self._g["d"], self._g["acc"]
-            for k, v in src.items():           # the graphs read the rollout from fixed addresses
-                if v is not None:
-                    d[k].copy_(v)
-        else:
-            d = src
-            acc = self._new_acc(dev)
+        d = src
+        acc = self._new_acc(dev)
         for v in acc.values():
             v.zero_()
         stats = {"kl": 0.0}
@@ -557,30 +559,12 @@ class PPOTrainer:
             acc["kl"].zero_()
             nmb = 0
             for s in range(0, total - mb + 1, mb):
-                if self.graphs:
-                    g = self._g
-                    g["idx"].copy_(perm[s:s + mb])
-                    g["a"].replay()
-                    if self.dist_on:
-                        self._exchange(g["flat"])
-                    g["b"].replay()
-                    # Both graphs consist of KERNEL nodes only.  With hipMemsetAsync / small device-to-device copies captured as memset /
-                    # memcpy nodes (the zeroing of the 40-byte gradient buffer of the objective kernel, of the two squared norms, the
-                    # copy of the log-std gradient into the flat buffer) the replayed update went wrong on this ROCm 7.2 stack, from run
-                    # to run differently: pointer-like garbage appeared in the 40-byte tensor between the graph that wrote it and the
-                    # graph that read it, the gradient norm became inf, the actor froze and the adaptive learning rate ran to its
-                    # ceiling.  Round 2 first met it as "more than 16 graph launches queued" and drained the stream every 8 steps, which
-                    # only moved the odds; with kernel-only graphs 25 of 25 runs are exact with and without the drain.  The drain stays
-                    # as a cheap bound on the host's run-ahead (no measurable cost).
-                    if nmb % 8 == 7:
-                        torch.cuda.current_stream(dev).synchronize()
-                else:
-                    self._mb_backward(d, perm[s:s + mb], acc)
-                    if self.dist_on:
-                        fl = self._flatten_grads()
-                        self._exchange(fl)
-                        self._unflatten_grads(fl)
-                    self._mb_apply(gathered=self.dist_on)
+                self._mb_backward(d, perm[s:s + mb], acc)
+                if self.dist_on:
+                    fl = self._flatten_grads()
+                    self._exchange(fl)
+                    self._unflatten_grads(fl)
+                self._mb_apply(gathered=self.dist_on)
                 nmb += 1
             count += nmb
             kl = acc["kl"] / max(nmb, 1)
@@ -598,10 +582,7 @@ class PPOTrainer:
                 if not self.net.central:
                     self.flat_opt.set_lr(1, self.lr)
             for g in (self.opt.param_groups[:1] if self.net.central else self.opt.param_groups):
-                if torch.is_tensor(g["lr"]):
-                    g["lr"].fill_(self.lr)
-                else:
-                    g["lr"] = self.lr
+                g["lr"] = self.lr
         for k in ("loss", "a_loss", "c_loss"):
             stats[k] = float(acc[k]) / max(count, 1)
         stats["lr"] = self.lr

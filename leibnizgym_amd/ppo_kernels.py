@@ -1,8 +1,7 @@
 """ctypes binding and autograd wrapper of the trainer's hand-written HIP kernel (leibnizgym_amd/csrc/ppo_kernels.hip).
 
 `fused_ppo_loss` evaluates the whole PPO objective and its gradients in ONE launch (the eager form is ~60 elementwise and
-reduction launches forwards and backwards).  It launches on torch's current stream, so it is captured into the trainer's HIP
-graphs like any other kernel.  GPU only: the CPU tests of the trainer run its plain-torch form, which is also the fp32
+reduction launches forwards and backwards).  It launches on torch's current stream.  GPU only: the CPU tests of the trainer run its plain-torch form, which is also the fp32
 reference the GPU tests compare the kernel with (tests/test_ppo_kernels.py).
 
 Tried and dropped (measured on MI355X, batch 8192): a fused ELU-derivative + bias-gradient backward kernel - the column sums
@@ -17,8 +16,6 @@ _F = C.POINTER(C.c_float)
 
 
 def library_path():
-    if os.environ.get("TFP_HIP_LIB"):                     # developer override (kernel experiments); never set by the package
-        return os.environ["TFP_HIP_LIB"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_ppo.so")
 
 
@@ -108,7 +105,7 @@ class FlatClipAdam:
     (csrc/ppo_kernels.hip: tfp_clip_adam) instead of torch's multi-tensor clip + two fused-Adam launches (~110 us for the 32
     small tensors of the two MLPs).  Same arithmetic as `torch.nn.utils.clip_grad_norm_` per group followed by `torch.optim.Adam`
     (no weight decay, no amsgrad).  The parameters are re-pointed to views of the flat buffer (their values are kept); learning
-    rates and the step counter live on the device, so a step is capturable into a HIP graph."""
+    rates and the step counter live on the device (no host value enters a launch)."""
 
     def __init__(self, group0, group1, lr0, lr1, max_norm0, max_norm1, betas=(0.9, 0.999), eps=1e-8):
         params = list(group0) + list(group1)
@@ -200,6 +197,12 @@ def gemm_nn(a, b, y=None):
 
 
 _PENDING_SUMS = []        # (part, gw, gb, splits, N1, N2) of the layers whose chunk products wait for flush_partial_sums()
+
+
+def discard_partial_sums():
+    """drop whatever is still queued (a launch raised between `mlp_backward` and `flush_partial_sums`)"""
+    global _PENDING_SUMS
+    _PENDING_SUMS = []
 
 
 def flush_partial_sums():

@@ -414,6 +414,18 @@ void tf_model_set_box(TfModel* m, const float size[3], float density) {
     const double sx = size[0], sy = size[1], sz = size[2];
     const double mass = (double)density * sx * sy * sz;
     const double I[3] = {mass * (sy * sy + sz * sz) / 12.0, mass * (sx * sx + sz * sz) / 12.0, mass * (sx * sx + sy * sy) / 12.0};
+    {   /* the default cube (65 mm, 291.3 kg/m^3) asked for as a "box" stays the cube: box = 0, headline kernels, isotropic arithmetic */
+        TfModel d;
+        tf_default_model(&d);
+        if ((float)(0.5 * sx) == d.cube_half && (float)(0.5 * sy) == d.cube_half && (float)(0.5 * sz) == d.cube_half && fabs(mass - (double)d.cube_mass) <= 1e-6 * (double)d.cube_mass) {     /* size and density arrive as floats */
+            m->box = 0; m->box_gyroscopic = d.box_gyroscopic;
+            for (int i = 0; i < 3; ++i) { m->box_half[i] = d.box_half[i]; m->box_inertia[i] = d.box_inertia[i]; }
+            m->cube_half = d.cube_half; m->cube_mass = d.cube_mass; m->cube_inertia = d.cube_inertia;
+            m->obj_radius_3d = d.obj_radius_3d; m->obj_max_com_dist = d.obj_max_com_dist; m->obj_min_height = d.obj_min_height;
+            m->obj_span_min_height = d.obj_span_min_height; m->obj_span_radius = d.obj_span_radius;
+            return;
+        }
+    }
     m->box = 1;
     m->box_gyroscopic = 1;
     m->box_half[0] = (float)(0.5 * sx); m->box_half[1] = (float)(0.5 * sy); m->box_half[2] = (float)(0.5 * sz);
@@ -1883,12 +1895,14 @@ static float norm_p3(const float a[3], const float b[3], int p) {
     const float ax = f_abs(a[0] - b[0]), ay = f_abs(a[1] - b[1]), az = f_abs(a[2] - b[2]);
     if (p == 1) return (ax + ay) + az;
     if (p == TF_NORM_INF) return f_max(f_max(ax, ay), az);
-    const float s = (ipow(ax, p) + ipow(ay, p)) + ipow(az, p);
-    if (!(s > 0.0f)) return 0.0f;
+    /* the largest component is taken out first: d^p of a 4 mm distance underflows fp32 from p = 10 on */
+    const float mx = f_max(f_max(ax, ay), az);
+    if (!(mx > 0.0f)) return 0.0f;
+    const float s = (ipow(ax / mx, p) + ipow(ay / mx, p)) + ipow(az / mx, p);      /* in [1, 3] */
     float y = tf_exp(tf_log(s) / (float)p);
     const float yp1 = ipow(y, p - 1);
     y = y - (yp1 * y - s) / ((float)p * yp1);
-    return y;
+    return mx * y;
 }
 
 /* fingertip link state in the world frame: position, quaternion (xyzw), linear and angular velocity */

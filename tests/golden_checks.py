@@ -281,6 +281,39 @@ def check_finger_rewards(lib, device):
             eng.close()
 
 
+def check_finger_reach_small_distances(lib, device):
+    """FingerReachObjectRatePenalty with a large p when the fingertips are millimetres from the object centre (rewards.py:203-235:
+    torch.norm(d, p)): d^p of a 2-4 mm distance underflows fp32 from p = 10 on, so the p-norm is formed on d / max|d|.  Reference
+    value: the same expression in float64."""
+    g = golden("finger_rewards")
+    n = g["q"].shape[0]
+    rng = np.random.default_rng(5)
+    for p in (3, 10, 16):
+        terms = {name: {"activate": False} for name in capi.REWARD_TERM_ORDER}
+        terms["finger_reach_object_rate"] = {"activate": True, "weight": -750.0, "norm_p": float(p)}
+        cfg = make_config(lib, n, command_mode="torque", reward_terms=terms, dt=0.02, success={"activate": False})
+        eng = TrifingerEngine(cfg, device=device, lib=lib)
+        eng.q.copy_(T(g["q_prev"].T, device))
+        eng.post_step()
+        eng.q.copy_(T(g["q"].T, device))
+        # the object centre 1-4 mm from fingertip 0 in both frames (a physically impossible pose: the reward arithmetic alone is tested)
+        off_prev = rng.uniform(-1.0, 1.0, (n, 3)) * 0.002 + 0.001
+        off_now = rng.uniform(-1.0, 1.0, (n, 3)) * 0.003 + 0.0005
+        obj_prev = (g["tips_prev"][:, 0, :] + off_prev).astype(np.float32)
+        obj_now = (g["tips"][:, 0, :] + off_now).astype(np.float32)
+        eng.view(capi.S_CUBE_P, 3).copy_(T(obj_now.T, device))
+        eng.view(capi.S_PREV_OBJ_P, 3).copy_(T(obj_prev.T, device))
+        eng.post_step()
+        sync(device)
+        tips, tips_prev = g["tips"].astype(np.float64), g["tips_prev"].astype(np.float64)
+        norm = lambda d: (np.abs(d) ** p).sum(-1) ** (1.0 / p)      # noqa: E731
+        want = -750.0 * sum(norm(tips[:, f] - obj_now.astype(np.float64)) - norm(tips_prev[:, f] - obj_prev.astype(np.float64)) for f in range(3))
+        d0 = norm(tips[:, 0] - obj_now.astype(np.float64))
+        assert d0.min() < 0.004 and (np.abs(tips[:, 0] - obj_now) ** p).sum(-1).min() < (1e-38 if p >= 16 else 1.0)
+        close(eng.reward.cpu().numpy(), want, atol=3e-4, rtol=2e-5, what=f"reach term at mm distances, norm_p={p}")
+        eng.close()
+
+
 def check_termination(lib, device):
     """T8: flags, counts, bonus, successes for difficulty {1,4,5} x activate {T,F}."""
     g = golden("termination")

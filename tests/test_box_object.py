@@ -52,6 +52,16 @@ def test_box_model_numbers(oracle):
     assert d.obj_min_height == np.float32(0.0325) and d.obj_span_radius == np.float32(0.04370835)
 
 
+def test_default_cube_asked_for_as_a_box_stays_the_cube(oracle):
+    """include/trifinger.h: "a cubic size keeps box = 0 when it equals the default cube" - `native.object_size = [0.065] * 3`
+    must not push an env onto the EXT kernels and the inertia-scaled arithmetic."""
+    import ctypes
+    d, m = oracle.default_model(), oracle.box_model((0.065, 0.065, 0.065), 291.3)
+    assert m.box == 0 and bytes(ctypes.string_at(ctypes.byref(m), ctypes.sizeof(m))) == bytes(ctypes.string_at(ctypes.byref(d), ctypes.sizeof(d)))
+    assert oracle.box_model((0.065, 0.065, 0.065), 500.0).box == 1          # another density is another object
+    assert oracle.box_model((0.065, 0.065, 0.0651), 291.3).box == 1
+
+
 def _rest(lib, device):
     """the box lying on each kind of face stays where it is, at the height of that half extent"""
     for up_axis, quat in ((2, (0, 0, 0, 1)), (1, (np.sin(np.pi / 4), 0, 0, np.cos(np.pi / 4))),

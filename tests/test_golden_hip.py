@@ -37,6 +37,10 @@ def test_finger_rewards(hip):
     gc.check_finger_rewards(hip, DEV)
 
 
+def test_finger_reach_small_distances(hip):
+    gc.check_finger_reach_small_distances(hip, DEV)
+
+
 def test_termination(hip):
     gc.check_termination(hip, DEV)
 

@@ -31,6 +31,10 @@ def test_finger_rewards(oracle):
     gc.check_finger_rewards(oracle, "cpu")
 
 
+def test_finger_reach_small_distances(oracle):
+    gc.check_finger_reach_small_distances(oracle, "cpu")
+
+
 def test_termination(oracle):
     gc.check_termination(oracle, "cpu")
 

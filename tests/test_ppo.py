@@ -81,16 +81,15 @@ def test_data_parallel_ranks_stay_in_sync(tmp_path):
 
 
 @pytest.mark.gpu
-def test_graph_captured_update_matches_eager(hip):
-    """The HIP-graph minibatch step (one-rank form and the split form used around the gradient all-reduce) takes the
-    same optimisation steps as the eager code."""
-    def run(use_graphs, split):
+def test_split_update_matches_unsplit(hip):
+    """The minibatch step split at the gradient exchange (flat gradient buffer -> all-reduce -> optimiser; what every rank of a
+    data-parallel run executes) takes the same optimisation steps as the one-rank form."""
+    def run(split):
         cfg = gym_config("trifinger_difficulty_4")
         cfg.update(num_instances=256, seed=1, physics_engine="physx", asymmetric_obs=True, episode_length=20)
         env = TrifingerEnv(config=cfg, device="cuda:0", verbose=False)
         ad = RlGamesGpuEnvAdapter("rlgpu", 256, env=VecTaskPython(env, rl_device="cuda:0"))
-        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2, use_graphs=use_graphs),
-                        device="cuda:0")
+        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2), device="cuda:0")
         if split:                                     # one rank: the average of one gradient is itself
             from types import SimpleNamespace
             tr.dist_on = True
@@ -99,13 +98,43 @@ def test_graph_captured_update_matches_eager(hip):
         torch.manual_seed(11)
         stats = tr.train(2)
         return [p.detach().clone() for p in tr.net.parameters()], stats
-    eager, s0 = run(False, False)
-    graph, s1 = run(True, False)
-    split, s2 = run(True, True)
-    for a, b, c in zip(eager, graph, split):
-        assert torch.allclose(a, b, atol=2e-5, rtol=1e-4) and torch.allclose(a, c, atol=2e-5, rtol=1e-4)
-    assert abs(s0[-1]["loss"] - s1[-1]["loss"]) < 1e-3 * max(1.0, abs(s0[-1]["loss"]))
+    eager, s0 = run(False)
+    split, s2 = run(True)
+    for a, c in zip(eager, split):
+        assert torch.allclose(a, c, atol=2e-5, rtol=1e-4)
     assert abs(s0[-1]["kl"] - s2[-1]["kl"]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("writer,reader", [(False, True), (True, False), (True, True)])
+def test_checkpoint_restores_across_optimiser_paths(hip, tmp_path, writer, reader):
+    """A checkpoint written by the torch optimiser (fused_kernels=False, the CPU form) restores into the flat hand-written
+    optimiser of the GPU path and the reverse: moments per parameter, step counter and learning rates arrive, and the next
+    update is the one the writer itself would have taken."""
+    def make(fused):
+        cfg = gym_config("trifinger_difficulty_4")
+        cfg.update(num_instances=256, seed=1, physics_engine="physx", asymmetric_obs=True, episode_length=20)
+        env = TrifingerEnv(config=cfg, device="cuda:0", verbose=False)
+        ad = RlGamesGpuEnvAdapter("rlgpu", 256, env=VecTaskPython(env, rl_device="cuda:0"))
+        return PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2, fused_kernels=fused), device="cuda:0")
+    a = make(writer)
+    a.train(2)
+    path = a.save(os.path.join(tmp_path, "ck.pth"))
+    b = make(reader)
+    b.restore(path)
+    sa, sb = a._optimizer_state(), b._optimizer_state()
+    assert sa["step"] == sb["step"] > 0 and sa["lrs"] == pytest.approx(sb["lrs"])
+    for k in sa["exp_avg"]:
+        assert torch.equal(sa["exp_avg"][k], sb["exp_avg"][k]) and torch.equal(sa["exp_avg_sq"][k], sb["exp_avg_sq"][k]), k
+    assert float(sa["exp_avg_sq"]["log_std"].abs().sum()) > 0.0
+    for (ka, pa), (kb, pb) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+        assert torch.equal(pa, pb), ka
+    # the same minibatch through both trainers: same parameters afterwards (two implementations of clip + Adam: tolerance)
+    buf = a.rollout()
+    torch.manual_seed(5); a.update(buf)
+    torch.manual_seed(5); b.update(buf)
+    for pa, pb in zip(a.net.state_dict().values(), b.net.state_dict().values()):
+        assert torch.allclose(pa, pb, atol=3e-5, rtol=1e-4)
 
 
 def test_split_k_linear_matches_linear():
@@ -127,39 +156,3 @@ def test_split_k_linear_matches_linear():
     x2 = torch.randn(100, 41, requires_grad=True)
     _SplitKLinear.apply(x2, w, b).sum().backward()
     assert x2.grad.shape == (100, 41)
-
-
-@pytest.mark.gpu
-def test_graph_mode_stays_exact_over_many_queued_steps(hip):
-    """BASELINE configs[4] shape (8192 envs, 32 minibatches x 4 mini-epochs of the full asymm.yaml settings), five epochs: the
-    graph-replayed update follows the eager one.  Regression test of the run-ahead hazard documented in PPOTrainer.update -
-    with a whole mini-epoch of graph launches queued behind one another the gradients went to zero / garbage from the fourth
-    epoch on and the adaptive learning rate ran away."""
-    from leibnizgym_amd.config import compose
-
-    def run(use_graphs):
-        cfg = compose(["gym=trifinger_difficulty_4", "args.num_envs=8192", "args.headless=True"])
-        env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False)
-        ad = RlGamesGpuEnvAdapter("rlgpu", 8192, env=VecTaskPython(env, rl_device="cuda:0"))
-        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig.from_rlg(cfg["rlg"], num_envs=8192, use_graphs=use_graphs), device="cuda:0")
-        st = tr.train(5)
-        env.close()
-        return st
-    eager, graph = run(False), run(True)
-    for a, b in zip(eager, graph):
-        assert a["lr"] == b["lr"], (a["lr"], b["lr"])
-        assert abs(a["kl"] - b["kl"]) < 0.1 * a["kl"] and abs(a["c_loss"] - b["c_loss"]) < 0.05 * a["c_loss"] + 1e-4, (a, b)
-    assert 0.004 < graph[-1]["kl"] < 0.02
-
-
-@pytest.mark.gpu
-def test_graph_mode_stays_exact_in_a_fresh_process(hip):
-    """The same comparison as the first thing a process does on the GPU, twice: with memset / memcpy nodes in the trainer's graphs this
-    order (an eager trainer, then the graph-replaying one) went wrong in two of three processes while it passed inside the test-suite,
-    where earlier tests had used the GPU (tests/ppo_graph_check.py)."""
-    import subprocess
-    import sys
-    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ppo_graph_check.py")
-    for _ in range(2):
-        r = subprocess.run([sys.executable, script, "5"], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "graph == eager" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

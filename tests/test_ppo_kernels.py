@@ -77,7 +77,7 @@ def test_trainer_with_and_without_the_kernels(hip):
         cfg.update(num_instances=256, seed=1, physics_engine="physx", asymmetric_obs=True, episode_length=20)
         env = TrifingerEnv(config=cfg, device="cuda:0", verbose=False)
         ad = RlGamesGpuEnvAdapter("rlgpu", 256, env=VecTaskPython(env, rl_device="cuda:0"))
-        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2, use_graphs=False, fused_kernels=fused),
+        tr = PPOTrainer(ad, 41, 113, 9, PPOConfig(horizon=8, minibatches=4, mini_epochs=2, fused_kernels=fused),
                         device="cuda:0")
         torch.manual_seed(11)
         stats = tr.train(2)

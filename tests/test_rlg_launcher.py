@@ -144,7 +144,9 @@ def test_native_runner_trains_checkpoints_resumes_and_plays(oracle, tmp_path, mo
     # resume: the checkpoint reproduces the policy (same deterministic actions) and carries the counters and the moments
     ck = os.path.join(run_dir, "nn", "trifinger.pth")
     saved = torch.load(ck, weights_only=False)
-    assert saved["epoch"] == 2 and saved["frames"] == 2 * 4 * 16 and len(saved["optimizer"]["state"]) > 0
+    opt = saved["optimizer"]                               # one format whichever optimiser wrote it: moments per parameter name
+    assert saved["epoch"] == 2 and saved["frames"] == 2 * 4 * 16 and opt["kind"] == "adam_per_parameter" and opt["step"] > 0
+    assert set(opt["exp_avg"]) == set(saved["model"]) and float(opt["exp_avg_sq"]["log_std"].sum()) > 0
     rlg_train.configure(small_cfg(tmp_path)["gym"], small_cfg(tmp_path)["args"], None, None, lib=oracle, sim_device="cpu")
     vec = rlg_train.create_rlgpu_env()
     ad = rlg_train.RlGamesGpuEnvAdapter("rlgpu", 16, env=vec)
@@ -158,6 +160,8 @@ def test_native_runner_trains_checkpoints_resumes_and_plays(oracle, tmp_path, mo
     ref = ActorCritic(41, 113, 9, [400, 200, 100])
     ref.load_state_dict(want)
     assert torch.equal(ref.dist(obs)[0], fresh.act(obs))
+    got = fresh._optimizer_state()                         # the moments and the step counter arrived
+    assert got["step"] == opt["step"] and all(torch.equal(got["exp_avg"][k], opt["exp_avg"][k]) for k in opt["exp_avg"])
     st = fresh.train(1)                                    # training continues from the restored moments
     assert st[0]["epoch"] == 2 and math.isfinite(st[0]["loss"])
     # play through the launcher: args.play + args.checkpoint (scripts/rlg_hydra.py:275-276)

@@ -1,10 +1,11 @@
 """Developer tool (GPU box): start / end wall time of every workgroup of one forward GEMM (needs a -DGEMM_TIMING build of
 csrc/ppo_kernels.hip:  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DGEMM_TIMING -shared -o /tmp/ppo_timing.so ppo_kernels.hip;
-TFP_HIP_LIB=/tmp/ppo_timing.so python tools/gemm_wg_timing.py)"""
+python tools/gemm_wg_timing.py /tmp/ppo_timing.so)"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from leibnizgym_amd import ppo_kernels as pk
+if len(sys.argv) > 1: pk.library_path = lambda: sys.argv[1]
 dev="cuda:0"
 M,K,N=8192,400,200
 x=torch.randn(M,K,device=dev); w=torch.randn(N,K,device=dev); b=torch.randn(N,device=dev)

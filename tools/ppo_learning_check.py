@@ -1,6 +1,7 @@
-"""Developer tool (GPU box): train the in-repo PPO on difficulty 1 (cube to a goal position on the table) and then roll the
-deterministic policy, reporting what the cube physically does - distance to the goal, speeds, heights - so that a learning
-curve cannot hide an exploit of the contact model.   python tools/ppo_learning_check.py [epochs] [num_envs] [seed] [fused|plain] [graphs|nographs]"""
+"""Developer tool (GPU box): train the in-repo PPO on difficulty 1 (cube to a goal position on the table; default) or any other
+difficulty (4 = the headline task: lift to a 6-DoF pose goal) and then roll the policy, reporting what the cube physically does -
+distance to the goal, speeds, heights, fraction of cubes lifted, goal counts - so that a learning curve cannot hide an exploit of
+the contact model.   python tools/ppo_learning_check.py [epochs] [num_envs] [seed] [fused|plain] [difficulty]"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -16,16 +17,20 @@ epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 fused = (sys.argv[4] != "plain") if len(sys.argv) > 4 else True
-graphs = (sys.argv[5] == "graphs") if len(sys.argv) > 5 else False
-cfg = compose(["gym=trifinger_difficulty_1", f"args.num_envs={n}", "args.headless=True"])
+difficulty = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+cfg = compose([f"gym=trifinger_difficulty_{difficulty}", f"args.num_envs={n}", "args.headless=True"])
 env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False)
 tr = PPOTrainer(RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device="cuda:0")), env.get_obs_dim(), env.get_state_dim(),
-                env.get_action_dim(), PPOConfig.from_rlg(cfg["rlg"], num_envs=n, seed=seed, fused_kernels=fused, use_graphs=graphs), device="cuda:0")
+                env.get_action_dim(), PPOConfig.from_rlg(cfg["rlg"], num_envs=n, seed=seed, fused_kernels=fused), device="cuda:0")
 t0 = time.perf_counter()
 for st in tr.train(epochs):
-    if st["epoch"] % 10 == 9:
+    if st["epoch"] % (10 if epochs <= 300 else 50) == 9:
+        s_ = env._engine.state
+        lifted = float((s_[capi.S_CUBE_P + 2] > 0.05).float().mean())
+        d_ = (s_[capi.S_CUBE_P:capi.S_CUBE_P + 3] - s_[capi.S_GOAL_P:capi.S_GOAL_P + 3]).norm(dim=0)
         print(f"epoch {st['epoch']:4d} frames {st['frames']:10d} reward/step {st['mean_reward']:8.3f} kl {st['kl']:.4f} "
-              f"{st['frames'] / (time.perf_counter() - t0):.3e} frames/s", flush=True)
+              f"{st['frames'] / (time.perf_counter() - t0):.3e} frames/s  cube above 5 cm {100 * lifted:5.1f} %  "
+              f"dist to goal median {float(d_.median()) * 1e3:6.1f} mm", flush=True)
 for DET in (False, True):
     print(f'---- play, deterministic={DET}, log_std {tr.net.log_std.detach().cpu().numpy().round(2)}')
     eng = env._engine
@@ -45,9 +50,12 @@ for DET in (False, True):
         zmax = max(zmax, float(s[capi.S_CUBE_P + 2].max()))
         tipmin = min(tipmin, float(s[capi.S_TIP_P + 2:capi.S_TIP_P + 9:3].min()))
         if k % 100 == 99:
-            dist.append((k + 1, float(d.mean()), float(d.median()), float((d < 0.02).float().mean())))
-    for k, mean, med, frac in dist:
-        print(f"play step {k:4d}: distance to the goal mean {mean * 1e3:6.1f} mm  median {med * 1e3:6.1f} mm  within 2 cm {100 * frac:5.1f} %")
+            dist.append((k + 1, float(d.mean()), float(d.median()), float((d < 0.02).float().mean()),
+                         float((s[capi.S_CUBE_P + 2] > 0.05).float().mean()),
+                         {kk.split("/")[-2] if kk.endswith("count") else kk.split("/")[-1]: round(float(v), 1) for kk, v in info_.items() if "goal" in kk or "success" in kk}))
+    for k, mean, med, frac, lifted, counts in dist:
+        print(f"play step {k:4d}: distance to the goal mean {mean * 1e3:6.1f} mm  median {med * 1e3:6.1f} mm  within 2 cm {100 * frac:5.1f} %  "
+              f"cube above 5 cm {100 * lifted:5.1f} %  env info {counts}")
     print(f"mean reward per step in play {rsum / 700:.3f}")
     print(f"over the episode: cube speed max {vmax:.2f} m/s, spin max {wmax:.1f} rad/s, height max {zmax * 1e3:.1f} mm (rest 32.5), "
           f"fingertip height min {tipmin * 1e3:.1f} mm (radius 10.2)")
