@@ -23,14 +23,20 @@ env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False)
 tr = PPOTrainer(RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device="cuda:0")), env.get_obs_dim(), env.get_state_dim(),
                 env.get_action_dim(), PPOConfig.from_rlg(cfg["rlg"], num_envs=n, seed=seed, fused_kernels=fused), device="cuda:0")
 t0 = time.perf_counter()
-for st in tr.train(epochs):
-    if st["epoch"] % (10 if epochs <= 300 else 50) == 9:
+every = 10 if epochs <= 300 else 50
+
+
+def log(st):                                   # called by the trainer after every epoch: the state rows are this epoch's
+    if st["epoch"] % every == every - 1:
         s_ = env._engine.state
         lifted = float((s_[capi.S_CUBE_P + 2] > 0.05).float().mean())
         d_ = (s_[capi.S_CUBE_P:capi.S_CUBE_P + 3] - s_[capi.S_GOAL_P:capi.S_GOAL_P + 3]).norm(dim=0)
         print(f"epoch {st['epoch']:4d} frames {st['frames']:10d} reward/step {st['mean_reward']:8.3f} kl {st['kl']:.4f} "
               f"{st['frames'] / (time.perf_counter() - t0):.3e} frames/s  cube above 5 cm {100 * lifted:5.1f} %  "
               f"dist to goal median {float(d_.median()) * 1e3:6.1f} mm", flush=True)
+
+
+tr.train(epochs, log=log)
 for DET in (False, True):
     print(f'---- play, deterministic={DET}, log_std {tr.net.log_std.detach().cpu().numpy().round(2)}')
     eng = env._engine
