@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TF_API_VERSION 3
+#define TF_API_VERSION 4
 
 typedef enum TfStatus {
     TF_OK = 0,
@@ -102,7 +102,7 @@ enum {
     /* Warm start of the contact solver (an implementation choice, not algorithmic traffic: SURVEY 8d).  The impulses
      * of the last substep seed the next one when the contact kept its identity; a reset clears them.               */
     TF_S_LAM_FC = 98,    /* 12 finger-cube contact of finger f at [4f..4f+3]: normal impulse, world friction impulse (3) */
-    TF_S_FC_LINK = 110,  /*  3 link that held the finger-cube contact (0 none, 1 upper, 2 middle, 3 distal)       */
+    TF_S_FC_LINK = 110,  /*  3 link that held the finger-cube contact (0 none, 1 upper, 2 middle, 3 distal: any of its capsules) */
     TF_S_LAM_TF = 113,   /*  9 fingertip-floor contact of finger f at [3f..3f+2]: normal, tangent 1, tangent 2       */
     TF_S_LAM_TW = 122,   /*  9 fingertip-boundary-wall contact of finger f, same layout                             */
     TF_S_LAM_CF = 131,   /* 12 cube corner i against the floor at [3i..3i+2]: +z (normal), +x, +y                   */
@@ -135,6 +135,14 @@ enum { TF_DR_CUBE_MASS = 0, TF_DR_CUBE_SIZE = 1, TF_DR_FRICTION = 2, TF_DR_MOTOR
 enum { TF_INFO_REW0 = 0, TF_INFO_POS_COUNT = 6, TF_INFO_ORI_COUNT = 7, TF_INFO_SUCCESS_MEAN = 8,
        TF_INFO_NUM_RESETS = 9, TF_INFO_NUM_NONFINITE = 10 };
 
+/* One capsule of a finger link's collision shape: segment a-b in the frame of `link` (1 upper, 2 middle, 3 lower), radius. */
+#define TF_MAX_CAPS 10
+typedef struct TfCapsule {
+    int32_t link;
+    float a[3], b[3];
+    float radius;
+} TfCapsule;
+
 typedef struct TfRewardTerm {
     int32_t activate;
     float weight;
@@ -164,16 +172,16 @@ typedef struct TfModel {
     float tau_max;                /* 0.36 Nm                                                         */
     float link_angular_damping;   /* 0.01 (trifinger_env.py:866)                                     */
     float q_default[3];           /* (0, 0.9, -1.7)                                                  */
-    /* collision primitives (build's choice: capsules fitted to the convex hulls of the link meshes
-     * meshes/stl/pro/SIM__BL-Finger_{Proximal,Intermediate,Tip_without_tip,Tip_actual_tip}.obj with the collision
-     * origins of trifingerpro.urdf:88-153; every finger link has a shape, trifinger_env.py:874-879) */
-    float cap_a[3], cap_b[3];     /* distal-link capsule end points in the lower frame; b = tip sphere centre */
-    float cap_radius;             /* 0.0102                                                          */
-    float cap2_a[3], cap2_b[3];   /* middle-link capsule in the middle frame                         */
-    float cap2_radius;            /* 0.022                                                           */
-    float cap1_a[3], cap1_b[3];   /* upper-link capsule in the upper frame (along the joint-1 axis)  */
-    float cap1_radius;            /* 0.024                                                           */
-    float upper_check_z;          /* the upper-link candidate is only tested for a cube centre above this height */
+    /* collision primitives (build's choice): every finger link is a UNION OF CAPSULES that covers the convex hull the reference
+     * loads for it (meshes/stl/pro/SIM__BL-Finger_{Proximal,Intermediate,Tip_without_tip,Tip_actual_tip}.obj with the collision
+     * origins of trifingerpro.urdf:88-153; one hull per link, trifinger_env.py:859-879) to within 3 mm, fitted by
+     * tools/fit_link_capsules.py to the hull vertices of tests/golden/model.npz; tests/test_model_fixture.py holds the coverage. */
+    float cap_a[3], cap_b[3];     /* FINGERTIP capsule of the distal link (lower frame): the tube, b = centre of the fingertip sphere;
+                                   * it is also the shape of the fingertip-floor / fingertip-wall / finger-finger contacts        */
+    float cap_radius;             /* 0.0102: radius of the fingertip sphere (SIM__BL-Finger_Tip_actual_tip.obj)                   */
+    int32_t n_caps;               /* the other capsules of the three links, tested in table order after the fingertip capsule      */
+    TfCapsule caps[TF_MAX_CAPS];
+    float upper_check_z;          /* capsules of the upper link (link 1) are only tested for a cube centre above this height       */
     /* cube (cube_multicolor_rrc.urdf:10-18) */
     float cube_half;              /* 0.0325 */
     float cube_mass;              /* 291.3 * 0.065^3 */

@@ -11,7 +11,8 @@ same binding at the CPU oracle; nothing in this package ever does.
 import ctypes as C
 import os
 
-TF_API_VERSION = 3
+TF_API_VERSION = 4
+TF_MAX_CAPS = 10
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
 TF_STATE_ROWS = 157
@@ -55,6 +56,10 @@ class TfRewardTerm(C.Structure):
                 ("sched_start", C.c_double), ("sched_end", C.c_double)]
 
 
+class TfCapsule(C.Structure):
+    _fields_ = [("link", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("radius", C.c_float)]
+
+
 class TfModel(C.Structure):
     _fields_ = [
         ("base_height", C.c_float),
@@ -66,8 +71,7 @@ class TfModel(C.Structure):
         ("qd_max", C.c_float), ("tau_max", C.c_float), ("link_angular_damping", C.c_float),
         ("q_default", C.c_float * 3),
         ("cap_a", C.c_float * 3), ("cap_b", C.c_float * 3), ("cap_radius", C.c_float),
-        ("cap2_a", C.c_float * 3), ("cap2_b", C.c_float * 3), ("cap2_radius", C.c_float),
-        ("cap1_a", C.c_float * 3), ("cap1_b", C.c_float * 3), ("cap1_radius", C.c_float),
+        ("n_caps", C.c_int32), ("caps", TfCapsule * TF_MAX_CAPS),
         ("upper_check_z", C.c_float),
         ("cube_half", C.c_float), ("cube_mass", C.c_float), ("cube_inertia", C.c_float),
         ("cube_linear_damping", C.c_float), ("cube_angular_damping", C.c_float),

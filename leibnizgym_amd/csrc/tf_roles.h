@@ -589,7 +589,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
             quat_to_rot(cq, R);
-            // finger vs cube: the link capsule with the smallest gap holds the contact
+            // finger vs cube: the capsule with the smallest gap holds the contact.  The fingertip capsule first, then the table of the
+            // model (TfModel.caps, scalar loads from the parameter block; a rolled loop).  A capsule can only win when a LOWER BOUND of
+            // its gap - distance of the cube centre to its axis minus radius minus the cube's circumradius - is below the best gap so
+            // far (the per-env rule, the same in the oracle); a wavefront in which no lane passes that test skips the closest-point
+            // routine for this capsule.
             float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
             int link = 0;
             {
@@ -602,38 +606,40 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 link = 3; radius = m.cap_radius;
             }
             {
-                float Ab[3], Bb[3], A2[3], B2[3];
-                link_point<2>(k, m.cap2_a, Ab);
-                link_point<2>(k, m.cap2_b, Bb);
-                base_to_world(yw, Ab, A2);
-                base_to_world(yw, Bb, B2);
-                float da[3] = {A2[0] - cp[0], A2[1] - cp[1], A2[2] - cp[2]};
-                float db[3] = {B2[0] - cp[0], B2[1] - cp[1], B2[2] - cp[2]};
-                float a[3], b[3], gx[3], gy[3], gn[3], gg;
-                mat3T_mul(R, da, a);
-                mat3T_mul(R, db, b);
-                seg_box(a, b, hc, m.cap2_radius, gg, gx, gy, gn);
-                const bool take = gg < gap;
-                link = take ? 2 : link; gap = take ? gg : gap; radius = take ? m.cap2_radius : radius;
+                const float circ = f_sqrt(dot3(hc, hc));
+                const bool upper_ok = cp[2] > m.upper_check_z;
+                const bool upper_any = __builtin_amdgcn_ballot_w64(upper_ok) != 0ull;      // practically never
+#pragma unroll 1
+                for (int ci = 0; ci < m.n_caps; ++ci) {
+                    const TfCapsule& cap = m.caps[ci];
+                    const int lk = cap.link;                    // wave-uniform
+                    if (lk == 1 && !upper_any) continue;
+                    float Ab[3], Bb[3], A2[3], B2[3];
+                    if (lk == 3) { link_point<3>(k, cap.a, Ab); link_point<3>(k, cap.b, Bb); }
+                    else if (lk == 2) { link_point<2>(k, cap.a, Ab); link_point<2>(k, cap.b, Bb); }
+                    else { link_point<1>(k, cap.a, Ab); link_point<1>(k, cap.b, Bb); }
+                    base_to_world(yw, Ab, A2);
+                    base_to_world(yw, Bb, B2);
+                    float da[3] = {A2[0] - cp[0], A2[1] - cp[1], A2[2] - cp[2]};
+                    float db[3] = {B2[0] - cp[0], B2[1] - cp[1], B2[2] - cp[2]};
+                    float lb;
+                    {   // lower bound of the gap: |centre - axis| - radius - circumradius
+                        float d[3] = {db[0] - da[0], db[1] - da[1], db[2] - da[2]};
+                        const float t = f_clamp(-dot3(da, d) * f_rcp(f_max(dot3(d, d), 1e-12f)), 0.0f, 1.0f);
+                        float e[3] = {FMA(t, d[0], da[0]), FMA(t, d[1], da[1]), FMA(t, d[2], da[2])};
+                        lb = (f_sqrt(dot3(e, e)) - cap.radius) - circ;
+                    }
+                    const bool need = (lb < gap) && (lk != 1 || upper_ok);
+                    if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+                    float a[3], b[3], gx[3], gy[3], gn[3], gg;
+                    mat3T_mul(R, da, a);
+                    mat3T_mul(R, db, b);
+                    seg_box(a, b, hc, cap.radius, gg, gx, gy, gn);
+                    const bool take = need && (gg < gap);
+                    link = take ? lk : link; gap = take ? gg : gap; radius = take ? cap.radius : radius;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
-            }
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(cp[2] > m.upper_check_z) != 0ull, 0)) {   // wave-level: practically never
-                float Ab[3], Bb[3], A1[3], B1[3];
-                link_point<1>(k, m.cap1_a, Ab);
-                link_point<1>(k, m.cap1_b, Bb);
-                base_to_world(yw, Ab, A1);
-                base_to_world(yw, Bb, B1);
-                float da[3] = {A1[0] - cp[0], A1[1] - cp[1], A1[2] - cp[2]};
-                float db[3] = {B1[0] - cp[0], B1[1] - cp[1], B1[2] - cp[2]};
-                float a[3], b[3], gx[3], gy[3], gn[3], gg;
-                mat3T_mul(R, da, a);
-                mat3T_mul(R, db, b);
-                seg_box(a, b, hc, m.cap1_radius, gg, gx, gy, gn);
-                const bool take = (cp[2] > m.upper_check_z) && (gg < gap);
-                link = take ? 1 : link; gap = take ? gg : gap; radius = take ? m.cap1_radius : radius;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+                    for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+                }
             }
             STAMP(sb_ + 2);
             BAR();                                              // S1b: the finger-finger pass of the cube role is done

@@ -29,6 +29,7 @@
 #include <math.h>
 
 #include "tf_roles.h"
+#include "../../include/trifinger_default_caps.h"
 
 #define SCR_STRIDE TF_SCR_STRIDE
 
@@ -225,14 +226,11 @@ void tf_default_model(TfModel* m) {
     m->cap_a[0] = 0.0135f;
     m->cap_b[0] = 0.0185f; m->cap_b[2] = -0.1592f;
     m->cap_radius = 0.0102f;
-    // middle link: bar along -z of the middle frame (hull x[0,0.050] y[-0.029,0.024] z[-0.184,0.022], trifingerpro.urdf:108-113)
-    m->cap2_a[0] = 0.028f;
-    m->cap2_b[0] = 0.028f; m->cap2_b[2] = -0.16f;
-    m->cap2_radius = 0.022f;
-    // upper link: motor housing along the joint-1 axis (hull x[-0.022,0.032] y[0.0235,0.233] z[-0.0255,0.0255], :88-93)
-    m->cap1_a[0] = 0.005f; m->cap1_a[1] = 0.045f;
-    m->cap1_b[0] = 0.005f; m->cap1_b[1] = 0.21f;
-    m->cap1_radius = 0.024f;
+    {   // the other capsules of the three links: include/trifinger_default_caps.h (fitted to the collision hulls)
+        static const TfCapsule caps[] = { TF_DEFAULT_CAPS };
+        m->n_caps = (int32_t)(sizeof(caps) / sizeof(caps[0]));
+        for (int i = 0; i < m->n_caps; ++i) m->caps[i] = caps[i];
+    }
     m->upper_check_z = 0.17f;
     m->cube_half = 0.0325f;
     m->cube_mass = (float)(291.3 * 0.065 * 0.065 * 0.065);

@@ -35,6 +35,7 @@
 #include <string.h>
 
 #include "../include/trifinger.h"
+#include "../include/trifinger_default_caps.h"
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -360,16 +361,11 @@ void tf_default_model(TfModel* m) {
     m->cap_a[0] = 0.0135f; m->cap_a[1] = 0.0f; m->cap_a[2] = 0.0f;
     m->cap_b[0] = 0.0185f; m->cap_b[1] = 0.0f; m->cap_b[2] = -0.1592f; /* tip origin + (0,0,0.0034) */
     m->cap_radius = 0.0102f;
-    /* middle link: bar along -z of the middle frame, hull x[0,0.050] y[-0.029,0.024] z[-0.184,0.022] (mesh rotated by the
-     * collision rpy of trifingerpro.urdf:108-113) */
-    m->cap2_a[0] = 0.028f; m->cap2_a[1] = 0.0f; m->cap2_a[2] = 0.0f;
-    m->cap2_b[0] = 0.028f; m->cap2_b[1] = 0.0f; m->cap2_b[2] = -0.16f;
-    m->cap2_radius = 0.022f;
-    /* upper link: motor housing along the joint-1 axis, hull x[-0.022,0.032] y[0.0235,0.233] z[-0.0255,0.0255]
-     * (trifingerpro.urdf:88-93) */
-    m->cap1_a[0] = 0.005f; m->cap1_a[1] = 0.045f; m->cap1_a[2] = 0.0f;
-    m->cap1_b[0] = 0.005f; m->cap1_b[1] = 0.21f; m->cap1_b[2] = 0.0f;
-    m->cap1_radius = 0.024f;
+    {   /* the other capsules of the three links: include/trifinger_default_caps.h (fitted to the collision hulls) */
+        static const TfCapsule caps[] = { TF_DEFAULT_CAPS };
+        m->n_caps = (int32_t)(sizeof(caps) / sizeof(caps[0]));
+        for (int i = 0; i < m->n_caps; ++i) m->caps[i] = caps[i];
+    }
     m->upper_check_z = 0.17f;             /* base height 0.29 - capsule radius - cube half diagonal - margin */
     m->cube_half = 0.0325f;               /* trifinger_env.py:143 */
     m->cube_mass = (float)(291.3 * 0.065 * 0.065 * 0.065);
@@ -1316,21 +1312,32 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         /* --- finger vs cube: the link capsule with the smallest gap holds the contact --- */
         float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
         int link = 0;
-        for (int cand = 3; cand >= 1; --cand) {
+        /* the fingertip capsule first, then the table of the model in order; a capsule is looked at only when a lower bound of its
+         * gap (distance of the cube centre to its axis - radius - circumradius of the cube) is below the best gap so far */
+        const float circ = sqrtf(dot3(hc, hc));
+        for (int ci = -1; ci < m->n_caps; ++ci) {
+            const int cand = (ci < 0) ? 3 : m->caps[ci].link;
+            const float* la = (ci < 0) ? m->cap_a : m->caps[ci].a;
+            const float* lb_ = (ci < 0) ? m->cap_b : m->caps[ci].b;
+            const float rad = (ci < 0) ? m->cap_radius : m->caps[ci].radius;
             if (cand == 1 && !(cube_top_check > m->upper_check_z)) continue;
-            const float* la = (cand == 3) ? m->cap_a : ((cand == 2) ? m->cap2_a : m->cap1_a);
-            const float* lb = (cand == 3) ? m->cap_b : ((cand == 2) ? m->cap2_b : m->cap1_b);
-            const float rad = (cand == 3) ? m->cap_radius : ((cand == 2) ? m->cap2_radius : m->cap1_radius);
             float Ab[3], Bb[3], Aw[3], Bw[3];
-            if (cand == 3) { for (int i = 0; i < 3; ++i) { Aw[i] = g->Aw[i]; Bw[i] = g->Bw[i]; } }
+            if (ci < 0) { for (int i = 0; i < 3; ++i) { Aw[i] = g->Aw[i]; Bw[i] = g->Bw[i]; } }
             else {
                 link_point(k, cand, la, Ab);
-                link_point(k, cand, lb, Bb);
+                link_point(k, cand, lb_, Bb);
                 base_to_world(m, f, Ab, Aw);
                 base_to_world(m, f, Bb, Bw);
             }
             float da[3] = {Aw[0] - cpr[0], Aw[1] - cpr[1], Aw[2] - cpr[2]};
             float db[3] = {Bw[0] - cpr[0], Bw[1] - cpr[1], Bw[2] - cpr[2]};
+            if (ci >= 0) {
+                float d[3] = {db[0] - da[0], db[1] - da[1], db[2] - da[2]};
+                const float t = f_clamp(-dot3(da, d) * f_rcp(f_max(dot3(d, d), 1e-12f)), 0.0f, 1.0f);
+                float e_[3] = {FMA(t, d[0], da[0]), FMA(t, d[1], da[1]), FMA(t, d[2], da[2])};
+                const float lbound = (sqrtf(dot3(e_, e_)) - rad) - circ;
+                if (!(lbound < gap)) continue;
+            }
             float a[3], b[3], gx[3], gy[3], gn[3], gg;
             mat3T_mul(R, da, a);
             mat3T_mul(R, db, b);

@@ -17,15 +17,21 @@ from scipy.optimize import minimize, minimize_scalar
 
 from test_physics_analytic import LINKS, frames, kinetic_matrix, potential, G  # noqa: F401  fp64 URDF model
 
-H_BASE = 0.29
-YAW = (0.0, -2.09439510239, -4.18879020479)
-CAPS = {3: (np.array([0.0135, 0.0, 0.0]), np.array([0.0185, 0.0, -0.1592]), 0.0102),
-        2: (np.array([0.028, 0.0, 0.0]), np.array([0.028, 0.0, -0.16]), 0.022),
-        1: (np.array([0.005, 0.045, 0.0]), np.array([0.005, 0.21, 0.0]), 0.024)}
-UPPER_CHECK_Z = 0.17
-CUBE_HALF = 0.0325
-CUBE_MASS = 291.3 * 0.065 ** 3
-CUBE_INERTIA = CUBE_MASS * 0.065 ** 2 / 6.0
+# robot and object numbers: the reference's asset files (tests/golden/model.npz via tests/model_fixture.py); the build's own
+# choices - collision capsules, boundary steps - are read from tf_default_model of the oracle library (pinned against the fixture
+# by tests/test_model_fixture.py), so that this model follows the spec instead of restating its literals
+import model_fixture as MF
+from oracle_util import load_oracle
+
+H_BASE = MF.H_BASE
+YAW = MF.YAW
+_M = load_oracle().default_model()
+CAPSULES = MF.model_capsules(_M)            # [(link, a, b, radius)]: fingertip capsule first, then the table, in test order
+TIP_CAP = CAPSULES[0]
+UPPER_CHECK_Z = float(_M.upper_check_z)
+CUBE_HALF = MF.CUBE_SIZE / 2.0
+CUBE_MASS = MF.CUBE_DENSITY * MF.CUBE_SIZE ** 3
+CUBE_INERTIA = CUBE_MASS * MF.CUBE_SIZE ** 2 / 6.0
 LINK_DAMP, CUBE_LIN_DAMP, CUBE_ANG_DAMP = 0.01, 0.0, 0.05
 MU = dict(fc=1.0, cf=0.55, tf=0.55, cw=1.0, tw=1.0, ff=1.0)
 REST_F, REST_FF, BOUNCE = 0.4, 0.8, 0.5
@@ -34,8 +40,26 @@ Q_LO = np.array([-0.33, 0.0, -2.7])
 Q_HI = np.array([1.0, 1.57, 0.0])
 QD_MAX = 10.0
 FF_ITERATIONS = 4
-WALL_R = (0.192, 0.208, 0.249, 0.260)
-WALL_Z = (0.06, 0.10, 0.14, 0.176)
+WALL_R = tuple(float(x) for x in _M.wall_r)
+WALL_Z = tuple(float(x) for x in _M.wall_z)
+
+
+def link_capsules(link):
+    """[(a, b, radius)] of the capsules of one link (1 upper, 2 middle, 3 lower)"""
+    return [(a, b, r) for lk, a, b, r in CAPSULES if lk == link]
+
+
+def finger_gaps(f, qf, cube_p, R, hc, links=(3, 2, 1)):
+    """gap of every capsule of finger f (of the given links) against the box at cube_p / R with half extents hc: [(gap, link)]"""
+    out = []
+    for lk, la, lb, rad in CAPSULES:
+        if lk not in links:
+            continue
+        a = R.T @ (link_point_world(f, qf, lk, la) - cube_p)
+        b = R.T @ (link_point_world(f, qf, lk, lb) - cube_p)
+        x, y = segment_box(a, b, hc)
+        out.append((np.linalg.norm(x - y) - rad, lk))
+    return out
 
 
 def rot_z(a):
@@ -210,8 +234,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
     distal = []
     for f in range(3):
         sl = slice(3 * f, 3 * f + 3)
-        a3 = link_point_world(f, q[sl], 3, CAPS[3][0])
-        b3 = link_point_world(f, q[sl], 3, CAPS[3][1])
+        a3 = link_point_world(f, q[sl], 3, TIP_CAP[1])
+        b3 = link_point_world(f, q[sl], 3, TIP_CAP[2])
         distal.append((a3, b3))
         tipsphere.append(b3)
     # ---- finger-finger pre-pass on the free velocities: pairs in turn, one frictionless normal row each ----
@@ -222,7 +246,7 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         dist = np.linalg.norm(Pa - Pb)
         if not dist > 1e-6:
             continue
-        rad = CAPS[3][2]
+        rad = TIP_CAP[3]
         gap = dist - 2 * rad
         if not gap < MARGIN:
             continue
@@ -243,10 +267,9 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         sl = slice(3 * f, 3 * f + 3)
         qf = q[sl]
         best = None
-        for cand in (3, 2, 1):
+        for cand, la, lb, rad in CAPSULES:            # every capsule of the finger: the smallest gap holds the contact
             if cand == 1 and not cp[2] > UPPER_CHECK_Z:
                 continue
-            la, lb, rad = CAPS[cand]
             a = R.T @ (link_point_world(f, qf, cand, la) - cp)
             b = R.T @ (link_point_world(f, qf, cand, lb) - cp)
             x, y = segment_box(a, b, hc)
@@ -269,7 +292,7 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
                 details["fc"].append((f, link, gap, nr))
         # fingertip sphere against the floor and against the boundary wall
         B = tipsphere[f]
-        rad = CAPS[3][2]
+        rad = TIP_CAP[3]
         rho = np.hypot(B[0], B[1])
         for kind in ("floor", "wall"):
             if kind == "floor":

@@ -140,7 +140,7 @@ def make_box_case(rng, half):
     while True:
         q = np.concatenate([rng.uniform(PR.Q_LO + 0.05, PR.Q_HI - 0.05) for _ in range(3)])
         f0 = rng.integers(3)
-        tip = PR.link_point_world(f0, q[3 * f0:3 * f0 + 3], 3, PR.CAPS[3][1])
+        tip = PR.link_point_world(f0, q[3 * f0:3 * f0 + 3], 3, PR.TIP_CAP[2])
         if tip[2] < 0.012:
             continue
         d = rng.normal(size=3)
@@ -170,15 +170,10 @@ def make_box_case(rng, half):
         ok, near = True, False
         for f in range(3):
             qf = q[3 * f:3 * f + 3]
-            for cand in (3, 2, 1):
-                la, lb, rad = PR.CAPS[cand]
-                a = R.T @ (PR.link_point_world(f, qf, cand, la) - c)
-                b = R.T @ (PR.link_point_world(f, qf, cand, lb) - c)
-                x, y = PR.segment_box(a, b, half)
-                g = np.linalg.norm(x - y) - rad
+            for g, _ in PR.finger_gaps(f, qf, c, R, half):
                 ok &= g >= -0.004
                 near |= g < 0.004
-            tipf = PR.link_point_world(f, qf, 3, PR.CAPS[3][1])
+            tipf = PR.link_point_world(f, qf, 3, PR.TIP_CAP[2])
             ok &= tipf[2] - 0.0102 >= -0.003
             ok &= PR.wall_radius_at(tipf[2]) - np.hypot(tipf[0], tipf[1]) - 0.0102 >= -0.003
         if not ok or not near:

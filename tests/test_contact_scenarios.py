@@ -18,8 +18,8 @@ import physics_ref as PR
 import test_physics_analytic as T
 from leibnizgym_amd import _capi as capi
 
-R_TIP = PR.CAPS[3][2]
-TIP = PR.CAPS[3][1]
+R_TIP = PR.TIP_CAP[3]
+TIP = PR.TIP_CAP[2]
 
 
 def ik(f, target_world, q0=(0.0, 0.9, -1.7)):
@@ -186,12 +186,8 @@ def test_impact_impulse_and_restitution_gpu(hip):
 
 # ---- middle link vs cube -------------------------------------------------------------------------------------------
 def _capsule_gap(f, qf, link, cube):
-    la, lb, rad = PR.CAPS[link]
-    R = PR.quat_rot(cube[3:7])
-    a = R.T @ (PR.link_point_world(f, qf, link, la) - cube[0:3])
-    b = R.T @ (PR.link_point_world(f, qf, link, lb) - cube[0:3])
-    x, y = PR.segment_box(a, b, PR.CUBE_HALF)
-    return np.linalg.norm(x - y) - rad
+    """smallest gap of the capsules of one link against the cube"""
+    return min(g for g, _ in PR.finger_gaps(f, qf, cube[0:3], PR.quat_rot(cube[3:7]), np.full(3, PR.CUBE_HALF), links=(link,)))
 
 
 def _middle_link_run(lib, device, contacts_on):
@@ -200,11 +196,19 @@ def _middle_link_run(lib, device, contacts_on):
             m.contact_margin = -1.0
     eng = torque_engine(lib, device, edit, gravity=(0.0, 0.0, 0.0))
     q = np.array([-0.25, 0.35, -1.2])
-    mid = 0.5 * (PR.link_point_world(0, q, 2, PR.CAPS[2][0]) + PR.link_point_world(0, q, 2, PR.CAPS[2][1]))
-    # a floating cube beside the middle of finger 0's middle link, on the side joint 1 is about to swing it to
-    side = PR.link_point_world(0, q + np.array([0.3, 0, 0]), 2, 0.5 * (PR.CAPS[2][0] + PR.CAPS[2][1])) - mid
+    mid_local = np.array([0.028, 0.0, -0.08])          # centre of mass of the middle link (trifingerpro.urdf:114-118): mid-way along it
+    mid = PR.link_point_world(0, q, 2, mid_local)
+    # a floating cube beside the middle of finger 0's middle link, on the side joint 1 is about to swing it to, 1 cm from its capsules
+    side = PR.link_point_world(0, q + np.array([0.3, 0, 0]), 2, mid_local) - mid
     side /= np.linalg.norm(side)
-    centre = mid + side * (PR.CAPS[2][2] + PR.CUBE_HALF + 0.01)
+    lo_, hi_ = 0.0, 0.2
+    for _ in range(50):                                 # bisection on the distance along `side` at which the link's gap is 1 cm
+        d_ = 0.5 * (lo_ + hi_)
+        if _capsule_gap(0, q, 2, np.concatenate([mid + side * d_, [0, 0, 0, 1]])) < 0.01:
+            lo_ = d_
+        else:
+            hi_ = d_
+    centre = mid + side * hi_
     f32 = dict(dtype=torch.float32, device=device)
     eng.q[0:3, 0] = torch.tensor(q, **f32)
     eng.cube[0:3, 0] = torch.tensor(centre, **f32)
@@ -254,7 +258,7 @@ def _finger_finger_run(lib, device, contacts_on):
     for i in range(150):
         step_torque(eng, impedance_torques(state_np(eng), [meet, meet, None], kp=120.0, kd=2.0))
         st = state_np(eng)
-        segs = [(PR.link_point_world(f, st[3 * f:3 * f + 3], 3, PR.CAPS[3][0]), PR.link_point_world(f, st[3 * f:3 * f + 3], 3, TIP))
+        segs = [(PR.link_point_world(f, st[3 * f:3 * f + 3], 3, PR.TIP_CAP[1]), PR.link_point_world(f, st[3 * f:3 * f + 3], 3, TIP))
                 for f in (0, 1)]
         Pa, Pb = PR.segment_segment(segs[0][0], segs[0][1], segs[1][0], segs[1][1])
         dists.append(np.linalg.norm(Pa - Pb))

@@ -27,15 +27,8 @@ def rot_x(a):
     return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
 
 
-LINKS = [  # (mass, com in link frame, inertia diag about com)
-    (0.26, np.array([0, 0.06, 0]), np.diag([0.000459333333333, 6.93333333333e-05, 0.000459333333333])),
-    (0.25, np.array([0.028, 0, -0.08]), np.diag([0.000441666666667, 0.000441666666667, 6.66666666667e-05])),
-    (0.021, np.array([0, 0, -0.06]), np.diag([3.5e-05, 3.5e-05, 1.4e-06])),
-    (0.031, np.array([0.0185, 0, -0.1626]), np.eye(3) * 5.16666666667e-07),   # tip link, rigidly on the lower link
-]
-J2 = np.array([0.01685, 0.0505, 0.0])
-J3 = np.array([0.04922, 0.0, -0.16])
-TIP = np.array([0.0185, 0.0, -0.1626])
+# link inertials, joint origins: tests/golden/model.npz = the numbers of the reference's trifingerpro.urdf (tests/model_fixture.py)
+from model_fixture import LINKS, J2, J3, TIP  # noqa: E402
 
 
 def frames(q):
@@ -361,7 +354,7 @@ def test_fingertip_does_not_sink_through_the_floor(oracle):
         eng.step(tau)
         q = eng.q[0:3, 0].numpy().astype(np.float64)
         R3, p3 = frames(q)[2]
-        ball = p3 + R3 @ np.array([0.0185, 0.0, -0.1592])
+        ball = p3 + R3 @ np.array(list(oracle.default_model().cap_b), dtype=np.float64)
         low = min(low, ball[2] + 0.29 - 0.0102)
     assert low > -1.5e-3, low                                         # at most the speculative-contact slop
     assert low < 0.02                                                 # and it did reach the floor
