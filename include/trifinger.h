@@ -136,7 +136,7 @@ enum { TF_INFO_REW0 = 0, TF_INFO_POS_COUNT = 6, TF_INFO_ORI_COUNT = 7, TF_INFO_S
        TF_INFO_NUM_RESETS = 9, TF_INFO_NUM_NONFINITE = 10 };
 
 /* One capsule of a finger link's collision shape: segment a-b in the frame of `link` (1 upper, 2 middle, 3 lower), radius. */
-#define TF_MAX_CAPS 10
+#define TF_MAX_CAPS 16
 typedef struct TfCapsule {
     int32_t link;
     float a[3], b[3];
@@ -187,9 +187,10 @@ typedef struct TfModel {
     float cube_mass;              /* 291.3 * 0.065^3 */
     float cube_inertia;           /* m s^2 / 6 (isotropic)                                           */
     float cube_linear_damping, cube_angular_damping;
-    /* arena: the boundary annulus as a stack of vertical cylinders, inner radius wall_r[i] for heights below
-     * wall_z[i] (measured from meshes/convex_table_boundary/convex_*.obj; high_table_boundary.urdf:20-259);
-     * nothing above wall_z[3] */
+    /* arena: inner radius of the boundary annulus as a function of height, piecewise linear through the knots (wall_z[i], wall_r[i]):
+     * a vertical ring below wall_z[0], the flaring cone of the stage between the knots, nothing above wall_z[3]; from the 40 convex
+     * pieces of meshes/convex_table_boundary/convex_*.obj (high_table_boundary.urdf:20-259) via tests/golden/model.npz: mid-way
+     * between the chords and the corners of the polygonal inner surface.  The contact normal is horizontal (cone tilt ignored). */
     float wall_r[4], wall_z[4];
     /* materials: PhysX "average" combine of trifinger_env.py:364-365,876-878,914-915,934-936 */
     float mu_finger_cube, mu_cube_floor, mu_tip_floor, mu_cube_wall, mu_tip_wall, mu_finger_finger;

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 TF_API_VERSION = 4
-TF_MAX_CAPS = 10
+TF_MAX_CAPS = 16
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
 TF_STATE_ROWS = 157

@@ -130,13 +130,15 @@ DEV void seg_seg(const float p1[3], const float q1[3], const float p2[3], const 
     for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
 }
 
-// inner radius of the boundary at height z (a stack of vertical cylinders; 1e3 = no wall)
-DEV float wall_radius_at(const TfModel& m, float z) {
-    float r = 1000.0f;
-    if (z < m.wall_z[3]) r = m.wall_r[3];
-    if (z < m.wall_z[2]) r = m.wall_r[2];
-    if (z < m.wall_z[1]) r = m.wall_r[1];
-    if (z < m.wall_z[0]) r = m.wall_r[0];
+// inner radius of the boundary at height z: the piecewise-linear profile through the knots (wall_z[i], wall_r[i]) - a vertical ring below
+// the first knot, the flaring cone of the stage above it (slopes wall_s precomputed at tf_create), nothing above the last knot (1e3)
+DEV float wall_radius_at(const DevParams& P, float z) {
+    const TfModel& m = P.m;
+    float r = m.wall_r[0];
+    r = (z > m.wall_z[0]) ? FMA(z - m.wall_z[0], P.wall_s[0], m.wall_r[0]) : r;
+    r = (z > m.wall_z[1]) ? FMA(z - m.wall_z[1], P.wall_s[1], m.wall_r[1]) : r;
+    r = (z > m.wall_z[2]) ? FMA(z - m.wall_z[2], P.wall_s[2], m.wall_r[2]) : r;
+    r = (z < m.wall_z[3]) ? r : 1000.0f;
     return r;
 }
 

@@ -590,10 +590,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
             quat_to_rot(cq, R);
             // finger vs cube: the capsule with the smallest gap holds the contact.  The fingertip capsule first, then the table of the
-            // model (TfModel.caps, scalar loads from the parameter block; a rolled loop).  A capsule can only win when a LOWER BOUND of
-            // its gap - distance of the cube centre to its axis minus radius minus the cube's circumradius - is below the best gap so
-            // far (the per-env rule, the same in the oracle); a wavefront in which no lane passes that test skips the closest-point
-            // routine for this capsule.
+            // model (TfModel.caps, scalar loads from the parameter block; rolled loops).  Consecutive entries of one link form a group.
+            // A group, and inside it a capsule, is looked at only when a LOWER BOUND of its gap - exact distance of the centre of its
+            // bounding sphere to the cube minus the sphere's radius - is below the best gap so far (the per-env rule, the same in the
+            // oracle); a wavefront in which no lane passes a test skips what it guards.
             float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
             int link = 0;
             {
@@ -606,39 +606,50 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 link = 3; radius = m.cap_radius;
             }
             {
-                const float circ = f_sqrt(dot3(hc, hc));
                 const bool upper_ok = cp[2] > m.upper_check_z;
                 const bool upper_any = __builtin_amdgcn_ballot_w64(upper_ok) != 0ull;      // practically never
-#pragma unroll 1
-                for (int ci = 0; ci < m.n_caps; ++ci) {
-                    const TfCapsule& cap = m.caps[ci];
-                    const int lk = cap.link;                    // wave-uniform
-                    if (lk == 1 && !upper_any) continue;
-                    float Ab[3], Bb[3], A2[3], B2[3];
-                    if (lk == 3) { link_point<3>(k, cap.a, Ab); link_point<3>(k, cap.b, Bb); }
-                    else if (lk == 2) { link_point<2>(k, cap.a, Ab); link_point<2>(k, cap.b, Bb); }
-                    else { link_point<1>(k, cap.a, Ab); link_point<1>(k, cap.b, Bb); }
-                    base_to_world(yw, Ab, A2);
-                    base_to_world(yw, Bb, B2);
-                    float da[3] = {A2[0] - cp[0], A2[1] - cp[1], A2[2] - cp[2]};
-                    float db[3] = {B2[0] - cp[0], B2[1] - cp[1], B2[2] - cp[2]};
-                    float lb;
-                    {   // lower bound of the gap: |centre - axis| - radius - circumradius
-                        float d[3] = {db[0] - da[0], db[1] - da[1], db[2] - da[2]};
-                        const float t = f_clamp(-dot3(da, d) * f_rcp(f_max(dot3(d, d), 1e-12f)), 0.0f, 1.0f);
-                        float e[3] = {FMA(t, d[0], da[0]), FMA(t, d[1], da[1]), FMA(t, d[2], da[2])};
-                        lb = (f_sqrt(dot3(e, e)) - cap.radius) - circ;
-                    }
-                    const bool need = (lb < gap) && (lk != 1 || upper_ok);
-                    if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
-                    float a[3], b[3], gx[3], gy[3], gn[3], gg;
-                    mat3T_mul(R, da, a);
-                    mat3T_mul(R, db, b);
-                    seg_box(a, b, hc, cap.radius, gg, gx, gy, gn);
-                    const bool take = need && (gg < gap);
-                    link = take ? lk : link; gap = take ? gg : gap; radius = take ? cap.radius : radius;
+                // distance of a link-frame point to the cube (exact outside the cube, 0 inside): what the bounding spheres are tested with
+                auto box_dist = [&](int lk, const float local[3]) __attribute__((always_inline)) -> float {
+                    float Pb_[3], Pw_[3], pl[3];
+                    if (lk == 3) link_point<3>(k, local, Pb_);
+                    else if (lk == 2) link_point<2>(k, local, Pb_);
+                    else link_point<1>(k, local, Pb_);
+                    base_to_world(yw, Pb_, Pw_);
+                    float dd[3] = {Pw_[0] - cp[0], Pw_[1] - cp[1], Pw_[2] - cp[2]};
+                    mat3T_mul(R, dd, pl);
+                    float e[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+                    for (int j = 0; j < 3; ++j) e[j] = f_max(f_abs(pl[j]) - hc[j], 0.0f);
+                    return f_sqrt(dot3(e, e));
+                };
+#pragma unroll 1
+                for (int g = 0; g < P.n_groups; ++g) {
+                    const int lk = P.grp_link[g];               // wave-uniform
+                    if (lk == 1 && !upper_any) continue;
+                    const bool grp_need = ((box_dist(lk, P.grp_c[g]) - P.grp_r[g]) < gap) && (lk != 1 || upper_ok);
+                    if (__builtin_amdgcn_ballot_w64(grp_need) == 0ull) continue;
+#pragma unroll 1
+                    for (int ci = P.grp_first[g]; ci < P.grp_first[g] + P.grp_count[g]; ++ci) {
+                        const TfCapsule& cap = m.caps[ci];
+                        const bool need = grp_need && ((box_dist(lk, P.cap_mid[ci]) - P.cap_bound[ci]) < gap);
+                        if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+                        float Ab[3], Bb[3], A2[3], B2[3];
+                        if (lk == 3) { link_point<3>(k, cap.a, Ab); link_point<3>(k, cap.b, Bb); }
+                        else if (lk == 2) { link_point<2>(k, cap.a, Ab); link_point<2>(k, cap.b, Bb); }
+                        else { link_point<1>(k, cap.a, Ab); link_point<1>(k, cap.b, Bb); }
+                        base_to_world(yw, Ab, A2);
+                        base_to_world(yw, Bb, B2);
+                        float da[3] = {A2[0] - cp[0], A2[1] - cp[1], A2[2] - cp[2]};
+                        float db[3] = {B2[0] - cp[0], B2[1] - cp[1], B2[2] - cp[2]};
+                        float a[3], b[3], gx[3], gy[3], gn[3], gg;
+                        mat3T_mul(R, da, a);
+                        mat3T_mul(R, db, b);
+                        seg_box(a, b, hc, cap.radius, gg, gx, gy, gn);
+                        const bool take = need && (gg < gap);
+                        link = take ? lk : link; gap = take ? gg : gap; radius = take ? cap.radius : radius;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+                    }
                 }
             }
             STAMP(sb_ + 2);
@@ -728,7 +739,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { c.Dinv[j] = 0.0f; c.lam[j] = 0.0f; c.arm[j] = 0.0f; }
                     c.bias = 0.0f; c.mu = 0.0f;
-                    float gp_ = (t == 0) ? (bz - m.cap_radius) : ((wall_radius_at(m, bz) - rho) - m.cap_radius);
+                    float gp_ = (t == 0) ? (bz - m.cap_radius) : ((wall_radius_at(P, bz) - rho) - m.cap_radius);
                     const bool on = ((t == 0) || (rho > 1e-6f)) && (gp_ < m.contact_margin);
                     if (__builtin_expect(on, t == 0)) {
                         float dir[9] = {0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1429,7 +1440,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     float rho2 = FMA(px, px, py * py);
                     float inv = f_rsqrt(f_max(rho2, 1e-24f));
                     float rho = rho2 * inv;
-                    float gap = wall_radius_at(m, pz) - rho;
+                    float gap = wall_radius_at(P, pz) - rho;
                     if (__builtin_expect(any && gap < m.contact_margin && rho > 1e-6f, 0)) {
                         float nn[2] = {-px * inv, -py * inv};
                         float a[3], b[3], c3[3];

@@ -237,10 +237,12 @@ void tf_default_model(TfModel* m) {
     m->cube_inertia = (float)(291.3 * 0.065 * 0.065 * 0.065 * 0.065 * 0.065 / 6.0);
     m->cube_linear_damping = 0.0f;
     m->cube_angular_damping = 0.05f;
-    m->wall_r[0] = 0.192f; m->wall_z[0] = 0.06f;
-    m->wall_r[1] = 0.208f; m->wall_z[1] = 0.10f;
-    m->wall_r[2] = 0.249f; m->wall_z[2] = 0.14f;
-    m->wall_r[3] = 0.260f; m->wall_z[3] = 0.176f;
+    // boundary profile (knots of a piecewise-linear r(z)): vertical ring up to 32 mm, then the flaring cone of the stage; radii = mid-way
+    // between the chords and the corners of the 40 convex pieces (tests/golden/model.npz: boundary_profile_*; tests/test_model_fixture.py)
+    m->wall_r[0] = 0.1895f; m->wall_z[0] = 0.032f;
+    m->wall_r[1] = 0.2093f; m->wall_z[1] = 0.06f;
+    m->wall_r[2] = 0.2319f; m->wall_z[2] = 0.10f;
+    m->wall_r[3] = 0.2741f; m->wall_z[3] = 0.176f;
     m->mu_finger_cube = 1.0f;
     m->mu_cube_floor = 0.55f;
     m->mu_tip_floor = 0.55f;
@@ -346,6 +348,38 @@ static void build_tables(const TfConfig* c, int A, float* tab, int* obs_dim, int
     }
 }
 
+// Bounding spheres of the capsule table (double precision, then rounded): every entry (mid point, half length + radius) and every group
+// of consecutive entries of one link (centre = mean of the members' mid points, radius = the farthest member sphere).
+static void cap_bounds(DevParams& P) {
+    const TfModel& m = P.m;
+    P.n_groups = 0;
+    double mid[TF_MAX_CAPS][3], bound[TF_MAX_CAPS];
+    for (int i = 0; i < m.n_caps; ++i) {
+        double l2 = 0.0;
+        for (int k = 0; k < 3; ++k) { mid[i][k] = 0.5 * ((double)m.caps[i].a[k] + (double)m.caps[i].b[k]); const double d = (double)m.caps[i].b[k] - (double)m.caps[i].a[k]; l2 += d * d; }
+        bound[i] = 0.5 * sqrt(l2) + (double)m.caps[i].radius;
+        for (int k = 0; k < 3; ++k) P.cap_mid[i][k] = (float)mid[i][k];
+        P.cap_bound[i] = (float)bound[i];
+    }
+    for (int i = 0; i < m.n_caps;) {
+        int j = i;
+        while (j < m.n_caps && m.caps[j].link == m.caps[i].link) ++j;
+        double c[3] = {0.0, 0.0, 0.0}, r = 0.0;
+        for (int t = i; t < j; ++t) for (int k = 0; k < 3; ++k) c[k] += mid[t][k] / (double)(j - i);
+        for (int t = i; t < j; ++t) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) d2 += (mid[t][k] - c[k]) * (mid[t][k] - c[k]);
+            const double rr = sqrt(d2) + bound[t];
+            r = rr > r ? rr : r;
+        }
+        const int g = P.n_groups++;
+        P.grp_link[g] = m.caps[i].link; P.grp_first[g] = i; P.grp_count[g] = j - i;
+        for (int k = 0; k < 3; ++k) P.grp_c[g][k] = (float)c[k];
+        P.grp_r[g] = (float)r;
+        i = j;
+    }
+}
+
 int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (!cfg || !out) return TF_ERR_INVALID_ARG;
     if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
@@ -396,6 +430,10 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     P.dt = cfg->dt; P.hsub = cfg->dt / (float)cfg->substeps;
     for (int i = 0; i < 3; ++i) P.grav[i] = cfg->gravity[i];
     P.m = cfg->model;
+    if (P.m.n_caps < 0 || P.m.n_caps > TF_MAX_CAPS) { delete h; return TF_ERR_INVALID_ARG; }
+    for (int i = 0; i < P.m.n_caps; ++i) if (P.m.caps[i].link < 1 || P.m.caps[i].link > 3) { delete h; return TF_ERR_INVALID_ARG; }
+    cap_bounds(P);
+    for (int i = 0; i < 3; ++i) P.wall_s[i] = (float)(((double)P.m.wall_r[i + 1] - (double)P.m.wall_r[i]) / ((double)P.m.wall_z[i + 1] - (double)P.m.wall_z[i]));
     void* tk = nullptr;
     e = hipMalloc(&tk, STAT_WORDS * sizeof(unsigned long long));
     if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(tickets)"); }

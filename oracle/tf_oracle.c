@@ -285,6 +285,12 @@ struct TfHandle_ {
     int timing_on;
     double timed_ms;
     int64_t timed_launches;
+    /* bounding spheres of the capsule table (tf_create): groups of consecutive entries of one link, and every entry */
+    int n_groups;
+    int grp_link[TF_MAX_CAPS], grp_first[TF_MAX_CAPS], grp_count[TF_MAX_CAPS];
+    float grp_c[TF_MAX_CAPS][3], grp_r[TF_MAX_CAPS];
+    float cap_mid[TF_MAX_CAPS][3], cap_bound[TF_MAX_CAPS];
+    float wall_s[3];                    /* slopes of the boundary profile between its knots */
 };
 
 static char g_err[256] = "";
@@ -373,10 +379,10 @@ void tf_default_model(TfModel* m) {
     m->cube_linear_damping = 0.0f;
     m->cube_angular_damping = 0.05f;
     /* boundary: inner radius by height (measured from convex_table_boundary/convex_*.obj) */
-    m->wall_r[0] = 0.192f; m->wall_z[0] = 0.06f;
-    m->wall_r[1] = 0.208f; m->wall_z[1] = 0.10f;
-    m->wall_r[2] = 0.249f; m->wall_z[2] = 0.14f;
-    m->wall_r[3] = 0.260f; m->wall_z[3] = 0.176f;
+    m->wall_r[0] = 0.1895f; m->wall_z[0] = 0.032f;   /* knots of the piecewise-linear profile r(z): ring, then the flaring cone */
+    m->wall_r[1] = 0.2093f; m->wall_z[1] = 0.06f;
+    m->wall_r[2] = 0.2319f; m->wall_z[2] = 0.10f;
+    m->wall_r[3] = 0.2741f; m->wall_z[3] = 0.176f;
     m->mu_finger_cube = 1.0f;             /* avg(1.0, 1.0) */
     m->mu_cube_floor = 0.55f;             /* avg(1.0, 0.1) */
     m->mu_tip_floor = 0.55f;
@@ -497,6 +503,42 @@ static int needs_ext(const TfConfig* c) {
     return 0;
 }
 
+/* bounding spheres of the capsule table, in double precision and then rounded: entry = (mid point, half length + radius); group of
+ * consecutive entries of one link = (mean of the members' mid points, the farthest member sphere) */
+static void cap_bounds(struct TfHandle_* h) {
+    const TfModel* m = &h->cfg.model;
+    double mid[TF_MAX_CAPS][3], bound[TF_MAX_CAPS];
+    h->n_groups = 0;
+    for (int i = 0; i < m->n_caps; ++i) {
+        double l2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            mid[i][k] = 0.5 * ((double)m->caps[i].a[k] + (double)m->caps[i].b[k]);
+            const double d = (double)m->caps[i].b[k] - (double)m->caps[i].a[k];
+            l2 += d * d;
+        }
+        bound[i] = 0.5 * sqrt(l2) + (double)m->caps[i].radius;
+        for (int k = 0; k < 3; ++k) h->cap_mid[i][k] = (float)mid[i][k];
+        h->cap_bound[i] = (float)bound[i];
+    }
+    for (int i = 0; i < m->n_caps;) {
+        int j = i;
+        while (j < m->n_caps && m->caps[j].link == m->caps[i].link) ++j;
+        double c[3] = {0.0, 0.0, 0.0}, r = 0.0;
+        for (int t = i; t < j; ++t) for (int k = 0; k < 3; ++k) c[k] += mid[t][k] / (double)(j - i);
+        for (int t = i; t < j; ++t) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) d2 += (mid[t][k] - c[k]) * (mid[t][k] - c[k]);
+            const double rr = sqrt(d2) + bound[t];
+            r = rr > r ? rr : r;
+        }
+        const int g = h->n_groups++;
+        h->grp_link[g] = m->caps[i].link; h->grp_first[g] = i; h->grp_count[g] = j - i;
+        for (int k = 0; k < 3; ++k) h->grp_c[g][k] = (float)c[k];
+        h->grp_r[g] = (float)r;
+        i = j;
+    }
+}
+
 int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (!cfg || !out) return TF_ERR_INVALID_ARG;
     if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
@@ -509,6 +551,8 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
     if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
+    if (cfg->model.n_caps < 0 || cfg->model.n_caps > TF_MAX_CAPS) return TF_ERR_INVALID_ARG;
+    for (int i = 0; i < cfg->model.n_caps; ++i) if (cfg->model.caps[i].link < 1 || cfg->model.caps[i].link > 3) return TF_ERR_INVALID_ARG;
     struct TfHandle_* h = (struct TfHandle_*)calloc(1, sizeof(*h));
     if (h) { h->clip_obs = 3.402823466e38f; h->clip_act = 3.402823466e38f; }
     if (!h) return TF_ERR_INVALID_ARG;
@@ -517,6 +561,9 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     h->action_dim = tf_action_dim(cfg->command_mode);
     build_tables(h);
     h->ext = needs_ext(&h->cfg);
+    cap_bounds(h);
+    for (int i = 0; i < 3; ++i)
+        h->wall_s[i] = (float)(((double)cfg->model.wall_r[i + 1] - (double)cfg->model.wall_r[i]) / ((double)cfg->model.wall_z[i + 1] - (double)cfg->model.wall_z[i]));
     *out = h;
     return TF_OK;
 }
@@ -940,13 +987,15 @@ static void seg_seg(const float p1[3], const float q1[3], const float p2[3], con
     for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
 }
 
-/* inner radius of the boundary at height z (a stack of vertical cylinders; 1e3 = no wall) */
-static float wall_radius_at(const TfModel* m, float z) {
-    float r = 1000.0f;
-    if (z < m->wall_z[3]) r = m->wall_r[3];
-    if (z < m->wall_z[2]) r = m->wall_r[2];
-    if (z < m->wall_z[1]) r = m->wall_r[1];
-    if (z < m->wall_z[0]) r = m->wall_r[0];
+/* inner radius of the boundary at height z: piecewise-linear profile through the knots (wall_z[i], wall_r[i]); a vertical ring below
+ * the first knot, nothing above the last (1e3) */
+static float wall_radius_at(const struct TfHandle_* H, float z) {
+    const TfModel* m = &H->cfg.model;
+    float r = m->wall_r[0];
+    if (z > m->wall_z[0]) r = FMA(z - m->wall_z[0], H->wall_s[0], m->wall_r[0]);
+    if (z > m->wall_z[1]) r = FMA(z - m->wall_z[1], H->wall_s[1], m->wall_r[1]);
+    if (z > m->wall_z[2]) r = FMA(z - m->wall_z[2], H->wall_s[2], m->wall_r[2]);
+    if (!(z < m->wall_z[3])) r = 1000.0f;
     return r;
 }
 
@@ -1102,6 +1151,17 @@ static inline float pair_factor(float mu_a, float fa1, float mu_b, float fb1) {
     return FMA(mu_b * inv, fb1, FMA(mu_a * inv, fa1, 1.0f));
 }
 
+/* distance of a point given in the frame of link `lk` of finger f to the cube (exact outside the cube, 0 inside) */
+static float box_dist(const TfModel* m, int f, const FK* k, int lk, const float local[3], const float cpr[3], const float R[9], const float hc[3]) {
+    float Pb[3], Pw[3], pl[3], e[3];
+    link_point(k, lk, local, Pb);
+    base_to_world(m, f, Pb, Pw);
+    float dd[3] = {Pw[0] - cpr[0], Pw[1] - cpr[1], Pw[2] - cpr[2]};
+    mat3T_mul(R, dd, pl);
+    for (int j = 0; j < 3; ++j) e[j] = f_max(f_abs(pl[j]) - hc[j], 0.0f);
+    return sqrtf(dot3(e, e));
+}
+
 /* One solver substep of length h for one env.  Phases and roles: F1 free motion of each finger,
  * C1 cube free motion and corner contacts, FF finger-finger pre-pass, F2 finger contact generation, then the sweeps. */
 static void substep(const struct TfHandle_* H, Env* e, float h) {
@@ -1245,7 +1305,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             float rho2 = FMA(px, px, py * py);
             float inv = f_rsqrt(f_max(rho2, 1e-24f));
             float rho = rho2 * inv;
-            float gap = wall_radius_at(m, pz) - rho;
+            float gap = wall_radius_at(H, pz) - rho;
             if (!(any && gap < m->contact_margin && rho > 1e-6f)) continue;
             c->n[0] = -px * inv; c->n[1] = -py * inv;
             {
@@ -1312,39 +1372,41 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         /* --- finger vs cube: the link capsule with the smallest gap holds the contact --- */
         float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
         int link = 0;
-        /* the fingertip capsule first, then the table of the model in order; a capsule is looked at only when a lower bound of its
-         * gap (distance of the cube centre to its axis - radius - circumradius of the cube) is below the best gap so far */
-        const float circ = sqrtf(dot3(hc, hc));
-        for (int ci = -1; ci < m->n_caps; ++ci) {
-            const int cand = (ci < 0) ? 3 : m->caps[ci].link;
-            const float* la = (ci < 0) ? m->cap_a : m->caps[ci].a;
-            const float* lb_ = (ci < 0) ? m->cap_b : m->caps[ci].b;
-            const float rad = (ci < 0) ? m->cap_radius : m->caps[ci].radius;
-            if (cand == 1 && !(cube_top_check > m->upper_check_z)) continue;
-            float Ab[3], Bb[3], Aw[3], Bw[3];
-            if (ci < 0) { for (int i = 0; i < 3; ++i) { Aw[i] = g->Aw[i]; Bw[i] = g->Bw[i]; } }
-            else {
-                link_point(k, cand, la, Ab);
-                link_point(k, cand, lb_, Bb);
-                base_to_world(m, f, Ab, Aw);
-                base_to_world(m, f, Bb, Bw);
-            }
-            float da[3] = {Aw[0] - cpr[0], Aw[1] - cpr[1], Aw[2] - cpr[2]};
-            float db[3] = {Bw[0] - cpr[0], Bw[1] - cpr[1], Bw[2] - cpr[2]};
-            if (ci >= 0) {
-                float d[3] = {db[0] - da[0], db[1] - da[1], db[2] - da[2]};
-                const float t = f_clamp(-dot3(da, d) * f_rcp(f_max(dot3(d, d), 1e-12f)), 0.0f, 1.0f);
-                float e_[3] = {FMA(t, d[0], da[0]), FMA(t, d[1], da[1]), FMA(t, d[2], da[2])};
-                const float lbound = (sqrtf(dot3(e_, e_)) - rad) - circ;
-                if (!(lbound < gap)) continue;
-            }
-            float a[3], b[3], gx[3], gy[3], gn[3], gg;
+        /* the fingertip capsule first, then the table of the model: consecutive entries of one link form a group; a group, and inside
+         * it a capsule, is looked at only when a lower bound of its gap - exact distance of the centre of its bounding sphere to the
+         * cube minus the sphere's radius - is below the best gap so far */
+        {
+            float da[3] = {g->Aw[0] - cpr[0], g->Aw[1] - cpr[1], g->Aw[2] - cpr[2]};
+            float db[3] = {g->Bw[0] - cpr[0], g->Bw[1] - cpr[1], g->Bw[2] - cpr[2]};
+            float a[3], b[3];
             mat3T_mul(R, da, a);
             mat3T_mul(R, db, b);
-            seg_box(a, b, hc, rad, &gg, gx, gy, gn);
-            if (link == 0 || gg < gap) {
-                link = cand; gap = gg; radius = rad;
-                for (int i = 0; i < 3; ++i) { x[i] = gx[i]; y[i] = gy[i]; nc[i] = gn[i]; }
+            seg_box(a, b, hc, m->cap_radius, &gap, x, y, nc);
+            link = 3; radius = m->cap_radius;
+        }
+        const int upper_ok = cube_top_check > m->upper_check_z;
+        for (int gi = 0; gi < H->n_groups; ++gi) {
+            const int lk = H->grp_link[gi];
+            if (lk == 1 && !upper_ok) continue;
+            if (!((box_dist(m, f, k, lk, H->grp_c[gi], cpr, R, hc) - H->grp_r[gi]) < gap)) continue;
+            for (int ci = H->grp_first[gi]; ci < H->grp_first[gi] + H->grp_count[gi]; ++ci) {
+                const TfCapsule* cap = &m->caps[ci];
+                if (!((box_dist(m, f, k, lk, H->cap_mid[ci], cpr, R, hc) - H->cap_bound[ci]) < gap)) continue;
+                float Ab[3], Bb[3], Aw[3], Bw[3];
+                link_point(k, lk, cap->a, Ab);
+                link_point(k, lk, cap->b, Bb);
+                base_to_world(m, f, Ab, Aw);
+                base_to_world(m, f, Bb, Bw);
+                float da[3] = {Aw[0] - cpr[0], Aw[1] - cpr[1], Aw[2] - cpr[2]};
+                float db[3] = {Bw[0] - cpr[0], Bw[1] - cpr[1], Bw[2] - cpr[2]};
+                float a[3], b[3], gx[3], gy[3], gn[3], gg;
+                mat3T_mul(R, da, a);
+                mat3T_mul(R, db, b);
+                seg_box(a, b, hc, cap->radius, &gg, gx, gy, gn);
+                if (gg < gap) {
+                    link = lk; gap = gg; radius = cap->radius;
+                    for (int i = 0; i < 3; ++i) { x[i] = gx[i]; y[i] = gy[i]; nc[i] = gn[i]; }
+                }
             }
         }
         g->fc_link = 0;
@@ -1399,7 +1461,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             for (int t = 0; t < 2; ++t) {
                 TipContact* c = &g->tc[t];
                 memset(c, 0, sizeof(*c));
-                float gp_ = (t == 0) ? (bz - m->cap_radius) : ((wall_radius_at(m, bz) - rho) - m->cap_radius);
+                float gp_ = (t == 0) ? (bz - m->cap_radius) : ((wall_radius_at(H, bz) - rho) - m->cap_radius);
                 if (t == 1 && !(rho > 1e-6f)) continue;
                 if (!(gp_ < m->contact_margin)) continue;
                 float dir[3][3] = {{0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};

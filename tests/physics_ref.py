@@ -55,6 +55,11 @@ def finger_gaps(f, qf, cube_p, R, hc, links=(3, 2, 1)):
     for lk, la, lb, rad in CAPSULES:
         if lk not in links:
             continue
+        mid = R.T @ (link_point_world(f, qf, lk, 0.5 * (la + lb)) - cube_p)
+        far = np.linalg.norm(np.maximum(np.abs(mid) - hc, 0.0)) - (0.5 * np.linalg.norm(lb - la) + rad)
+        if far > 0.05:                                # more than 5 cm away whatever its orientation: the bound is reported as its gap
+            out.append((far, lk))
+            continue
         a = R.T @ (link_point_world(f, qf, lk, la) - cube_p)
         b = R.T @ (link_point_world(f, qf, lk, lb) - cube_p)
         x, y = segment_box(a, b, hc)
@@ -123,10 +128,11 @@ def contact_live(gap, vn0, h):
 
 
 def wall_radius_at(z):
-    for r, zz in zip(WALL_R, WALL_Z):
-        if z < zz:
-            return r
-    return 1000.0
+    """the boundary profile of the spec: piecewise linear through the knots (WALL_Z[i], WALL_R[i]), a vertical ring below the first
+    knot, no wall above the last"""
+    if not z < WALL_Z[-1]:
+        return 1000.0
+    return float(np.interp(z, WALL_Z, WALL_R))
 
 
 def segment_box(a, b, hc):
@@ -270,6 +276,10 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         for cand, la, lb, rad in CAPSULES:            # every capsule of the finger: the smallest gap holds the contact
             if cand == 1 and not cp[2] > UPPER_CHECK_Z:
                 continue
+            if best is not None:                      # (a capsule whose bounding sphere is farther than the best gap cannot win: skip the minimiser)
+                mid = R.T @ (link_point_world(f, qf, cand, 0.5 * (la + lb)) - cp)
+                if np.linalg.norm(np.maximum(np.abs(mid) - hc, 0.0)) - (0.5 * np.linalg.norm(lb - la) + rad) >= best[0]:
+                    continue
             a = R.T @ (link_point_world(f, qf, cand, la) - cp)
             b = R.T @ (link_point_world(f, qf, cand, lb) - cp)
             x, y = segment_box(a, b, hc)

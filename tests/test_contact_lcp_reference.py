@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 import torch
 
+from leibnizgym_amd import _capi as capi
 import physics_ref as PR
 import test_physics_analytic as T
 
@@ -92,11 +93,15 @@ def _run(lib, device, n_cases, sweeps_list):
     rng = np.random.default_rng(20261002)
     errs = []
     kinds = {"fc": 0, "chain": 0, "te": 0, "ff": 0, "wall": 0, "link2": 0}
-    for _ in range(n_cases):
+    skipped = 0
+    while len(errs) < n_cases:
         q, qd, cube, tau = make_case(rng)
         ref = PR.ref_substep(q, qd, cube, tau, H, max_sweeps=50000)
         det = ref[3]
-        assert det["sweeps"] < 50000, "reference did not reach its fixed point"
+        if det["sweeps"] >= 50000:               # a (rare) configuration whose fp64 Gauss-Seidel has not settled to 1e-13: no reference value
+            skipped += 1
+            assert skipped <= max(2, n_cases // 50), "the reference fails to reach its fixed point too often"
+            continue
         live = [x for x in det["fc"] if x[3].lam > 0]
         kinds["fc"] += bool(live)
         kinds["chain"] += bool(live) and det["n_floor"] > 0
@@ -127,6 +132,60 @@ def _check(errs, kinds, sweeps_list, n_cases):
     assert p90[0] >= p90[1] >= p90[last] and errs[:, 1].max() < 0.3 * max(errs[:, 0].max(), 1e-3)
     # what the shipped 8 sweeps (cold start) leave: documented in DESIGN.md section 2
     assert med[0] < 1e-4 and p90[0] < 2e-2 and errs[:, 0].max() < 0.2
+
+
+def _run_warm(lib, device, n_cases, k_warm=4, sweeps=8):
+    """Residual of the SHIPPED sweep count in the warm state: the product runs `k_warm` substeps from a random contact state (its
+    warm-start rows fill), then substep k_warm + 1 is compared with the fp64 fixed point computed from the state it started
+    from - once with the warm rows the product carried there, once cold (rows cleared) from the same state."""
+    rng = np.random.default_rng(20261003)
+    warm, cold, kept = [], [], 0
+    f32 = dict(dtype=torch.float32, device=device)
+    while kept < n_cases:
+        q, qd, cube, tau = make_case(rng)
+        eng = T.engine(lib, device=device, dt=H, substeps=1, solver_iterations=sweeps)
+        eng.q[:, 0] = torch.tensor(q, **f32); eng.qd[:, 0] = torch.tensor(qd, **f32)
+        eng.cube[:, 0] = torch.tensor(cube, **f32); eng.tau[:, 0] = torch.tensor(tau, **f32)
+        for _ in range(k_warm):
+            eng.simulate()
+        st = eng.state[:, 0].cpu().numpy().astype(np.float64)
+        q1, qd1, cube1 = st[0:9], st[9:18], st[18:31]
+        try:
+            ref = PR.ref_substep(q1, qd1, cube1, tau, H, max_sweeps=50000)
+        except ValueError:                      # a capsule axis ended up inside the cube: outside the domain of the reference
+            eng.close()
+            continue
+        det = ref[3]
+        persistent = any(x[3].lam > 0 for x in det["fc"]) or any(x[3].lam > 0 for x in det["te"])
+        if det["sweeps"] >= 50000 or not persistent:
+            eng.close()
+            continue
+        saved = eng.state[:, 0].clone()
+        eng.simulate()
+        s2 = eng.state[:, 0].cpu().numpy().astype(np.float64)
+        warm.append(scaled_error((s2[9:18], s2[25:28], s2[28:31]), ref[:3]))
+        eng.state[:, 0] = saved
+        eng.state[capi.S_LAM_FC:, 0] = 0.0      # every warm-start row
+        eng.simulate()
+        s3 = eng.state[:, 0].cpu().numpy().astype(np.float64)
+        cold.append(scaled_error((s3[9:18], s3[25:28], s3[28:31]), ref[:3]))
+        eng.close()
+        kept += 1
+    return np.array(warm), np.array(cold)
+
+
+def _report_warm(warm, cold):
+    print("\nshipped sweeps, substep 5 of a persistent contact: scaled velocity error vs the fp64 fixed point")
+    for name, e in (("warm start", warm), ("cold start", cold)):
+        print(f"{name}:  median {np.median(e):.3e}  p90 {np.percentile(e, 90):.3e}  p99 {np.percentile(e, 99):.3e}  max {e.max():.3e}")
+
+
+def test_warm_state_residual_of_the_shipped_sweeps(oracle):
+    """what 8 sweeps leave once the warm start has had four substeps to fill."""
+    warm, cold = _run_warm(oracle, "cpu", 16)        # (the fp64 reference needs ~5 s per case; the 120-case table is in profiles/r3_b_pgs_variants.txt)
+    _report_warm(warm, cold)
+    assert np.median(warm) <= np.median(cold) * 2.0 + 1e-5
+    assert np.median(warm) < 5e-3 and warm.max() < 0.5, (np.median(warm), warm.max())
 
 
 def test_substep_converges_to_the_independent_lcp_solution(oracle):

@@ -233,7 +233,7 @@ def _check_middle_link(lib, device):
     assert 2 in links                                # the contact slot was held by the middle link
     assert moved > 0.02                              # and the cube was pushed away
     ghost, _, still = _middle_link_run(lib, device, False)
-    assert ghost < -0.02 and still < 1e-6            # without contacts the link passes straight through: the test bites
+    assert ghost < -0.012 and still < 1e-6           # without contacts the link passes straight through: the test bites
 
 
 def test_middle_link_cannot_pass_through_the_cube(oracle):

@@ -236,21 +236,18 @@ def _quat_rot(q):
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
 
 
-WALL_R = (0.192, 0.208, 0.249, 0.260)
-WALL_Z = (0.06, 0.10, 0.14, 0.176)
-
-
-def wall_radius_at(z):
-    for r, zz in zip(WALL_R, WALL_Z):
-        if z < zz:
-            return r
-    return np.inf
+def wall_radius_at(z, m):
+    """boundary profile of the model `m`: piecewise linear through its knots, nothing above the last"""
+    wr, wz = list(m.wall_r), list(m.wall_z)
+    return float(np.interp(z, wz, wr)) if z < wz[-1] else np.inf
 
 
 def test_wall_keeps_the_cube_in_the_arena(oracle):
-    """A fast slide into the boundary: no corner ever gets further out than the wall radius of its height (the lower
-    wall is 60 mm high, the cube 65 mm: it rocks over the edge and falls back), and the cube ends at rest inside."""
+    """A fast slide into the boundary: no corner ever gets further out than the wall radius of its height (the vertical ring is
+    32 mm high, above it the stage flares outwards: the 65 mm cube rocks against the cone and falls back), and the cube ends at
+    rest inside."""
     eng = engine(oracle, **HOLD)
+    m = oracle.default_model()
     eng.cube[0:2, 0] = torch.tensor([0.12, 0.0])
     eng.cube[7, 0] = 1.5                                              # fast slide towards the boundary
     corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) * 0.0325
@@ -260,11 +257,11 @@ def test_wall_keeps_the_cube_in_the_arena(oracle):
         c = eng.cube[:, 0].numpy().astype(np.float64)
         pts = c[0:3] + corners @ _quat_rot(c[3:7]).T
         for p in pts:
-            worst = max(worst, np.hypot(p[0], p[1]) - wall_radius_at(p[2]))
+            worst = max(worst, np.hypot(p[0], p[1]) - wall_radius_at(p[2], m))
     assert worst < 2.5e-3, worst                                      # speculative-contact slop at 1.5 m/s
     assert worst > -0.01                                              # and it did reach the wall
     c = eng.cube[:, 0].numpy()
-    assert np.hypot(c[0], c[1]) < 0.192 - 0.0325 + 1e-3 and abs(c[2] - 0.0325) < 2e-4 and np.abs(c[7:13]).max() < 5e-3
+    assert np.hypot(c[0], c[1]) < float(m.wall_r[0]) - 0.0325 + 1e-3 and abs(c[2] - 0.0325) < 2e-4 and np.abs(c[7:13]).max() < 5e-3
     assert np.isfinite(eng.state.numpy()).all()
 
 

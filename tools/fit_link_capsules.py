@@ -73,7 +73,7 @@ class Body:
         parts = []
         for i, V in enumerate(hull_vertex_sets):
             V = np.asarray(V, dtype=np.float64)
-            S, h = surface_samples(V, 5000, i)
+            S, h = surface_samples(V, 2500, i)
             self.hulls.append(h)
             parts.append(S)
         keep = []
@@ -85,19 +85,23 @@ class Body:
             keep.append(S[k])
         self.S = np.vstack(keep)
 
-    def coverage(self, caps, nsurf=300):
-        """(largest distance of a hull-surface point outside the union, largest distance of a capsule-surface point outside the body)"""
+    def coverage(self, caps, nsurf=300, weight=None):
+        """(largest distance of a hull-surface point outside the union, largest distance of a capsule-surface point outside the body;
+        `weight(points)` scales the latter per point - the fit uses it to keep the fingertip region tight)"""
         gap = np.min([seg_dist(self.S, np.asarray(a, float), np.asarray(b, float)) - r for a, b, r in caps], axis=0)
         over = 0.0
         for a, b, r in caps:
             Q = capsule_surface(np.asarray(a, float), np.asarray(b, float), r, nsurf)
-            over = max(over, np.min([sd_hull(Q, h) for h in self.hulls], axis=0).max())
+            sd = np.min([sd_hull(Q, h) for h in self.hulls], axis=0)
+            if weight is not None:
+                sd = sd * weight(Q)
+            over = max(over, sd.max())
         return gap.max(), over
 
 
-def fit(body, build, x0, seed, iters=2500):
+def fit(body, build, x0, seed, iters=2500, weight=None):
     def cost(p):
-        u, o = body.coverage(build(p))
+        u, o = body.coverage(build(p), weight=weight)
         return max(o, 0.0) + 30.0 * max(0.0, u - UNDER_MAX)
     best = None
     rng = np.random.default_rng(seed)
@@ -116,32 +120,38 @@ TIP_CAP = ((0.0135, 0.0, 0.0), TIP_C, 0.0102)
 def distal(seed):
     body = Body([G["hull_lower"], G["hull_tip_in_lower"]])
 
-    def build(p):            # tip capsule (fixed) + a symmetric pair fanning out from the tip to the joint housing + one capsule across it
-        x1, y1, z1, x2, y2, z2, r, hx1, hx2, hz, hr = p
+    def build(p):   # fingertip capsule (fixed) + a symmetric pair fanning out from the tube to the joint housing + two capsules ACROSS the
+        x1, y1, z1, x2, y2, z2, r, hx, hy, hz1, hz2, hr = p     # housing (a 22 mm thick puck of radius 22 mm about the joint axis)
         return [TIP_CAP, ((x1, y1, z1), (x2, y2, z2), abs(r)), ((x1, -y1, z1), (x2, -y2, z2), abs(r)),
-                ((hx1, 0.0, hz), (hx2, 0.0, hz), abs(hr))]
-    x = fit(body, build, [0.012, 0.009, -0.012, 0.018, 0.002, -0.12, 0.0115, 0.009, 0.013, 0.0, 0.019], seed)
+                ((hx, -hy, hz1), (hx, hy, hz1), abs(hr)), ((hx, -hy, hz2), (hx, hy, hz2), abs(hr))]
+    w = lambda Q: np.where(Q[:, 2] < -0.10, 4.0, 1.0)      # noqa: E731  the fingertip region must not be inflated
+    x = fit(body, build, [0.012, 0.0115, -0.002, 0.017, 0.003, -0.095, 0.0105, 0.011, 0.010, 0.010, -0.010, 0.011], seed, weight=w)
     return body, build(x)
 
 
 def middle(seed):
     body = Body([G["hull_middle"]])
 
-    def build(p):            # two capsules along the body (the hull is not symmetric in y: own centre), one across each joint housing
-        xa1, xa2, ya, yc, z1, z2, ra, tx1, tx2, tz, tr, bx1, bx2, bz, br = p
+    def build(p):   # 2 x 2 capsules along the body (the hull is not symmetric in y: own centre), one sphere-like capsule across each joint housing
+        xa1, xa2, xb1, xb2, ya, yb, yc, z1, z2, ra, rb, tx1, tx2, tz, tr, bx1, bx2, bz, br = p
         return [((xa1, yc + ya, z1), (xa2, yc + ya, z2), abs(ra)), ((xa1, yc - ya, z1), (xa2, yc - ya, z2), abs(ra)),
+                ((xb1, yc + yb, z1), (xb2, yc + yb, z2), abs(rb)), ((xb1, yc - yb, z1), (xb2, yc - yb, z2), abs(rb)),
                 ((tx1, yc, tz), (tx2, yc, tz), abs(tr)), ((bx1, 0.0, bz), (bx2, 0.0, bz), abs(br))]
-    x = fit(body, build, [0.022, 0.036, 0.006, -0.002, -0.03, -0.14, 0.020, 0.022, 0.026, -0.004, 0.026, 0.033, 0.039, -0.160, 0.024], seed)
+    # over-coverage at the flat faces of the two joint housings (where the neighbouring links sit) is harmless: weight 0.4 there
+    w = lambda Q: np.where((Q[:, 2] > -0.022) | (Q[:, 2] < -0.150), 0.4, 1.0)      # noqa: E731
+    x = fit(body, build, [0.012, 0.031, 0.036, 0.037, 0.011, 0.011, -0.003, -0.020, -0.150, 0.0135, 0.0135,
+                          0.017, 0.019, -0.003, 0.029, 0.037, 0.033, -0.166, 0.024], seed, iters=3500, weight=w)
     return body, build(x)
 
 
 def upper(seed):
     body = Body([G["hull_upper"]])
 
-    def build(p):            # a symmetric pair along the link (it is never reached by the cube on the table: two are enough)
-        x1, x2, za, y1, y2, ra = p
-        return [((x1, y1, za), (x2, y2, za), abs(ra)), ((x1, y1, -za), (x2, y2, -za), abs(ra))]
-    x = fit(body, build, [0.002, 0.006, 0.007, 0.045, 0.21, 0.021], seed)
+    def build(p):   # two symmetric pairs along the link (it is never reached by the cube on the table; its capsules cost nothing)
+        xa1, xa2, xb1, xb2, za, zb, y1, y2, ra, rb = p
+        return [((xa1, y1, za), (xa2, y2, za), abs(ra)), ((xa1, y1, -za), (xa2, y2, -za), abs(ra)),
+                ((xb1, y1, zb), (xb2, y2, zb), abs(rb)), ((xb1, y1, -zb), (xb2, y2, -zb), abs(rb))]
+    x = fit(body, build, [-0.004, -0.008, 0.010, 0.016, 0.010, 0.009, 0.042, 0.218, 0.014, 0.015], seed)
     return body, build(x)
 
 
