@@ -135,13 +135,15 @@ enum { TF_DR_CUBE_MASS = 0, TF_DR_CUBE_SIZE = 1, TF_DR_FRICTION = 2, TF_DR_MOTOR
 enum { TF_INFO_REW0 = 0, TF_INFO_POS_COUNT = 6, TF_INFO_ORI_COUNT = 7, TF_INFO_SUCCESS_MEAN = 8,
        TF_INFO_NUM_RESETS = 9, TF_INFO_NUM_NONFINITE = 10 };
 
-/* One capsule of a finger link's collision shape: segment a-b in the frame of `link` (1 upper, 2 middle, 3 lower), radius. */
-#define TF_MAX_CAPS 16
-typedef struct TfCapsule {
-    int32_t link;
-    float a[3], b[3];
-    float radius;
-} TfCapsule;
+/* Collision shape of a finger link, in the frame of the link: a TAPERED ROUNDED BOX swept along the axis a -> b.  At parameter s in
+ * [0, 1] of the axis the cross-section is a rectangle with half widths w1(s), w2(s) along two fixed directions of the link frame
+ * (upper link: x and z; middle and lower link: x and y), corner rounding rho(s) <= w and centre offset (o1(s), o2(s)) from the axis;
+ * every quantity is linear in s and given at s = 0 and s = 1.  w1 = w2 = rho is a capsule.  Distance to the cube: the exact closest
+ * points of the AXIS and the cube give s, the distance D and the unit direction u from the axis point to the cube point; the gap is
+ * D - [(w1 - rho) |u1| + (w2 - rho) |u2| + rho + o1 u1 + o2 u2] - the support function of the cross-section along u: exact against
+ * a face of the cube, a few millimetres early against an edge or a corner in a diagonal direction of the cross-section.          */
+typedef struct TfLinkShape { float a[3], b[3], w1[2], w2[2], rho[2], o1[2], o2[2]; } TfLinkShape;
+typedef struct TfSphere { float c[3], radius; } TfSphere;
 
 typedef struct TfRewardTerm {
     int32_t activate;
@@ -172,16 +174,21 @@ typedef struct TfModel {
     float tau_max;                /* 0.36 Nm                                                         */
     float link_angular_damping;   /* 0.01 (trifinger_env.py:866)                                     */
     float q_default[3];           /* (0, 0.9, -1.7)                                                  */
-    /* collision primitives (build's choice): every finger link is a UNION OF CAPSULES that covers the convex hull the reference
-     * loads for it (meshes/stl/pro/SIM__BL-Finger_{Proximal,Intermediate,Tip_without_tip,Tip_actual_tip}.obj with the collision
-     * origins of trifingerpro.urdf:88-153; one hull per link, trifinger_env.py:859-879) to within 3 mm, fitted by
-     * tools/fit_link_capsules.py to the hull vertices of tests/golden/model.npz; tests/test_model_fixture.py holds the coverage. */
-    float cap_a[3], cap_b[3];     /* FINGERTIP capsule of the distal link (lower frame): the tube, b = centre of the fingertip sphere;
-                                   * it is also the shape of the fingertip-floor / fingertip-wall / finger-finger contacts        */
+    /* collision primitives (build's choice): every finger link is a tapered rounded box (+ a sphere per joint housing) that covers the
+     * convex hull the reference loads for it (meshes/stl/pro/SIM__BL-Finger_{Proximal,Intermediate,Tip_without_tip,Tip_actual_tip}.obj
+     * with the collision origins of trifingerpro.urdf:88-153; one hull per link, trifinger_env.py:859-879) to within 3 mm, fitted by
+     * tools/fit_link_shapes.py to the hull vertices of tests/golden/model.npz; tests/test_model_fixture.py holds the coverage.     */
+    float cap_a[3], cap_b[3];     /* FINGERTIP capsule of the distal link (lower frame): the tube, b = centre of the fingertip sphere:
+                                   * the shape of the fingertip-floor / fingertip-wall / finger-finger contacts and the axis of shape3 */
     float cap_radius;             /* 0.0102: radius of the fingertip sphere (SIM__BL-Finger_Tip_actual_tip.obj)                   */
-    int32_t n_caps;               /* the other capsules of the three links, tested in table order after the fingertip capsule      */
-    TfCapsule caps[TF_MAX_CAPS];
-    float upper_check_z;          /* capsules of the upper link (link 1) are only tested for a cube centre above this height       */
+    /* the shapes of the three links (include/trifinger_default_caps.h, fitted to the hulls by tools/fit_link_shapes.py); candidates of
+     * the finger-cube contact in this order, a later one takes over only with a strictly smaller gap: shape3, sph3, shape2, sph2[0],
+     * sph2[1], and - only for a cube above upper_check_z - shape1.  shape3 has the axis cap_a -> cap_b and ends (s = 1) in the
+     * fingertip sphere: w1 = w2 = rho = cap_radius there.  The joint housings are pucks about the joint axes: one sphere each.   */
+    TfLinkShape shape3; TfSphere sph3[1];     /* distal body (lower link + tip link); the joint-3 housing at its top                 */
+    TfLinkShape shape2; TfSphere sph2[2];     /* middle link; the joint-2 housing (top) and the joint-3 housing (bottom)             */
+    TfLinkShape shape1;                       /* upper link                                                                          */
+    float upper_check_z;          /* the capsules of the upper link are only tested for a cube centre above this height            */
     /* cube (cube_multicolor_rrc.urdf:10-18) */
     float cube_half;              /* 0.0325 */
     float cube_mass;              /* 291.3 * 0.065^3 */

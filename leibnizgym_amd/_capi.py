@@ -12,7 +12,6 @@ import ctypes as C
 import os
 
 TF_API_VERSION = 4
-TF_MAX_CAPS = 16
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
 TF_STATE_ROWS = 157
@@ -56,8 +55,13 @@ class TfRewardTerm(C.Structure):
                 ("sched_start", C.c_double), ("sched_end", C.c_double)]
 
 
-class TfCapsule(C.Structure):
-    _fields_ = [("link", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3), ("radius", C.c_float)]
+class TfLinkShape(C.Structure):
+    _fields_ = [("a", C.c_float * 3), ("b", C.c_float * 3), ("w1", C.c_float * 2), ("w2", C.c_float * 2), ("rho", C.c_float * 2),
+                ("o1", C.c_float * 2), ("o2", C.c_float * 2)]
+
+
+class TfSphere(C.Structure):
+    _fields_ = [("c", C.c_float * 3), ("radius", C.c_float)]
 
 
 class TfModel(C.Structure):
@@ -71,7 +75,7 @@ class TfModel(C.Structure):
         ("qd_max", C.c_float), ("tau_max", C.c_float), ("link_angular_damping", C.c_float),
         ("q_default", C.c_float * 3),
         ("cap_a", C.c_float * 3), ("cap_b", C.c_float * 3), ("cap_radius", C.c_float),
-        ("n_caps", C.c_int32), ("caps", TfCapsule * TF_MAX_CAPS),
+        ("shape3", TfLinkShape), ("sph3", TfSphere * 1), ("shape2", TfLinkShape), ("sph2", TfSphere * 2), ("shape1", TfLinkShape),
         ("upper_check_z", C.c_float),
         ("cube_half", C.c_float), ("cube_mass", C.c_float), ("cube_inertia", C.c_float),
         ("cube_linear_damping", C.c_float), ("cube_angular_damping", C.c_float),

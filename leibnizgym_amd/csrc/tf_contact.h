@@ -65,7 +65,7 @@ DEV float seg_box_g(const float a[3], const float d[3], float s, const float hc[
 // breakpoint with g <= 0 and the first with g > 0 (end points included): one linear interpolation, no iteration, no
 // branches.  x on the segment, y on the box, unit direction nc from y to x, gap = |x - y| - radius.  A segment point inside
 // the box is pushed out through the nearest face.
-DEV void seg_box(const float a[3], const float b[3], const float hc[3], float radius, float& gap_out, float x[3], float y[3], float nc[3]) {
+DEV void seg_box(const float a[3], const float b[3], const float hc[3], float radius, float& gap_out, float x[3], float y[3], float nc[3], float& s_out) {
     float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     const float g0 = seg_box_g(a, d, 0.0f, hc), g1 = seg_box_g(a, d, 1.0f, hc);
     float lo = 0.0f, glo = g0, hi = 1.0f, ghi = g1;
@@ -89,8 +89,36 @@ DEV void seg_box(const float a[3], const float b[3], const float hc[3], float ra
     float s = f_clamp(FMA(-glo, (hi - lo) * f_rcp(f_max(ghi - glo, 1e-30f)), lo), lo, hi);
     if (g0 > 0.0f) s = 0.0f;
     if (!(g1 > 0.0f)) s = 1.0f;
+    s_out = s;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc[i], hc[i]); }
+    float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
+    float dist2 = dot3(ev, ev);
+    if (__builtin_expect(dist2 > 1e-12f, 1)) {
+        float inv = f_rsqrt(dist2);
+        float dist = dist2 * inv;
+        nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
+        gap_out = dist - radius;
+    } else {
+        int bi = 0;
+        float best = f_abs(x[0]) - hc[0];
+        float p1 = f_abs(x[1]) - hc[1];
+        if (p1 > best) { best = p1; bi = 1; }
+        float p2 = f_abs(x[2]) - hc[2];
+        if (p2 > best) { best = p2; bi = 2; }
+        float xb = (bi == 0) ? x[0] : ((bi == 1) ? x[1] : x[2]);
+        float sg = (xb < 0.0f) ? -1.0f : 1.0f;
+        nc[0] = (bi == 0) ? sg : 0.0f; nc[1] = (bi == 1) ? sg : 0.0f; nc[2] = (bi == 2) ? sg : 0.0f;
+        y[0] = (bi == 0) ? sg * hc[0] : y[0]; y[1] = (bi == 1) ? sg * hc[1] : y[1]; y[2] = (bi == 2) ? sg * hc[2] : y[2];
+        gap_out = best - radius;
+    }
+}
+
+// the same for a sphere (centre x in the box frame): the tail of seg_box for a segment of zero length
+// (x, y, nc, gap as in seg_box)
+DEV void point_box(const float x[3], const float hc[3], float radius, float& gap_out, float y[3], float nc[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y[i] = f_clamp(x[i], -hc[i], hc[i]);
     float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
     float dist2 = dot3(ev, ev);
     if (__builtin_expect(dist2 > 1e-12f, 1)) {

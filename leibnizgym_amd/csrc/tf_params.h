@@ -72,12 +72,6 @@ struct DevParams {
     float dt, hsub;
     float grav[3];
     TfModel m;
-    // derived from m.caps at tf_create: consecutive entries of one link form a GROUP with a bounding sphere (centre gc in the link frame,
-    // radius gr); every entry has its own bounding sphere (mid point, half length + radius).  The candidate loop culls with them.
-    int32_t n_groups;
-    int32_t grp_link[TF_MAX_CAPS], grp_first[TF_MAX_CAPS], grp_count[TF_MAX_CAPS];
-    float grp_c[TF_MAX_CAPS][3], grp_r[TF_MAX_CAPS];
-    float cap_mid[TF_MAX_CAPS][3], cap_bound[TF_MAX_CAPS];
     float wall_s[3];         // slopes of the boundary profile between its knots: (wall_r[i+1] - wall_r[i]) / (wall_z[i+1] - wall_z[i])
     // obs/states offset and 1/range tables, action limits, PD gains (index = TAB_*).  Embedded so that every access
     // is a scalar load at a constant offset of the parameter block (a pointer member would be fetched per lane).

@@ -589,67 +589,77 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
             quat_to_rot(cq, R);
-            // finger vs cube: the capsule with the smallest gap holds the contact.  The fingertip capsule first, then the table of the
-            // model (TfModel.caps, scalar loads from the parameter block; rolled loops).  Consecutive entries of one link form a group.
-            // A group, and inside it a capsule, is looked at only when a LOWER BOUND of its gap - exact distance of the centre of its
-            // bounding sphere to the cube minus the sphere's radius - is below the best gap so far (the per-env rule, the same in the
-            // oracle); a wavefront in which no lane passes a test skips what it guards.
+            // finger vs cube: the shape with the smallest gap holds the contact (TfLinkShape, include/trifinger.h): the distal body
+            // first - its axis is the fingertip capsule's, it ends in the fingertip sphere -, its housing sphere, the middle link with
+            // its two housing spheres and - only for a cube above upper_check_z, practically never - the upper link; a later candidate
+            // takes over only with a strictly smaller gap.  All shape constants are scalars of the parameter block.
             float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
             int link = 0;
+            // a point of link LK (link frame) in the cube frame
+            auto to_cube = [&](auto lkc, const float local[3], float out[3]) __attribute__((always_inline)) {
+                constexpr int LK = decltype(lkc)::value;
+                float Pb_[3], Pw_[3];
+                link_point<LK>(k, local, Pb_);
+                base_to_world(yw, Pb_, Pw_);
+                float dd[3] = {Pw_[0] - cp[0], Pw_[1] - cp[1], Pw_[2] - cp[2]};
+                mat3T_mul(R, dd, out);
+            };
+            // tapered rounded box of link LK against the cube: closest points of its axis (a, b: cube frame), then the support function
+            // of the cross-section at that point of the axis along the direction to the cube
+            auto try_shape = [&](auto lkc, const TfLinkShape& sh, const float a[3], const float b[3], bool allowed) __attribute__((always_inline)) {
+                constexpr int LK = decltype(lkc)::value;
+                float gx[3], gy[3], gn[3], D, sp;
+                seg_box(a, b, hc, 0.0f, D, gx, gy, gn, sp);
+                float uw[3], ub[3], ul[3];
+                mat3_mul(R, gn, uw);                            // world direction from the cube point to the axis point
+                dir_world_to_base(yw, uw, ub);
+                rot_link_T<LK>(k, ub, ul);
+                const float u1 = -ul[0], u2 = (LK == 1) ? -ul[2] : -ul[1];      // towards the cube, along the two width directions
+                const float rho = FMA(sp, sh.rho[1] - sh.rho[0], sh.rho[0]);
+                const float h1 = FMA(sp, sh.w1[1] - sh.w1[0], sh.w1[0]) - rho, h2 = FMA(sp, sh.w2[1] - sh.w2[0], sh.w2[0]) - rho;
+                const float o1 = FMA(sp, sh.o1[1] - sh.o1[0], sh.o1[0]), o2 = FMA(sp, sh.o2[1] - sh.o2[0], sh.o2[0]);
+                const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
+                const float gg = D - ext;
+                const bool take = allowed && ((link == 0) || (gg < gap));
+                link = take ? LK : link; gap = take ? gg : gap; radius = take ? ext : radius;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+            };
+            auto try_sphere = [&](auto lkc, const TfSphere& sp) __attribute__((always_inline)) {
+                constexpr int LK = decltype(lkc)::value;
+                float c[3], gy[3], gn[3], gg;
+                to_cube(lkc, sp.c, c);
+                point_box(c, hc, sp.radius, gg, gy, gn);
+                const bool take = gg < gap;
+                link = take ? LK : link; gap = take ? gg : gap; radius = take ? sp.radius : radius;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { x[j] = take ? c[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
+            };
             {
-                float da[3] = {Aw[0] - cp[0], Aw[1] - cp[1], Aw[2] - cp[2]};
-                float db[3] = {Bw[0] - cp[0], Bw[1] - cp[1], Bw[2] - cp[2]};
-                float a[3], b[3];
-                mat3T_mul(R, da, a);
-                mat3T_mul(R, db, b);
-                seg_box(a, b, hc, m.cap_radius, gap, x, y, nc);
-                link = 3; radius = m.cap_radius;
-            }
-            {
+                using L3 = std::integral_constant<int, 3>; using L2 = std::integral_constant<int, 2>; using L1 = std::integral_constant<int, 1>;
+                {   // distal body: its axis end points are the fingertip capsule's (Aw, Bw of the free-motion phase)
+                    float da[3] = {Aw[0] - cp[0], Aw[1] - cp[1], Aw[2] - cp[2]};
+                    float db[3] = {Bw[0] - cp[0], Bw[1] - cp[1], Bw[2] - cp[2]};
+                    float a[3], b[3];
+                    mat3T_mul(R, da, a);
+                    mat3T_mul(R, db, b);
+                    try_shape(L3{}, m.shape3, a, b, true);
+                }
+                try_sphere(L3{}, m.sph3[0]);
+                {
+                    float a[3], b[3];
+                    to_cube(L2{}, m.shape2.a, a);
+                    to_cube(L2{}, m.shape2.b, b);
+                    try_shape(L2{}, m.shape2, a, b, true);
+                }
+                try_sphere(L2{}, m.sph2[0]);
+                try_sphere(L2{}, m.sph2[1]);
                 const bool upper_ok = cp[2] > m.upper_check_z;
-                const bool upper_any = __builtin_amdgcn_ballot_w64(upper_ok) != 0ull;      // practically never
-                // distance of a link-frame point to the cube (exact outside the cube, 0 inside): what the bounding spheres are tested with
-                auto box_dist = [&](int lk, const float local[3]) __attribute__((always_inline)) -> float {
-                    float Pb_[3], Pw_[3], pl[3];
-                    if (lk == 3) link_point<3>(k, local, Pb_);
-                    else if (lk == 2) link_point<2>(k, local, Pb_);
-                    else link_point<1>(k, local, Pb_);
-                    base_to_world(yw, Pb_, Pw_);
-                    float dd[3] = {Pw_[0] - cp[0], Pw_[1] - cp[1], Pw_[2] - cp[2]};
-                    mat3T_mul(R, dd, pl);
-                    float e[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) e[j] = f_max(f_abs(pl[j]) - hc[j], 0.0f);
-                    return f_sqrt(dot3(e, e));
-                };
-#pragma unroll 1
-                for (int g = 0; g < P.n_groups; ++g) {
-                    const int lk = P.grp_link[g];               // wave-uniform
-                    if (lk == 1 && !upper_any) continue;
-                    const bool grp_need = ((box_dist(lk, P.grp_c[g]) - P.grp_r[g]) < gap) && (lk != 1 || upper_ok);
-                    if (__builtin_amdgcn_ballot_w64(grp_need) == 0ull) continue;
-#pragma unroll 1
-                    for (int ci = P.grp_first[g]; ci < P.grp_first[g] + P.grp_count[g]; ++ci) {
-                        const TfCapsule& cap = m.caps[ci];
-                        const bool need = grp_need && ((box_dist(lk, P.cap_mid[ci]) - P.cap_bound[ci]) < gap);
-                        if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
-                        float Ab[3], Bb[3], A2[3], B2[3];
-                        if (lk == 3) { link_point<3>(k, cap.a, Ab); link_point<3>(k, cap.b, Bb); }
-                        else if (lk == 2) { link_point<2>(k, cap.a, Ab); link_point<2>(k, cap.b, Bb); }
-                        else { link_point<1>(k, cap.a, Ab); link_point<1>(k, cap.b, Bb); }
-                        base_to_world(yw, Ab, A2);
-                        base_to_world(yw, Bb, B2);
-                        float da[3] = {A2[0] - cp[0], A2[1] - cp[1], A2[2] - cp[2]};
-                        float db[3] = {B2[0] - cp[0], B2[1] - cp[1], B2[2] - cp[2]};
-                        float a[3], b[3], gx[3], gy[3], gn[3], gg;
-                        mat3T_mul(R, da, a);
-                        mat3T_mul(R, db, b);
-                        seg_box(a, b, hc, cap.radius, gg, gx, gy, gn);
-                        const bool take = need && (gg < gap);
-                        link = take ? lk : link; gap = take ? gg : gap; radius = take ? cap.radius : radius;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
-                    }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(upper_ok) != 0ull, 0)) {      // wave-level: practically never
+                    float a[3], b[3];
+                    to_cube(L1{}, m.shape1.a, a);
+                    to_cube(L1{}, m.shape1.b, b);
+                    try_shape(L1{}, m.shape1, a, b, upper_ok);
                 }
             }
             STAMP(sb_ + 2);

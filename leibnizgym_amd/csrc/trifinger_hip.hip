@@ -226,10 +226,11 @@ void tf_default_model(TfModel* m) {
     m->cap_a[0] = 0.0135f;
     m->cap_b[0] = 0.0185f; m->cap_b[2] = -0.1592f;
     m->cap_radius = 0.0102f;
-    {   // the other capsules of the three links: include/trifinger_default_caps.h (fitted to the collision hulls)
-        static const TfCapsule caps[] = { TF_DEFAULT_CAPS };
-        m->n_caps = (int32_t)(sizeof(caps) / sizeof(caps[0]));
-        for (int i = 0; i < m->n_caps; ++i) m->caps[i] = caps[i];
+    {   // shapes of the three links: include/trifinger_default_caps.h (fitted to the collision hulls by tools/fit_link_shapes.py)
+        static const TfLinkShape sh3 = TF_DEFAULT_SHAPE3, sh2 = TF_DEFAULT_SHAPE2, sh1 = TF_DEFAULT_SHAPE1;
+        static const TfSphere s3[1] = { TF_DEFAULT_SPH3 }, s2[2] = { TF_DEFAULT_SPH2 };
+        m->shape3 = sh3; m->shape2 = sh2; m->shape1 = sh1;
+        m->sph3[0] = s3[0]; m->sph2[0] = s2[0]; m->sph2[1] = s2[1];
     }
     m->upper_check_z = 0.17f;
     m->cube_half = 0.0325f;
@@ -348,38 +349,6 @@ static void build_tables(const TfConfig* c, int A, float* tab, int* obs_dim, int
     }
 }
 
-// Bounding spheres of the capsule table (double precision, then rounded): every entry (mid point, half length + radius) and every group
-// of consecutive entries of one link (centre = mean of the members' mid points, radius = the farthest member sphere).
-static void cap_bounds(DevParams& P) {
-    const TfModel& m = P.m;
-    P.n_groups = 0;
-    double mid[TF_MAX_CAPS][3], bound[TF_MAX_CAPS];
-    for (int i = 0; i < m.n_caps; ++i) {
-        double l2 = 0.0;
-        for (int k = 0; k < 3; ++k) { mid[i][k] = 0.5 * ((double)m.caps[i].a[k] + (double)m.caps[i].b[k]); const double d = (double)m.caps[i].b[k] - (double)m.caps[i].a[k]; l2 += d * d; }
-        bound[i] = 0.5 * sqrt(l2) + (double)m.caps[i].radius;
-        for (int k = 0; k < 3; ++k) P.cap_mid[i][k] = (float)mid[i][k];
-        P.cap_bound[i] = (float)bound[i];
-    }
-    for (int i = 0; i < m.n_caps;) {
-        int j = i;
-        while (j < m.n_caps && m.caps[j].link == m.caps[i].link) ++j;
-        double c[3] = {0.0, 0.0, 0.0}, r = 0.0;
-        for (int t = i; t < j; ++t) for (int k = 0; k < 3; ++k) c[k] += mid[t][k] / (double)(j - i);
-        for (int t = i; t < j; ++t) {
-            double d2 = 0.0;
-            for (int k = 0; k < 3; ++k) d2 += (mid[t][k] - c[k]) * (mid[t][k] - c[k]);
-            const double rr = sqrt(d2) + bound[t];
-            r = rr > r ? rr : r;
-        }
-        const int g = P.n_groups++;
-        P.grp_link[g] = m.caps[i].link; P.grp_first[g] = i; P.grp_count[g] = j - i;
-        for (int k = 0; k < 3; ++k) P.grp_c[g][k] = (float)c[k];
-        P.grp_r[g] = (float)r;
-        i = j;
-    }
-}
-
 int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (!cfg || !out) return TF_ERR_INVALID_ARG;
     if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
@@ -430,9 +399,6 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     P.dt = cfg->dt; P.hsub = cfg->dt / (float)cfg->substeps;
     for (int i = 0; i < 3; ++i) P.grav[i] = cfg->gravity[i];
     P.m = cfg->model;
-    if (P.m.n_caps < 0 || P.m.n_caps > TF_MAX_CAPS) { delete h; return TF_ERR_INVALID_ARG; }
-    for (int i = 0; i < P.m.n_caps; ++i) if (P.m.caps[i].link < 1 || P.m.caps[i].link > 3) { delete h; return TF_ERR_INVALID_ARG; }
-    cap_bounds(P);
     for (int i = 0; i < 3; ++i) P.wall_s[i] = (float)(((double)P.m.wall_r[i + 1] - (double)P.m.wall_r[i]) / ((double)P.m.wall_z[i + 1] - (double)P.m.wall_z[i]));
     void* tk = nullptr;
     e = hipMalloc(&tk, STAT_WORDS * sizeof(unsigned long long));

@@ -285,11 +285,6 @@ struct TfHandle_ {
     int timing_on;
     double timed_ms;
     int64_t timed_launches;
-    /* bounding spheres of the capsule table (tf_create): groups of consecutive entries of one link, and every entry */
-    int n_groups;
-    int grp_link[TF_MAX_CAPS], grp_first[TF_MAX_CAPS], grp_count[TF_MAX_CAPS];
-    float grp_c[TF_MAX_CAPS][3], grp_r[TF_MAX_CAPS];
-    float cap_mid[TF_MAX_CAPS][3], cap_bound[TF_MAX_CAPS];
     float wall_s[3];                    /* slopes of the boundary profile between its knots */
 };
 
@@ -367,10 +362,11 @@ void tf_default_model(TfModel* m) {
     m->cap_a[0] = 0.0135f; m->cap_a[1] = 0.0f; m->cap_a[2] = 0.0f;
     m->cap_b[0] = 0.0185f; m->cap_b[1] = 0.0f; m->cap_b[2] = -0.1592f; /* tip origin + (0,0,0.0034) */
     m->cap_radius = 0.0102f;
-    {   /* the other capsules of the three links: include/trifinger_default_caps.h (fitted to the collision hulls) */
-        static const TfCapsule caps[] = { TF_DEFAULT_CAPS };
-        m->n_caps = (int32_t)(sizeof(caps) / sizeof(caps[0]));
-        for (int i = 0; i < m->n_caps; ++i) m->caps[i] = caps[i];
+    {   /* shapes of the three links: include/trifinger_default_caps.h (fitted to the collision hulls by tools/fit_link_shapes.py) */
+        static const TfLinkShape sh3 = TF_DEFAULT_SHAPE3, sh2 = TF_DEFAULT_SHAPE2, sh1 = TF_DEFAULT_SHAPE1;
+        static const TfSphere s3[1] = { TF_DEFAULT_SPH3 }, s2[2] = { TF_DEFAULT_SPH2 };
+        m->shape3 = sh3; m->shape2 = sh2; m->shape1 = sh1;
+        m->sph3[0] = s3[0]; m->sph2[0] = s2[0]; m->sph2[1] = s2[1];
     }
     m->upper_check_z = 0.17f;             /* base height 0.29 - capsule radius - cube half diagonal - margin */
     m->cube_half = 0.0325f;               /* trifinger_env.py:143 */
@@ -503,42 +499,6 @@ static int needs_ext(const TfConfig* c) {
     return 0;
 }
 
-/* bounding spheres of the capsule table, in double precision and then rounded: entry = (mid point, half length + radius); group of
- * consecutive entries of one link = (mean of the members' mid points, the farthest member sphere) */
-static void cap_bounds(struct TfHandle_* h) {
-    const TfModel* m = &h->cfg.model;
-    double mid[TF_MAX_CAPS][3], bound[TF_MAX_CAPS];
-    h->n_groups = 0;
-    for (int i = 0; i < m->n_caps; ++i) {
-        double l2 = 0.0;
-        for (int k = 0; k < 3; ++k) {
-            mid[i][k] = 0.5 * ((double)m->caps[i].a[k] + (double)m->caps[i].b[k]);
-            const double d = (double)m->caps[i].b[k] - (double)m->caps[i].a[k];
-            l2 += d * d;
-        }
-        bound[i] = 0.5 * sqrt(l2) + (double)m->caps[i].radius;
-        for (int k = 0; k < 3; ++k) h->cap_mid[i][k] = (float)mid[i][k];
-        h->cap_bound[i] = (float)bound[i];
-    }
-    for (int i = 0; i < m->n_caps;) {
-        int j = i;
-        while (j < m->n_caps && m->caps[j].link == m->caps[i].link) ++j;
-        double c[3] = {0.0, 0.0, 0.0}, r = 0.0;
-        for (int t = i; t < j; ++t) for (int k = 0; k < 3; ++k) c[k] += mid[t][k] / (double)(j - i);
-        for (int t = i; t < j; ++t) {
-            double d2 = 0.0;
-            for (int k = 0; k < 3; ++k) d2 += (mid[t][k] - c[k]) * (mid[t][k] - c[k]);
-            const double rr = sqrt(d2) + bound[t];
-            r = rr > r ? rr : r;
-        }
-        const int g = h->n_groups++;
-        h->grp_link[g] = m->caps[i].link; h->grp_first[g] = i; h->grp_count[g] = j - i;
-        for (int k = 0; k < 3; ++k) h->grp_c[g][k] = (float)c[k];
-        h->grp_r[g] = (float)r;
-        i = j;
-    }
-}
-
 int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (!cfg || !out) return TF_ERR_INVALID_ARG;
     if (cfg->api_version != TF_API_VERSION || cfg->num_envs <= 0) return TF_ERR_INVALID_ARG;
@@ -551,8 +511,6 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
     if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
-    if (cfg->model.n_caps < 0 || cfg->model.n_caps > TF_MAX_CAPS) return TF_ERR_INVALID_ARG;
-    for (int i = 0; i < cfg->model.n_caps; ++i) if (cfg->model.caps[i].link < 1 || cfg->model.caps[i].link > 3) return TF_ERR_INVALID_ARG;
     struct TfHandle_* h = (struct TfHandle_*)calloc(1, sizeof(*h));
     if (h) { h->clip_obs = 3.402823466e38f; h->clip_act = 3.402823466e38f; }
     if (!h) return TF_ERR_INVALID_ARG;
@@ -561,7 +519,6 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     h->action_dim = tf_action_dim(cfg->command_mode);
     build_tables(h);
     h->ext = needs_ext(&h->cfg);
-    cap_bounds(h);
     for (int i = 0; i < 3; ++i)
         h->wall_s[i] = (float)(((double)cfg->model.wall_r[i + 1] - (double)cfg->model.wall_r[i]) / ((double)cfg->model.wall_z[i + 1] - (double)cfg->model.wall_z[i]));
     *out = h;
@@ -927,7 +884,7 @@ static inline float seg_box_g(const float a[3], const float d[3], float s, const
  * box, unit direction nc from y to x, gap = |x - y| - radius.  A segment point inside the box is pushed out through
  * the nearest face. */
 static void seg_box(const float a[3], const float b[3], const float hc[3], float radius, float* gap_out, float x[3], float y[3],
-                    float nc[3]) {
+                    float nc[3], float* s_out) {
     float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     const float g0 = seg_box_g(a, d, 0.0f, hc), g1 = seg_box_g(a, d, 1.0f, hc);
     float lo = 0.0f, glo = g0, hi = 1.0f, ghi = g1;
@@ -947,6 +904,7 @@ static void seg_box(const float a[3], const float b[3], const float hc[3], float
     float s = f_clamp(FMA(-glo, (hi - lo) * f_rcp(f_max(ghi - glo, 1e-30f)), lo), lo, hi);
     if (g0 > 0.0f) s = 0.0f;
     if (!(g1 > 0.0f)) s = 1.0f;
+    *s_out = s;
     for (int i = 0; i < 3; ++i) { x[i] = FMA(s, d[i], a[i]); y[i] = f_clamp(x[i], -hc[i], hc[i]); }
     float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
     float dist2 = dot3(ev, ev);
@@ -972,6 +930,31 @@ static void seg_box(const float a[3], const float b[3], const float hc[3], float
 
 /* closest points of two segments p1-q1 and p2-q2 (Ericson, Real-Time Collision Detection 5.1.9; both segments have
  * positive length) */
+/* the same for a sphere (centre x in the box frame): the tail of seg_box for a segment of zero length */
+static void point_box(const float x[3], const float hc[3], float radius, float* gap_out, float y[3], float nc[3]) {
+    for (int i = 0; i < 3; ++i) y[i] = f_clamp(x[i], -hc[i], hc[i]);
+    float ev[3] = {x[0] - y[0], x[1] - y[1], x[2] - y[2]};
+    float dist2 = dot3(ev, ev);
+    if (dist2 > 1e-12f) {
+        float inv = f_rsqrt(dist2);
+        float dist = dist2 * inv;
+        nc[0] = ev[0] * inv; nc[1] = ev[1] * inv; nc[2] = ev[2] * inv;
+        *gap_out = dist - radius;
+    } else {
+        int bi = 0;
+        float best = f_abs(x[0]) - hc[0];
+        float p1 = f_abs(x[1]) - hc[1];
+        if (p1 > best) { best = p1; bi = 1; }
+        float p2 = f_abs(x[2]) - hc[2];
+        if (p2 > best) { best = p2; bi = 2; }
+        float xb = x[bi];
+        float sg = (xb < 0.0f) ? -1.0f : 1.0f;
+        nc[0] = (bi == 0) ? sg : 0.0f; nc[1] = (bi == 1) ? sg : 0.0f; nc[2] = (bi == 2) ? sg : 0.0f;
+        y[bi] = sg * hc[bi];
+        *gap_out = best - radius;
+    }
+}
+
 static void seg_seg(const float p1[3], const float q1[3], const float p2[3], const float q2[3], float c1[3], float c2[3]) {
     float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]};
     float d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
@@ -1151,15 +1134,13 @@ static inline float pair_factor(float mu_a, float fa1, float mu_b, float fb1) {
     return FMA(mu_b * inv, fb1, FMA(mu_a * inv, fa1, 1.0f));
 }
 
-/* distance of a point given in the frame of link `lk` of finger f to the cube (exact outside the cube, 0 inside) */
-static float box_dist(const TfModel* m, int f, const FK* k, int lk, const float local[3], const float cpr[3], const float R[9], const float hc[3]) {
-    float Pb[3], Pw[3], pl[3], e[3];
+/* a point given in the frame of link `lk` of finger f, in the cube frame */
+static void to_cube(const TfModel* m, int f, const FK* k, int lk, const float local[3], const float cpr[3], const float R[9], float out[3]) {
+    float Pb[3], Pw[3];
     link_point(k, lk, local, Pb);
     base_to_world(m, f, Pb, Pw);
     float dd[3] = {Pw[0] - cpr[0], Pw[1] - cpr[1], Pw[2] - cpr[2]};
-    mat3T_mul(R, dd, pl);
-    for (int j = 0; j < 3; ++j) e[j] = f_max(f_abs(pl[j]) - hc[j], 0.0f);
-    return sqrtf(dot3(e, e));
+    mat3T_mul(R, dd, out);
 }
 
 /* One solver substep of length h for one env.  Phases and roles: F1 free motion of each finger,
@@ -1372,41 +1353,47 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         /* --- finger vs cube: the link capsule with the smallest gap holds the contact --- */
         float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
         int link = 0;
-        /* the fingertip capsule first, then the table of the model: consecutive entries of one link form a group; a group, and inside
-         * it a capsule, is looked at only when a lower bound of its gap - exact distance of the centre of its bounding sphere to the
-         * cube minus the sphere's radius - is below the best gap so far */
-        {
-            float da[3] = {g->Aw[0] - cpr[0], g->Aw[1] - cpr[1], g->Aw[2] - cpr[2]};
-            float db[3] = {g->Bw[0] - cpr[0], g->Bw[1] - cpr[1], g->Bw[2] - cpr[2]};
-            float a[3], b[3];
-            mat3T_mul(R, da, a);
-            mat3T_mul(R, db, b);
-            seg_box(a, b, hc, m->cap_radius, &gap, x, y, nc);
-            link = 3; radius = m->cap_radius;
-        }
-        const int upper_ok = cube_top_check > m->upper_check_z;
-        for (int gi = 0; gi < H->n_groups; ++gi) {
-            const int lk = H->grp_link[gi];
-            if (lk == 1 && !upper_ok) continue;
-            if (!((box_dist(m, f, k, lk, H->grp_c[gi], cpr, R, hc) - H->grp_r[gi]) < gap)) continue;
-            for (int ci = H->grp_first[gi]; ci < H->grp_first[gi] + H->grp_count[gi]; ++ci) {
-                const TfCapsule* cap = &m->caps[ci];
-                if (!((box_dist(m, f, k, lk, H->cap_mid[ci], cpr, R, hc) - H->cap_bound[ci]) < gap)) continue;
-                float Ab[3], Bb[3], Aw[3], Bw[3];
-                link_point(k, lk, cap->a, Ab);
-                link_point(k, lk, cap->b, Bb);
-                base_to_world(m, f, Ab, Aw);
-                base_to_world(m, f, Bb, Bw);
-                float da[3] = {Aw[0] - cpr[0], Aw[1] - cpr[1], Aw[2] - cpr[2]};
-                float db[3] = {Bw[0] - cpr[0], Bw[1] - cpr[1], Bw[2] - cpr[2]};
-                float a[3], b[3], gx[3], gy[3], gn[3], gg;
-                mat3T_mul(R, da, a);
-                mat3T_mul(R, db, b);
-                seg_box(a, b, hc, cap->radius, &gg, gx, gy, gn);
-                if (gg < gap) {
-                    link = lk; gap = gg; radius = cap->radius;
-                    for (int i = 0; i < 3; ++i) { x[i] = gx[i]; y[i] = gy[i]; nc[i] = gn[i]; }
+        /* candidates in order (a later one takes over only with a strictly smaller gap): the distal body (TfLinkShape: tapered rounded
+         * box along the fingertip capsule's axis), its housing sphere, the middle link, its two housing spheres, and - for a cube above
+         * upper_check_z - the upper link */
+        for (int pi = 0; pi < 6; ++pi) {
+            /* 0: shape3  1: sph3  2: shape2  3, 4: sph2  5: shape1 */
+            const int lk = (pi < 2) ? 3 : ((pi < 5) ? 2 : 1);
+            const TfLinkShape* sh = (pi == 0) ? &m->shape3 : ((pi == 2) ? &m->shape2 : ((pi == 5) ? &m->shape1 : NULL));
+            const TfSphere* sp = (pi == 1) ? &m->sph3[0] : ((pi == 3 || pi == 4) ? &m->sph2[pi - 3] : NULL);
+            if (lk == 1 && !(cube_top_check > m->upper_check_z)) continue;
+            float gx[3], gy[3], gn[3], gg, rad;
+            if (sh) {
+                float a[3], b[3], D, spar;
+                if (pi == 0) {               /* the axis end points of the distal body are the fingertip capsule's */
+                    float da[3] = {g->Aw[0] - cpr[0], g->Aw[1] - cpr[1], g->Aw[2] - cpr[2]};
+                    float db[3] = {g->Bw[0] - cpr[0], g->Bw[1] - cpr[1], g->Bw[2] - cpr[2]};
+                    mat3T_mul(R, da, a);
+                    mat3T_mul(R, db, b);
+                } else {
+                    to_cube(m, f, k, lk, sh->a, cpr, R, a);
+                    to_cube(m, f, k, lk, sh->b, cpr, R, b);
                 }
+                seg_box(a, b, hc, 0.0f, &D, gx, gy, gn, &spar);
+                float uw[3], ub[3], ul[3];
+                mat3_mul(R, gn, uw);
+                dir_world_to_base(m, f, uw, ub);
+                rot_link_T(k, lk, ub, ul);
+                const float u1 = -ul[0], u2 = (lk == 1) ? -ul[2] : -ul[1];
+                const float rho = FMA(spar, sh->rho[1] - sh->rho[0], sh->rho[0]);
+                const float h1 = FMA(spar, sh->w1[1] - sh->w1[0], sh->w1[0]) - rho, h2 = FMA(spar, sh->w2[1] - sh->w2[0], sh->w2[0]) - rho;
+                const float o1 = FMA(spar, sh->o1[1] - sh->o1[0], sh->o1[0]), o2 = FMA(spar, sh->o2[1] - sh->o2[0], sh->o2[0]);
+                const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
+                gg = D - ext;
+                rad = ext;
+            } else {
+                to_cube(m, f, k, lk, sp->c, cpr, R, gx);
+                point_box(gx, hc, sp->radius, &gg, gy, gn);
+                rad = sp->radius;
+            }
+            if (link == 0 || gg < gap) {
+                link = lk; gap = gg; radius = rad;
+                for (int i = 0; i < 3; ++i) { x[i] = gx[i]; y[i] = gy[i]; nc[i] = gn[i]; }
             }
         }
         g->fc_link = 0;

@@ -30,10 +30,25 @@ PHASE3_SIZE = tuple(float(x) for x in FIXTURE["phase3_size"])
 PHASE3_DENSITY = float(FIXTURE["phase3_density"])
 
 
-def model_capsules(m):
-    """[(link, a, b, radius)] of a TfModel: the fingertip capsule first, then its table - the order the step tests them in"""
-    caps = [(3, np.array(list(m.cap_a), dtype=np.float64), np.array(list(m.cap_b), dtype=np.float64), float(m.cap_radius))]
-    for i in range(m.n_caps):
-        c = m.caps[i]
-        caps.append((int(c.link), np.array(list(c.a), dtype=np.float64), np.array(list(c.b), dtype=np.float64), float(c.radius)))
-    return caps
+E12 = {3: (np.array([1.0, 0, 0]), np.array([0, 1.0, 0])), 2: (np.array([1.0, 0, 0]), np.array([0, 1.0, 0])), 1: (np.array([1.0, 0, 0]), np.array([0, 0, 1.0]))}
+
+
+def model_shapes(m):
+    """the collision shapes of a TfModel in the order the step tests them: [("shape", link, dict) | ("sphere", link, centre, radius)];
+    a shape dict holds the axis a, b, the width directions e1, e2 of the link frame and the (s = 0, s = 1) pairs w1, w2, rho, o1, o2"""
+    v = lambda x: np.array(list(x), dtype=np.float64)      # noqa: E731
+    out = []
+    for link, sh, spheres in ((3, m.shape3, m.sph3), (2, m.shape2, m.sph2), (1, m.shape1, ())):
+        out.append(("shape", link, dict(a=v(sh.a), b=v(sh.b), e1=E12[link][0], e2=E12[link][1], w1=v(sh.w1), w2=v(sh.w2), rho=v(sh.rho),
+                                        o1=v(sh.o1), o2=v(sh.o2))))
+        for sp in spheres:
+            out.append(("sphere", link, v(sp.c), float(sp.radius)))
+    return out
+
+
+def shape_extent(sh, s, u_link):
+    """support function of the cross-section of a link shape at parameter s of its axis along the unit direction u_link (link frame)"""
+    lerp = lambda p: p[0] + s * (p[1] - p[0])      # noqa: E731
+    rho = lerp(sh["rho"])
+    u1, u2 = float(u_link @ sh["e1"]), float(u_link @ sh["e2"])
+    return (lerp(sh["w1"]) - rho) * abs(u1) + (lerp(sh["w2"]) - rho) * abs(u2) + rho + lerp(sh["o1"]) * u1 + lerp(sh["o2"]) * u2

@@ -26,8 +26,8 @@ from oracle_util import load_oracle
 H_BASE = MF.H_BASE
 YAW = MF.YAW
 _M = load_oracle().default_model()
-CAPSULES = MF.model_capsules(_M)            # [(link, a, b, radius)]: fingertip capsule first, then the table, in test order
-TIP_CAP = CAPSULES[0]
+SHAPES = MF.model_shapes(_M)                # the collision shapes of the three links in test order (tests/model_fixture.py)
+TIP_CAP = (3, np.array(list(_M.cap_a), dtype=np.float64), np.array(list(_M.cap_b), dtype=np.float64), float(_M.cap_radius))
 UPPER_CHECK_Z = float(_M.upper_check_z)
 CUBE_HALF = MF.CUBE_SIZE / 2.0
 CUBE_MASS = MF.CUBE_DENSITY * MF.CUBE_SIZE ** 3
@@ -44,27 +44,47 @@ WALL_R = tuple(float(x) for x in _M.wall_r)
 WALL_Z = tuple(float(x) for x in _M.wall_z)
 
 
-def link_capsules(link):
-    """[(a, b, radius)] of the capsules of one link (1 upper, 2 middle, 3 lower)"""
-    return [(a, b, r) for lk, a, b, r in CAPSULES if lk == link]
+def link_rotation_world(f, q, link):
+    return rot_z(YAW[f]) @ frames(q)[link - 1][0]
+
+
+def shape_candidates(f, qf, cube_p, R, hc, links=(3, 2, 1)):
+    """every collision shape of finger f (of the given links) against the box at cube_p / R with half extents hc:
+    [(gap, link, x, y, ext)] with x the axis point (or sphere centre) and y the closest point of the box, both in the box frame, and
+    ext what lies between x and the shape's surface along the line to y.  A tapered rounded box (include/trifinger.h: TfLinkShape):
+    closest points of its AXIS and the box, then the support function of its cross-section along the direction to the box."""
+    out = []
+    for entry in SHAPES:
+        link = entry[1]
+        if link not in links:
+            continue
+        if entry[0] == "sphere":
+            c = R.T @ (link_point_world(f, qf, link, entry[2]) - cube_p)
+            yb = np.clip(c, -hc, hc)
+            d = np.linalg.norm(c - yb)
+            if d <= 1e-6:                           # centre inside the cube: outside the domain of the reference (reported as a deep overlap)
+                out.append((-1.0, link, c, yb, entry[3]))
+                continue
+            out.append((d - entry[3], link, c, yb, entry[3]))
+            continue
+        sh = entry[2]
+        a = R.T @ (link_point_world(f, qf, link, sh["a"]) - cube_p)
+        b = R.T @ (link_point_world(f, qf, link, sh["b"]) - cube_p)
+        x, yb = segment_box(a, b, hc)
+        D = np.linalg.norm(x - yb)
+        if D <= 1e-6:                               # axis inside the cube: outside the domain of the reference (reported as a deep overlap)
+            out.append((-1.0, link, x, yb, 0.0))
+            continue
+        spar = float(np.clip((x - a) @ (b - a) / ((b - a) @ (b - a)), 0.0, 1.0))
+        u_link = link_rotation_world(f, qf, link).T @ (R @ ((yb - x) / D))       # from the axis point towards the cube, link frame
+        ext = MF.shape_extent(sh, spar, u_link)
+        out.append((D - ext, link, x, yb, ext))
+    return out
 
 
 def finger_gaps(f, qf, cube_p, R, hc, links=(3, 2, 1)):
-    """gap of every capsule of finger f (of the given links) against the box at cube_p / R with half extents hc: [(gap, link)]"""
-    out = []
-    for lk, la, lb, rad in CAPSULES:
-        if lk not in links:
-            continue
-        mid = R.T @ (link_point_world(f, qf, lk, 0.5 * (la + lb)) - cube_p)
-        far = np.linalg.norm(np.maximum(np.abs(mid) - hc, 0.0)) - (0.5 * np.linalg.norm(lb - la) + rad)
-        if far > 0.05:                                # more than 5 cm away whatever its orientation: the bound is reported as its gap
-            out.append((far, lk))
-            continue
-        a = R.T @ (link_point_world(f, qf, lk, la) - cube_p)
-        b = R.T @ (link_point_world(f, qf, lk, lb) - cube_p)
-        x, y = segment_box(a, b, hc)
-        out.append((np.linalg.norm(x - y) - rad, lk))
-    return out
+    """[(gap, link)] of every collision shape of finger f (of the given links) against the box"""
+    return [(g, lk) for g, lk, _, _, _ in shape_candidates(f, qf, cube_p, R, hc, links)]
 
 
 def rot_z(a):
@@ -273,23 +293,12 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         sl = slice(3 * f, 3 * f + 3)
         qf = q[sl]
         best = None
-        for cand, la, lb, rad in CAPSULES:            # every capsule of the finger: the smallest gap holds the contact
-            if cand == 1 and not cp[2] > UPPER_CHECK_Z:
-                continue
-            if best is not None:                      # (a capsule whose bounding sphere is farther than the best gap cannot win: skip the minimiser)
-                mid = R.T @ (link_point_world(f, qf, cand, 0.5 * (la + lb)) - cp)
-                if np.linalg.norm(np.maximum(np.abs(mid) - hc, 0.0)) - (0.5 * np.linalg.norm(lb - la) + rad) >= best[0]:
-                    continue
-            a = R.T @ (link_point_world(f, qf, cand, la) - cp)
-            b = R.T @ (link_point_world(f, qf, cand, lb) - cp)
-            x, y = segment_box(a, b, hc)
-            dist = np.linalg.norm(x - y)
-            if dist <= 1e-6:
-                raise ValueError("capsule axis inside the cube: outside the domain of the reference")
-            gap = dist - rad
-            if best is None or gap < best[0]:
-                best = (gap, cand, x, y, rad)
+        for gap_c, cand, xc, yc, ext in shape_candidates(f, qf, cp, R, hc, links=(3, 2, 1) if cp[2] > UPPER_CHECK_Z else (3, 2)):
+            if best is None or gap_c < best[0]:       # the shape with the smallest gap holds the contact (first wins a tie)
+                best = (gap_c, cand, xc, yc, ext)
         gap, link, x, y, rad = best
+        if gap <= -1.0:
+            raise ValueError("a shape's axis lies inside the cube: outside the domain of the reference")
         if gap < MARGIN:
             n = R @ ((x - y) / np.linalg.norm(x - y))
             t1, t2 = tangent_basis(n)
