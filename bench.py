@@ -41,7 +41,7 @@ N_SIMD = 256 * 4                 # SIMDs of the chip (MI355X_MICROARCH.md: 256 C
 VALU_CYCLES_PER_INST = 2.0       # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
 TF_OBS_BASE, TF_STATES_EXTRA = 32, 72     # include/trifinger.h: obs = 32 + A values, states = obs + 72
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs (algorithmic)
-FLOP_PER_ENV_STEP = 33.0e3       # SURVEY.md 8(d) estimate (2 substeps, 8 PGS iterations)
+FLOP_PER_ENV_STEP_ESTIMATE = 33.0e3     # SURVEY.md 8(d) paper estimate; used only when no counter profile of this workload exists
 
 
 def load_pmc_profile(n, asym, ext=False):
@@ -183,8 +183,25 @@ def cpu_baseline(asym, budget_s=12.0):
         if best is None or r[3] > best[3]:
             best = r
     used, sa, ea, va = best
+    # the per-GPU size of BASELINE configs[1] / [3] / [4] as well: same team size, a small budget
+    n_small = 8192
+    acts_s = [(torch.rand(n_small, 9) * 2 - 1).contiguous() for _ in range(4)]
+
+    def run_small(threads, budget):
+        lib.dll.tfo_omp_threads(threads)
+        eng = TrifingerEngine(make_config(lib, n_small, seed=7, **workload_kwargs(asym)), device="cpu", lib=lib)
+        eng.reset()
+        eng.step(acts_s[0])
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < budget:
+            eng.step(acts_s[k % 4]); k += 1
+        el = time.perf_counter() - t0
+        eng.close()
+        return n_small * k / el
+    v_small = run_small(used, 1.5)
     return {"value": va, "unit": "env-steps/s", "cores": used, "kind": "port",
-            "single_thread_value": v1,
+            "single_thread_value": v1, "value_at_8192_envs": v_small,
             "sample": f"{n} envs x {sa} steps of the same workload on {used} OpenMP threads (static schedule over envs, "
                       f"{ea:.1f} s) and x {s1} steps on 1 thread ({e1:.1f} s); reference IsaacGym CPU pipeline not "
                       f"available, baseline is this repo's CPU oracle (oracle/tf_oracle.c)"}
@@ -396,7 +413,13 @@ def main():
             "valu_issue": issue,
             "valu_issue_frac": issue["valu_issue_frac"] if issue else None,
             "simd_valu_busy": simd_busy,
-            "fp32_frac_est": (FLOP_PER_ENV_STEP * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
+            # measured operation count: vector-ALU lane-operations per env-step = SQ_INSTS_VALU x 64 lanes / N (every wave64 VALU
+            # instruction of the launch, fp32 arithmetic and the integer / select / move instructions around it alike; an FMA is ONE
+            # lane-operation).  The chip retires 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-operations/s (its 157.3 TFLOP/s
+            # count an FMA as two), so valu_lane_ops_frac = lane-operations/s / 78.6e12.
+            "valu_lane_ops_per_env_step": (pmc["SQ_INSTS_VALU"] * 64.0 / n) if (pmc and "SQ_INSTS_VALU" in pmc) else None,
+            "valu_lane_ops_frac": (pmc["SQ_INSTS_VALU"] * 64.0 / kern_avg_s / (FP32_PEAK_TFLOPS * 0.5e12)) if (pmc and kern_n and "SQ_INSTS_VALU" in pmc) else None,
+            "fp32_frac_est": (FLOP_PER_ENV_STEP_ESTIMATE * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
         },
     }
     if global_stats is not None:
