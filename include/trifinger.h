@@ -102,13 +102,15 @@ enum {
     /* Warm start of the contact solver (an implementation choice, not algorithmic traffic: SURVEY 8d).  The impulses
      * of the last substep seed the next one when the contact kept its identity; a reset clears them.               */
     TF_S_LAM_FC = 98,    /* 12 finger-cube contact of finger f at [4f..4f+3]: normal impulse, world friction impulse (3) */
-    TF_S_FC_LINK = 110,  /*  3 link that held the finger-cube contact (0 none, 1 upper, 2 middle, 3 distal: any of its capsules) */
+    TF_S_FC_LINK = 110,  /*  3 activity code of finger f's warm-start rows: link that held the finger-cube contact (0 none, 1 upper, 2 middle,
+                              3 distal) + 4 if the fingertip-boundary contact pushed; the rows of an inactive contact (TF_S_LAM_FC of a
+                              finger with link 0, TF_S_LAM_TW without the 4) are neither read nor written: content undefined          */
     TF_S_LAM_TF = 113,   /*  9 fingertip-floor contact of finger f at [3f..3f+2]: normal, tangent 1, tangent 2       */
     TF_S_LAM_TW = 122,   /*  9 fingertip-boundary-wall contact of finger f, same layout                             */
     TF_S_LAM_CF = 131,   /* 12 cube corner i against the floor at [3i..3i+2]: +z (normal), +x, +y                   */
     TF_S_CF_FACE = 143,  /*  1 cube face whose corners those were (0 none, 1..6)                                   */
     TF_S_LAM_CW = 144,   /* 12 cube corner i against the boundary wall at [3i..3i+2]: normal, tangent, +z          */
-    TF_S_CW_FACE = 156,  /*  1 cube face whose corners those were                                                  */
+    TF_S_CW_FACE = 156,  /*  1 cube face whose corners those were; 0 while no corner touches the boundary (TF_S_LAM_CW then undefined) */
     TF_STATE_ROWS = 157
 };
 #define TF_NUM_DR 14
@@ -182,13 +184,13 @@ typedef struct TfModel {
                                    * the shape of the fingertip-floor / fingertip-wall / finger-finger contacts and the axis of shape3 */
     float cap_radius;             /* 0.0102: radius of the fingertip sphere (SIM__BL-Finger_Tip_actual_tip.obj)                   */
     /* the shapes of the three links (include/trifinger_default_caps.h, fitted to the hulls by tools/fit_link_shapes.py); candidates of
-     * the finger-cube contact in this order, a later one takes over only with a strictly smaller gap: shape3, sph3, shape2, sph2[0],
-     * sph2[1], and - only for a cube above upper_check_z - shape1.  shape3 has the axis cap_a -> cap_b and ends (s = 1) in the
+     * the finger-cube contact in this order, a later one takes over only with a strictly smaller gap: shape3, sph3, shape2, sph2[1],
+     * and - only for a cube above upper_check_z, because they hang at the height of the base - sph2[0] and shape1.  shape3 has the axis cap_a -> cap_b and ends (s = 1) in the
      * fingertip sphere: w1 = w2 = rho = cap_radius there.  The joint housings are pucks about the joint axes: one sphere each.   */
     TfLinkShape shape3; TfSphere sph3[1];     /* distal body (lower link + tip link); the joint-3 housing at its top                 */
     TfLinkShape shape2; TfSphere sph2[2];     /* middle link; the joint-2 housing (top) and the joint-3 housing (bottom)             */
     TfLinkShape shape1;                       /* upper link                                                                          */
-    float upper_check_z;          /* the capsules of the upper link are only tested for a cube centre above this height            */
+    float upper_check_z;          /* the upper link and the joint-2 housing are only tested for a cube centre above this height    */
     /* cube (cube_multicolor_rrc.urdf:10-18) */
     float cube_half;              /* 0.0325 */
     float cube_mass;              /* 291.3 * 0.065^3 */

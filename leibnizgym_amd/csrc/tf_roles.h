@@ -360,6 +360,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
     }
     float lam0_fc[4], lam0_link = 0.0f, lam0_tf[3], lam0_tw[3];  // solver warm start for the first substep
+    // activity code of this finger's warm-start rows (row TF_S_FC_LINK): link that held the finger-cube contact + 4 if the fingertip-wall
+    // contact pushed.  The rows of an inactive contact are neither loaded nor stored (their content is then undefined).
+    float fc_code = 0.0f;
+    if (MODE & M_SIM) fc_code = LDST(TF_S_FC_LINK + f);
     if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
     if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
     else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
@@ -369,11 +373,21 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     // The warm-start rows are first needed when the contact rows are built, a free-motion phase later: issued here, behind the
     // barrier, they stay out of the load burst every workgroup of the launch starts with.
     if (MODE & M_SIM) {
+        const int code = (int)fc_code;
+        const bool fc_was = (code & 3) != 0, tw_was = (code & 4) != 0;
+        lam0_link = (float)(code & 3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lam0_fc[j] = LDST(TF_S_LAM_FC + 4 * f + j);
-        lam0_link = LDST(TF_S_FC_LINK + f);
+        for (int j = 0; j < 4; ++j) lam0_fc[j] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { lam0_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam0_tw[j] = LDST(TF_S_LAM_TW + 3 * f + j); }
+        for (int j = 0; j < 3; ++j) { lam0_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam0_tw[j] = 0.0f; }
+        if (__builtin_amdgcn_ballot_w64(fc_was) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float t = LDST(TF_S_LAM_FC + 4 * f + j); lam0_fc[j] = fc_was ? t : 0.0f; }
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tw_was) != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const float t = LDST(TF_S_LAM_TW + 3 * f + j); lam0_tw[j] = tw_was ? t : 0.0f; }
+        }
     }
     // ---- masked _reset_impl for this finger (trifinger_env.py:373-423, 1101-1147) ----
     const bool rflag = (MODE & M_RESETS) && (IS_RESET || fl_reset != 0);
@@ -468,8 +482,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = t[j];
-        if (!(MODE & M_SIM) || !ASYM) {                         // fingertip wrench accumulator of the step: a launch that also simulates
-#pragma unroll                                                  // starts from zero in registers and stores after its first substep
+        if (!(MODE & M_SIM)) {                                  // fingertip wrench accumulator of the step: a launch that also simulates
+#pragma unroll                                                  // starts from zero in registers (and the fused step never stores it)
             for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, 0.0f);
         }
     }
@@ -477,19 +491,21 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) STST(TF_S_TAU + 3 * f + j, tau[j]);
     }
-    if (MODE & M_RESETS) {                                      // a reset clears the solver warm start
-        if (rflag) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, 0.0f);
+    if (MODE & M_RESETS) {                                      // a reset clears the solver warm start: activity code 0 (the finger-cube and
+        if (rflag) {                                            // fingertip-wall rows are then ignored), fingertip-floor rows zero
             STST(TF_S_FC_LINK + f, 0.0f);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { STST(TF_S_LAM_TF + 3 * f + j, 0.0f); STST(TF_S_LAM_TW + 3 * f + j, 0.0f); }
+            for (int j = 0; j < 3; ++j) STST(TF_S_LAM_TF + 3 * f + j, 0.0f);
         }
     }
     // =================================================================================================================
     // physics: decimation x substeps solver substeps
     // =================================================================================================================
     STAMP(2);
+    // A launch that simulates AND emits the observations (the fused step) hands the fingertip wrench of the step from its last substep to
+    // the post phase in registers: the TF_S_FT rows ("split path only") are neither written nor read by it.
+    constexpr bool FT_IN_REGS = ((MODE & M_SIM) != 0) && ((MODE & M_POST) != 0);
+    float ft_keep[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (MODE & M_SIM) {
         const float h = P.hsub, inv_h = 1.0f / h;
         const int nsub = sa.nsim * P.substeps;
@@ -591,7 +607,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             quat_to_rot(cq, R);
             // finger vs cube: the shape with the smallest gap holds the contact (TfLinkShape, include/trifinger.h): the distal body
             // first - its axis is the fingertip capsule's, it ends in the fingertip sphere -, its housing sphere, the middle link with
-            // its two housing spheres and - only for a cube above upper_check_z, practically never - the upper link; a later candidate
+            // its joint-3 housing sphere and - only for a cube above upper_check_z, practically never - its joint-2 housing sphere and the
+            // upper link; a later candidate
             // takes over only with a strictly smaller gap.  All shape constants are scalars of the parameter block.
             float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
             int link = 0;
@@ -625,12 +642,12 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { x[j] = take ? gx[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
             };
-            auto try_sphere = [&](auto lkc, const TfSphere& sp) __attribute__((always_inline)) {
+            auto try_sphere = [&](auto lkc, const TfSphere& sp, bool allowed) __attribute__((always_inline)) {
                 constexpr int LK = decltype(lkc)::value;
                 float c[3], gy[3], gn[3], gg;
                 to_cube(lkc, sp.c, c);
                 point_box(c, hc, sp.radius, gg, gy, gn);
-                const bool take = gg < gap;
+                const bool take = allowed && (gg < gap);
                 link = take ? LK : link; gap = take ? gg : gap; radius = take ? sp.radius : radius;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { x[j] = take ? c[j] : x[j]; y[j] = take ? gy[j] : y[j]; nc[j] = take ? gn[j] : nc[j]; }
@@ -645,17 +662,19 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     mat3T_mul(R, db, b);
                     try_shape(L3{}, m.shape3, a, b, true);
                 }
-                try_sphere(L3{}, m.sph3[0]);
+                try_sphere(L3{}, m.sph3[0], true);
                 {
                     float a[3], b[3];
                     to_cube(L2{}, m.shape2.a, a);
                     to_cube(L2{}, m.shape2.b, b);
                     try_shape(L2{}, m.shape2, a, b, true);
                 }
-                try_sphere(L2{}, m.sph2[0]);
-                try_sphere(L2{}, m.sph2[1]);
+                try_sphere(L2{}, m.sph2[1], true);
+                // the joint-2 housing of the middle link and the upper link hang at the height of the base (0.29 m): only a cube above
+                // upper_check_z can reach them
                 const bool upper_ok = cp[2] > m.upper_check_z;
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(upper_ok) != 0ull, 0)) {      // wave-level: practically never
+                    try_sphere(L2{}, m.sph2[0], upper_ok);
                     float a[3], b[3];
                     to_cube(L1{}, m.shape1.a, a);
                     to_cube(L1{}, m.shape1.b, b);
@@ -887,11 +906,18 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             // ---- impulses kept for the next substep (state rows), fingertip wrench sensor, integration ----
             const bool last_sub = s == nsub - 1;                // wave-uniform: state rows after the last substep, LDS parking otherwise
             if (last_sub) {
+                const bool tw_now = tc[1].lam[0] > 0.0f;
+                STST(TF_S_FC_LINK + f, (float)(cur_link + (tw_now ? 4 : 0)));
+                if (cur_link != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, lam_fc[j]);
-                STST(TF_S_FC_LINK + f, (float)cur_link);
+                    for (int j = 0; j < 4; ++j) STST(TF_S_LAM_FC + 4 * f + j, lam_fc[j]);
+                }
 #pragma unroll
-                for (int d = 0; d < 3; ++d) { STST(TF_S_LAM_TF + 3 * f + d, tc[0].lam[d]); STST(TF_S_LAM_TW + 3 * f + d, tc[1].lam[d]); }
+                for (int d = 0; d < 3; ++d) STST(TF_S_LAM_TF + 3 * f + d, tc[0].lam[d]);
+                if (__builtin_expect(tw_now, 0)) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) STST(TF_S_LAM_TW + 3 * f + d, tc[1].lam[d]);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) LD(L_PARK(f) + PK_FC + j) = lam_fc[j];
@@ -924,7 +950,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
                 if (last_sub) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) STST(TF_S_FT + 6 * f + j, ft[j]);
+                    for (int j = 0; j < 6; ++j) { if (FT_IN_REGS) ft_keep[j] = ft[j]; else STST(TF_S_FT + 6 * f + j, ft[j]); }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) LD(L_PARK(f) + PK_FT + j) = ft[j];
@@ -952,10 +978,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         for (int j = 0; j < 3; ++j) { boff_p[j] = (EXT && P.dr_enable) ? LDST(TF_S_DR + TF_DR_BASE_POS + j) : 0.0f; if (EXT) tips[j] = tips[j] + boff_p[j]; }   // robot frame -> world
         float tip_prev[3], tau_p[3], act_p[AJ], ft[6];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j); tau_p[j] = LDST(TF_S_TAU + 3 * f + j); }
+        for (int j = 0; j < 3; ++j) { tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j); tau_p[j] = (MODE & M_TORQUE) ? tau[j] : LDST(TF_S_TAU + 3 * f + j); }
         if (ASYM) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ft[j] = LDST(TF_S_FT + 6 * f + j);
+            for (int j = 0; j < 6; ++j) ft[j] = FT_IN_REGS ? ft_keep[j] : LDST(TF_S_FT + 6 * f + j);
         }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {         // the last command, as _action_buf holds it (written above by this workgroup)
@@ -976,7 +1002,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
             for (int j = 0; j < 3; ++j) { q[j] = m.q_default[j]; qd[j] = 0.0f; }
 #pragma unroll
-            for (int j = 0; j < 6; ++j) { ft[j] = 0.0f; STST(TF_S_FT + 6 * f + j, 0.0f); }
+            for (int j = 0; j < 6; ++j) { ft[j] = 0.0f; if (!FT_IN_REGS) STST(TF_S_FT + 6 * f + j, 0.0f); }
             fk_setup(m, q, pk);
             tip_state(m, yw, pk, q, qd, tips);
 #pragma unroll
@@ -1213,9 +1239,15 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     BAR();                                                      // #1
     STAMP(1);
     if (MODE & (M_SIM | M_RESETS)) {                            // warm-start rows: behind the barrier, out of the launch's first load burst
-#pragma unroll
-        for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = LDST(TF_S_LAM_CW + j); }
         cf_face = LDST(TF_S_CF_FACE); cw_face = LDST(TF_S_CW_FACE);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { lam_cf[j] = LDST(TF_S_LAM_CF + j); lam_cw[j] = 0.0f; }
+        // the wall-corner rows exist only while a corner touches the boundary (cw_face != 0): otherwise they are neither loaded nor stored
+        const bool cw_was = cw_face != 0.0f;
+        if (__builtin_amdgcn_ballot_w64(cw_was) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { const float t = LDST(TF_S_LAM_CW + j); lam_cw[j] = cw_was ? t : 0.0f; }
+        }
     }
     // flags carried in registers to the bookkeeping at the end of the step
     bool c_reset = fl_reset != 0, c_goal_reset = fl_goal_reset != 0, c_successes = fl_successes != 0;
@@ -1439,7 +1471,6 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 float sk = (pk < 0.0f) ? -1.0f : 1.0f;
                 const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
                 const float keep = (face == cw_face) ? ws : 0.0f;
-                cw_face = face;
                 wall_lane = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -1471,6 +1502,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
                     wall_lane = wall_lane || (Dinv[0] > 0.0f);
                 }
+                cw_face = wall_lane ? face : 0.0f;              // 0: no corner touches the boundary (the rows carry nothing)
             }
             // wave-uniform: no lane of this wavefront has a live wall corner (the usual case) -> the sweeps skip the wall block
             // without its four dependent LDS round trips
@@ -1888,8 +1920,12 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     }
     if (MODE & (M_RESETS | M_SIM)) {
 #pragma unroll
-        for (int j = 0; j < 12; ++j) { STST(TF_S_LAM_CF + j, lam_cf[j]); STST(TF_S_LAM_CW + j, lam_cw[j]); }
+        for (int j = 0; j < 12; ++j) STST(TF_S_LAM_CF + j, lam_cf[j]);
         STST(TF_S_CF_FACE, cf_face); STST(TF_S_CW_FACE, cw_face);
+        if (__builtin_expect(cw_face != 0.0f, 0)) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) STST(TF_S_LAM_CW + j, lam_cw[j]);
+        }
     }
     if ((MODE & M_POST) && P.goal_rotation_activate) {
         float gq2[4], gw2[3];

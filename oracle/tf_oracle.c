@@ -1357,11 +1357,12 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
          * box along the fingertip capsule's axis), its housing sphere, the middle link, its two housing spheres, and - for a cube above
          * upper_check_z - the upper link */
         for (int pi = 0; pi < 6; ++pi) {
-            /* 0: shape3  1: sph3  2: shape2  3, 4: sph2  5: shape1 */
+            /* 0: shape3  1: sph3  2: shape2  3: sph2[1] (joint-3 housing)  then, only for a cube above upper_check_z (they hang at the
+             * height of the base):  4: sph2[0] (joint-2 housing)  5: shape1 */
             const int lk = (pi < 2) ? 3 : ((pi < 5) ? 2 : 1);
             const TfLinkShape* sh = (pi == 0) ? &m->shape3 : ((pi == 2) ? &m->shape2 : ((pi == 5) ? &m->shape1 : NULL));
-            const TfSphere* sp = (pi == 1) ? &m->sph3[0] : ((pi == 3 || pi == 4) ? &m->sph2[pi - 3] : NULL);
-            if (lk == 1 && !(cube_top_check > m->upper_check_z)) continue;
+            const TfSphere* sp = (pi == 1) ? &m->sph3[0] : ((pi == 3) ? &m->sph2[1] : ((pi == 4) ? &m->sph2[0] : NULL));
+            if (pi >= 4 && !(cube_top_check > m->upper_check_z)) continue;
             float gx[3], gy[3], gn[3], gg, rad;
             if (sh) {
                 float a[3], b[3], D, spar;
@@ -1646,7 +1647,11 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
     }
     for (int i = 0; i < 4; ++i) for (int d = 0; d < 3; ++d) { e->lam_cf[i][d] = cf[i].lam[d]; e->lam_cw[i][d] = cwl[i].lam[d]; }
     e->cf_face = cf_face;
-    e->cw_face = cw_face;
+    {   /* 0 while no corner touches the boundary: the wall-corner rows then carry nothing */
+        int any_wall = 0;
+        for (int i = 0; i < 4; ++i) any_wall |= cwl[i].active;
+        e->cw_face = any_wall ? cw_face : 0.0f;
+    }
     /* ---- integrate ---- */
     for (int f = 0; f < 3; ++f) for (int jj = 0; jj < 3; ++jj) {
         const int j = 3 * f + jj;
@@ -1686,17 +1691,24 @@ static void env_load(const struct TfHandle_* h, int i, Env* e) {
     for (int j = 0; j < 4; ++j) { e->cq[j] = ST(h, TF_S_CUBE_Q + j, i); e->gq[j] = ST(h, TF_S_GOAL_Q + j, i); }
     for (int j = 0; j < 18; ++j) e->ft[j] = ST(h, TF_S_FT + j, i);
     for (int j = 0; j < TF_NUM_DR; ++j) e->dr[j] = (h->cfg.dr_enable && (h->ext || j < TF_DR_BASE_POS)) ? ST(h, TF_S_DR + j, i) : TF_DR_NEUTRAL(j);   /* rows are read only when the feature is on */
+    /* warm-start rows.  Row TF_S_FC_LINK + f is the activity code of finger f: link that held the finger-cube contact + 4 if the
+     * fingertip-wall contact pushed; TF_S_CW_FACE is 0 while no corner of the cube touches the boundary.  The rows of an inactive
+     * contact are neither read nor written (their content is undefined). */
     for (int f = 0; f < 3; ++f) {
-        for (int j = 0; j < 4; ++j) e->lam_fc[f][j] = ST(h, TF_S_LAM_FC + 4 * f + j, i);
-        for (int j = 0; j < 3; ++j) { e->lam_tf[f][j] = ST(h, TF_S_LAM_TF + 3 * f + j, i); e->lam_tw[f][j] = ST(h, TF_S_LAM_TW + 3 * f + j, i); }
-        e->fc_link[f] = ST(h, TF_S_FC_LINK + f, i);
-    }
-    for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) {
-        e->lam_cf[c][j] = ST(h, TF_S_LAM_CF + 3 * c + j, i);
-        e->lam_cw[c][j] = ST(h, TF_S_LAM_CW + 3 * c + j, i);
+        const int code = (int)ST(h, TF_S_FC_LINK + f, i);
+        e->fc_link[f] = (float)(code & 3);
+        for (int j = 0; j < 4; ++j) e->lam_fc[f][j] = (code & 3) ? ST(h, TF_S_LAM_FC + 4 * f + j, i) : 0.0f;
+        for (int j = 0; j < 3; ++j) {
+            e->lam_tf[f][j] = ST(h, TF_S_LAM_TF + 3 * f + j, i);
+            e->lam_tw[f][j] = (code & 4) ? ST(h, TF_S_LAM_TW + 3 * f + j, i) : 0.0f;
+        }
     }
     e->cf_face = ST(h, TF_S_CF_FACE, i);
     e->cw_face = ST(h, TF_S_CW_FACE, i);
+    for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) {
+        e->lam_cf[c][j] = ST(h, TF_S_LAM_CF + 3 * c + j, i);
+        e->lam_cw[c][j] = (e->cw_face != 0.0f) ? ST(h, TF_S_LAM_CW + 3 * c + j, i) : 0.0f;
+    }
 }
 static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_ft) {
     for (int j = 0; j < 9; ++j) { ST(h, TF_S_Q + j, i) = e->q[j]; ST(h, TF_S_QD + j, i) = e->qd[j]; ST(h, TF_S_TAU + j, i) = e->tau[j]; }
@@ -1708,13 +1720,15 @@ static void env_store(const struct TfHandle_* h, int i, const Env* e, int store_
     if (store_ft) for (int j = 0; j < 18; ++j) ST(h, TF_S_FT + j, i) = e->ft[j];
     if (h->cfg.dr_enable) for (int j = 0; j < (h->ext ? TF_NUM_DR : TF_DR_BASE_POS); ++j) ST(h, TF_S_DR + j, i) = e->dr[j];
     for (int f = 0; f < 3; ++f) {
-        for (int j = 0; j < 4; ++j) ST(h, TF_S_LAM_FC + 4 * f + j, i) = e->lam_fc[f][j];
-        for (int j = 0; j < 3; ++j) { ST(h, TF_S_LAM_TF + 3 * f + j, i) = e->lam_tf[f][j]; ST(h, TF_S_LAM_TW + 3 * f + j, i) = e->lam_tw[f][j]; }
-        ST(h, TF_S_FC_LINK + f, i) = e->fc_link[f];
+        const int link = (int)e->fc_link[f], tw_now = e->lam_tw[f][0] > 0.0f;
+        ST(h, TF_S_FC_LINK + f, i) = (float)(link + (tw_now ? 4 : 0));
+        if (link != 0) for (int j = 0; j < 4; ++j) ST(h, TF_S_LAM_FC + 4 * f + j, i) = e->lam_fc[f][j];
+        for (int j = 0; j < 3; ++j) ST(h, TF_S_LAM_TF + 3 * f + j, i) = e->lam_tf[f][j];
+        if (tw_now) for (int j = 0; j < 3; ++j) ST(h, TF_S_LAM_TW + 3 * f + j, i) = e->lam_tw[f][j];
     }
     for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) {
         ST(h, TF_S_LAM_CF + 3 * c + j, i) = e->lam_cf[c][j];
-        ST(h, TF_S_LAM_CW + 3 * c + j, i) = e->lam_cw[c][j];
+        if (e->cw_face != 0.0f) ST(h, TF_S_LAM_CW + 3 * c + j, i) = e->lam_cw[c][j];
     }
     ST(h, TF_S_CF_FACE, i) = e->cf_face;
     ST(h, TF_S_CW_FACE, i) = e->cw_face;
@@ -2199,7 +2213,7 @@ static int run_step(tf_handle h, const float* action, int is_reset, int random_a
             for (int s = 0; s < nsim * c->substeps; ++s) substep(h, &e, hsub);
             post_step_env(h, i, &e, prev_obj, &rc, !is_reset, &local);
             goal_advance(h, &e, nsim * c->substeps, hsub);
-            env_store(h, i, &e, 1);
+            env_store(h, i, &e, 0);          /* the fused step keeps the fingertip wrench of the step to itself: TF_S_FT is split-path state */
             if (!is_reset) finish_env(h, i);
         }
 #pragma omp critical

@@ -48,16 +48,19 @@ def link_rotation_world(f, q, link):
     return rot_z(YAW[f]) @ frames(q)[link - 1][0]
 
 
-def shape_candidates(f, qf, cube_p, R, hc, links=(3, 2, 1)):
+def shape_candidates(f, qf, cube_p, R, hc, links=(3, 2, 1), high=True):
     """every collision shape of finger f (of the given links) against the box at cube_p / R with half extents hc:
     [(gap, link, x, y, ext)] with x the axis point (or sphere centre) and y the closest point of the box, both in the box frame, and
     ext what lies between x and the shape's surface along the line to y.  A tapered rounded box (include/trifinger.h: TfLinkShape):
     closest points of its AXIS and the box, then the support function of its cross-section along the direction to the box."""
     out = []
-    for entry in SHAPES:
+    first_sphere_of_2 = next(i for i, e in enumerate(SHAPES) if e[0] == "sphere" and e[1] == 2)
+    for i, entry in enumerate(SHAPES):
         link = entry[1]
         if link not in links:
             continue
+        if not high and (link == 1 or i == first_sphere_of_2):      # the upper link and the joint-2 housing of the middle link hang at the
+            continue                                                  # height of the base: only a cube above UPPER_CHECK_Z reaches them
         if entry[0] == "sphere":
             c = R.T @ (link_point_world(f, qf, link, entry[2]) - cube_p)
             yb = np.clip(c, -hc, hc)
@@ -293,7 +296,7 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         sl = slice(3 * f, 3 * f + 3)
         qf = q[sl]
         best = None
-        for gap_c, cand, xc, yc, ext in shape_candidates(f, qf, cp, R, hc, links=(3, 2, 1) if cp[2] > UPPER_CHECK_Z else (3, 2)):
+        for gap_c, cand, xc, yc, ext in shape_candidates(f, qf, cp, R, hc, links=(3, 2, 1), high=cp[2] > UPPER_CHECK_Z):
             if best is None or gap_c < best[0]:       # the shape with the smallest gap holds the contact (first wins a tie)
                 best = (gap_c, cand, xc, yc, ext)
         gap, link, x, y, rad = best

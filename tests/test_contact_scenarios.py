@@ -221,7 +221,7 @@ def _middle_link_run(lib, device, contacts_on):
         st = state_np(eng)
         cube = st[capi.S_CUBE_P:capi.S_CUBE_P + 13]
         worst = min(worst, _capsule_gap(0, st[0:3], 2, cube))
-        links.add(int(st[capi.S_FC_LINK]))
+        links.add(int(st[capi.S_FC_LINK]) & 3)         # activity code: link + 4 x (fingertip-wall contact pushing)
         moved = max(moved, np.linalg.norm(cube[0:3] - centre))
     eng.close()
     return worst, links, moved
