@@ -359,7 +359,6 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
     }
-    float lam0_fc[4], lam0_link = 0.0f, lam0_tf[3], lam0_tw[3];  // solver warm start for the first substep
     // activity code of this finger's warm-start rows (row TF_S_FC_LINK): link that held the finger-cube contact + 4 if the fingertip-wall
     // contact pushed.  The rows of an inactive contact are neither loaded nor stored (their content is then undefined).
     float fc_code = 0.0f;
@@ -372,23 +371,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     STAMP(1);
     // The warm-start rows are first needed when the contact rows are built, a free-motion phase later: issued here, behind the
     // barrier, they stay out of the load burst every workgroup of the launch starts with.
-    if (MODE & M_SIM) {
-        const int code = (int)fc_code;
-        const bool fc_was = (code & 3) != 0, tw_was = (code & 4) != 0;
-        lam0_link = (float)(code & 3);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lam0_fc[j] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { lam0_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j); lam0_tw[j] = 0.0f; }
-        if (__builtin_amdgcn_ballot_w64(fc_was) != 0ull) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float t = LDST(TF_S_LAM_FC + 4 * f + j); lam0_fc[j] = fc_was ? t : 0.0f; }
-        }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tw_was) != 0ull, 0)) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { const float t = LDST(TF_S_LAM_TW + 3 * f + j); lam0_tw[j] = tw_was ? t : 0.0f; }
-        }
-    }
+    // (the warm-start rows themselves are loaded in the first substep, where the contact rows are built: kept across the free motion
+    // they would only be spilled)
     // ---- masked _reset_impl for this finger (trifinger_env.py:373-423, 1101-1147) ----
     const bool rflag = (MODE & M_RESETS) && (IS_RESET || fl_reset != 0);
     if (MODE & M_RESETS) {
@@ -412,11 +396,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) tau[j] = 0.0f;          // the stored torque (what an action repeat re-applies)
-            if (MODE & M_SIM) {                                 // ... and the solver warm start
-                lam0_fc[0] = 0.0f; lam0_fc[1] = 0.0f; lam0_fc[2] = 0.0f; lam0_fc[3] = 0.0f; lam0_link = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) { lam0_tf[j] = 0.0f; lam0_tw[j] = 0.0f; }
-            }
+            if (MODE & M_SIM) fc_code = -1.0f;                  // ... and the solver warm start (-1: the rows are not looked at)
         }
     }
     // ---- this finger's action values: clipped, zeroed by a reset (trifinger_env.py:387), written back for _action_buf ----
@@ -504,8 +484,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     STAMP(2);
     // A launch that simulates AND emits the observations (the fused step) hands the fingertip wrench of the step from its last substep to
     // the post phase in registers: the TF_S_FT rows ("split path only") are neither written nor read by it.
-    constexpr bool FT_IN_REGS = ((MODE & M_SIM) != 0) && ((MODE & M_POST) != 0);
-    float ft_keep[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr bool FT_IN_REGS = ((MODE & M_SIM) != 0) && ((MODE & M_POST) != 0);      // (in LDS, to be exact: the parking slots of the last substep)
     if (MODE & M_SIM) {
         const float h = P.hsub, inv_h = 1.0f / h;
         const int nsub = sa.nsim * P.substeps;
@@ -522,10 +501,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                 for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = dr[j];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { taus[j] = tau[j]; lam_tf[j] = lam0_tf[j]; lam_tw[j] = lam0_tw[j]; }
+                for (int j = 0; j < 3; ++j) { taus[j] = tau[j]; lam_tf[j] = 0.0f; lam_tw[j] = 0.0f; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lam_fc[j] = lam0_fc[j];
-                fc_link = lam0_link;
+                for (int j = 0; j < 4; ++j) lam_fc[j] = 0.0f;
+                fc_link = 0.0f;
                 if (ASYM) {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) ft_run[j] = (MODE & M_TORQUE) ? 0.0f : LDST(TF_S_FT + 6 * f + j);
@@ -605,6 +584,21 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) cq[j] = LD(L_POSE_A + 3 + j);
             quat_to_rot(cq, R);
+            if (s == 0 && !(fc_code < 0.0f)) {                  // warm-start rows of the step (wave-uniform branches; consumed at the end of this phase)
+                const int code = (int)fc_code;
+                const bool fc_was = (code & 3) != 0, tw_was = (code & 4) != 0;
+                fc_link = (float)(code & 3);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) lam_tf[j] = LDST(TF_S_LAM_TF + 3 * f + j);
+                if (__builtin_amdgcn_ballot_w64(fc_was) != 0ull) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float t = LDST(TF_S_LAM_FC + 4 * f + j); lam_fc[j] = fc_was ? t : 0.0f; }
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(tw_was) != 0ull, 0)) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { const float t = LDST(TF_S_LAM_TW + 3 * f + j); lam_tw[j] = tw_was ? t : 0.0f; }
+                }
+            }
             // finger vs cube: the shape with the smallest gap holds the contact (TfLinkShape, include/trifinger.h): the distal body
             // first - its axis is the fingertip capsule's, it ends in the fingertip sphere -, its housing sphere, the middle link with
             // its joint-3 housing sphere and - only for a cube above upper_check_z, practically never - its joint-2 housing sphere and the
@@ -950,7 +944,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
                 if (last_sub) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) { if (FT_IN_REGS) ft_keep[j] = ft[j]; else STST(TF_S_FT + 6 * f + j, ft[j]); }
+                    for (int j = 0; j < 6; ++j) { if (FT_IN_REGS) LD(L_PARK(f) + PK_FT + j) = ft[j]; else STST(TF_S_FT + 6 * f + j, ft[j]); }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) LD(L_PARK(f) + PK_FT + j) = ft[j];
@@ -978,10 +972,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         for (int j = 0; j < 3; ++j) { boff_p[j] = (EXT && P.dr_enable) ? LDST(TF_S_DR + TF_DR_BASE_POS + j) : 0.0f; if (EXT) tips[j] = tips[j] + boff_p[j]; }   // robot frame -> world
         float tip_prev[3], tau_p[3], act_p[AJ], ft[6];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j); tau_p[j] = (MODE & M_TORQUE) ? tau[j] : LDST(TF_S_TAU + 3 * f + j); }
+        for (int j = 0; j < 3; ++j) { tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j); tau_p[j] = LDST(TF_S_TAU + 3 * f + j); }
         if (ASYM) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ft[j] = FT_IN_REGS ? ft_keep[j] : LDST(TF_S_FT + 6 * f + j);
+            for (int j = 0; j < 6; ++j) ft[j] = FT_IN_REGS ? LD(L_PARK(f) + PK_FT + j) : LDST(TF_S_FT + 6 * f + j);   // (own slots, untouched until the tile is written behind P1)
         }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {         // the last command, as _action_buf holds it (written above by this workgroup)
