@@ -122,7 +122,7 @@ FULL_DR = {"activate": True, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "
 
 def kernel_name(asym, action_dim=9, ext=False):
     """rocprofv3's name of the fused-step instantiation a workload launches (EXT: extended DR or the box object)."""
-    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, 63, {'true' if ext else 'false'}>"
+    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, 63, {int(ext)}>"
 
 
 def workload_kwargs(asym, difficulty=4, dr=False):
@@ -326,7 +326,7 @@ def main():
     kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
     bytes_per_launch = BYTES_PER_ENV_STEP[asym] * n
     achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
-    ext = bool(args.dr or args.box)               # extended DR / box object -> the EXT instantiation of the fused step
+    ext = 2 if args.box else (1 if args.dr else 0)     # extended DR -> EXT = 1, box object -> EXT = 2 instantiation of the fused step
     pmc, pmc_path = load_pmc_profile(n, asym, ext) if (headline or ext) else (None, None)
     traffic = traffic_raw = issue = None
     traffic_how = None

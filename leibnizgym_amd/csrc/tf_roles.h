@@ -336,8 +336,10 @@ struct TipContact {            // fingertip sphere against one feature of the ar
     float arm[3];             // contact point relative to the tip-link origin (fingertip wrench sensor)
 };
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, bool EXT>
+template <int A, bool IS_RESET, bool ASYM, int MODE, int X>
 DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
+    constexpr bool EXT = X != 0;      // X: 0 the headline kernels, 1 extended domain randomisation, 2 the same with the general box object
+    constexpr bool BOXK = X == 2;
     const TfModel& m = P.m;
     const int f = cx.role, lane = cx.lane;
     constexpr int OD = TF_OBS_DIM_BASE + A, SD = OD + TF_STATES_EXTRA;
@@ -538,7 +540,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             const float boff[3] = {dr[TF_DR_BASE_POS], dr[TF_DR_BASE_POS + 1], dr[TF_DR_BASE_POS + 2]};
             const float soff[2] = {dr[TF_DR_STAGE_POS], dr[TF_DR_STAGE_POS + 1]};
             const float ws = m.warm_start;
-            const bool box = EXT ? (m.box != 0) : false;      // general box object: only in the EXT kernel instantiations, the cube kernels carry none of it
+            constexpr bool box = BOXK;                        // general box object: its own kernel instantiations, the cube kernels carry none of it
             float hc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) hc[j] = (box ? m.box_half[j] : m.cube_half) * dr[1];
@@ -1199,8 +1201,10 @@ DEV void wall_arms(bool box, const float* lds, int lane, const float r[3], const
     }
 }
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, bool EXT>
+template <int A, bool IS_RESET, bool ASYM, int MODE, int X>
 DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
+    constexpr bool EXT = X != 0;
+    constexpr bool BOXK = X == 2;
     const TfModel& m = P.m;
     const int lane = cx.lane;
     constexpr int OD = TF_OBS_DIM_BASE + A, SD = OD + TF_STATES_EXTRA;
@@ -1345,7 +1349,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             const float soff[2] = {dr[TF_DR_STAGE_POS], dr[TF_DR_STAGE_POS + 1]};
             const float rest_ff = m.restitution_ff * dr[5];
             const float ws = m.warm_start;
-            const bool box = EXT ? (m.box != 0) : false;      // general box object: only in the EXT kernel instantiations, the cube kernels carry none of it
+            constexpr bool box = BOXK;                        // general box object: its own kernel instantiations, the cube kernels carry none of it
             float hc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) hc[j] = (box ? m.box_half[j] : m.cube_half) * dr[1];

@@ -34,9 +34,9 @@
 #define SCR_STRIDE TF_SCR_STRIDE
 
 // One launch = one or more hooks of the reference step (MODE) for every env of the handle.
-template <int A, bool IS_RESET, bool ASYM, int MODE, bool EXT>
+template <int A, bool IS_RESET, bool ASYM, int MODE, int EXT>
 __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
-    __shared__ __attribute__((aligned(16))) float lds[(EXT ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
+    __shared__ __attribute__((aligned(16))) float lds[((EXT == 2) ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
     const DevParams& P = *Pp;
     {   // Warm the scalar cache with the parameter block (one dword per 64-byte line) BEFORE the state loads of every workgroup of the
         // launch saturate the L2: the model constants the free motion needs then come out of the constant cache instead of queueing
@@ -508,7 +508,7 @@ static inline int n_waves(const TfHandle_* h) { return (h->cfg.num_envs + WAVE -
         if (e_ != hipSuccess) return hip_fail(e_, what);           \
     } while (0)
 
-template <int MODE, bool IS_RESET, bool EXT>
+template <int MODE, bool IS_RESET, int EXT>
 static void launch_env_obj(TfHandle_* h, const float* action, hipStream_t s) {
     dim3 grid(n_waves(h)), block(NT);
     const bool asym = h->cfg.asymmetric_obs != 0;
@@ -520,22 +520,25 @@ static void launch_env_obj(TfHandle_* h, const float* action, hipStream_t s) {
         else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
     }
 }
-// The general box object (TfModel.box) and the extended domain randomisation (robot base / stage position, per-body friction)
-// live in their own instantiations (EXT): the kernels of the headline path stay exactly what they were - a run-time flag
-// for either cost 9 to 26 us per step through register pressure.
-static bool needs_ext(const TfConfig& c) {
-    if (c.model.box) return true;
-    if (!c.dr_enable) return false;
-    for (int i = 0; i < 3; ++i) if (c.dr_base_pos[i] > 0.0f) return true;
-    for (int i = 0; i < 2; ++i) if (c.dr_stage_pos[i] > 0.0f) return true;
+// The extended domain randomisation (robot base / stage position, per-body friction) and the general box object (TfModel.box) live in
+// their own instantiations (EXT = 1, 2): the kernels of the headline path stay exactly what they were - a run-time flag for either cost
+// 9 to 26 us per step through register pressure - and the extended randomisation with the cube (BASELINE configs[3]) does not carry the
+// box code either (round 3: with both behind one template flag the cube role of that kernel spilled 95 registers on its serial chain).
+static int ext_kind(const TfConfig& c) {
+    if (c.model.box) return 2;
+    if (!c.dr_enable) return 0;
+    for (int i = 0; i < 3; ++i) if (c.dr_base_pos[i] > 0.0f) return 1;
+    for (int i = 0; i < 2; ++i) if (c.dr_stage_pos[i] > 0.0f) return 1;
     const float* f[3] = {c.dr_friction_robot, c.dr_friction_object, c.dr_friction_stage};
-    for (int b = 0; b < 3; ++b) if (f[b][0] != 1.0f || f[b][1] != 1.0f) return true;
-    return false;
+    for (int b = 0; b < 3; ++b) if (f[b][0] != 1.0f || f[b][1] != 1.0f) return 1;
+    return 0;
 }
 template <int MODE, bool IS_RESET>
 static void launch_env(TfHandle_* h, const float* action, hipStream_t s) {
-    if (needs_ext(h->cfg)) launch_env_obj<MODE, IS_RESET, true>(h, action, s);
-    else launch_env_obj<MODE, IS_RESET, false>(h, action, s);
+    const int k = ext_kind(h->cfg);
+    if (k == 2) launch_env_obj<MODE, IS_RESET, 2>(h, action, s);
+    else if (k == 1) launch_env_obj<MODE, IS_RESET, 1>(h, action, s);
+    else launch_env_obj<MODE, IS_RESET, 0>(h, action, s);
 }
 
 static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStream_t s, bool random_actions = false) {

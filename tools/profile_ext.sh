@@ -4,9 +4,9 @@
 #   tools/profile_ext.sh <tag>  ->  gpurun_out/<tag>_ext_{dr,box}_<N>_{bench.json,kernel_trace.txt,pmc.txt}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=${1:-rX}; O=gpurun_out
-K='k_env<9, false, true, 63, true>'
 mkdir -p $O
 for W in dr box; do
+  K="k_env<9, false, true, 63, $([ $W = box ] && echo 2 || echo 1)>"
   for N in 16384 65536; do
     B="python3 bench.py --$W --envs $N --no-cpu-baseline"
     P=$O/${T}_ext_${W}_${N}
