@@ -87,7 +87,11 @@ struct Ctx {
 #else
 #define TF_SCR_STRIDE 16
 #define NOW() 0u
+#ifdef TF_PHASE_FENCE      // developer variant: the phase boundaries are scheduling barriers for the compiler (no instruction is emitted)
+#define STAMP(id) __builtin_amdgcn_sched_barrier(0)
+#else
 #define STAMP(id) do { } while (0)
+#endif
 #define STAMPV(id, val) do { } while (0)
 #endif
 
