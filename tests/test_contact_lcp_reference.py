@@ -2,7 +2,7 @@
 
 tests/physics_ref.py restates one solver substep in fp64 numpy without sharing any code with the C oracle or the HIP
 kernels (finite-difference Jacobians of the fp64 URDF model, scipy closest points, projected Gauss-Seidel iterated to
-a fixed point).  For >= 200 random contact configurations - fingertips and link capsules against the cube, the cube on
+a fixed point).  For 120 random contact configurations - fingertips and link capsules against the cube, the cube on
 the floor under a finger (finger-cube-floor chains), against the boundary, floating, penetrating by up to 4 mm or
 separated by up to 4 mm, with random velocities and torques - the product's substep must converge to that solution as
 its sweep count grows.  What the shipped 8 sweeps leave is measured here and quoted in DESIGN.md section 2.
