@@ -224,6 +224,56 @@ def test_shape_gap_is_close_to_its_minimum_over_the_axis():
     assert hidden < 4e-3, hidden
 
 
+def test_only_the_fingertip_can_reach_floor_and_boundary(oracle):
+    """The step gives floor and boundary contacts to the fingertip sphere only (review round 2, item 8: "non-tip links vs floor and
+    boundary").  With the reference's kinematics and joint limits nothing else CAN touch them: over the whole joint range the upper
+    link, the middle link and the joint housings stay more than 8 cm above the floor and more than 5 cm inside the boundary, and
+    wherever a point of the distal body comes within 3 mm of the floor the fingertip sphere is at least 8 mm lower - the fingertip
+    contact stops the finger first.  Against the BOUNDARY the same holds to within 3 mm only: in outstretched poses the thick part
+    of the distal body can reach the flared wall about as early as the fingertip (not modelled: DESIGN.md section 10)."""
+    import physics_ref as PR
+    from test_physics_analytic import frames
+    m = oracle.default_model()
+    wr, wz = np.array(list(m.wall_r)), np.array(list(m.wall_z))
+    wall = lambda z: float(np.interp(z, wz, wr)) if z < wz[-1] else 1e3      # noqa: E731
+    rng = np.random.default_rng(1)
+    low = {1: 9.0, 2: 9.0, "housing": 9.0}
+    wgap = {1: 9.0, 2: 9.0, "housing": 9.0}
+    floor_margin, wall_margin = 9.0, 9.0
+    ss = np.linspace(0.0, 1.0, 11)
+    for _ in range(4000):
+        q = rng.uniform(PR.Q_LO, PR.Q_HI)
+        fr = frames(q)
+        for e in PR.SHAPES:
+            link = e[1]
+            Rl, pl = fr[link - 1]
+            if e[0] == "sphere":
+                c = pl + Rl @ e[2]
+                low["housing"] = min(low["housing"], c[2] + PR.H_BASE - e[3])
+                wgap["housing"] = min(wgap["housing"], wall(c[2] + PR.H_BASE) - (np.hypot(c[0], c[1]) + e[3]))
+                continue
+            sh = e[2]
+            zl, wl = [], []
+            for t in ss:
+                x = pl + Rl @ (sh["a"] + t * (sh["b"] - sh["a"]))
+                zc = x[2] + PR.H_BASE
+                rn = np.hypot(x[0], x[1])
+                rdir = np.array([x[0], x[1], 0.0]) / rn if rn > 1e-9 else np.array([1.0, 0.0, 0.0])
+                zl.append(zc - MF.shape_extent(sh, t, Rl.T @ np.array([0.0, 0.0, -1.0])))
+                wl.append(wall(zc) - (rn + MF.shape_extent(sh, t, Rl.T @ rdir)))
+            if link != 3:
+                low[link] = min(low[link], min(zl))
+                wgap[link] = min(wgap[link], min(wl))
+            else:                                   # distal body: s <= 0.9 against the fingertip sphere (s = 1)
+                if min(zl[:-1]) < 0.003:
+                    floor_margin = min(floor_margin, min(zl[:-1]) - zl[-1])
+                if min(wl[:-1]) < 0.003:
+                    wall_margin = min(wall_margin, min(wl[:-1]) - wl[-1])
+    assert low[1] > 0.25 and low[2] > 0.11 and low["housing"] > 0.08, low
+    assert wgap[1] > 0.06 and wgap[2] > 0.06 and wgap["housing"] > 0.05, wgap
+    assert floor_margin > 0.008 and wall_margin > -0.003, (floor_margin, wall_margin)
+
+
 def test_boundary_profile_lies_in_the_band_of_the_convex_pieces(oracle):
     """high_table_boundary.urdf loads 40 convex pieces; each spans up to ~50 degrees of arc, so the inner surface is polygonal:
     at height z its distance to the axis runs from the chord value `boundary_profile_r` (fixture) to that value / cos(25 deg) at
