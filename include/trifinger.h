@@ -191,6 +191,9 @@ typedef struct TfModel {
     TfLinkShape shape2; TfSphere sph2[2];     /* middle link; the joint-2 housing (top) and the joint-3 housing (bottom)             */
     TfLinkShape shape1;                       /* upper link                                                                          */
     float upper_check_z;          /* the upper link and the joint-2 housing are only tested for a cube centre above this height    */
+    float middle_check_z;         /* the middle link's body (shape2) is only tested when the highest point of the object is
+                                   * above this height (0.075: over the whole joint range the middle link stays >= 0.12 m above the
+                                   * floor - tests/test_model_fixture.py -, contact_margin is 0.04)                                  */
     /* cube (cube_multicolor_rrc.urdf:10-18) */
     float cube_half;              /* 0.0325 */
     float cube_mass;              /* 291.3 * 0.065^3 */

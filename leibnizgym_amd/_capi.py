@@ -76,7 +76,7 @@ class TfModel(C.Structure):
         ("q_default", C.c_float * 3),
         ("cap_a", C.c_float * 3), ("cap_b", C.c_float * 3), ("cap_radius", C.c_float),
         ("shape3", TfLinkShape), ("sph3", TfSphere * 1), ("shape2", TfLinkShape), ("sph2", TfSphere * 2), ("shape1", TfLinkShape),
-        ("upper_check_z", C.c_float),
+        ("upper_check_z", C.c_float), ("middle_check_z", C.c_float),
         ("cube_half", C.c_float), ("cube_mass", C.c_float), ("cube_inertia", C.c_float),
         ("cube_linear_damping", C.c_float), ("cube_angular_damping", C.c_float),
         ("wall_r", C.c_float * 4), ("wall_z", C.c_float * 4),

@@ -663,13 +663,16 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     try_shape(L3{}, m.shape3, a, b, true);
                 }
                 try_sphere(L3{}, m.sph3[0], true);
-                {
+                // the middle link never comes lower than 0.12 m: it can only matter for an object whose highest
+                // point is above middle_check_z - a lifted or tumbling one (wave-level branch: a fifth of the wavefronts under random actions)
+                const bool mid_ok = FMA(f_abs(R[8]), hc[2], FMA(f_abs(R[7]), hc[1], FMA(f_abs(R[6]), hc[0], cp[2]))) > m.middle_check_z;
+                if (__builtin_amdgcn_ballot_w64(mid_ok) != 0ull) {
                     float a[3], b[3];
                     to_cube(L2{}, m.shape2.a, a);
                     to_cube(L2{}, m.shape2.b, b);
-                    try_shape(L2{}, m.shape2, a, b, true);
+                    try_shape(L2{}, m.shape2, a, b, mid_ok);
                 }
-                try_sphere(L2{}, m.sph2[1], true);
+                try_sphere(L2{}, m.sph2[1], true);              // (its joint-3 housing comes down to 0.096 m: always looked at)
                 // the joint-2 housing of the middle link and the upper link hang at the height of the base (0.29 m): only a cube above
                 // upper_check_z can reach them
                 const bool upper_ok = cp[2] > m.upper_check_z;

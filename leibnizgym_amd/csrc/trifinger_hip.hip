@@ -233,6 +233,7 @@ void tf_default_model(TfModel* m) {
         m->sph3[0] = s3[0]; m->sph2[0] = s2[0]; m->sph2[1] = s2[1];
     }
     m->upper_check_z = 0.17f;
+    m->middle_check_z = 0.075f;
     m->cube_half = 0.0325f;
     m->cube_mass = (float)(291.3 * 0.065 * 0.065 * 0.065);
     m->cube_inertia = (float)(291.3 * 0.065 * 0.065 * 0.065 * 0.065 * 0.065 / 6.0);

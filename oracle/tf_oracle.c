@@ -369,6 +369,7 @@ void tf_default_model(TfModel* m) {
         m->sph3[0] = s3[0]; m->sph2[0] = s2[0]; m->sph2[1] = s2[1];
     }
     m->upper_check_z = 0.17f;             /* base height 0.29 - capsule radius - cube half diagonal - margin */
+    m->middle_check_z = 0.075f;
     m->cube_half = 0.0325f;               /* trifinger_env.py:143 */
     m->cube_mass = (float)(291.3 * 0.065 * 0.065 * 0.065);
     m->cube_inertia = (float)(291.3 * 0.065 * 0.065 * 0.065 * 0.065 * 0.065 / 6.0);
@@ -1363,6 +1364,8 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             const TfLinkShape* sh = (pi == 0) ? &m->shape3 : ((pi == 2) ? &m->shape2 : ((pi == 5) ? &m->shape1 : NULL));
             const TfSphere* sp = (pi == 1) ? &m->sph3[0] : ((pi == 3) ? &m->sph2[1] : ((pi == 4) ? &m->sph2[0] : NULL));
             if (pi >= 4 && !(cube_top_check > m->upper_check_z)) continue;
+            if (pi == 2 && !(FMA(f_abs(R[8]), hc[2], FMA(f_abs(R[7]), hc[1], FMA(f_abs(R[6]), hc[0], cpr[2]))) > m->middle_check_z))
+                continue;                    /* the middle link stays >= 0.12 m above the floor: only an object that reaches up there */
             float gx[3], gy[3], gn[3], gg, rad;
             if (sh) {
                 float a[3], b[3], D, spar;

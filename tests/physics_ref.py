@@ -29,6 +29,7 @@ _M = load_oracle().default_model()
 SHAPES = MF.model_shapes(_M)                # the collision shapes of the three links in test order (tests/model_fixture.py)
 TIP_CAP = (3, np.array(list(_M.cap_a), dtype=np.float64), np.array(list(_M.cap_b), dtype=np.float64), float(_M.cap_radius))
 UPPER_CHECK_Z = float(_M.upper_check_z)
+MIDDLE_CHECK_Z = float(_M.middle_check_z)
 CUBE_HALF = MF.CUBE_SIZE / 2.0
 CUBE_MASS = MF.CUBE_DENSITY * MF.CUBE_SIZE ** 3
 CUBE_INERTIA = CUBE_MASS * MF.CUBE_SIZE ** 2 / 6.0
@@ -61,6 +62,8 @@ def shape_candidates(f, qf, cube_p, R, hc, links=(3, 2, 1), high=True):
             continue
         if not high and (link == 1 or i == first_sphere_of_2):      # the upper link and the joint-2 housing of the middle link hang at the
             continue                                                  # height of the base: only a cube above UPPER_CHECK_Z reaches them
+        if link == 2 and entry[0] == "shape" and not (cube_p[2] + float(np.abs(R[2, :]) @ hc)) > MIDDLE_CHECK_Z:
+            continue                                                  # the middle link stays >= 0.12 m above the floor
         if entry[0] == "sphere":
             c = R.T @ (link_point_world(f, qf, link, entry[2]) - cube_p)
             yb = np.clip(c, -hc, hc)

@@ -270,6 +270,7 @@ def test_only_the_fingertip_can_reach_floor_and_boundary(oracle):
                 if min(wl[:-1]) < 0.003:
                     wall_margin = min(wall_margin, min(wl[:-1]) - wl[-1])
     assert low[1] > 0.25 and low[2] > 0.11 and low["housing"] > 0.08, low
+    assert low[2] - float(m.contact_margin) - 0.004 >= float(m.middle_check_z)      # what the middle-link height gate of the step relies on (4 mm: base-offset DR)
     assert wgap[1] > 0.06 and wgap[2] > 0.06 and wgap["housing"] > 0.05, wgap
     assert floor_margin > 0.008 and wall_margin > -0.003, (floor_margin, wall_margin)
 
