@@ -245,6 +245,69 @@ def test_middle_link_cannot_pass_through_the_cube_gpu(hip):
     _check_middle_link(hip, "cuda:0")
 
 
+# ---- the thick upper part of the distal body vs cube (round 3: the link shapes follow the reference's collision hulls) ---------------
+def _distal_body_run(lib, device, contacts_on, local_point):
+    """finger 0 swings about joint 1 so that a point of its distal body - given in the lower-link frame, far from the fingertip -
+    sweeps into a floating cube placed 1 cm beside it"""
+    def edit(m):
+        if not contacts_on:
+            m.contact_margin = -1.0
+    eng = torque_engine(lib, device, edit, gravity=(0.0, 0.0, 0.0))
+    q = np.array([-0.25, 0.5, -1.0])
+    p0 = PR.link_point_world(0, q, 3, local_point)
+    side = PR.link_point_world(0, q + np.array([0.3, 0, 0]), 3, local_point) - p0
+    side /= np.linalg.norm(side)
+    lo_, hi_ = 0.0, 0.2
+    for _ in range(50):                                 # bisection: distance along `side` at which the distal body's gap is 1 cm
+        d_ = 0.5 * (lo_ + hi_)
+        if _capsule_gap(0, q, 3, np.concatenate([p0 + side * d_, [0, 0, 0, 1]])) < 0.01:
+            lo_ = d_
+        else:
+            hi_ = d_
+    centre = p0 + side * hi_
+    f32 = dict(dtype=torch.float32, device=device)
+    eng.q[0:3, 0] = torch.tensor(q, **f32)
+    eng.cube[0:3, 0] = torch.tensor(centre, **f32)
+    worst, links, moved = 1.0, set(), 0.0
+    tip_gap_at_contact = None
+    for _ in range(40):
+        tau = np.zeros(9)
+        tau[0] = 0.2
+        step_torque(eng, tau)
+        st = state_np(eng)
+        cube = st[capi.S_CUBE_P:capi.S_CUBE_P + 13]
+        g = _capsule_gap(0, st[0:3], 3, cube)
+        worst = min(worst, g)
+        if (int(st[capi.S_FC_LINK]) & 3) == 3 and tip_gap_at_contact is None and st[capi.S_LAM_FC] > 0:
+            tip = PR.link_point_world(0, st[0:3], 3, PR.TIP_CAP[2])
+            loc = PR.quat_rot(cube[3:7]).T @ (tip - cube[0:3])
+            tip_gap_at_contact = np.linalg.norm(np.maximum(np.abs(loc) - PR.CUBE_HALF, 0.0)) - PR.TIP_CAP[3]
+        links.add(int(st[capi.S_FC_LINK]) & 3)
+        moved = max(moved, np.linalg.norm(cube[0:3] - centre))
+    eng.close()
+    return worst, links, moved, tip_gap_at_contact
+
+
+def _check_distal_body(lib, device):
+    for local in (np.array([0.012, 0.0, -0.03]), np.array([0.011, 0.0, 0.0])):     # the thick part of the body; the joint-3 housing
+        worst, links, moved, tip_gap = _distal_body_run(lib, device, True, local)
+        assert worst > -8e-3, (local, worst)             # the shape stops at the cube: a finger swinging at 5-7 rad/s juggles a weightless cube
+                                                         # spinning at 10 rad/s; single-step overlaps of a few mm (8 sweeps, one-point gap rule)
+        assert 3 in links and moved > 0.02               # the distal body held the contact and pushed the cube away
+        assert tip_gap is not None and tip_gap > 0.03    # ... with the fingertip sphere centimetres away: it was the body, not the tip
+        ghost, _, still, _ = _distal_body_run(lib, device, False, local)
+        assert ghost < -0.012 and still < 1e-6           # without contacts it passes straight through
+
+
+def test_distal_body_cannot_pass_through_the_cube(oracle):
+    _check_distal_body(oracle, "cpu")
+
+
+@pytest.mark.gpu
+def test_distal_body_cannot_pass_through_the_cube_gpu(hip):
+    _check_distal_body(hip, "cuda:0")
+
+
 # ---- finger vs finger ----------------------------------------------------------------------------------------------
 def _finger_finger_run(lib, device, contacts_on):
     def edit(m):
