@@ -41,7 +41,12 @@ N_SIMD = 256 * 4                 # SIMDs of the chip (MI355X_MICROARCH.md: 256 C
 VALU_CYCLES_PER_INST = 2.0       # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
 TF_OBS_BASE, TF_STATES_EXTRA = 32, 72     # include/trifinger.h: obs = 32 + A values, states = obs + 72
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs (algorithmic)
-FLOP_PER_ENV_STEP_ESTIMATE = 33.0e3     # SURVEY.md 8(d) paper estimate; used only when no counter profile of this workload exists
+# exact fp32 operation count of one env-step of this workload on a scalar machine (the oracle's instrumented build, oracle/tf_flops.h:
+# 2404 add + 4505 mul + 18 div + 12 sqrt + 6379 fma counted twice; beside them 3854 comparisons / min / max / abs and 112 conversions):
+# tests/test_flop_count.py holds this constant to the count, profiles/r3_l_flops.txt is its table.  It replaces SURVEY.md 8(d)'s 33 kFLOP
+# paper estimate.  The GPU executes more than this (a wavefront runs a contact row whenever one of its 64 envs needs it): that is
+# valu_lane_ops_per_env_step, from the counters.
+FLOPS_PER_ENV_STEP = 19.7e3
 
 
 def load_pmc_profile(n, asym, ext=False):
@@ -419,7 +424,9 @@ def main():
             # count an FMA as two), so valu_lane_ops_frac = lane-operations/s / 78.6e12.
             "valu_lane_ops_per_env_step": (pmc["SQ_INSTS_VALU"] * 64.0 / n) if (pmc and "SQ_INSTS_VALU" in pmc) else None,
             "valu_lane_ops_frac": (pmc["SQ_INSTS_VALU"] * 64.0 / kern_avg_s / (FP32_PEAK_TFLOPS * 0.5e12)) if (pmc and kern_n and "SQ_INSTS_VALU" in pmc) else None,
-            "fp32_frac_est": (FLOP_PER_ENV_STEP_ESTIMATE * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
+            "flops_per_env_step": FLOPS_PER_ENV_STEP,
+            "flops_source": "exact count of the oracle's instrumented build (tests/test_flop_count.py, profiles/r3_l_flops.txt)",
+            "fp32_frac": (FLOPS_PER_ENV_STEP * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
         },
     }
     if global_stats is not None:

@@ -50,7 +50,11 @@ __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp,
     Ctx cx;
     cx.tid = (int)threadIdx.x;
     cx.lane = (int)threadIdx.x & (WAVE - 1);
+#if defined(TF_ROLE_ROT)         // developer variant: which wavefront of the workgroup takes which role rotates with the workgroup index
+    cx.role = __builtin_amdgcn_readfirstlane((((int)threadIdx.x >> 6) + ((int)blockIdx.x >> TF_ROLE_ROT)) & 3);
+#else
     cx.role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#endif
     cx.wave_first = (int)blockIdx.x * WAVE;
     const int i_raw = cx.wave_first + cx.lane;
     cx.valid = i_raw < P.N;

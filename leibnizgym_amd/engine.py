@@ -272,6 +272,37 @@ class TrifingerEngine:
     def frame_count(self, v):
         check(self.lib, self.lib.tf_set_frame_count(self._handle, int(v)), "tf_set_frame_count")
 
+    # -- checkpoint / exact replay (the reference never checkpoints env state; optional here) -----------------
+    _CHECKPOINT_BUFFERS = ("state", "action_buf", "obs", "states", "reward", "reset_buf", "goal_reset_buf", "successes", "dones",
+                           "steps", "reset_count", "info")
+
+    def state_dict(self):
+        """Everything a bit-exact continuation of the rollout needs: copies of the caller-owned buffers of TfBuffers (the SoA state
+        with the solver's warm start, flags, step and reset counters - the Philox counters of every sampler -, outputs of the last
+        step) and the frame count (reward schedule, noise and action-repeat counters).  The handle holds nothing else that the step
+        reads back: gravity, clipping and the configuration are settings of the caller."""
+        d = {k: getattr(self, k).detach().clone() for k in self._CHECKPOINT_BUFFERS}
+        d["frame_count"] = self.frame_count
+        d["layout"] = dict(api_version=int(capi.TF_API_VERSION), num_envs=self.num_envs, action_dim=self.action_dim,
+                           states_dim=self.states_dim, env_id_offset=int(self.cfg.env_id_offset), seed=int(self.cfg.seed))
+        return d
+
+    def load_state_dict(self, d):
+        """Restore `state_dict()` in place (the buffers stay where the handle is bound to them).  Raises ValueError when the
+        checkpoint was written by another state layout, env count, action / states width, shard offset or seed."""
+        mine = dict(api_version=int(capi.TF_API_VERSION), num_envs=self.num_envs, action_dim=self.action_dim,
+                    states_dim=self.states_dim, env_id_offset=int(self.cfg.env_id_offset), seed=int(self.cfg.seed))
+        theirs = dict(d["layout"])
+        if theirs != mine:
+            raise ValueError(f"checkpoint of another engine: {theirs} (this engine: {mine})")
+        for k in self._CHECKPOINT_BUFFERS:
+            dst, src = getattr(self, k), d[k]
+            if tuple(dst.shape) != tuple(src.shape) or dst.dtype != src.dtype:
+                raise ValueError(f"checkpoint buffer '{k}': {tuple(src.shape)} {src.dtype}, expected {tuple(dst.shape)} {dst.dtype}")
+        for k in self._CHECKPOINT_BUFFERS:
+            getattr(self, k).copy_(d[k])
+        self.frame_count = int(d["frame_count"])
+
     def set_clipping(self, clip_obs, clip_actions):
         """Fuse the wrapper's clamps into the step (<= 0 switches a clamp off)."""
         check(self.lib, self.lib.tf_set_clipping(self._handle, float(clip_obs), float(clip_actions)), "tf_set_clipping")

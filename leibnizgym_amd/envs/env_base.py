@@ -237,6 +237,15 @@ class IsaacEnvBase:
         self._engine.set_clipping(clip_obs, clip_actions)
         return True
 
+    def state_dict(self) -> dict:
+        """Checkpoint of the simulation (not in the reference, whose env state lives inside IsaacGym and is never saved; SURVEY.md
+        section 5 lists it as optional): buffers + counters from which `load_state_dict` continues the rollout bit for bit."""
+        return self._engine.state_dict()
+
+    def load_state_dict(self, state: dict):
+        self._engine.load_state_dict(state)
+        self._step_info = dict(self._info_items)
+
     def render(self):
         if self.visualize:
             print_warn("render(): the HIP environment is headless; no viewer is available.")

@@ -34,6 +34,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef TF_COUNT_FLOPS   /* developer build (make -C oracle flops): this file as C++, every `float` a wrapper that counts its operations */
+#include "tf_flops.h"
+#endif
 #include "../include/trifinger.h"
 #include "../include/trifinger_default_caps.h"
 
@@ -44,7 +47,11 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* deterministic elementary functions (coefficients: Cephes single-precision minimax polynomials)    */
 /* ------------------------------------------------------------------------------------------------ */
+#ifdef TF_COUNT_FLOPS
+#define FMA(a, b, c) cf_fma((a), (b), (c))
+#else
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#endif
 
 /* min / max / clamp with the semantics of the GPU's v_min_f32 / v_max_f32 / v_med3_f32 on non-NaN inputs:
  * a total order in which -0 < +0.  They differ from (a < b) ? a : b only when both operands are zeros of
@@ -410,7 +417,7 @@ void tf_default_model(TfModel* m) {
 /* The object as a general box: mass, principal moments about the body axes, reference inertia of the scaled solve (the mean
  * of the principal moments), CuboidalObject constants (reference envs/trifinger/utils.py:122-131, ARENA_RADIUS :54). */
 void tf_model_set_box(TfModel* m, const float size[3], float density) {
-    const double sx = size[0], sy = size[1], sz = size[2];
+    const double sx = (double)size[0], sy = (double)size[1], sz = (double)size[2];
     const double mass = (double)density * sx * sy * sz;
     const double I[3] = {mass * (sy * sy + sz * sz) / 12.0, mass * (sx * sx + sz * sz) / 12.0, mass * (sx * sx + sy * sy) / 12.0};
     {   /* the default cube (65 mm, 291.3 kg/m^3) asked for as a "box" stays the cube: box = 0, headline kernels, isotropic arithmetic */

@@ -402,3 +402,43 @@ def test_fused_random_action_source(backend):
     imp.step_random()
     assert imp.action_buf.shape == (64, 18) and imp.action_buf.abs().max() <= 1 and imp.action_buf[:, 17].std() > 0.3
     imp.close()
+
+
+def test_env_state_checkpoint_continues_bit_for_bit(backend, tmp_path):
+    """a state_dict of the SoA buffers + counters; a rollout continued from it - in the same env or in a
+    fresh one, through torch.save / torch.load - is the original rollout bit for bit (resets, goal resets, reward schedule, the
+    observation noise and action repeats of the domain randomisation and the solver's warm start included)."""
+    cfg = dict(num_instances=48, seed=5, episode_length=12, asymmetric_obs=True, task_difficulty=4,
+               domain_randomization=dict(activate=True, obs_noise=0.002, action_repeat_prob=0.2))
+    env = make_env(backend, **cfg)
+    g = torch.Generator().manual_seed(1)
+    acts = [(torch.rand(48, 9, generator=g) * 2 - 1).to(backend[1]) for _ in range(40)]
+    env.reset()
+    for a in acts[:15]:
+        env.step(a)
+    ck = env.state_dict()
+    assert ck["frame_count"] == 16 and ck["state"].data_ptr() != env._engine.state.data_ptr()
+    path = os.path.join(tmp_path, "env.pt")
+    torch.save(ck, path)
+
+    def run(e):
+        out = []
+        for a in acts[15:]:
+            obs, rew, dones, info = e.step(a)
+            out.append((obs.clone(), rew.clone(), e._reset_buf.clone(), e.states_buf.clone(), e._engine.state.clone(), dict(info)))
+        return out
+    first = run(env)
+    assert any(bool(o[2].any()) for o in first), "the continuation must cross a time-out"
+    env.load_state_dict(ck)                                              # back in time, same env
+    fresh = make_env(backend, **cfg)                                     # and a new env that never ran the first 15 steps
+    fresh.load_state_dict(torch.load(path, map_location=backend[1]))
+    assert fresh.env_steps_count == env.env_steps_count == 16 * 48
+    for other in (run(env), run(fresh)):
+        for x, y in zip(first, other):
+            for k in range(5):
+                assert torch.equal(x[k].view(torch.uint8) if x[k].dtype == torch.bool else x[k].view(torch.int32), y[k].view(torch.uint8) if y[k].dtype == torch.bool else y[k].view(torch.int32))
+            assert {k: float(v) for k, v in x[5].items()} == {k: float(v) for k, v in y[5].items()}
+    # a checkpoint of another layout is refused
+    small = make_env(backend, **dict(cfg, num_instances=16))
+    with pytest.raises(ValueError, match="checkpoint of another engine"):
+        small.load_state_dict(ck)
