@@ -1,6 +1,6 @@
 """Debug helper (GPU box): first step at which the fused HIP rollout leaves the oracle, which state rows differ and how."""
 import sys, os
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np, torch
 import parity_util as pu

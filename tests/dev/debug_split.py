@@ -1,6 +1,6 @@
 """Debug helper (GPU box): walk the split path hook by hook on both libraries and report the first divergence."""
 import sys, os
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np, torch
 import parity_util as pu

@@ -1,6 +1,6 @@
 """One-off stress of the bit-exact parity (GPU box): more envs, more seeds, longer rollouts than the test-suite."""
 import sys, os
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 import parity_util as pu
 from oracle_util import load_oracle

@@ -4,9 +4,9 @@ tests/test_contact_lcp_reference.py after four product substeps (persistent cont
 per-corner friction (the spec) vs PATCH friction for the cube-floor / cube-wall contact (4 normals + 2 anchor tangents + torsion), a
 3x3 BLOCK update of every finger-cube contact (joint solve of normal + tangents, sequential projection when infeasible), successive
 over-relaxation, symmetric / floor-first / repeated-block row orders.  Error = scaled velocity error of k sweeps against the variant's
-own fixed point (4000 sweeps).   python tools/pgs_variants.py [cases]      result of round 3: profiles/r3_b_pgs_variants.txt"""
+own fixed point (4000 sweeps).   python tests/dev/pgs_variants.py [cases]      result of round 3: profiles/r3_b_pgs_variants.txt"""
 import sys, os
-REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0,os.path.join(REPO,'tests')); sys.path.insert(0,REPO)
 import numpy as np, torch
 import test_contact_lcp_reference as L
