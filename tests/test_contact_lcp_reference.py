@@ -197,3 +197,81 @@ def test_substep_converges_to_the_independent_lcp_solution(oracle):
 def test_substep_converges_to_the_independent_lcp_solution_gpu(hip):
     errs, kinds = _run(hip, "cuda:0", 60, SWEEPS)
     _check(errs, kinds, SWEEPS, 60)
+
+
+# ---- the boundary above its vertical ring: cube corners and fingertips against the flared part ---------------------------------------
+def _boundary_cases(rng, n):
+    """cube thrown at the flared part of the boundary (any orientation, some corner within -2 .. +3 mm of the surface, above the
+    vertical ring), and fingertips stretched out to it; everything else far from any contact"""
+    out = []
+    hc = PR.CUBE_HALF
+    corners = np.array([[sx, sy, sz] for sx in (-hc, hc) for sy in (-hc, hc) for sz in (-hc, hc)])
+    q_rest = np.array([0.0, 0.9, -1.7] * 3)
+    while len(out) < n:
+        if len(out) % 4 != 3:
+            cq = _rand_quat(rng)
+            R = PR.quat_rot(cq)
+            phi, zc, g0 = rng.uniform(0, 2 * np.pi), rng.uniform(0.06, 0.13), rng.uniform(-0.002, 0.003)
+            ed = np.array([np.cos(phi), np.sin(phi), 0.0])
+
+            def min_gap(rc):
+                P = rc * ed + np.array([0.0, 0.0, zc]) + corners @ R.T
+                return min(PR.wall_radius_at(p[2]) - np.hypot(p[0], p[1]) for p in P)
+            lo, hi = 0.05, 0.30
+            for _ in range(50):
+                mid = 0.5 * (lo + hi)
+                lo, hi = (mid, hi) if min_gap(mid) > g0 else (lo, mid)
+            c = lo * ed + np.array([0.0, 0.0, zc])
+            if min((c + corners @ R.T)[:, 2]) < 0.034:          # keep the contact on the cone, not on the ring or the floor
+                continue
+            try:                                                # and the resting fingers out of it
+                if min(g for f in range(3) for g, _ in PR.finger_gaps(f, q_rest[3 * f:3 * f + 3], c, R, np.full(3, hc))) < 0.01:
+                    continue
+            except ValueError:
+                continue
+            v = ed * rng.uniform(0.2, 1.0) + rng.normal(size=3) * 0.1
+            cube = np.concatenate([c, cq, v, rng.uniform(-3, 3, 3)])
+            out.append((q_rest.copy(), np.zeros(9), cube, np.zeros(9)))
+        else:
+            q = q_rest.copy()
+            q[0:3] = rng.uniform(PR.Q_LO + 0.05, PR.Q_HI - 0.05)
+            tip = PR.link_point_world(0, q[0:3], 3, PR.TIP_CAP[2])
+            g = PR.wall_radius_at(tip[2]) - np.hypot(tip[0], tip[1]) - 0.0102
+            if not (-0.002 < g < 0.003 and tip[2] > 0.04):
+                continue
+            qd = np.zeros(9)
+            qd[0:3] = rng.uniform(-2, 2, 3)
+            tau = np.zeros(9)
+            tau[0:3] = rng.uniform(-0.36, 0.36, 3)
+            cube = np.array([0.0, 0.0, 0.0325, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0])
+            out.append((q, qd, cube, tau))
+    return out
+
+
+def _check_boundary(lib, device, n):
+    errs, hits = [], 0
+    for q, qd, cube, tau in _boundary_cases(np.random.default_rng(77), n):
+        ref = PR.ref_substep(q, qd, cube, tau, H, max_sweeps=50000)
+        det = ref[3]
+        assert det["sweeps"] < 50000
+        hits += det["n_wall"] > 0 or any(x[1] == "wall" and x[3].lam > 0 for x in det["te"])
+        errs.append([scaled_error(product_substep(lib, device, q, qd, cube, tau, k), ref[:3]) for k in (8, 1024)])
+    errs = np.array(errs)
+    print(f"\nboundary cases with a pushing contact on the cone: {hits} of {n};  8 sweeps median {np.median(errs[:, 0]):.2e} max {errs[:, 0].max():.2e};"
+          f"  1024 sweeps median {np.median(errs[:, 1]):.2e} max {errs[:, 1].max():.2e}")
+    assert hits >= n // 2
+    # converged, the rows agree with the reference; 8 cold sweeps leave up to O(1) on an edge of the flying cube that hits the cone with two
+    # corners at once (friction rows of the two corners against each other - the slow case of Gauss-Seidel, DESIGN.md section 2)
+    assert errs[:, 1].max() < 1e-3 and np.median(errs[:, 1]) < 2e-5 and np.median(errs[:, 0]) < 5e-3, errs
+
+
+def test_boundary_rows_on_the_flared_part_agree_with_the_independent_solution(oracle):
+    """Cube corners (any orientation, flying) and fingertips against the flared part of the boundary - radius from the piecewise-linear
+    profile at the height of the contact, horizontal inward normal, rows n, t, +z - against the fp64 reference, which builds them from its
+    own geometry (the random cases of the main test hold only a handful of boundary contacts)."""
+    _check_boundary(oracle, "cpu", 16)
+
+
+@pytest.mark.gpu
+def test_boundary_rows_on_the_flared_part_agree_with_the_independent_solution_gpu(hip):
+    _check_boundary(hip, "cuda:0", 16)
