@@ -43,4 +43,13 @@ for lab, a, b in rows:
 for s in (0, 1):
     b = 4 + 12 * s
     print(f"  sub{s}: barrier wait inside sweeps: finger {v(b + 8, 0):.0f} | cube {v(b + 8, 3):.0f};  cube finger-cube rows {v(b + 10, 3):.0f}; up to the end of the floor rows (incl. W1) {v(b + 11, 3):.0f}")
+# how the workgroups spread around their median: the launch is one round of workgroups, so it ends with its slowest one
+cube = S[:, :, 3, :]
+tot = (cube[:, :, 35] - cube[:, :, 0]) & 0xffffffff
+pct = lambda a: "  ".join(f"p{q} {np.percentile(a, q):.0f}" for q in (1, 50, 90, 99, 100))      # noqa: E731
+print(f"  per workgroup (cube role) start -> end: {pct(tot)}      (s_memtime of different XCDs is not synchronised: no cross-workgroup spans)")
+for s_ in (0, 1):
+    b = 4 + 12 * s_
+    sw = (cube[:, :, b + 6] - cube[:, :, b + 5]) & 0xffffffff
+    print(f"  sub{s_} sweeps per workgroup (cube role): {pct(sw)}")
 eng.close()
