@@ -1474,14 +1474,24 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 if (out[2] > best) { best = out[2]; k = 2; }
                 float pk = (k == 0) ? pr[0] : ((k == 1) ? pr[1] : pr[2]);
                 float sk = (pk < 0.0f) ? -1.0f : 1.0f;
-                const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
+                // Slot order of the four corners: the LOWER pair of the face first (slots 0, 1), the upper pair behind it.  A cube that lies at
+                // the boundary touches it with its lower pair, so the lanes of a wavefront agree on which slots are live and the sweeps run two
+                // corner blocks instead of up to four (the step ends with its slowest workgroup: DESIGN.md section 4).  With a < b the two axes of
+                // the face, the "heavy" one is the axis whose corner offset has the larger vertical component; the pair is chosen by its sign,
+                // the order inside a pair by the sign along the other axis; the choice is part of the feature the warm start is keyed by.
+                const int a_ = (k == 0) ? 1 : 0, b_ = (k == 2) ? 1 : 2;
+                const float wa_ = hc[a_] * ((a_ == 0) ? R[6] : R[7]), wb_ = hc[b_] * ((b_ == 1) ? R[7] : R[8]);
+                const bool heavy_b = f_abs(wb_) > f_abs(wa_);
+                const int lowh = ((heavy_b ? wb_ : wa_) < 0.0f) ? 1 : 0;      // sign bit of the heavy axis that points down
+                const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0) + 8 * ((heavy_b ? 2 : 0) + lowh));
                 const float keep = (face == cw_face) ? ws : 0.0f;
                 wall_lane = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int wb = L_WALL + 12 * c;
                     float r[3], n[2] = {0.0f, 0.0f}, Dinv[3] = {0.0f, 0.0f, 0.0f}, bias = 0.0f, lam[3] = {0.0f, 0.0f, 0.0f};
-                    cube_corner(R, hc, k, sk, c, r);
+                    const int hbit = (c >> 1) ^ lowh, lbit = c & 1;
+                    cube_corner(R, hc, k, sk, heavy_b ? (lbit | (hbit << 1)) : (hbit | (lbit << 1)), r);
                     float px = cx_ + r[0], py = cy_ + r[1], pz = cp[2] + r[2];
                     float rho2 = FMA(px, px, py * py);
                     float inv = f_rsqrt(f_max(rho2, 1e-24f));

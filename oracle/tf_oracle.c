@@ -1284,12 +1284,19 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         if (out[1] > best) { best = out[1]; k = 1; }
         if (out[2] > best) { best = out[2]; k = 2; }
         float sk = (pr[k] < 0.0f) ? -1.0f : 1.0f;
-        cw_face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
+        /* slot order of the four corners: the lower pair of the face first (the heavy axis - the one whose corner offset has the larger
+         * vertical component - picks the pair, the other axis the order inside it); part of the feature the warm start is keyed by */
+        const int a_ = (k == 0) ? 1 : 0, b_ = (k == 2) ? 1 : 2;
+        const float wa_ = hc[a_] * R[6 + a_], wb_ = hc[b_] * R[6 + b_];
+        const int heavy_b = f_abs(wb_) > f_abs(wa_);
+        const int lowh = ((heavy_b ? wb_ : wa_) < 0.0f) ? 1 : 0;
+        cw_face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0) + 8 * ((heavy_b ? 2 : 0) + lowh));
         const float keep = (cw_face == e->cw_face) ? ws : 0.0f;
         for (int i = 0; i < 4; ++i) {
             CubeContact* c = &cwl[i];
             memset(c, 0, sizeof(*c));
-            cube_corner(R, hc, k, sk, i, c->r);
+            const int hbit = (i >> 1) ^ lowh, lbit = i & 1;
+            cube_corner(R, hc, k, sk, heavy_b ? (lbit | (hbit << 1)) : (hbit | (lbit << 1)), c->r);
             float px = cx_ + c->r[0], py = cy_ + c->r[1], pz = e->cp[2] + c->r[2];
             float rho2 = FMA(px, px, py * py);
             float inv = f_rsqrt(f_max(rho2, 1e-24f));

@@ -1,6 +1,7 @@
 """Developer tool (GPU box): penetration-depth statistics of a headline-size rollout: fingertip sphere vs
 floor, cube corners vs floor, fingertip sphere vs cube - percentiles over every env and sampled step, random actions and (optionally)
-domain randomisation.   python tools/penetration_stats.py [num_envs] [steps] [dr]"""
+domain randomisation.   python tools/penetration_stats.py [num_envs] [steps] [dr|-] [contact_slack]   (a slack other than the model's: the
+experiment of DESIGN.md section 4; the fused-step time is printed beside the depths)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -16,6 +17,11 @@ lib = capi.load_hip_library()
 dev = "cuda:0"
 kw = bench.workload_kwargs(True)
 kw.update(episode_length=300)
+slack = float(sys.argv[4]) if len(sys.argv) > 4 else None
+if slack is not None:
+    mm = lib.default_model()
+    mm.contact_slack = slack
+    kw.update(model=mm)
 if dr:
     kw.update(domain_randomization={"activate": True})
 eng = TrifingerEngine(make_config(lib, n, seed=11, **kw), device=dev, lib=lib)
@@ -23,6 +29,7 @@ m = lib.default_model()
 g = torch.Generator(device=dev).manual_seed(3)
 ring = [(torch.rand(n, 9, device=dev, generator=g) * 2 - 1) for _ in range(32)]
 eng.reset()
+eng.enable_kernel_timing(steps)
 R_TIP, HALF = float(m.cap_radius), float(m.cube_half)
 J2, J3, CB = (torch.tensor(list(x), device=dev) for x in (m.j2_origin, m.j3_origin, m.cap_b))
 YC, YS, HB = list(m.base_yaw_cos), list(m.base_yaw_sin), float(m.base_height)
@@ -75,8 +82,10 @@ for k in range(steps):
         pen["cube-floor"].append((hc[:, 0] * R[2].abs().sum(0)) - cp[:, 2])
         pen["fingertip-cube"].append(torch.stack(tc).flatten())
 torch.cuda.synchronize()
+ms_, cnt_ = eng.kernel_time_ms()
 print(f"{n} envs x {steps} steps, random actions{', domain randomisation' if dr else ''}, sampled every 25 steps; penetration depth in mm "
-      f"(positive = inside; contact_offset is 2 mm)")
+      f"(positive = inside; contact_offset is 2 mm); contact_slack {slack if slack is not None else float(m.contact_slack):.4f} m; "
+      f"fused step {ms_ / max(cnt_, 1) * 1e3:.2f} us (with a host synchronisation every 25 steps)")
 for name, v in pen.items():
     x = torch.cat(v).float() * 1e3
     touching = x > -1.0

@@ -52,4 +52,14 @@ for s_ in (0, 1):
     b = 4 + 12 * s_
     sw = (cube[:, :, b + 6] - cube[:, :, b + 5]) & 0xffffffff
     print(f"  sub{s_} sweeps per workgroup (cube role): {pct(sw)}")
+# what the slow workgroups spend their sweeps on (cube role, substep 0): finger-cube rows | W1 + floor rows | boundary rows + W2
+b = 4
+sw = ((cube[:, :, b + 6] - cube[:, :, b + 5]) & 0xffffffff).astype(np.float64).ravel()
+fc = cube[:, :, b + 10].astype(np.float64).ravel()
+fl = cube[:, :, b + 11].astype(np.float64).ravel() - fc
+rest = sw - fc - fl
+for lab, lo, hi in (("all", 0, 100), ("p40-p60", 40, 60), ("p85-p95", 85, 95), ("p98-p100", 98, 100)):
+    a, z = np.percentile(sw, lo), np.percentile(sw, hi)
+    m = (sw >= a) & (sw <= z)
+    print(f"  sweeps of sub0, workgroups {lab:9s}: total {np.median(sw[m]):6.0f} = finger-cube rows {np.median(fc[m]):6.0f} + W1 and floor rows {np.median(fl[m]):6.0f} + boundary rows and W2 {np.median(rest[m]):6.0f}")
 eng.close()
