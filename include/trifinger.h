@@ -110,8 +110,8 @@ enum {
     TF_S_LAM_CF = 131,   /* 12 cube corner i against the floor at [3i..3i+2]: +z (normal), +x, +y                   */
     TF_S_CF_FACE = 143,  /*  1 cube face whose corners those were (0 none, 1..6)                                   */
     TF_S_LAM_CW = 144,   /* 12 cube corner i against the boundary wall at [3i..3i+2]: normal, tangent, +z          */
-    TF_S_CW_FACE = 156,  /*  1 feature those rows belong to: cube face 1..6 + 8 x slot order of its corners (0..3: lower pair first); 0 while no
-                          *    corner touches the boundary (TF_S_LAM_CW then undefined) */
+    TF_S_CW_FACE = 156,  /*  1 feature those rows belong to: cube face 1..6 + 8 x which pair of its corners is the lower one (0..3) + 32 x order
+                          *    inside that pair (nearer corner first); 0 while no corner touches the boundary (TF_S_LAM_CW then undefined) */
     TF_STATE_ROWS = 157
 };
 #define TF_NUM_DR 14

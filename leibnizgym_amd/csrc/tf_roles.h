@@ -1452,6 +1452,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 }
             }
             bool wall_lane = false;
+            bool slot_any[4] = {false, false, false, false};     // wave-uniform: a lane of this wavefront has a live corner in slot c
             {   // cube vs boundary wall: the four corners of the face that points outward most; rows go to LDS
                 const float cx_ = EXT ? cp[0] - soff[0] : cp[0], cy_ = EXT ? cp[1] - soff[1] : cp[1];      // relative to the stage centre
                 float rc2 = FMA(cx_, cx_, cy_ * cy_);
@@ -1478,19 +1479,41 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 // the boundary touches it with its lower pair, so the lanes of a wavefront agree on which slots are live and the sweeps run two
                 // corner blocks instead of up to four (the step ends with its slowest workgroup: DESIGN.md section 4).  With a < b the two axes of
                 // the face, the "heavy" one is the axis whose corner offset has the larger vertical component; the pair is chosen by its sign,
-                // the order inside a pair by the sign along the other axis; the choice is part of the feature the warm start is keyed by.
+                // inside the lower pair the corner nearer to the boundary comes first (a cube usually touches the concave wall with one corner: it
+                // then sits in slot 0 in every lane), decided anew in every substep - the warm-start rows follow their corner when the order of
+                // the pair changes; the upper pair is ordered by the sign along the other axis.  The feature the warm start is keyed by is
+                // face + 8 x pair, stored with the order: + 32 x order.
                 const int a_ = (k == 0) ? 1 : 0, b_ = (k == 2) ? 1 : 2;
                 const float wa_ = hc[a_] * ((a_ == 0) ? R[6] : R[7]), wb_ = hc[b_] * ((b_ == 1) ? R[7] : R[8]);
                 const bool heavy_b = f_abs(wb_) > f_abs(wa_);
                 const int lowh = ((heavy_b ? wb_ : wa_) < 0.0f) ? 1 : 0;      // sign bit of the heavy axis that points down
-                const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0) + 8 * ((heavy_b ? 2 : 0) + lowh));
-                const float keep = (face == cw_face) ? ws : 0.0f;
+                const float face_pair = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0) + 8 * ((heavy_b ? 2 : 0) + lowh));
+                int order, swap01;
+                float keep, lam_old[6];
+                {
+                    const float prev_o = (cw_face >= 32.0f) ? 1.0f : 0.0f;
+                    float gl[2];
+#pragma unroll
+                    for (int lb = 0; lb < 2; ++lb) {             // horizontal gap of the two corners of the lower pair
+                        float rr[3];
+                        cube_corner(R, hc, k, sk, heavy_b ? (lb | (lowh << 1)) : (lowh | (lb << 1)), rr);
+                        const float qx = cx_ + rr[0], qy = cy_ + rr[1];
+                        const float q2 = FMA(qx, qx, qy * qy);
+                        gl[lb] = wall_radius_at(P, cp[2] + rr[2]) - q2 * f_rsqrt(f_max(q2, 1e-24f));
+                    }
+                    order = (gl[1] < gl[0]) ? 1 : 0;
+                    swap01 = order ^ (int)prev_o;
+                    keep = (FMA(-32.0f, prev_o, cw_face) == face_pair) ? ws : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) lam_old[j] = LD(L_WALL + 12 * (j / 3) + 9 + (j % 3));      // slots 0 and 1 before they are rewritten
+                }
+                const float face = FMA(32.0f, (float)order, face_pair);
                 wall_lane = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int wb = L_WALL + 12 * c;
                     float r[3], n[2] = {0.0f, 0.0f}, Dinv[3] = {0.0f, 0.0f, 0.0f}, bias = 0.0f, lam[3] = {0.0f, 0.0f, 0.0f};
-                    const int hbit = (c >> 1) ^ lowh, lbit = c & 1;
+                    const int hbit = (c >> 1) ^ lowh, lbit = (c < 2) ? ((c & 1) ^ order) : (c & 1);
                     cube_corner(R, hc, k, sk, heavy_b ? (lbit | (hbit << 1)) : (hbit | (lbit << 1)), r);
                     float px = cx_ + r[0], py = cy_ + r[1], pz = cp[2] + r[2];
                     float rho2 = FMA(px, px, py * py);
@@ -1509,19 +1532,19 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                             Dinv[2] = box ? f_rcp2(FMA(dot3(c3, c3), inv_I, inv_m)) : f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                             bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
 #pragma unroll
-                            for (int d = 0; d < 3; ++d) lam[d] = LD(wb + 9 + d) * keep;
+                            for (int d = 0; d < 3; ++d) lam[d] = ((c < 2) ? (((c ^ swap01) == 0) ? lam_old[d] : lam_old[3 + d]) : LD(wb + 9 + d)) * keep;
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { LD(wb + j) = r[j]; LD(wb + 5 + j) = Dinv[j]; LD(wb + 9 + j) = lam[j]; }
                     LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
                     wall_lane = wall_lane || (Dinv[0] > 0.0f);
+                    slot_any[c] = __builtin_amdgcn_ballot_w64(Dinv[0] > 0.0f) != 0ull;
                 }
                 cw_face = wall_lane ? face : 0.0f;              // 0: no corner touches the boundary (the rows carry nothing)
             }
-            // wave-uniform: no lane of this wavefront has a live wall corner (the usual case) -> the sweeps skip the wall block
-            // without its four dependent LDS round trips
-            const bool wall_any = __builtin_amdgcn_ballot_w64(wall_lane) != 0ull;
+            // wave-uniform flags per corner slot: the sweeps enter the block of a slot only when a lane of this wavefront has a live corner
+            // there - no LDS round trip for the others (with the lower pair in slots 0 and 1, slots 2 and 3 are practically never live)
             STAMP(sb_ + 0);
             BAR();                                              // S1
             STAMP(sb_ + 1);
@@ -1630,11 +1653,11 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     }
                 }
             }
-            if (__builtin_expect(wall_any, 0)) {
+            {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int wb = L_WALL + 12 * c;
-                if (LD(wb + 5) > 0.0f) {
+                if (slot_any[c] && LD(wb + 5) > 0.0f) {
                     float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
                     float a[3], b[3], c3[3];
                     wall_arms(box, lds, lane, r, n, a, b, c3);
@@ -1725,12 +1748,13 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     }
                 }
                 t_floor += NOW() - tf0_;
-                if (__builtin_expect(wall_any, 0)) {
+                {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                   // cube - wall: rows n (normal), t, +z
+                    if (!slot_any[c]) continue;                 // wave-uniform
                     const int wb = L_WALL + 12 * c;
                     const float D0 = LD(wb + 5);
-                    if (__builtin_expect(D0 > 0.0f, 0)) {
+                    if (D0 > 0.0f) {
                         float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
                         float Dinv[3] = {D0, LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
                         float lam[3] = {LD(wb + 9), LD(wb + 10), LD(wb + 11)};

@@ -1290,12 +1290,30 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         const float wa_ = hc[a_] * R[6 + a_], wb_ = hc[b_] * R[6 + b_];
         const int heavy_b = f_abs(wb_) > f_abs(wa_);
         const int lowh = ((heavy_b ? wb_ : wa_) < 0.0f) ? 1 : 0;
-        cw_face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0) + 8 * ((heavy_b ? 2 : 0) + lowh));
-        const float keep = (cw_face == e->cw_face) ? ws : 0.0f;
+        /* inside the lower pair the corner nearer to the boundary comes first, decided anew in every substep; the warm-start rows follow
+         * their corner when the order changes.  Feature the warm start is keyed by: face + 8 x pair; stored with the order (+ 32 x order) */
+        const float face_pair = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0) + 8 * ((heavy_b ? 2 : 0) + lowh));
+        int order, swap01;
+        float keep;
+        {
+            const float prev_o = (e->cw_face >= 32.0f) ? 1.0f : 0.0f;
+            float gl[2];
+            for (int lb = 0; lb < 2; ++lb) {
+                float rr[3];
+                cube_corner(R, hc, k, sk, heavy_b ? (lb | (lowh << 1)) : (lowh | (lb << 1)), rr);
+                const float qx = cx_ + rr[0], qy = cy_ + rr[1];
+                const float q2 = FMA(qx, qx, qy * qy);
+                gl[lb] = wall_radius_at(H, e->cp[2] + rr[2]) - q2 * f_rsqrt(f_max(q2, 1e-24f));
+            }
+            order = (gl[1] < gl[0]) ? 1 : 0;
+            swap01 = order ^ (int)prev_o;
+            keep = (FMA(-32.0f, prev_o, e->cw_face) == face_pair) ? ws : 0.0f;
+        }
+        cw_face = FMA(32.0f, (float)order, face_pair);
         for (int i = 0; i < 4; ++i) {
             CubeContact* c = &cwl[i];
             memset(c, 0, sizeof(*c));
-            const int hbit = (i >> 1) ^ lowh, lbit = i & 1;
+            const int hbit = (i >> 1) ^ lowh, lbit = (i < 2) ? ((i & 1) ^ order) : (i & 1);
             cube_corner(R, hc, k, sk, heavy_b ? (lbit | (hbit << 1)) : (hbit | (lbit << 1)), c->r);
             float px = cx_ + c->r[0], py = cy_ + c->r[1], pz = e->cp[2] + c->r[2];
             float rho2 = FMA(px, px, py * py);
@@ -1315,7 +1333,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                 c->Dinv[2] = box ? f_rcp2(FMA(dot3(c3, c3), inv_I, inv_m)) : f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
                 float vn0 = wn_vrel(c, a, v, w);
                 c->bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
-                for (int d = 0; d < 3; ++d) c->lam[d] = e->lam_cw[i][d] * keep;
+                for (int d = 0; d < 3; ++d) c->lam[d] = e->lam_cw[(i < 2) ? (i ^ swap01) : i][d] * keep;
             }
         }
     }
