@@ -1753,10 +1753,12 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 for (int c = 0; c < 4; ++c) {                   // cube - wall: rows n (normal), t, +z
                     if (!slot_any[c]) continue;                 // wave-uniform
                     const int wb = L_WALL + 12 * c;
-                    const float D0 = LD(wb + 5);
-                    if (D0 > 0.0f) {
+                    {   // No per-lane branch around the rows: a lane whose corner in this slot is not live holds n = 0, 1/D = 0, bias = 0 and
+                        // zero impulses there, so its rows come out as dl = +-0 and leave v, w as they are (they are never -0: they start at +0
+                        // and only ever pass through additions) - one LDS round trip per block instead of two, no exec-mask juggling; only the
+                        // impulses are stored per lane (a clamp to +-0 can yield -0, which must not reach the state row of a dead slot).
                         float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
-                        float Dinv[3] = {D0, LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
+                        float Dinv[3] = {LD(wb + 5), LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
                         float lam[3] = {LD(wb + 9), LD(wb + 10), LD(wb + 11)};
                         float a[3], b[3], c3[3];
                         wall_arms(box, lds, lane, r, n, a, b, c3);
@@ -1773,8 +1775,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                             dl = solve_tangent(lam[2], Dinv[2], cz_vrel(r, v, w), mu_cw * lam[0]);
                             cz_apply(r, dl, inv_m, inv_I, v, w);
                         }
+                        if (Dinv[0] > 0.0f) {
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
+                            for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
+                        }
                     }
                 }
                 }
