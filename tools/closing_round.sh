@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): everything a round's closing profiles/ entry holds, in one gpurun call.
-#   tools/r3_round.sh <tag>
+#   tools/closing_round.sh <tag>
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=${1:-rX}; O=gpurun_out; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/${T}_pytest_gpu.txt 2>&1; tail -3 $O/${T}_pytest_gpu.txt
