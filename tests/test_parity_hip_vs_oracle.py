@@ -19,6 +19,36 @@ def test_rollout_bit_exact(hip, oracle, cfg_name):
         pu.assert_bit_equal(a, b, f"{cfg_name} step {t}")
 
 
+@pytest.mark.parametrize("cfg_name", ["d4_torque_asym", "d4_domain_randomization"])
+def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_name):
+    """The 40-step episodes above never let a cube reach the boundary of the arena.  With 750-step episodes under random actions the
+    rollout arrives at the steady state of the bench workload - a third of the envs with a live boundary contact - which is where the slot
+    order of the boundary corners, the per-slot flags and the branch-free boundary block of the sweeps do their work: HIP and oracle side by
+    side, compared every 100 steps."""
+    from leibnizgym_amd import _capi as capi
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    n, steps = 320, 900
+    engs = []
+    for lib, dev in ((hip, DEV), (oracle, "cpu")):
+        kw = dict(pu.CONFIGS[cfg_name])
+        kw.pop("_clipping", None)
+        engs.append(TrifingerEngine(make_config(lib, n, seed=21, episode_length=750, **kw), device=dev, lib=lib))
+    for e in engs:
+        e.reset()
+    live = 0.0
+    for t in range(steps):
+        act = pu.actions_for(t, n, engs[0].action_dim, 21)
+        engs[0].step(act.to(DEV))
+        engs[1].step(act)
+        if t % 100 == 99:
+            a, b = pu.snapshot(engs[0]), pu.snapshot(engs[1])
+            pu.assert_bit_equal(a, b, f"{cfg_name} step {t}")
+            live = max(live, float((b["state"][capi.S_CW_FACE] != 0).mean()))
+    for e in engs:
+        e.close()
+    assert live > 0.1, live          # the rollout did get to the boundary
+
+
 @pytest.mark.parametrize("extra", [dict(substeps=1, solver_iterations=4), dict(substeps=3, solver_iterations=1),
                                    dict(dt=0.01, solver_iterations=12, control_decimation=3),
                                    dict(gravity=(0.3, -0.2, -3.7)), dict(normalize_action=False, apply_safety_damping=False)])
