@@ -406,4 +406,6 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
             break
     details["sweeps"] = sweeps
     details["rows"] = rows
+    details["Minv"] = Minv                    # (developer experiments, tests/dev: the substep's contact problem as data)
+    details["v_start"] = v_ff
     return v[0:9].copy(), v[9:12].copy(), v[12:15].copy(), details
