@@ -125,9 +125,10 @@ FULL_DR = {"activate": True, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "
            "friction_robot": (0.8, 1.2), "friction_object": (0.8, 1.2), "friction_stage": (0.8, 1.2)}
 
 
-def kernel_name(asym, action_dim=9, ext=False):
-    """rocprofv3's name of the fused-step instantiation a workload launches (EXT: extended DR or the box object)."""
-    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, 63, {int(ext)}>"
+def kernel_name(asym, action_dim=9, ext=False, fused_actions=True):
+    """rocprofv3's name of the fused-step instantiation a workload launches (EXT: extended DR or the box object; MODE 127 = the step
+    with the action source fused in - tf_step_random, what `value` times -, 63 = the step that reads a resident action tensor)."""
+    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, {127 if fused_actions else 63}, {int(ext)}>"
 
 
 def workload_kwargs(asym, difficulty=4, dr=False):
@@ -230,6 +231,13 @@ def main():
     ap.add_argument("--stats-every", type=int, default=0,
                     help="all-reduce the episode statistics over the ranks every K steps on a side stream (the optional "
                          "exchange of the north star; RCCL on a multi-GPU run); 0: off")
+    ap.add_argument("--settle", type=int, default=-1,
+                    help="untimed steps of the same workload BEFORE the W warm-up steps that put the env population into the steady "
+                         "state of a long run: the per-env step counters are spread uniformly over the episode length first (an env "
+                         "population that has been stepping for a long time is at every episode phase at once), then this many steps are "
+                         "taken.  Default: one episode length (750), so that every env has gone through a time-out reset.  0: none - the timed "
+                         "region then starts --warmup steps after a reset of ALL envs (a correlated transient: "
+                         "profiles/r4_a_driver_repro.txt)")
     ap.add_argument("--time-window", type=int, default=8,
                     help="one HIP event pair per window of W consecutive k_step launches of the timed region (an event "
                          "pair costs ~3 us of stream time: per launch it would slow the region it measures and read "
@@ -273,8 +281,21 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     ring = [(torch.rand(n, eng.action_dim, device=dev, generator=gen) * 2 - 1).contiguous() for _ in range(16)]
     eng.reset()
+    # ---- steady state of the workload (untimed set-up, like generating the synthetic inputs) ----
+    # A reset of ALL envs at once is a state a long run never is in: every finger starts from the same pose, the contacts of all
+    # 65536 envs arrive in the same frames (frames 16-21 after the reset cost 75-77 us against 71 us in the steady state:
+    # profiles/r4_a_driver_repro.txt) and all episodes would time out in the same step.  The benchmark measures the steady state
+    # BASELINE.md section 4 asks for (time-out resets and both reward-schedule regimes inside the window): the step counters are
+    # spread over the episode, then one episode length of steps is taken, so every env has been through a time-out reset and the
+    # population sits at every episode phase at once.  None of this is timed; --settle 0 switches it off.
+    ep_len = int(cfg.episode_length)
+    settle = args.settle if args.settle >= 0 else ep_len
+    if settle > 0 and ep_len > 0:
+        eng.steps.copy_(torch.randint(0, ep_len, (n,), device=dev, generator=gen, dtype=torch.int32))
+        for k in range(settle):
+            eng.step_random()
     for k in range(args.warmup):
-        eng.step(ring[k % len(ring)])
+        eng.step_random()
 
     def barrier():
         if distributed:
@@ -290,20 +311,29 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group(backend="gloo" if one_device else "nccl", rank=0, world_size=1)
         reducer = EpisodeStatsReducer(eng, world * n, every=args.stats_every)
+    # ---- the timed region: EXACTLY --steps steps, actions 2*U-1 generated on the device in every step by the
+    # step itself (tf_step_random: Philox draws inside the launch) ----
     eng.enable_kernel_timing(8192 if args.time_window > 0 else 0, max(1, args.time_window))
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        eng.step(ring[k % len(ring)])
+        eng.step_random()
         if reducer is not None:
             reducer.step()
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = eng.kernel_time_ms()
     global_stats = reducer.result().cpu().tolist() if reducer is not None else None
-    # the same loop with the actions generated on the device inside it (2*U[0,1)-1 every step, as
-    # scripts/trifinger_random_action.py:33 does): reported beside `value`, never instead of it
     eng.enable_kernel_timing(0)
+    # beside it, over the same number of steps: the step fed from a ring of 16 RESIDENT action tensors (what rounds 1-3 printed as
+    # `value`) ...
+    barrier()
+    t2 = time.perf_counter()
+    for k in range(args.steps):
+        eng.step(ring[k % len(ring)])
+    barrier()
+    elapsed_ring = time.perf_counter() - t2
+    # ... and with torch.rand(N, A)*2-1 generated inside the loop (three extra elementwise launches per step), a quarter of the steps
     gen_steps = max(1, args.steps // 4)
     barrier()
     t1 = time.perf_counter()
@@ -311,17 +341,10 @@ def main():
         eng.step(torch.rand(n, eng.action_dim, device=dev, generator=gen) * 2 - 1)
     barrier()
     elapsed_gen = time.perf_counter() - t1
-    # ... and with the action source fused into the step itself (tf_step_random: Philox draws inside the launch)
-    barrier()
-    t2 = time.perf_counter()
-    for k in range(gen_steps):
-        eng.step_random()
-    barrier()
-    elapsed_fused = time.perf_counter() - t2
     if distributed:
-        t = torch.tensor([elapsed, elapsed_gen, elapsed_fused], device=dev if not one_device else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_gen, elapsed_ring], device=dev if not one_device else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_gen, elapsed_fused = float(t[0].item()), float(t[1].item()), float(t[2].item())
+        elapsed, elapsed_gen, elapsed_ring = float(t[0].item()), float(t[1].item()), float(t[2].item())
 
     # sanity on what was just timed: finite state, resets happened if steps crossed an episode boundary
     assert torch.isfinite(eng.state).all(), "non-finite state after the timed region"
@@ -332,7 +355,7 @@ def main():
     bytes_per_launch = BYTES_PER_ENV_STEP[asym] * n
     achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
     ext = 2 if args.box else (1 if args.dr else 0)     # extended DR -> EXT = 1, box object -> EXT = 2 instantiation of the fused step
-    pmc, pmc_path = load_pmc_profile(n, asym, ext) if (headline or ext) else (None, None)
+    pmc, pmc_path = load_pmc_profile(n, asym, ext) if (headline or ext) else (None, None)      # counters of the kernel `value` launches
     traffic = traffic_raw = issue = None
     traffic_how = None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -378,12 +401,17 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "value_with_action_generation": world * n * gen_steps / elapsed_fused,
+        "value_resident_actions": world * n * args.steps / elapsed_ring,
         "value_with_torch_action_generation": world * n * gen_steps / elapsed_gen,
-        "action_generation": f"`value` steps a ring of 16 resident action tensors; `value_with_action_generation`: timed region of "
-                             f"{gen_steps} steps of tf_step_random, the step with the action source fused in (every env draws 2*U-1 "
-                             f"with Philox inside the launch); `value_with_torch_action_generation`: the same number of steps with "
-                             f"torch.rand(N, A)*2-1 generated on the device inside the loop (three extra elementwise launches per step)",
+        "action_generation": f"`value`: every step generates its actions 2*U-1 on the device (BASELINE.md section 4) inside the launch itself "
+                             f"(tf_step_random: Philox draws keyed by global env id and frame count); `value_resident_actions`: the same "
+                             f"{args.steps} steps fed from a ring of 16 resident action tensors (what rounds 1-3 reported as `value`); "
+                             f"`value_with_torch_action_generation`: {gen_steps} steps with torch.rand(N, A)*2-1 generated inside the loop "
+                             f"(three extra elementwise launches per step)",
+        "steady_state_prelude": (f"untimed set-up before the {args.warmup} warm-up steps: per-env step counters spread uniformly over the episode "
+                                 f"length ({ep_len}), then {settle} steps of the same workload, so that the env population is at every episode "
+                                 f"phase at once as in a long run (a timed region right after a reset of all envs is a correlated transient: "
+                                 f"profiles/r4_a_driver_repro.txt); --settle 0 switches it off") if (settle > 0 and ep_len > 0) else "none (--settle 0)",
         "config": {
             "workload": f"trifinger_difficulty_{args.difficulty}{' + full domain randomisation' if args.dr else ''}{' + phase-3 cuboid object' if args.box else ''}, "
                         f"{n} envs/GPU x {world} GPU, torque mode, random actions 2*U-1, "

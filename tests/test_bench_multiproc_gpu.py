@@ -38,6 +38,19 @@ def test_two_ranks_print_one_aggregate_line(hip):
         assert k in d
 
 
+def test_eight_ranks_on_one_device(hip):
+    """The driver's 8-GPU command line (`--nproc-per-node 8 ... bench.py --gpus 8`) with all eight ranks on cuda:0 and small shards:
+    rank offsets 0, 2048, ..., one aggregate JSON line from rank 0 - so that the first real 8-GPU run cannot fail on plumbing."""
+    p = launch(["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5", "--envs", "2048", "--settle", "50"], nproc=8)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak"
+    assert d["config"]["envs_per_gpu"] == 2048 and d["config"]["global_envs"] == 16384
+    assert abs(d["value"] - 16384 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d
+
+
 def test_two_ranks_domain_randomisation_with_the_stats_all_reduce(hip):
     """BASELINE configs[3] per GPU (difficulty 4 + every DR feature, 16384 envs) with the optional episode-statistics
     all-reduce every 4 steps (EpisodeStatsReducer on its side stream): the exchange the RCCL path runs on a real node."""

@@ -1,5 +1,6 @@
-"""World-size-2 run on CPU (gloo): two shards of the env range reproduce one big engine bit for bit, and the
-optional episode-statistics all-reduce returns the big engine's info."""
+"""World-size-2 and world-size-8 runs on CPU (gloo): the shards of the env range reproduce one big engine bit for bit, and the
+optional episode-statistics all-reduce returns the big engine's info.  The 8-rank case is the shape of BASELINE configs[3]
+(131072 envs over 8 GPUs: shard_range(131072, r, 8)) at 8 x 64 envs."""
 import os
 import socket
 import sys
@@ -24,7 +25,7 @@ def test_shard_range_partitions():
             assert o0 + c0 == o1
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, TOTAL=TOTAL, STEPS=STEPS, CFG=CFG):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
@@ -52,11 +53,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_shards_equal_one_engine(oracle, tmp_path):
+@pytest.mark.parametrize("world,TOTAL,STEPS,CFG", [(2, TOTAL, STEPS, CFG), (8, 512, 40, "d4_domain_randomization_extended")])
+def test_shards_equal_one_engine(oracle, tmp_path, world, TOTAL, STEPS, CFG):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), TOTAL, STEPS, CFG), nprocs=world, join=True)
     # the single-engine run
     from leibnizgym_amd.engine import TrifingerEngine, make_config
     kw = dict(pu.CONFIGS[CFG])
@@ -66,14 +68,15 @@ def test_two_shards_equal_one_engine(oracle, tmp_path):
     for t in range(STEPS):
         eng.step(pu.actions_for(t, TOTAL, eng.action_dim, 3))
         infos.append(eng.info.numpy().copy())
-    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2)]
-    assert [int(p["off"]) for p in parts] == [0, 150]
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert [int(p["off"]) for p in parts] == [shard_range(TOTAL, r, world)[0] for r in range(world)]
+    assert [int(p["cnt"]) for p in parts] == [TOTAL // world] * world
     for key, axis in (("state", 1), ("obs", 0), ("states", 0), ("reward", 0), ("steps", 0), ("reset_count", 0)):
         got = np.concatenate([p[key] for p in parts], axis=axis)
         want = getattr(eng, key).numpy()
         assert got.shape == want.shape
         assert np.array_equal(got.view(np.uint32) if got.dtype == np.float32 else got,
                               want.view(np.uint32) if want.dtype == np.float32 else want), key
-    assert int(eng.reset_count.max()) >= 3          # resets and goal resets happened inside the window
-    for r in range(2):
+    assert int(eng.reset_count.max()) >= 2          # resets (and, with success termination on, goal resets) happened inside the window
+    for r in range(world):
         np.testing.assert_allclose(parts[r]["info"][:, :11], np.stack(infos)[:, :11], rtol=2e-5, atol=2e-4)

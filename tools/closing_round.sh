@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): everything a round's closing profiles/ entry holds, in one gpurun call.
 #   tools/closing_round.sh <tag>
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}; O=gpurun_out; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/${T}_pytest_gpu.txt 2>&1; tail -3 $O/${T}_pytest_gpu.txt
 bash tools/profile_round.sh $T > $O/${T}_profile_log.txt 2>&1

@@ -12,7 +12,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('value %.4e  ms_per_step %.4f  kernel_avg_us %.2f (%d launches timed)  with_action_generation %.4e' % (d['value'], d['ms_per_step'], r['kernel_avg_us'], r['kernel_launches_timed'], d['value_with_action_generation']))
+        print('value %.4e  ms_per_step %.4f  kernel_avg_us %.2f (%d launches timed)  resident_actions %.4e' % (d['value'], d['ms_per_step'], r['kernel_avg_us'], r['kernel_launches_timed'], d['value_resident_actions']))
 "; }
 {
 echo "# rocm-smi clocks before"; rocm-smi --showclocks 2>/dev/null | grep -i -E "sclk|mclk|fclk" | head -4

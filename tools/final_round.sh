@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): everything a round's closing profiles/ entry holds beyond tools/profile_round.sh, in one gpurun call.
 #   tools/final_round.sh <tag>  ->  gpurun_out/<tag>_{sweep,api_layers,phase_timing}.txt, <tag>_bench_config{1,3}.json, PPO rate + trace, GEMM table
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}; O=gpurun_out
 bash tools/profile_round.sh $T > $O/${T}_profile_log.txt 2>&1
 python3 tools/sweep.py 2>&1 | grep -v amdgpu.ids > $O/${T}_sweep.txt

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/r2_l_pmc_caches.txt; : > $O
 for C in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES" "SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_IFETCH_LEVEL SQ_INSTS_SMEM SQ_INSTS_VALU"; do
   d=gpurun_out/prof_c; rm -rf $d

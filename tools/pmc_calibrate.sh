@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): FETCH_SIZE / WRITE_SIZE of kernels with known byte counts -> gpurun_out/<tag>_pmc_calibration.txt
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}; O=gpurun_out/${T}_pmc_calibration.txt
 hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calibrate tools/microbench/pmc_calibrate.hip 2>/dev/null
 /tmp/pmc_calibrate > $O

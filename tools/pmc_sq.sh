@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): SQ counter passes over bench.py's k_step (separate --pmc runs, no tracing combined).
 #   tools/pmc_sq.sh <out-prefix>        writes gpurun_out/<prefix>_sq.txt
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 P=${1:-sq}
 OUT=gpurun_out/${P}_sq.txt
 : > $OUT

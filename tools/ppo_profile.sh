@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): frames/s of the in-repo PPO at the BASELINE configs[4] per-GPU shape, then its kernel trace.
 #   tools/ppo_profile.sh <tag>  ->  gpurun_out/<tag>_ppo_rate.txt, gpurun_out/<tag>_ppo_kernel_trace.txt
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}
 O=gpurun_out
 CMD="python3 scripts/train_ppo.py gym=trifinger_difficulty_4 args.num_envs=8192"

@@ -2,11 +2,11 @@
 # Developer tool (GPU box): time and profile what BASELINE configs[3] really launches - the EXT instantiation of the fused step
 # (every domain-randomisation feature incl. base / stage offsets and per-body friction) - and the box-object variant.
 #   tools/profile_ext.sh <tag>  ->  gpurun_out/<tag>_ext_{dr,box}_<N>_{bench.json,kernel_trace.txt,pmc.txt}
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}; O=gpurun_out
 mkdir -p $O
 for W in dr box; do
-  K="k_env<9, false, true, 63, $([ $W = box ] && echo 2 || echo 1)>"
+  K="k_env<9, false, true, 127, $([ $W = box ] && echo 2 || echo 1)>"
   for N in 16384 65536; do
     B="python3 bench.py --$W --envs $N --no-cpu-baseline"
     P=$O/${T}_ext_${W}_${N}

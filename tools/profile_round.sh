@@ -2,10 +2,10 @@
 # Developer tool (GPU box): everything a round's profiles/ entry needs, in one gpurun call.
 #   tools/profile_round.sh <tag>   ->  gpurun_out/<tag>_{bench.json,bench_symmetric.json,kernel_trace_stats.txt,pmc.txt}
 # Tracing and counters are separate rocprofv3 runs; the profiled program is python3 itself (no launcher hop).
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}
 O=gpurun_out
-K='k_env<9, false, true, 63, 0>'
+K='k_env<9, false, true, 127, 0>'
 mkdir -p $O
 CMD="python3 bench.py --steps 500 --warmup 5 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $O/prof_$T/trace -o r -- $CMD > /dev/null 2>&1
