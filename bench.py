@@ -291,7 +291,7 @@ def main():
     ep_len = int(cfg.episode_length)
     settle = args.settle if args.settle >= 0 else ep_len
     if settle > 0 and ep_len > 0:
-        eng.steps.copy_(torch.randint(0, ep_len, (n,), device=dev, generator=gen, dtype=torch.int32))
+        eng.steps.copy_(torch.randint(0, ep_len, (n,), device=dev, generator=gen, dtype=torch.int64))
         for k in range(settle):
             eng.step_random()
     for k in range(args.warmup):

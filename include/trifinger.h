@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TF_API_VERSION 4
+#define TF_API_VERSION 5
 
 typedef enum TfStatus {
     TF_OK = 0,
@@ -302,7 +302,7 @@ typedef struct TfBuffers {
     uint8_t* goal_reset_buf; /* [N] _goal_reset_buf                                                   */
     uint8_t* successes;      /* [N] _successes                                                        */
     uint8_t* dones;          /* [N] reset_buf & goal_reset_buf (env_base.py:399)                      */
-    int32_t* steps;          /* [N] _steps_count_buf                                                  */
+    int64_t* steps;          /* [N] _steps_count_buf: int64 as in the reference (torch.long, env_base.py:572); API 5    */
     uint32_t* reset_count;   /* [N] number of RNG draws consumed (Philox counter high word)           */
     float* info;             /* [TF_NUM_INFO]                                                         */
     float* scratch;          /* [tf_scratch_floats(N)] per-wave scratch (developer instrumentation)   */

@@ -29,6 +29,7 @@ struct RewardCoef {
 typedef GLOBAL_AS float gfloat;
 typedef GLOBAL_AS uint8_t gu8;
 typedef GLOBAL_AS int32_t gi32;
+typedef GLOBAL_AS int64_t gi64;
 typedef GLOBAL_AS uint32_t gu32;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -43,7 +44,7 @@ struct DevParams {
     gu8* goal_reset_buf;
     gu8* successes;
     gu8* dones;
-    gi32* steps;
+    gi64* steps;             // int64 like the reference's _steps_count_buf; the count itself fits 32 bits (episode lengths)
     gu32* reset_count;
     gfloat* info;
     gfloat* scratch;

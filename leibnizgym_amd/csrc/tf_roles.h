@@ -1235,7 +1235,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         fl_reset = P.reset_buf[(unsigned)cx.i];
         fl_goal_reset = P.goal_reset_buf[(unsigned)cx.i];
         fl_successes = P.successes[(unsigned)cx.i];
-        fl_steps = P.steps[(unsigned)cx.i];
+        fl_steps = (int)P.steps[(unsigned)cx.i];
         fl_count = P.reset_count[(unsigned)cx.i];
     }
     if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
@@ -1824,7 +1824,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         c_reset = P.reset_buf[(unsigned)cx.i] != 0;
         c_goal_reset = P.goal_reset_buf[(unsigned)cx.i] != 0;
         c_successes = P.successes[(unsigned)cx.i] != 0;
-        c_steps = P.steps[(unsigned)cx.i];
+        c_steps = (int)P.steps[(unsigned)cx.i];
     }
     if (MODE & M_POST) {
         float gp[3], gq[4], prev_obj[7];                        // cold through the physics: re-read from their rows
@@ -1984,7 +1984,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     if (MODE & M_FINISH) {                                      // env_base.py:391-399
         if (cx.valid) {
             int sN = c_steps + 1;
-            P.steps[(unsigned)cx.i] = sN;
+            P.steps[(unsigned)cx.i] = (int64_t)sN;
             bool rb = c_reset;
             if (P.episode_length > 0 && sN >= P.episode_length) { rb = true; P.reset_buf[(unsigned)cx.i] = 1; }
             P.dones[(unsigned)cx.i] = (uint8_t)(rb && c_goal_reset);

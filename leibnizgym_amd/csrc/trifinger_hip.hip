@@ -366,6 +366,13 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
     if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
+    /* boundary profile (TfModel.wall_z / wall_r, knots of a piecewise-linear r(z) since API 4 - before that: steps of a staircase): the
+     * knots must rise strictly and be finite, or the slopes between them are not defined */
+    for (int i = 0; i < 4; ++i) {
+        const float z = cfg->model.wall_z[i], r = cfg->model.wall_r[i];
+        if (!(z - z == 0.0f) || !(r - r == 0.0f) || !(r > 0.0f)) return TF_ERR_INVALID_ARG;
+        if (i > 0 && !(z > cfg->model.wall_z[i - 1])) return TF_ERR_INVALID_ARG;
+    }
     TfHandle_* h = new TfHandle_();
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
@@ -446,7 +453,7 @@ int tf_bind(tf_handle h, const TfBuffers* b) {
     P.state = (gfloat*)b->state; P.action_buf = (gfloat*)b->action_buf; P.obs = (gfloat*)b->obs;
     P.states = (gfloat*)b->states; P.reward = (gfloat*)b->reward;
     P.reset_buf = (gu8*)b->reset_buf; P.goal_reset_buf = (gu8*)b->goal_reset_buf; P.successes = (gu8*)b->successes;
-    P.dones = (gu8*)b->dones; P.steps = (gi32*)b->steps; P.reset_count = (gu32*)b->reset_count;
+    P.dones = (gu8*)b->dones; P.steps = (gi64*)b->steps; P.reset_count = (gu32*)b->reset_count;
     P.info = (gfloat*)b->info; P.scratch = (gfloat*)b->scratch;
     HIP_TRY(push_params(h));
     h->bound = 1;

@@ -210,7 +210,7 @@ class TrifingerEngine:
         self.goal_reset_buf = torch.zeros((n,), dtype=torch.bool, device=dev)
         self.successes = torch.zeros((n,), dtype=torch.bool, device=dev)
         self.dones = torch.zeros((n,), dtype=torch.bool, device=dev)
-        self.steps = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.steps = torch.zeros((n,), dtype=torch.int64, device=dev)        # torch.long like the reference's _steps_count_buf (env_base.py:572)
         self.reset_count = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.info = torch.zeros((capi.TF_NUM_INFO,), **f32)
         self.scratch = torch.zeros((int(lib.tf_scratch_floats(n)),), **f32)

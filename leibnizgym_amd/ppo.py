@@ -293,32 +293,52 @@ class PPOTrainer:
             lrs = [float(g["lr"]) for g in self.opt.param_groups]
         return {"kind": "adam_per_parameter", "exp_avg": m, "exp_avg_sq": v, "step": step, "lrs": lrs}
 
-    def _load_optimizer_state(self, sd, lr):
-        """inverse of `_optimizer_state`; also reads the two formats round-2 checkpoints hold (the flat buffers of FlatClipAdam with
-        their 16-byte padding per parameter, torch.optim.Adam's own state dict)"""
+    def _parse_optimizer_state(self, sd):
+        """Any of the three optimiser-state formats -> (first moments by parameter name, second moments by name, step, learning rates),
+        VALIDATED against this network (unknown names, wrong shapes, wrong total size raise ValueError) and without touching the
+        trainer: restore() calls this before it overwrites a single weight.  Formats: 'adam_per_parameter' (what `_optimizer_state`
+        writes), 'flat_clip_adam' (round 2, GPU path: the flat buffers of FlatClipAdam, every parameter padded to 4 floats, actor
+        group then critic group for a central-value net, net.parameters() order otherwise) and torch.optim.Adam.state_dict() (round 2,
+        CPU path: moments by parameter index in the order of the optimiser's groups)."""
         named = dict(self.net.named_parameters())
+        names = {id(p): n for n, p in named.items()}
         kind = sd.get("kind")
         if kind == "adam_per_parameter":
-            m, v, step, lrs = sd["exp_avg"], sd["exp_avg_sq"], float(sd["step"]), list(sd.get("lrs", []))
-        elif kind == "flat_clip_adam":                               # round 2, GPU path: parameters padded to 4 floats each
+            m, v, step, lrs = dict(sd["exp_avg"]), dict(sd["exp_avg_sq"]), float(sd["step"]), list(sd.get("lrs", []))
+        elif kind == "flat_clip_adam":
             order = self.net.actor_parameters() + self.net.critic_parameters() if self.net.central else list(self.net.parameters())
-            names = {id(p): n for n, p in named.items()}
+            if sum((p.numel() + 3) & ~3 for p in order) != sd["m"].numel() or sd["v"].numel() != sd["m"].numel():
+                raise ValueError("checkpoint optimizer state belongs to a network of another size")
             m, v, off = {}, {}, 0
             for p in order:
                 m[names[id(p)]] = sd["m"][off:off + p.numel()].view_as(p)
                 v[names[id(p)]] = sd["v"][off:off + p.numel()].view_as(p)
                 off += (p.numel() + 3) & ~3
-            if off != sd["m"].numel():
-                raise ValueError("optimizer state of another network size")
             step, lrs = float(sd["step"].item()), [float(x) for x in sd["lr"].tolist()]
-        else:                                                        # torch.optim.Adam.state_dict(): moments per parameter index
-            order = [p for g in self.opt.param_groups for p in g["params"]]
-            names = {id(p): n for n, p in named.items()}
+        elif "state" in sd and "param_groups" in sd:
+            order = [p for g in self.opt.param_groups for p in g["params"]]     # actor group (log_std last), then critic group
+            n_ck = sum(len(g["params"]) for g in sd["param_groups"])
+            if n_ck != len(order):
+                raise ValueError(f"checkpoint optimizer state holds {n_ck} parameters, this network {len(order)}")
             st = sd["state"]
             m = {names[id(p)]: st[i]["exp_avg"] for i, p in enumerate(order) if i in st}
             v = {names[id(p)]: st[i]["exp_avg_sq"] for i, p in enumerate(order) if i in st}
             step = max([float(x["step"]) for x in st.values()] or [0.0])
             lrs = [float(g["lr"]) for g in sd["param_groups"]]
+        else:
+            raise ValueError(f"unknown optimizer state format (kind = {kind!r})")
+        for which in (m, v):
+            for n, t in which.items():
+                if n not in named:
+                    raise ValueError(f"checkpoint optimizer state names a parameter this network does not have: {n}")
+                if tuple(t.shape) != tuple(named[n].shape):
+                    raise ValueError(f"checkpoint optimizer moment of '{n}': shape {tuple(t.shape)}, parameter {tuple(named[n].shape)}")
+        return m, v, step, lrs
+
+    def _load_optimizer_state(self, sd, lr, parsed=None):
+        """inverse of `_optimizer_state` (and of the two round-2 formats: `_parse_optimizer_state`)"""
+        named = dict(self.net.named_parameters())
+        m, v, step, lrs = parsed if parsed is not None else self._parse_optimizer_state(sd)
         lr_actor = float(lr) if lr is not None else (lrs[0] if lrs else self.lr)
         lr_value = lrs[1] if len(lrs) > 1 else None
         if self.flat_opt is not None:
@@ -357,17 +377,18 @@ class PPOTrainer:
 
     def restore(self, path: str):
         ck = torch.load(path, map_location=self.device, weights_only=False)
-        if "optimizer" in ck:                                        # validate before anything is overwritten
-            sd = ck["optimizer"]
-            if sd.get("kind") == "flat_clip_adam":
-                order = self.net.actor_parameters() + self.net.critic_parameters() if self.net.central else list(self.net.parameters())
-                if sum((p.numel() + 3) & ~3 for p in order) != sd["m"].numel():
-                    raise ValueError("checkpoint optimizer state belongs to a network of another size")
+        parsed = None
+        mine = self.net.state_dict()                                 # validate EVERYTHING before anything is overwritten
+        for k, t in mine.items():
+            if k not in ck["model"] or tuple(ck["model"][k].shape) != tuple(t.shape):
+                raise ValueError(f"checkpoint model entry '{k}' missing or of another shape")
+        if "optimizer" in ck:
+            parsed = self._parse_optimizer_state(ck["optimizer"])
         with torch.no_grad():                                        # in place: the parameters may be views of a flat buffer
             for k, v in self.net.state_dict().items():
                 v.copy_(ck["model"][k])
             if "optimizer" in ck:
-                self._load_optimizer_state(ck["optimizer"], ck.get("lr"))
+                self._load_optimizer_state(ck["optimizer"], ck.get("lr"), parsed)
         self.lr = float(ck.get("lr", self.lr))
         self.frames, self.epoch = int(ck.get("frames", 0)), int(ck.get("epoch", 0))
         self.best_reward = float(ck.get("best_reward", -float("inf")))

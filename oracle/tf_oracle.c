@@ -519,6 +519,13 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
     if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
+    /* boundary profile (TfModel.wall_z / wall_r, knots of a piecewise-linear r(z) since API 4 - before that: steps of a staircase): the
+     * knots must rise strictly and be finite, or the slopes between them are not defined */
+    for (int i = 0; i < 4; ++i) {
+        const float z = cfg->model.wall_z[i], r = cfg->model.wall_r[i];
+        if (!(z - z == 0.0f) || !(r - r == 0.0f) || !(r > 0.0f)) return TF_ERR_INVALID_ARG;
+        if (i > 0 && !(z > cfg->model.wall_z[i - 1])) return TF_ERR_INVALID_ARG;
+    }
     struct TfHandle_* h = (struct TfHandle_*)calloc(1, sizeof(*h));
     if (h) { h->clip_obs = 3.402823466e38f; h->clip_act = 3.402823466e38f; }
     if (!h) return TF_ERR_INVALID_ARG;
@@ -2180,7 +2187,7 @@ static void post_step_env(const struct TfHandle_* h, int i, Env* e, const float 
 
 /* env_base.py:391-399 */
 static void finish_env(const struct TfHandle_* h, int i) {
-    int s = h->buf.steps[i] + 1;
+    int s = (int)h->buf.steps[i] + 1;
     h->buf.steps[i] = s;
     if (h->cfg.episode_length > 0 && s >= h->cfg.episode_length) h->buf.reset_buf[i] = 1;
     h->buf.dones[i] = (uint8_t)(h->buf.reset_buf[i] && h->buf.goal_reset_buf[i]);

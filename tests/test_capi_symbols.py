@@ -116,6 +116,10 @@ def test_create_rejects_bad_configs(oracle):
         for bad_p in (0, 17, -2):                          # built: 1..16 and TF_NORM_INF (-1)
             cfg = make_config(lib, 4); cfg.finger_reach_norm_p = bad_p
             assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_UNSUPPORTED
+        cfg = make_config(lib, 4); cfg.model.wall_z[2] = cfg.model.wall_z[1]      # boundary knots must rise strictly (piecewise-linear profile)
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
+        cfg = make_config(lib, 4); cfg.model.wall_r[3] = float("nan")
+        assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
         cfg = make_config(lib, 4); cfg.api_version = 99
         assert lib.tf_create(C.byref(cfg), C.byref(h)) == capi.TF_ERR_INVALID_ARG
         assert lib.tf_step(None, None, None) == capi.TF_ERR_INVALID_ARG

@@ -156,3 +156,58 @@ def test_split_k_linear_matches_linear():
     x2 = torch.randn(100, 41, requires_grad=True)
     _SplitKLinear.apply(x2, w, b).sum().backward()
     assert x2.grad.shape == (100, 41)
+
+
+@pytest.mark.parametrize("central", [True, False])
+def test_legacy_optimizer_states_restore_and_bad_ones_are_rejected_before_the_weights_move(oracle, tmp_path, central):
+    """The two round-2 checkpoint formats of the optimiser state - FlatClipAdam's flat buffers (parameters padded to 4 floats; actor group
+    then critic group for a central-value net, net.parameters() order - log_std FIRST - otherwise) and torch.optim.Adam.state_dict() -
+    restore to the same per-parameter moments as the current format; a state of another network is rejected before a weight is
+    overwritten."""
+    env, ad = make(oracle)
+    cfg = PPOConfig(horizon=8, minibatches=4, mini_epochs=2)
+    sdim = 113 if central else 0                      # state_dim 0: no central value network (the critic reads obs)
+    a = PPOTrainer(ad, 41, sdim, 9, cfg, device="cpu")
+    assert a.net.central == central
+    a.train(1)
+    want = a._optimizer_state()
+    assert float(want["exp_avg_sq"]["log_std"].abs().sum()) > 0.0
+    # torch format
+    torch_sd = a.opt.state_dict()
+    # flat format, written here the way round 2's FlatClipAdam laid it out
+    order = a.net.actor_parameters() + a.net.critic_parameters() if a.net.central else list(a.net.parameters())
+    names = {id(p): n for n, p in a.net.named_parameters()}
+    if not central:
+        assert names[id(order[0])] == "log_std" and names[id(a.net.actor_parameters()[-1])] == "log_std"     # the two orders differ
+    size = sum((p.numel() + 3) & ~3 for p in order)
+    fm, fv, off = torch.zeros(size), torch.zeros(size), 0
+    for p in order:
+        fm[off:off + p.numel()] = want["exp_avg"][names[id(p)]].reshape(-1)
+        fv[off:off + p.numel()] = want["exp_avg_sq"][names[id(p)]].reshape(-1)
+        off += (p.numel() + 3) & ~3
+    flat_sd = {"kind": "flat_clip_adam", "m": fm, "v": fv, "step": torch.tensor(want["step"]), "lr": torch.tensor(want["lrs"])}
+    for sd in (torch_sd, flat_sd):
+        ck = a.state_dict(); ck["optimizer"] = sd
+        path = os.path.join(tmp_path, "legacy.pth"); torch.save(ck, path)
+        env2, ad2 = make(oracle)
+        b = PPOTrainer(ad2, 41, sdim, 9, cfg, device="cpu")
+        b.restore(path)
+        got = b._optimizer_state()
+        assert got["step"] == want["step"] and got["lrs"] == pytest.approx(want["lrs"])
+        for k in want["exp_avg"]:
+            assert torch.equal(got["exp_avg"][k], want["exp_avg"][k]) and torch.equal(got["exp_avg_sq"][k], want["exp_avg_sq"][k]), k
+    # mismatched states: rejected, and the model of the reader is untouched
+    env3, ad3 = make(oracle)
+    c = PPOTrainer(ad3, 41, sdim, 9, cfg, device="cpu")
+    before = {k: v.clone() for k, v in c.net.state_dict().items()}
+    bad_flat = dict(flat_sd, m=fm[:-4], v=fv[:-4])
+    bad_named = {"kind": "adam_per_parameter", "exp_avg": dict(want["exp_avg"], log_std=torch.zeros(3)), "exp_avg_sq": want["exp_avg_sq"],
+                 "step": 1.0, "lrs": want["lrs"]}
+    bad_torch = {"state": {}, "param_groups": [{"params": [0, 1], "lr": 1e-3}]}
+    for sd in (bad_flat, bad_named, bad_torch, {"kind": "something else"}):
+        ck = a.state_dict(); ck["optimizer"] = sd
+        path = os.path.join(tmp_path, "bad.pth"); torch.save(ck, path)
+        with pytest.raises(ValueError):
+            c.restore(path)
+        for k, v in c.net.state_dict().items():
+            assert torch.equal(v, before[k]), k
