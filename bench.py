@@ -300,6 +300,12 @@ def main():
     def barrier():
         if distributed:
             dist.barrier()
+        # the stream is drained by polling an event first: a blocking wait wakes the host 20-60 us late, which is 2-4 % of the
+        # 1.4 ms a `--steps 20` window lasts (profiles/r4_b_driver_repro.txt: same kernel time, value 8.6 ... 9.2e8)
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
         torch.cuda.synchronize()
 
     reducer = None
