@@ -118,6 +118,84 @@ def test_pinch_and_lift_gpu(hip):
     _check_pinch_and_lift(hip, "cuda:0")
 
 
+# ---- in-hand rotation: the pinch transmits torque ---------------------------------------------------------------------
+def _pinch_lift_twist(lib, device, yaw=0.45, tilt=0.25):
+    """Pinch and lift as above, then the three fingertip targets are rotated about the VERTICAL axis through the grasp centre by `yaw`
+    (and back to half of it), then about a HORIZONTAL axis by `tilt`: three frictional point contacts (one point per finger, no torsional
+    friction - PhysX applies none either without a patch radius, trifinger_env.py:877) must carry the cube along in all of its six degrees
+    of freedom.  Returns commanded and reached cube rotations."""
+    eng = torque_engine(lib, device)
+    d = PR.CUBE_HALF + R_TIP + 0.0005
+    tips = [np.array([0.0, d, 0.0325]), np.array([d, -d * np.tan(np.pi / 6), 0.0325]), np.array([-d, -d * np.tan(np.pi / 6), 0.0325])]
+    inward = [-t / np.linalg.norm(t[:2]) * np.array([1, 1, 0]) for t in tips]
+    eng.q[:, 0] = torch.tensor(np.concatenate([ik(f, tips[f]) for f in range(3)]), dtype=torch.float32, device=device)
+    grasp = [tips[f] + 0.0075 * inward[f] - np.array([0, 0, 0.0325]) for f in range(3)]      # relative to the grasp centre
+    lift, a_yaw, a_tilt, out = 0.0, 0.0, 0.0, {}
+
+    def rot(ax, a):
+        c, s_ = np.cos(a), np.sin(a)
+        return np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]) if ax == "z" else np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]])
+    for i in range(700):
+        if 50 <= i:
+            lift = min(0.055, lift + 0.001)
+        if 200 <= i < 350:
+            a_yaw = yaw * (i - 199) / 150.0
+        if 350 <= i < 425:
+            a_yaw = yaw * (1.0 - 0.5 * (i - 349) / 75.0)
+        if 450 <= i < 600:
+            a_tilt = tilt * (i - 449) / 150.0
+        Rt = rot("z", a_yaw) @ rot("x", a_tilt)
+        centre = np.array([0.0, 0.0, 0.0325 + lift])
+        targets = [centre + Rt @ grasp[f] for f in range(3)]
+        step_torque(eng, impedance_torques(state_np(eng), targets))
+        st = state_np(eng)
+        if i in (199, 349, 424, 449, 699):
+            c = st[capi.S_CUBE_P:capi.S_CUBE_P + 13]
+            out[i] = (c[0:3].copy(), PR.quat_rot(c[3:7]), Rt.copy())
+    assert np.isfinite(st).all()
+    lam = st[capi.S_LAM_FC:capi.S_LAM_FC + 12:4]
+    eng.close()
+    return out, lam
+
+
+def _check_twist(lib, device):
+    out, lam = _pinch_lift_twist(lib, device)
+
+    def rotvec(R):
+        ang = float(np.arccos(np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)))
+        ax = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        return ang, ax / max(np.linalg.norm(ax), 1e-12)
+    R0 = out[199][1]
+    # Fingertip SPHERES (radius r) roll on the faces of the cube (half width h): turning the ring of fingertip centres by theta about the
+    # grasp centre turns the cube by about theta (h + r) / h = 1.31 theta when the distal links keep their orientation (rolling without
+    # slipping: (h + r) dtheta = h dphi), a little less because they turn along.  Measured on this build: 1.23, the same on the way back.
+    ratio = (PR.CUBE_HALF + R_TIP) / PR.CUBE_HALF
+    a1, ax1 = rotvec(out[349][1] @ R0.T)
+    a2, ax2 = rotvec(out[424][1] @ R0.T)
+    assert 1.1 < a1 / 0.45 < ratio + 0.05 and 1.1 < a2 / 0.225 < ratio + 0.05, (a1, a2)
+    assert abs(a1 / 0.45 - a2 / 0.225) < 0.06                                           # no slip on the way back: the same gearing
+    assert ax1[2] > 0.995 and ax2[2] > 0.995                                             # about the vertical axis
+    a3, ax3 = rotvec(out[699][1] @ out[449][1].T)                                        # then the tilt about a horizontal axis of the grasp
+    want_axis = np.array([np.cos(0.225), np.sin(0.225), 0.0])
+    assert 0.9 < a3 / 0.25 < ratio + 0.15 and float(ax3 @ want_axis) > 0.97, (a3, ax3)
+    for key in (349, 424, 699):
+        pos = out[key][0]
+        assert pos[2] > 0.07 and np.hypot(pos[0], pos[1]) < 0.01, (key, pos)            # still held at the lifted grasp centre
+    assert (lam > 0.005).all()
+
+
+def test_three_fingertips_rotate_the_pinched_cube(oracle):
+    """does the contact model let a grasp change the cube's ORIENTATION (the half of the difficulty-4 goal that the
+    trained policy does not reach)?  Yes: a scripted pinch yaws the lifted cube by 0.55 rad, brings it half-way back and tilts it by 0.3 rad -
+    through friction at three separated points with the gearing of fingertip spheres rolling on its faces; no torsional friction needed."""
+    _check_twist(oracle, "cpu")
+
+
+@pytest.mark.gpu
+def test_three_fingertips_rotate_the_pinched_cube_gpu(hip):
+    _check_twist(hip, "cuda:0")
+
+
 # ---- fingertip - cube impact ---------------------------------------------------------------------------------------
 def _impact(lib, device, speed, gap=0.001):
     """Finger 0's tip flies at `speed` along -y onto the +y face of a cube floating at rest (no gravity): one substep."""

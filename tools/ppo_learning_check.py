@@ -1,7 +1,8 @@
 """Developer tool (GPU box): train the in-repo PPO on difficulty 1 (cube to a goal position on the table; default) or any other
 difficulty (4 = the headline task: lift to a 6-DoF pose goal) and then roll the policy, reporting what the cube physically does -
 distance to the goal, speeds, heights, fraction of cubes lifted, goal counts - so that a learning curve cannot hide an exploit of
-the contact model.   python tools/ppo_learning_check.py [epochs] [num_envs] [seed] [fused|plain] [difficulty]"""
+the contact model.   python tools/ppo_learning_check.py [epochs] [num_envs] [seed] [fused|plain] [difficulty] [hydra-style overrides ...]
+(overrides, e.g. gym.reward_terms.object_rot.weight=10000  gym.sim.physx.num_position_iterations=16  gym.native.solver=tgs)"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -18,7 +19,10 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 fused = (sys.argv[4] != "plain") if len(sys.argv) > 4 else True
 difficulty = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-cfg = compose([f"gym=trifinger_difficulty_{difficulty}", f"args.num_envs={n}", "args.headless=True"])
+overrides = sys.argv[6:]
+cfg = compose([f"gym=trifinger_difficulty_{difficulty}", f"args.num_envs={n}", "args.headless=True"] + overrides)
+if overrides:
+    print("overrides:", " ".join(overrides), flush=True)
 env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False)
 tr = PPOTrainer(RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device="cuda:0")), env.get_obs_dim(), env.get_state_dim(),
                 env.get_action_dim(), PPOConfig.from_rlg(cfg["rlg"], num_envs=n, seed=seed, fused_kernels=fused), device="cuda:0")
@@ -31,9 +35,11 @@ def log(st):                                   # called by the trainer after eve
         s_ = env._engine.state
         lifted = float((s_[capi.S_CUBE_P + 2] > 0.05).float().mean())
         d_ = (s_[capi.S_CUBE_P:capi.S_CUBE_P + 3] - s_[capi.S_GOAL_P:capi.S_GOAL_P + 3]).norm(dim=0)
+        info_ = env._engine.info
         print(f"epoch {st['epoch']:4d} frames {st['frames']:10d} reward/step {st['mean_reward']:8.3f} kl {st['kl']:.4f} "
               f"{st['frames'] / (time.perf_counter() - t0):.3e} frames/s  cube above 5 cm {100 * lifted:5.1f} %  "
-              f"dist to goal median {float(d_.median()) * 1e3:6.1f} mm", flush=True)
+              f"dist to goal median {float(d_.median()) * 1e3:6.1f} mm  envs at the position / orientation goal "
+              f"{int(info_[capi.INFO_POS_COUNT])} / {int(info_[capi.INFO_ORI_COUNT])}  sigma {float(tr.net.log_std.exp().mean()):.3f}", flush=True)
 
 
 tr.train(epochs, log=log)
