@@ -19,15 +19,17 @@ def test_rollout_bit_exact(hip, oracle, cfg_name):
         pu.assert_bit_equal(a, b, f"{cfg_name} step {t}")
 
 
-@pytest.mark.parametrize("cfg_name", ["d4_torque_asym", "d4_domain_randomization"])
-def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_name):
+@pytest.mark.parametrize("cfg_name,fused_actions", [("d4_torque_asym", False), ("d4_domain_randomization", False), ("d4_torque_asym", True)])
+def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_name, fused_actions):
     """The 40-step episodes above never let a cube reach the boundary of the arena.  With 750-step episodes under random actions the
     rollout arrives at the steady state of the bench workload - a third of the envs with a live boundary contact - which is where the slot
     order of the boundary corners, the per-slot flags and the branch-free boundary block of the sweeps do their work: HIP and oracle side by
-    side, compared every 100 steps."""
+    side, compared every 100 steps on the way there and every 10 steps in the steady state (steps 300-900, across the time-out resets at
+    750).  `fused_actions`: the same through tf_step_random - the kernel instantiation bench.py times as `value` (actions drawn inside the
+    launch), its action_buf included in the comparison."""
     from leibnizgym_amd import _capi as capi
     from leibnizgym_amd.engine import TrifingerEngine, make_config
-    n, steps = 320, 900
+    n, steps = 640, 900
     engs = []
     for lib, dev in ((hip, DEV), (oracle, "cpu")):
         kw = dict(pu.CONFIGS[cfg_name])
@@ -35,18 +37,23 @@ def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_na
         engs.append(TrifingerEngine(make_config(lib, n, seed=21, episode_length=750, **kw), device=dev, lib=lib))
     for e in engs:
         e.reset()
-    live = 0.0
+    live, compared = 0.0, 0
     for t in range(steps):
-        act = pu.actions_for(t, n, engs[0].action_dim, 21)
-        engs[0].step(act.to(DEV))
-        engs[1].step(act)
-        if t % 100 == 99:
+        if fused_actions:
+            engs[0].step_random()
+            engs[1].step_random()
+        else:
+            act = pu.actions_for(t, n, engs[0].action_dim, 21)
+            engs[0].step(act.to(DEV))
+            engs[1].step(act)
+        if t % 100 == 99 or (t >= 300 and t % 10 == 9):
             a, b = pu.snapshot(engs[0]), pu.snapshot(engs[1])
             pu.assert_bit_equal(a, b, f"{cfg_name} step {t}")
+            compared += 1
             live = max(live, float((b["state"][capi.S_CW_FACE] != 0).mean()))
     for e in engs:
         e.close()
-    assert live > 0.1, live          # the rollout did get to the boundary
+    assert live > 0.1 and compared >= 60, (live, compared)          # the rollout did get to the boundary
 
 
 @pytest.mark.parametrize("extra", [dict(substeps=1, solver_iterations=4), dict(substeps=3, solver_iterations=1),
