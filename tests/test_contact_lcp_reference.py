@@ -275,3 +275,38 @@ def test_boundary_rows_on_the_flared_part_agree_with_the_independent_solution(or
 @pytest.mark.gpu
 def test_boundary_rows_on_the_flared_part_agree_with_the_independent_solution_gpu(hip):
     _check_boundary(hip, "cuda:0", 16)
+
+
+def test_truncation_residual_of_the_shipped_sweeps_on_many_states(oracle):
+    """What the shipped 8 sweeps leave, measured on MANY states without the fp64 reference in the loop: the product's substep against the same
+    substep iterated 2048 times from the same state (same warm-start rows).  A regression guard at the measured level (round 4,
+    profiles/r4_a_solver_variants.txt: 939 states, warm p90 3.3e-2, p99 0.19; 16 sweeps: 9.6e-3 / 0.11) - the review's bar (warm p90 <= 5e-3,
+    p99 <= 5e-2) is NOT met by this iteration at any affordable sweep count."""
+    rng = np.random.default_rng(20261004)
+    n = 256
+    cases = [make_case(rng) for _ in range(n)]
+    f32 = dict(dtype=torch.float32)
+    res = {}
+    for sweeps in (8, 16):
+        eng = T.engine(oracle, n=n, dt=H, substeps=1, solver_iterations=sweeps)
+        ref = T.engine(oracle, n=n, dt=H, substeps=1, solver_iterations=2048)
+        for k, name in enumerate(("q", "qd", "cube", "tau")):
+            getattr(eng, name).copy_(torch.tensor(np.array([c[k] for c in cases]).T, **f32))
+        for _ in range(4):
+            eng.simulate()
+        saved = eng.state.clone()
+        eng.simulate()
+        ref.state.copy_(saved)
+        ref.simulate()
+        got, want = eng.state, ref.state
+        d = (got - want).abs()
+        err = torch.maximum(torch.maximum(d[9:18].max(0).values / 10.0, d[25:28].max(0).values), d[28:31].max(0).values / 20.0).numpy()
+        lam = want[capi.S_LAM_FC:]
+        live = ((((lam[12:15].to(torch.int32) & 3) != 0) & (lam[0:12:4] > 0)).any(0) | (lam[15:24:3] > 0).any(0)).numpy()
+        res[sweeps] = err[live]
+        eng.close(); ref.close()
+        print(f"\n{sweeps} sweeps, {int(live.sum())} states with a live finger contact: median {np.median(err[live]):.2e}  p90 {np.percentile(err[live], 90):.2e}  "
+              f"p99 {np.percentile(err[live], 99):.2e}  max {err[live].max():.2e}")
+    assert len(res[8]) >= 80
+    assert np.median(res[8]) < 5e-3 and np.percentile(res[8], 90) < 8e-2 and res[8].max() < 1.0
+    assert np.median(res[16]) < np.median(res[8]) and np.percentile(res[16], 90) < np.percentile(res[8], 90)     # more sweeps, less residual
