@@ -352,6 +352,8 @@ class TrifingerEngine:
         return ms.value, n.value
 
     # -- split path (tests) -----------------------------------------------------------------
+    # The fused step hands the fingertip wrench of a step to its observation phase without writing the TF_S_FT state rows; these entries use
+    # the rows.  Do not mix the two forms within an episode (a post_step() after fused steps reads a stale fingertip wrench): INTEGRATION.md.
     def apply_resets(self):
         check(self.lib, self.lib.tf_apply_resets(self._handle, self._stream()), "tf_apply_resets")
 
