@@ -1158,6 +1158,62 @@ static void to_cube(const TfModel* m, int f, const FK* k, int lk, const float lo
     mat3T_mul(R, dd, out);
 }
 
+/* finger f against the cube: the candidate shapes of its links in turn (a later one takes over only with a strictly smaller gap).  Out: gap,
+ * axis point / sphere centre x and closest box point y (cube frame), unit direction nc from y to x, what lies between x and the shape's surface
+ * (radius), link (1..3).  Cube pose relative to the robot base: cpr, R; half extents hc. */
+static void finger_cube_candidates(const TfModel* m, int f, const FK* k, const float Aw[3], const float Bw[3], const float cpr[3], const float R[9],
+                                   const float hc[3], float cube_top_check, float* gap_o, float x[3], float y[3], float nc[3], float* radius_o, int* link_o) {
+    float gap = 0.0f, radius = 0.0f;
+    int link = 0;
+    /* candidates in order (a later one takes over only with a strictly smaller gap): the distal body (TfLinkShape: tapered rounded
+     * box along the fingertip capsule's axis), its housing sphere, the middle link, its two housing spheres, and - for a cube above
+     * upper_check_z - the upper link */
+    for (int pi = 0; pi < 6; ++pi) {
+        /* 0: shape3  1: sph3  2: shape2  3: sph2[1] (joint-3 housing)  then, only for a cube above upper_check_z (they hang at the
+         * height of the base):  4: sph2[0] (joint-2 housing)  5: shape1 */
+        const int lk = (pi < 2) ? 3 : ((pi < 5) ? 2 : 1);
+        const TfLinkShape* sh = (pi == 0) ? &m->shape3 : ((pi == 2) ? &m->shape2 : ((pi == 5) ? &m->shape1 : NULL));
+        const TfSphere* sp = (pi == 1) ? &m->sph3[0] : ((pi == 3) ? &m->sph2[1] : ((pi == 4) ? &m->sph2[0] : NULL));
+        if (pi >= 4 && !(cube_top_check > m->upper_check_z)) continue;
+        if (pi == 2 && !(FMA(f_abs(R[8]), hc[2], FMA(f_abs(R[7]), hc[1], FMA(f_abs(R[6]), hc[0], cpr[2]))) > m->middle_check_z))
+            continue;                    /* the middle link stays >= 0.12 m above the floor: only an object that reaches up there */
+        float gx[3], gy[3], gn[3], gg, rad;
+        if (sh) {
+            float a[3], b[3], D, spar;
+            if (pi == 0) {               /* the axis end points of the distal body are the fingertip capsule's */
+                float da[3] = {Aw[0] - cpr[0], Aw[1] - cpr[1], Aw[2] - cpr[2]};
+                float db[3] = {Bw[0] - cpr[0], Bw[1] - cpr[1], Bw[2] - cpr[2]};
+                mat3T_mul(R, da, a);
+                mat3T_mul(R, db, b);
+            } else {
+                to_cube(m, f, k, lk, sh->a, cpr, R, a);
+                to_cube(m, f, k, lk, sh->b, cpr, R, b);
+            }
+            seg_box(a, b, hc, 0.0f, &D, gx, gy, gn, &spar);
+            float uw[3], ub[3], ul[3];
+            mat3_mul(R, gn, uw);
+            dir_world_to_base(m, f, uw, ub);
+            rot_link_T(k, lk, ub, ul);
+            const float u1 = -ul[0], u2 = (lk == 1) ? -ul[2] : -ul[1];
+            const float rho = FMA(spar, sh->rho[1] - sh->rho[0], sh->rho[0]);
+            const float h1 = FMA(spar, sh->w1[1] - sh->w1[0], sh->w1[0]) - rho, h2 = FMA(spar, sh->w2[1] - sh->w2[0], sh->w2[0]) - rho;
+            const float o1 = FMA(spar, sh->o1[1] - sh->o1[0], sh->o1[0]), o2 = FMA(spar, sh->o2[1] - sh->o2[0], sh->o2[0]);
+            const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
+            gg = D - ext;
+            rad = ext;
+        } else {
+            to_cube(m, f, k, lk, sp->c, cpr, R, gx);
+            point_box(gx, hc, sp->radius, &gg, gy, gn);
+            rad = sp->radius;
+        }
+        if (link == 0 || gg < gap) {
+            link = lk; gap = gg; radius = rad;
+            for (int i = 0; i < 3; ++i) { x[i] = gx[i]; y[i] = gy[i]; nc[i] = gn[i]; }
+        }
+    }
+    *gap_o = gap; *radius_o = radius; *link_o = link;
+}
+
 /* One solver substep of length h for one env.  Phases and roles: F1 free motion of each finger,
  * C1 cube free motion and corner contacts, FF finger-finger pre-pass, F2 finger contact generation, then the sweeps. */
 static void substep(const struct TfHandle_* H, Env* e, float h) {
@@ -1390,55 +1446,10 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         const FK* k = &g->k;
         FcRecord* rc_ = &rec[f];
         memset(rc_, 0, sizeof(*rc_));
-        /* --- finger vs cube: the link capsule with the smallest gap holds the contact --- */
+        /* --- finger vs cube: the shape with the smallest gap holds the contact --- */
         float gap = 0.0f, x[3], y[3], nc[3], radius = 0.0f;
         int link = 0;
-        /* candidates in order (a later one takes over only with a strictly smaller gap): the distal body (TfLinkShape: tapered rounded
-         * box along the fingertip capsule's axis), its housing sphere, the middle link, its two housing spheres, and - for a cube above
-         * upper_check_z - the upper link */
-        for (int pi = 0; pi < 6; ++pi) {
-            /* 0: shape3  1: sph3  2: shape2  3: sph2[1] (joint-3 housing)  then, only for a cube above upper_check_z (they hang at the
-             * height of the base):  4: sph2[0] (joint-2 housing)  5: shape1 */
-            const int lk = (pi < 2) ? 3 : ((pi < 5) ? 2 : 1);
-            const TfLinkShape* sh = (pi == 0) ? &m->shape3 : ((pi == 2) ? &m->shape2 : ((pi == 5) ? &m->shape1 : NULL));
-            const TfSphere* sp = (pi == 1) ? &m->sph3[0] : ((pi == 3) ? &m->sph2[1] : ((pi == 4) ? &m->sph2[0] : NULL));
-            if (pi >= 4 && !(cube_top_check > m->upper_check_z)) continue;
-            if (pi == 2 && !(FMA(f_abs(R[8]), hc[2], FMA(f_abs(R[7]), hc[1], FMA(f_abs(R[6]), hc[0], cpr[2]))) > m->middle_check_z))
-                continue;                    /* the middle link stays >= 0.12 m above the floor: only an object that reaches up there */
-            float gx[3], gy[3], gn[3], gg, rad;
-            if (sh) {
-                float a[3], b[3], D, spar;
-                if (pi == 0) {               /* the axis end points of the distal body are the fingertip capsule's */
-                    float da[3] = {g->Aw[0] - cpr[0], g->Aw[1] - cpr[1], g->Aw[2] - cpr[2]};
-                    float db[3] = {g->Bw[0] - cpr[0], g->Bw[1] - cpr[1], g->Bw[2] - cpr[2]};
-                    mat3T_mul(R, da, a);
-                    mat3T_mul(R, db, b);
-                } else {
-                    to_cube(m, f, k, lk, sh->a, cpr, R, a);
-                    to_cube(m, f, k, lk, sh->b, cpr, R, b);
-                }
-                seg_box(a, b, hc, 0.0f, &D, gx, gy, gn, &spar);
-                float uw[3], ub[3], ul[3];
-                mat3_mul(R, gn, uw);
-                dir_world_to_base(m, f, uw, ub);
-                rot_link_T(k, lk, ub, ul);
-                const float u1 = -ul[0], u2 = (lk == 1) ? -ul[2] : -ul[1];
-                const float rho = FMA(spar, sh->rho[1] - sh->rho[0], sh->rho[0]);
-                const float h1 = FMA(spar, sh->w1[1] - sh->w1[0], sh->w1[0]) - rho, h2 = FMA(spar, sh->w2[1] - sh->w2[0], sh->w2[0]) - rho;
-                const float o1 = FMA(spar, sh->o1[1] - sh->o1[0], sh->o1[0]), o2 = FMA(spar, sh->o2[1] - sh->o2[0], sh->o2[0]);
-                const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
-                gg = D - ext;
-                rad = ext;
-            } else {
-                to_cube(m, f, k, lk, sp->c, cpr, R, gx);
-                point_box(gx, hc, sp->radius, &gg, gy, gn);
-                rad = sp->radius;
-            }
-            if (link == 0 || gg < gap) {
-                link = lk; gap = gg; radius = rad;
-                for (int i = 0; i < 3; ++i) { x[i] = gx[i]; y[i] = gy[i]; nc[i] = gn[i]; }
-            }
-        }
+        finger_cube_candidates(m, f, k, g->Aw, g->Bw, cpr, R, hc, cube_top_check, &gap, x, y, nc, &radius, &link);
         g->fc_link = 0;
         for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) { g->fcJ[d][j] = 0.0f; g->fcW[d][j] = 0.0f; }
         g->fc_arm[0] = 0.0f; g->fc_arm[1] = 0.0f; g->fc_arm[2] = 0.0f;
@@ -2432,6 +2443,24 @@ int tf_test_finger_dynamics(tf_handle h, const float* q, const float* qd, float*
 }
 
 /* thread control for the OpenMP build (bench.py's cpu_baseline): set the team size, return what will be used */
+/* test entry (tests/test_model_fixture.py): gap and link of the finger-cube contact candidate of finger f for joint angles q and a cube pose (world),
+ * exactly as the substep selects it (default model geometry of `m`, no domain randomisation) */
+void tfo_finger_gap(const TfModel* m, int32_t f, const float q[3], const float cube_p[3], const float cube_q[4], float* gap_out, int32_t* link_out) {
+    FK k;
+    float Ab[3], Bb[3], Aw[3], Bw[3], R[9], hc[3], x[3], y[3], nc[3], gap, radius;
+    int link;
+    fk_setup(m, q, &k);
+    link_point(&k, 3, m->cap_a, Ab);
+    link_point(&k, 3, m->cap_b, Bb);
+    base_to_world(m, f, Ab, Aw);
+    base_to_world(m, f, Bb, Bw);
+    quat_to_rot(cube_q, R);
+    for (int i = 0; i < 3; ++i) hc[i] = m->box ? m->box_half[i] : m->cube_half;
+    finger_cube_candidates(m, f, &k, Aw, Bw, cube_p, R, hc, cube_p[2], &gap, x, y, nc, &radius, &link);
+    *gap_out = gap;
+    *link_out = link;
+}
+
 int tfo_omp_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

@@ -366,3 +366,52 @@ def test_contact_gap_against_the_distance_of_the_reference_hulls():
     print("\ncontact-model gap minus hull distance [mm]: median %.2f  p10 %.2f  p90 %.2f  min %.2f  max %.2f" % (
         np.median(err) * 1e3, np.percentile(err, 10) * 1e3, np.percentile(err, 90) * 1e3, err.min() * 1e3, err.max() * 1e3))
     assert np.median(np.abs(err)) < 1.5e-3 and np.percentile(np.abs(err), 90) < 3.5e-3 and np.abs(err).max() < 9e-3, err
+
+
+def test_finger_cube_gap_of_the_engine_against_the_independent_geometry(oracle):
+    """a STATIC check of the contact geometry, no dynamics - the gap and the link of the finger-cube contact candidate exactly as the
+    substep selects it (oracle entry tfo_finger_gap, the function substep() calls; the HIP kernels are bit-identical to it) against
+    tests/physics_ref.shape_candidates (fp64, scipy closest points, the support function written from the spec) on sampled poses with the cube
+    within a few centimetres of the finger.  A wrong sign in the support function, a swapped width direction or a wrong link frame shows up as
+    millimetres here; agreement is held to 0.05 mm."""
+    import ctypes as C
+    import physics_ref as PR
+    m = oracle.default_model()
+    fn = oracle.dll.tfo_finger_gap
+    fn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    fn.restype = None
+    rng = np.random.default_rng(5)
+    hc = np.full(3, PR.CUBE_HALF)
+    checked, by_link, worst = 0, {1: 0, 2: 0, 3: 0}, 0.0
+    while checked < 400:
+        f = int(rng.integers(3))
+        q = rng.uniform(PR.Q_LO + 0.02, PR.Q_HI - 0.02)
+        link = int(rng.choice([3, 3, 2, 1]))
+        # a cube placed near a random point of the chosen link
+        sh = [e for e in PR.SHAPES if e[0] == "shape" and e[1] == link][0][2]
+        pt = PR.link_point_world(f, q, link, sh["a"] + rng.uniform(0, 1) * (sh["b"] - sh["a"]))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        cp = pt + d * (PR.CUBE_HALF * rng.uniform(1.0, 1.7) + rng.uniform(0.01, 0.05))
+        if cp[2] < 0.0325:
+            continue
+        cq = rng.normal(size=4); cq /= np.linalg.norm(cq)
+        R = PR.quat_rot(cq)
+        cands = PR.shape_candidates(f, q, cp, R, hc, links=(3, 2, 1), high=cp[2] > PR.UPPER_CHECK_Z)
+        if any(c[0] <= -1.0 for c in cands):
+            continue                                   # an axis inside the cube: outside the domain of the reference
+        gaps = sorted(c[0] for c in cands)
+        if len(gaps) > 1 and gaps[1] - gaps[0] < 2e-4:
+            continue                                   # two shapes tie: which one holds the contact is a rounding matter
+        best = min(cands, key=lambda c: c[0])
+        if best[0] > 0.06:
+            continue
+        gap, lk = C.c_float(), C.c_int32()
+        fn(C.byref(m), f, (C.c_float * 3)(*q.astype(np.float32)), (C.c_float * 3)(*cp.astype(np.float32)), (C.c_float * 4)(*cq.astype(np.float32)),
+           C.byref(gap), C.byref(lk))
+        assert lk.value == best[1], (f, q, cp, lk.value, best[1])
+        worst = max(worst, abs(gap.value - best[0]))
+        assert abs(gap.value - best[0]) < 5e-5, (f, q, cp, gap.value, best[0], best[1])
+        by_link[best[1]] += 1
+        checked += 1
+    print(f"\n400 poses: worst gap difference {worst * 1e6:.1f} um; contacts held by link 3 / 2 / 1: {by_link[3]} / {by_link[2]} / {by_link[1]}")
+    assert by_link[3] >= 100 and by_link[2] >= 50 and by_link[1] >= 10
