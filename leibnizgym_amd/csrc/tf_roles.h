@@ -57,6 +57,8 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 #define PK_FT 14                        //   6
 #define L_VQFF 138                      //   9: joint velocities after the finger-finger pass; then Dinv[3] of finger f at 3 f
 #define L_INIT 147                      //   3: bias of finger f; after the last sweep the normal impulse of finger f
+#define L_DR0 32                        //  14: launch prologue only (behind the action tile, before any physics slot is live): the domain-randomisation rows of the
+                                        //      env, loaded once by the cube role and handed to the three finger roles through barrier #1
 #define LDS_SLOTS 150
 #define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
 #define LDS_SLOTS_BOX 156
@@ -359,11 +361,16 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     STAMP(0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { q[j] = LDST(TF_S_Q + 3 * f + j); qd[j] = LDST(TF_S_QD + 3 * f + j); }
-#pragma unroll
-    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);   // rows are read only when the feature is on
+    // (the domain-randomisation rows of the env are loaded once per workgroup, by the cube role, and arrive through LDS behind barrier #1: four
+    // wavefronts fetching the same 14 rows more than doubled the load burst every workgroup of a launch starts with)
     if (!(MODE & M_TORQUE) && (MODE & (M_RESETS | M_SIM))) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) tau[j] = LDST(TF_S_TAU + 3 * f + j);
+    }
+    float tau_prev[3] = {0.0f, 0.0f, 0.0f};                      // action repeat: the torque of the previous step, requested with the other loads of the prologue
+    if ((MODE & M_TORQUE) && !IS_RESET && P.dr_action_repeat > 0.0f) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tau_prev[j] = LDST(TF_S_TAU + 3 * f + j);
     }
     // activity code of this finger's warm-start rows (row TF_S_FC_LINK): link that held the finger-cube contact + 4 if the fingertip-wall
     // contact pushed.  The rows of an inactive contact are neither loaded nor stored (their content is then undefined).
@@ -374,6 +381,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
     BAR();                                                      // #1: action tile in LDS, flag loads have returned
+#pragma unroll
+    for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LD(L_DR0 + j) : TF_DR_NEUTRAL(j);
     STAMP(1);
     // The warm-start rows are first needed when the contact rows are built, a free-motion phase later: issued here, behind the
     // barrier, they stay out of the load burst every workgroup of the launch starts with.
@@ -462,7 +471,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             const bool keep = u[0] < P.dr_action_repeat;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float prev = rflag ? 0.0f : LDST(TF_S_TAU + 3 * f + j);
+                const float prev = rflag ? 0.0f : tau_prev[j];
                 t[j] = keep ? prev : t[j];
             }
         }
@@ -1055,7 +1064,13 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 BAR();                                          // P4: states tile stored; obs noise goes on top of slots 0..24
                 float nz[28];
 #pragma unroll
-                for (int b = 0; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+                for (int b = 0; b < 28; ++b) nz[b] = 0.0f;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {                   // only the Philox blocks that hold this finger's six slots (wave-uniform: f is)
+                    const int lo = 4 * b, hi = 4 * b + 3;
+                    const bool need = (lo <= 3 * f + 2 && hi >= 3 * f) || (lo <= 11 + 3 * f && hi >= 9 + 3 * f);
+                    if (need) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+                }
 #pragma unroll
                 for (int jj = 0; jj < 18; ++jj) {
                     const bool mine = (jj == 3 * f) || (jj == 3 * f + 1) || (jj == 3 * f + 2) || (jj == 9 + 3 * f) || (jj == 10 + 3 * f) || (jj == 11 + 3 * f);
@@ -1068,7 +1083,13 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             if (P.dr_obs_noise > 0.0f) {
                 float nz[28];
 #pragma unroll
-                for (int b = 0; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+                for (int b = 0; b < 28; ++b) nz[b] = 0.0f;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {                   // only the Philox blocks that hold this finger's six slots (wave-uniform: f is)
+                    const int lo = 4 * b, hi = 4 * b + 3;
+                    const bool need = (lo <= 3 * f + 2 && hi >= 3 * f) || (lo <= 11 + 3 * f && hi >= 9 + 3 * f);
+                    if (need) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+                }
 #pragma unroll
                 for (int jj = 0; jj < 18; ++jj) {
                     const bool mine = (jj == 3 * f) || (jj == 3 * f + 1) || (jj == 3 * f + 2) || (jj == 9 + 3 * f) || (jj == 10 + 3 * f) || (jj == 11 + 3 * f);
@@ -1241,6 +1262,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
     else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
+    if (P.dr_enable) {                                          // the env's domain-randomisation rows for the finger roles (L_DR0)
+#pragma unroll
+        for (int j = 0; j < NDR; ++j) LD(L_DR0 + j) = dr[j];
+    }
     BAR();                                                      // #1
     STAMP(1);
     if (MODE & (M_SIM | M_RESETS)) {                            // warm-start rows: behind the barrier, out of the launch's first load burst
@@ -1872,7 +1897,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         auto add_noise = [&]() {
             float nz[28];
 #pragma unroll
-            for (int b = 0; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
+            for (int b = 4; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);      // the blocks that hold slots 18..24
 #pragma unroll
             for (int jj = 18; jj < 25; ++jj) row[jj] = f_clamp(FMA(P.dr_obs_noise, 2.0f * nz[jj] - 1.0f, row[jj]), -co, co);
         };

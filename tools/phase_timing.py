@@ -11,7 +11,8 @@ from leibnizgym_amd import _capi
 lib = _capi.TfLib(os.path.join(REPO, "leibnizgym_amd", "csrc", "libtrifinger_hip_timing.so"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 asym = True
-eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym)), device="cuda:0", lib=lib)
+dr = len(sys.argv) > 3 and sys.argv[3] == "dr"          # phase_timing.py N WARMUP dr: every domain-randomisation feature (the EXT kernel)
+eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym, 4, dr)), device="cuda:0", lib=lib)
 g = torch.Generator(device="cuda:0").manual_seed(1)
 ring = [(torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1) for _ in range(8)]
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 10      # steps after the reset before sampling starts (600: the cubes have reached the boundary)
@@ -30,7 +31,7 @@ def d(a, b, role):                # median over steps and workgroups of stamp[b]
 def v(a, role):
     sel = S[:, :, role, :] if role == 3 else S[:, :, 0:3, :].reshape(S.shape[0], -1, 64)
     return np.median(sel[..., a])
-print(f"N={n} asym={asym}, sampled {warm}..{warm + 29} steps after the reset: median s_memtime ticks; finger role | cube role")
+print(f"N={n} asym={asym}{' + every DR feature (EXT kernel)' if dr else ''}, sampled {warm}..{warm + 29} steps after the reset: median s_memtime ticks; finger role | cube role")
 rows = [("loads + action tile (to #1)", 0, 1), ("resets, action_buf, torque", 1, 2)]
 for s in (0, 1):
     b = 4 + 12 * s
