@@ -343,8 +343,11 @@ __device__ unsigned long long g_wg[2048 * 2];     // [workgroup][start, end] in 
 #define TNOW() 0u
 #define TBAR() __syncthreads()
 #endif
+#ifndef GEMM_WPE
+#define GEMM_WPE 1       // wavefronts per SIMD the register allocation must leave room for (4: two workgroups of 8 wavefronts per CU)
+#endif
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
-__global__ void __launch_bounds__(512) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                               const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk) {
     // Role-specialised wavefronts: waves 0-3 multiply (one 32 x 32 accumulator each: LDS reads and MFMAs, nothing else), waves 4-7 stage
     // (global loads, the fix-ups, LDS writes).  A SIMD hosts one of each per workgroup, so the staging instructions of the producers issue

@@ -1247,9 +1247,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     uint32_t fl_count = 0;
     STAMP(0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { cp[j] = LDST(TF_S_CUBE_P + j); cv[j] = LDST(TF_S_CUBE_V + j); cw[j] = LDST(TF_S_CUBE_W + j); gp[j] = LDST(TF_S_GOAL_P + j); gw[j] = LDST(TF_S_GOAL_W + j); }
+    for (int j = 0; j < 3; ++j) { cp[j] = LDST(TF_S_CUBE_P + j); cv[j] = LDST(TF_S_CUBE_V + j); cw[j] = LDST(TF_S_CUBE_W + j); gp[j] = 0.0f; gw[j] = 0.0f; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { cq[j] = LDST(TF_S_CUBE_Q + j); gq[j] = LDST(TF_S_GOAL_Q + j); }
+    for (int j = 0; j < 4; ++j) { cq[j] = LDST(TF_S_CUBE_Q + j); gq[j] = 0.0f; }      // (the goal rows are only WRITTEN here, by a reset; the post phase reads them)
 #pragma unroll
     for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);   // rows are read only when the feature is on
     if (MODE & (M_RESETS | M_POST | M_FINISH)) {

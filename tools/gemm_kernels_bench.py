@@ -3,6 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from leibnizgym_amd import ppo_kernels as pk
+if os.environ.get("PPO_LIB"):                                  # a developer build of csrc/ppo_kernels.hip (compile-flag experiments)
+    pk.library_path = lambda: os.path.abspath(os.environ["PPO_LIB"])
 dev = "cuda:0"
 def t_us(f, n=20, reps=5):
     """device time per call: n calls captured in one HIP graph (no host time between the launches), replayed"""
