@@ -344,7 +344,8 @@ __device__ unsigned long long g_wg[2048 * 2];     // [workgroup][start, end] in 
 #define TBAR() __syncthreads()
 #endif
 #ifndef GEMM_WPE
-#define GEMM_WPE 1       // wavefronts per SIMD the register allocation must leave room for (4: two workgroups of 8 wavefronts per CU)
+#define GEMM_WPE 4       // wavefronts per SIMD the register allocation must leave room for: two workgroups of 8 wavefronts per CU (the k-contiguous scalar-load
+                         // instantiations - first layers, K = 41 / 113 - took 146 registers and ran ONE workgroup per CU: 20.7 -> 16.0 us, 29.2 -> 24.0 us)
 #endif
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
