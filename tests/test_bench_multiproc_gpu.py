@@ -25,6 +25,32 @@ def launch(script_args, nproc=2):
     return p
 
 
+def test_single_process_line_carries_the_contract(hip):
+    """`python bench.py` (N = 1): one JSON line with the contract's keys, `value` = envs x steps / elapsed of the step with on-device action
+    generation, `roofline` (bound / achieved / peak / unit / frac / traffic, measured kernel time) and what the steady-state prelude did."""
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "3", "--envs", "8192", "--settle", "30", "--no-cpu-baseline"],
+                       cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "value_resident_actions", "value_with_torch_action_generation", "steady_state_prelude"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 8192 * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_us", "kernel_launches_timed"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel_launches_timed"] == 40
+    assert "127" in r["kernel"]                                            # the instantiation with the action source fused in is what `value` launches
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["kernel_avg_us"] < d["ms_per_step"] * 1e3 * 1.05
+    assert "30 steps" in d["steady_state_prelude"] and "workload" in d["config"]
+    q = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "2", "--envs", "4096", "--settle", "0", "--no-cpu-baseline"],
+                       cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0 and json.loads([ln for ln in q.stdout.splitlines() if ln.startswith("{")][0])["steady_state_prelude"].startswith("none")
+
+
 def test_two_ranks_print_one_aggregate_line(hip):
     p = launch(["bench.py", "--gpus", "2", "--steps", "100", "--warmup", "5", "--envs", "8192"])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
