@@ -1,12 +1,12 @@
-"""Developer tool (CPU, oracle): TRUNCATION residual of the shipped sweep count in the product's own arithmetic - the substep with
+"""Developer checker (CPU, oracle; under tests/ because only tests/ may use oracle/): TRUNCATION residual of the shipped sweep count in the product's own arithmetic - the substep with
 `sweeps` solver iterations against the same substep (same state, same warm-start rows) iterated 4096 times, scaled as in
 tests/test_contact_lcp_reference.py (joints / 10 rad/s, cube m/s, cube rad/s / 20).  Thousands of states in seconds (no fp64 reference
 in the loop: what is measured is the solver, not the modelling differences between the spec and its fp64 restatement).
 State sets:  cases  - the random persistent-contact states of tests/test_contact_lcp_reference.make_case after `k_warm` product substeps
              rollout - states of the bench workload (random actions, 65536-env statistics on a sample) every 50 steps
-   python tools/solver_residual.py cases|rollout [n] [sweeps ...]"""
+   python tests/dev/solver_residual.py cases|rollout [n] [sweeps ...]"""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, REPO)
 import numpy as np, torch
 
