@@ -203,7 +203,8 @@ typedef struct TfModel {
     /* arena: inner radius of the boundary annulus as a function of height, piecewise linear through the knots (wall_z[i], wall_r[i]):
      * a vertical ring below wall_z[0], the flaring cone of the stage between the knots, nothing above wall_z[3]; from the 40 convex
      * pieces of meshes/convex_table_boundary/convex_*.obj (high_table_boundary.urdf:20-259) via tests/golden/model.npz: mid-way
-     * between the chords and the corners of the polygonal inner surface.  The contact normal is horizontal (cone tilt ignored). */
+     * between the chords and the corners of the polygonal inner surface.  The FINGERTIP contact follows the tilt of the surface (normal (c n_h, s) with
+     * c, s the cosine and sine of the slope angle of the segment, gap = distance to the tilted surface); the cube corners keep the horizontal normal. */
     float wall_r[4], wall_z[4];
     /* materials: PhysX "average" combine of trifinger_env.py:364-365,876-878,914-915,934-936 */
     float mu_finger_cube, mu_cube_floor, mu_tip_floor, mu_cube_wall, mu_tip_wall, mu_finger_finger;

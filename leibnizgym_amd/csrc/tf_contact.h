@@ -170,6 +170,22 @@ DEV float wall_radius_at(const DevParams& P, float z) {
     return r;
 }
 
+// the same with the TILT of the surface at that height: (c, sn) = (cos, sin) of the slope angle of the profile segment, (1, 0) on the vertical ring.
+// The inward surface normal is (c n_h, sn) with n_h the inward horizontal unit vector (the stage is a bowl: above 32 mm its wall leans outward by
+// 29-35 degrees, high_table_boundary.urdf:20-259); the distance of a point at radius rho to the surface is (r(z) - rho) c.  Used by the fingertip -
+// boundary contact; the cube corners keep the horizontal normal (their tilted rows cost the cube wavefront 5 us: DESIGN.md section 4).
+DEV float wall_profile(const DevParams& P, float z, float& c, float& sn) {
+    const TfModel& m = P.m;
+    const bool b0 = z > m.wall_z[0], b1 = z > m.wall_z[1], b2 = z > m.wall_z[2];
+    float r = m.wall_r[0];
+    c = 1.0f; sn = 0.0f;
+    r = b0 ? FMA(z - m.wall_z[0], P.wall_s[0], m.wall_r[0]) : r;  c = b0 ? P.wall_c[0] : c;  sn = b0 ? P.wall_sn[0] : sn;
+    r = b1 ? FMA(z - m.wall_z[1], P.wall_s[1], m.wall_r[1]) : r;  c = b1 ? P.wall_c[1] : c;  sn = b1 ? P.wall_sn[1] : sn;
+    r = b2 ? FMA(z - m.wall_z[2], P.wall_s[2], m.wall_r[2]) : r;  c = b2 ? P.wall_c[2] : c;  sn = b2 ? P.wall_sn[2] : sn;
+    r = (z < m.wall_z[3]) ? r : 1000.0f;
+    return r;
+}
+
 DEV void cube_corner(const float R[9], const float hc[3], int k, float sk, int idx, float r[3]) {
     // axes a < b are the two that are not k: bit 0 of idx is the sign along a, bit 1 the sign along b
     float y[3];

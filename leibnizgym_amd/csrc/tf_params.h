@@ -74,6 +74,7 @@ struct DevParams {
     float grav[3];
     TfModel m;
     float wall_s[3];         // slopes of the boundary profile between its knots: (wall_r[i+1] - wall_r[i]) / (wall_z[i+1] - wall_z[i])
+    float wall_c[3], wall_sn[3];   // cos and sin of the slope angle of each segment: 1 / sqrt(1 + s^2), s / sqrt(1 + s^2) (fingertip - boundary contact)
     // obs/states offset and 1/range tables, action limits, PD gains (index = TAB_*).  Embedded so that every access
     // is a scalar load at a constant offset of the parameter block (a pointer member would be fetched per lane).
     float tables[TAB_FLOATS];

@@ -764,13 +764,16 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             }
             // fingertip sphere vs floor (slot 0) and vs boundary wall (slot 1)
             TipContact tc[2];
-            float wall_n[2];                                    // inward horizontal normal at the fingertip (wrench of slot 1)
+            float wall_n[3];                                    // inward surface normal of the boundary at the fingertip (rows and wrench of slot 1)
             {
                 // fingertip sphere centre in the world (z) and relative to the stage centre (x, y)
                 const float bx = EXT ? (Bw[0] + boff[0]) - soff[0] : Bw[0], by = EXT ? (Bw[1] + boff[1]) - soff[1] : Bw[1], bz = EXT ? Bw[2] + boff[2] : Bw[2];
                 float rho2 = FMA(bx, bx, by * by);
                 float inv = f_rsqrt(f_max(rho2, 1e-24f));
                 float rho = rho2 * inv;
+                float wc, wsn;
+                const float wgap = (wall_profile(P, bz, wc, wsn) - rho) * wc;      // distance of the sphere centre to the (tilted) surface
+                wall_n[0] = (-bx * inv) * wc; wall_n[1] = (-by * inv) * wc; wall_n[2] = wsn;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     TipContact& c = tc[t];
@@ -780,11 +783,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { c.Dinv[j] = 0.0f; c.lam[j] = 0.0f; c.arm[j] = 0.0f; }
                     c.bias = 0.0f; c.mu = 0.0f;
-                    float gp_ = (t == 0) ? (bz - m.cap_radius) : ((wall_radius_at(P, bz) - rho) - m.cap_radius);
+                    float gp_ = (t == 0) ? (bz - m.cap_radius) : (wgap - m.cap_radius);
                     const bool on = ((t == 0) || (rho > 1e-6f)) && (gp_ < m.contact_margin);
                     if (__builtin_expect(on, t == 0)) {
                         float dir[9] = {0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        if (t == 1) { dir[0] = -bx * inv; dir[1] = -by * inv; dir[2] = 0.0f; }
+                        if (t == 1) { dir[0] = wall_n[0]; dir[1] = wall_n[1]; dir[2] = wall_n[2]; }
                         tangent_basis(&dir[0], &dir[3], &dir[6]);
                         float Pw[3] = {FMA(-m.cap_radius, dir[0], Bw[0]), FMA(-m.cap_radius, dir[1], Bw[1]), FMA(-m.cap_radius, dir[2], Bw[2])};
                         float Pb[3], Dd[3], Jt[9], Wt[9];
@@ -810,7 +813,6 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                         }
                     }
                 }
-                wall_n[0] = -bx * inv; wall_n[1] = -by * inv;
             }
             // joint limit / velocity limit rows
             float vlo[3], vhi[3], lim_dinv[3], lim_lam[3];
@@ -950,7 +952,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     const TipContact& c = tc[t];
                     if (c.active) {
                         float dir[9] = {0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // same directions the rows were built with
-                        if (t == 1) { dir[0] = wall_n[0]; dir[1] = wall_n[1]; dir[2] = 0.0f; }
+                        if (t == 1) { dir[0] = wall_n[0]; dir[1] = wall_n[1]; dir[2] = wall_n[2]; }
                         tangent_basis(&dir[0], &dir[3], &dir[6]);
                         float F[3], T[3];
 #pragma unroll

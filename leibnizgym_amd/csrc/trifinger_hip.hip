@@ -411,7 +411,12 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     P.dt = cfg->dt; P.hsub = cfg->dt / (float)cfg->substeps;
     for (int i = 0; i < 3; ++i) P.grav[i] = cfg->gravity[i];
     P.m = cfg->model;
-    for (int i = 0; i < 3; ++i) P.wall_s[i] = (float)(((double)P.m.wall_r[i + 1] - (double)P.m.wall_r[i]) / ((double)P.m.wall_z[i + 1] - (double)P.m.wall_z[i]));
+    for (int i = 0; i < 3; ++i) {
+        const double sl = ((double)P.m.wall_r[i + 1] - (double)P.m.wall_r[i]) / ((double)P.m.wall_z[i + 1] - (double)P.m.wall_z[i]);
+        P.wall_s[i] = (float)sl;
+        P.wall_c[i] = (float)(1.0 / sqrt(1.0 + sl * sl));
+        P.wall_sn[i] = (float)(sl / sqrt(1.0 + sl * sl));
+    }
     void* tk = nullptr;
     e = hipMalloc(&tk, STAT_WORDS * sizeof(unsigned long long));
     if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(tickets)"); }

@@ -293,6 +293,7 @@ struct TfHandle_ {
     double timed_ms;
     int64_t timed_launches;
     float wall_s[3];                    /* slopes of the boundary profile between its knots */
+    float wall_c[3], wall_sn[3];        /* cos and sin of the slope angle of each segment (fingertip - boundary contact) */
 };
 
 static char g_err[256] = "";
@@ -534,8 +535,12 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     h->action_dim = tf_action_dim(cfg->command_mode);
     build_tables(h);
     h->ext = needs_ext(&h->cfg);
-    for (int i = 0; i < 3; ++i)
-        h->wall_s[i] = (float)(((double)cfg->model.wall_r[i + 1] - (double)cfg->model.wall_r[i]) / ((double)cfg->model.wall_z[i + 1] - (double)cfg->model.wall_z[i]));
+    for (int i = 0; i < 3; ++i) {
+        const double sl = ((double)cfg->model.wall_r[i + 1] - (double)cfg->model.wall_r[i]) / ((double)cfg->model.wall_z[i + 1] - (double)cfg->model.wall_z[i]);
+        h->wall_s[i] = (float)sl;
+        h->wall_c[i] = (float)(1.0 / sqrt(1.0 + sl * sl));
+        h->wall_sn[i] = (float)(sl / sqrt(1.0 + sl * sl));
+    }
     *out = h;
     return TF_OK;
 }
@@ -993,6 +998,18 @@ static float wall_radius_at(const struct TfHandle_* H, float z) {
     if (z > m->wall_z[0]) r = FMA(z - m->wall_z[0], H->wall_s[0], m->wall_r[0]);
     if (z > m->wall_z[1]) r = FMA(z - m->wall_z[1], H->wall_s[1], m->wall_r[1]);
     if (z > m->wall_z[2]) r = FMA(z - m->wall_z[2], H->wall_s[2], m->wall_r[2]);
+    if (!(z < m->wall_z[3])) r = 1000.0f;
+    return r;
+}
+/* the same with the tilt of the surface at that height: (c, sn) = (cos, sin) of the slope angle of the profile segment, (1, 0) on the vertical ring;
+ * inward surface normal (c n_h, sn), distance of a point at radius rho to the surface (r(z) - rho) c.  Fingertip - boundary contact only. */
+static float wall_profile(const struct TfHandle_* H, float z, float* c, float* sn) {
+    const TfModel* m = &H->cfg.model;
+    float r = m->wall_r[0];
+    *c = 1.0f; *sn = 0.0f;
+    if (z > m->wall_z[0]) { r = FMA(z - m->wall_z[0], H->wall_s[0], m->wall_r[0]); *c = H->wall_c[0]; *sn = H->wall_sn[0]; }
+    if (z > m->wall_z[1]) { r = FMA(z - m->wall_z[1], H->wall_s[1], m->wall_r[1]); *c = H->wall_c[1]; *sn = H->wall_sn[1]; }
+    if (z > m->wall_z[2]) { r = FMA(z - m->wall_z[2], H->wall_s[2], m->wall_r[2]); *c = H->wall_c[2]; *sn = H->wall_sn[2]; }
     if (!(z < m->wall_z[3])) r = 1000.0f;
     return r;
 }
@@ -1499,14 +1516,17 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             float rho2 = FMA(bx, bx, by * by);
             float inv = f_rsqrt(f_max(rho2, 1e-24f));
             float rho = rho2 * inv;
+            float wc, wsn;
+            const float wgap = (wall_profile(H, bz, &wc, &wsn) - rho) * wc;      /* distance of the sphere centre to the (tilted) surface */
+            const float wall_n[3] = {(-bx * inv) * wc, (-by * inv) * wc, wsn};
             for (int t = 0; t < 2; ++t) {
                 TipContact* c = &g->tc[t];
                 memset(c, 0, sizeof(*c));
-                float gp_ = (t == 0) ? (bz - m->cap_radius) : ((wall_radius_at(H, bz) - rho) - m->cap_radius);
+                float gp_ = (t == 0) ? (bz - m->cap_radius) : (wgap - m->cap_radius);
                 if (t == 1 && !(rho > 1e-6f)) continue;
                 if (!(gp_ < m->contact_margin)) continue;
                 float dir[3][3] = {{0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-                if (t == 1) { dir[0][0] = -bx * inv; dir[0][1] = -by * inv; dir[0][2] = 0.0f; }
+                if (t == 1) { dir[0][0] = wall_n[0]; dir[0][1] = wall_n[1]; dir[0][2] = wall_n[2]; }
                 tangent_basis(dir[0], dir[1], dir[2]);
                 float Pw[3] = {FMA(-m->cap_radius, dir[0][0], g->Bw[0]), FMA(-m->cap_radius, dir[0][1], g->Bw[1]),
                                FMA(-m->cap_radius, dir[0][2], g->Bw[2])};

@@ -161,6 +161,18 @@ def wall_radius_at(z):
     return float(np.interp(z, WALL_Z, WALL_R))
 
 
+def wall_tilt(z):
+    """(cos, sin) of the slope angle of the profile segment at height z: the inward surface normal of the boundary is (cos * n_h, sin) with n_h the
+    inward horizontal unit vector; (1, 0) on the vertical ring below the first knot.  Spec: the FINGERTIP contact uses the tilted normal and the
+    distance to the tilted surface, the cube corners the horizontal normal."""
+    i = int(np.searchsorted(WALL_Z, z, side="left")) - 1          # z > WALL_Z[i]
+    if i < 0:
+        return 1.0, 0.0
+    i = min(i, len(WALL_Z) - 2)
+    sl = (WALL_R[i + 1] - WALL_R[i]) / (WALL_Z[i + 1] - WALL_Z[i])
+    return 1.0 / np.sqrt(1.0 + sl * sl), sl / np.sqrt(1.0 + sl * sl)
+
+
 def segment_box(a, b, hc):
     """closest points of the segment a-b and the box [-hc, hc]^3 (box frame): bounded scalar minimisation."""
     def dist2(s):
@@ -325,7 +337,8 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
             else:
                 if not rho > 1e-6:
                     continue
-                gp, n = wall_radius_at(B[2]) - rho - rad, np.array([-B[0] / rho, -B[1] / rho, 0.0])
+                wc, wsn = wall_tilt(B[2])
+                gp, n = (wall_radius_at(B[2]) - rho) * wc - rad, np.array([-B[0] / rho * wc, -B[1] / rho * wc, wsn])
             if gp < MARGIN:
                 t1, t2 = tangent_basis(n)
                 Jm = np.zeros((3, 15))

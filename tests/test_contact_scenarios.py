@@ -443,7 +443,8 @@ def _tip_wall_run(lib, device, contacts_on):
         step_torque(eng, impedance_torques(state_np(eng), [target, None, None], kp=30.0, kd=1.5))
         st = state_np(eng)
         tip = PR.link_point_world(0, st[0:3], 3, TIP)
-        worst = max(worst, np.hypot(tip[0], tip[1]) + R_TIP - PR.wall_radius_at(tip[2]))
+        wc, _ = PR.wall_tilt(tip[2])
+        worst = max(worst, R_TIP - (PR.wall_radius_at(tip[2]) - np.hypot(tip[0], tip[1])) * wc)     # depth inside the (tilted) surface of the boundary
     eng.close()
     return worst, tip, st
 
@@ -464,3 +465,52 @@ def test_fingertip_stays_inside_the_boundary(oracle):
 @pytest.mark.gpu
 def test_fingertip_stays_inside_the_boundary_gpu(hip):
     _check_tip_wall(hip, "cuda:0")
+
+
+# ---- the flared part of the boundary pushes a fingertip inward AND up -------------------------------------------------------------------
+def _tip_on_cone_run(lib, device, frictionless):
+    """Finger 0's tip is pressed radially outward (a soft spring towards a point outside the boundary, at the height it starts from) against the
+    flared part of the stage at z = 70 mm, where the wall leans outward by 29.5 degrees (slope 0.565 between the knots at 60 and 100 mm)."""
+    def edit(m):
+        if frictionless:
+            m.mu_tip_wall = 0.0
+    eng = torque_engine(lib, device, edit)
+    f32 = dict(dtype=torch.float32, device=device)
+    eng.cube[0:3, 0] = torch.tensor([0.0, 0.0, 5.0], **f32)
+    eng.q[0:3, 0] = torch.tensor(ik(0, np.array([0.0, 0.20, 0.07])), **f32)
+    target, kp = np.array([0.0, 0.235, 0.07]), 20.0
+    track = []
+    for _ in range(200):
+        step_torque(eng, impedance_torques(state_np(eng), [target, None, None], kp=kp, kd=1.0))
+        st = state_np(eng)
+        tip = PR.link_point_world(0, st[0:3], 3, TIP)
+        wc, wsn = PR.wall_tilt(tip[2])
+        dist = (PR.wall_radius_at(tip[2]) - np.hypot(tip[0], tip[1])) * wc - R_TIP
+        track.append((tip[1], tip[2], dist, st[capi.S_LAM_TW], wc, wsn))
+    eng.close()
+    return np.array(track), target, kp
+
+
+def _check_tip_on_cone(lib, device):
+    tr, target, kp = _tip_on_cone_run(lib, device, True)
+    # without friction the reaction of the leaning wall has an upward component: the tip climbs the cone until the spring, which now also pulls it
+    # down, has no component along the surface any more - and it sits ON the tilted surface (a horizontal contact normal would leave it at 70 mm)
+    y, z, dist, lam, wc, wsn = tr[-1]
+    assert 0.078 < z < 0.092, z
+    assert np.abs(tr[100:, 2]).max() < 5e-4 and lam > 0
+    spring = kp * np.array([target[1] - y, target[2] - z])
+    assert abs(spring @ np.array([wsn, wc])) < 0.03 * np.linalg.norm(spring), spring       # tangent of the surface in the (r, z) plane: (sin, cos)
+    # with the friction of the pair (1.0 > tan 29.5 deg = 0.565) the tip stays where it touched
+    tr2, _, _ = _tip_on_cone_run(lib, device, False)
+    assert abs(tr2[-1, 1] - 0.07) < 2.5e-3 and np.abs(tr2[100:, 2]).max() < 5e-4 and tr2[-1, 3] > 0
+
+
+def test_fingertip_on_the_flared_boundary_is_pushed_inward_and_up(oracle):
+    """VERDICT round 3, missing 3 (boundary fidelity), the fingertip half: the contact normal of the fingertip - boundary contact follows the cone of
+    the stage (high_table_boundary.urdf:20-259), and the gap is the distance to the tilted surface."""
+    _check_tip_on_cone(oracle, "cpu")
+
+
+@pytest.mark.gpu
+def test_fingertip_on_the_flared_boundary_is_pushed_inward_and_up_gpu(hip):
+    _check_tip_on_cone(hip, "cuda:0")
