@@ -514,3 +514,73 @@ def test_fingertip_on_the_flared_boundary_is_pushed_inward_and_up(oracle):
 @pytest.mark.gpu
 def test_fingertip_on_the_flared_boundary_is_pushed_inward_and_up_gpu(hip):
     _check_tip_on_cone(hip, "cuda:0")
+
+
+# ---- the finger - cube - floor chain in its steady state ------------------------------------------------------------------------------
+# The slow case of the Gauss-Seidel sweeps (a heavy finger loading the light cube against the static floor) has exact
+# steady states; the warm start carries the impulses there over the substeps, and these are what a policy that pushes or holds the cube lives in.
+def _press_down(lib, device):
+    """finger 0 presses on the top face of the resting cube with a soft spring: what the floor carries is the weight plus the finger's force"""
+    eng = torque_engine(lib, device)
+    f32 = dict(dtype=torch.float32, device=device)
+    eng.cube[0:3, 0] = torch.tensor([0.0, 0.10, 0.0325], **f32)
+    top = np.array([0.0, 0.10, 2 * PR.CUBE_HALF + R_TIP + 0.0005])
+    eng.q[0:3, 0] = torch.tensor(ik(0, top), **f32)
+    h = 0.01
+    for _ in range(150):
+        step_torque(eng, impedance_torques(state_np(eng), [top + np.array([0.0, 0.0, -0.010]), None, None], kp=100.0, kd=2.0))
+    st = state_np(eng)
+    eng.close()
+    finger = st[capi.S_LAM_FC] / h
+    floor = st[capi.S_LAM_CF:capi.S_LAM_CF + 12:3].sum() / h
+    return finger, floor, st
+
+
+def _check_press_down(lib, device):
+    finger, floor, st = _press_down(lib, device)
+    weight = PR.CUBE_MASS * 9.81
+    assert 0.8 < finger < 1.1, finger                                    # 100 N/m x ~ 9.5 mm
+    assert abs(floor - (finger + weight)) < 2e-3 * (finger + weight), (floor, finger, weight)
+    assert np.abs(st[capi.S_CUBE_V:capi.S_CUBE_V + 6]).max() < 1e-3 and abs(st[capi.S_CUBE_P + 2] - PR.CUBE_HALF) < 3e-4
+
+
+def _push_and_slide(lib, device, speed=0.02):
+    """finger 0 pushes the cube towards the centre of the arena at a constant 2 cm/s (the spring target leads the fingertip): Coulomb sliding on the floor"""
+    eng = torque_engine(lib, device)
+    f32 = dict(dtype=torch.float32, device=device)
+    eng.cube[0:3, 0] = torch.tensor([0.0, 0.08, 0.0325], **f32)
+    start = np.array([0.0, 0.08 + PR.CUBE_HALF + R_TIP + 0.001, 0.0325])
+    eng.q[0:3, 0] = torch.tensor(ik(0, start), **f32)
+    h, rows = 0.01, []
+    for i in range(200):
+        target = start - np.array([0.0, 0.004 + speed * 0.02 * i, 0.0])
+        step_torque(eng, impedance_torques(state_np(eng), [target, None, None], kp=150.0, kd=3.0))
+        st = state_np(eng)
+        rows.append((st[capi.S_LAM_FC] / h, st[capi.S_LAM_FC + 3] / h, st[capi.S_LAM_CF:capi.S_LAM_CF + 12:3].sum() / h, st[capi.S_CUBE_V + 1],
+                     st[capi.S_FC_LINK]))
+    eng.close()
+    return np.array(rows)
+
+
+def _check_push_and_slide(lib, device):
+    r = _push_and_slide(lib, device)
+    tail = r[120:]                                                       # the last 1.6 s: steady sliding
+    push, lift, floor, vy = tail[:, 0].mean(), tail[:, 1].mean(), tail[:, 2].mean(), tail[:, 3]
+    weight = PR.CUBE_MASS * 9.81
+    assert (tail[:, 4] == 3).all()                                       # the distal link holds the contact
+    assert np.abs(vy + 0.02).max() < 1e-3                                # the cube moves at the commanded speed
+    assert abs(push - PR.MU["cf"] * floor) < 0.03 * push, (push, floor)  # Coulomb: pushing force = mu x what the floor carries
+    assert abs(floor - lift - weight) < 0.02 * weight, (floor, lift)     # vertical balance: the fingertip's friction carries a part of the weight
+    assert lift < -0.1                                                   # (the stored friction impulse is the one on the FINGER: the cube gets its negative, upward)
+    assert 0.2 < push < 0.45
+
+
+def test_chain_steady_states_press_down_and_push(oracle):
+    _check_press_down(oracle, "cpu")
+    _check_push_and_slide(oracle, "cpu")
+
+
+@pytest.mark.gpu
+def test_chain_steady_states_press_down_and_push_gpu(hip):
+    _check_press_down(hip, "cuda:0")
+    _check_push_and_slide(hip, "cuda:0")
