@@ -36,6 +36,9 @@ def test_shapes_specs_and_getters(backend):
     # scale tables (trifinger_env.py:663-710)
     assert env._observations_scale.low.shape[0] == 41 and env._states_scale.high.shape[0] == 113
     assert torch.equal(env._action_scale.high.cpu(), torch.full((9,), 0.36))
+    # buffer dtypes of the reference (env_base.py:560-572): float obs / states / reward, torch.long step counter
+    assert env._steps_count_buf.dtype == torch.long and env._steps_count_buf.shape == (4,)
+    assert env._obs_buf.dtype == torch.float32 and env._reward_buf.dtype == torch.float32
 
 
 def test_reset_and_step_contract(backend):
