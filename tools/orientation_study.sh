@@ -21,7 +21,7 @@ case $PART in
     run rot_delta_x4 7 $E gym.reward_terms.object_rot_delta.activate=True gym.reward_terms.object_rot_delta.weight=-1000
     run rot_delta_x4_no_rot 7 $E gym.reward_terms.object_rot_delta.activate=True gym.reward_terms.object_rot_delta.weight=-1000 gym.reward_terms.object_rot.activate=False ;;
   seeds) E=${3:-3200}
-    for S in 7 11 23 1 2 3; do run rot_delta_${E}_seed$S $S $E gym.reward_terms.object_rot_delta.activate=True; done ;;
+    for S in ${SEEDS:-7 11 23 1 2 3}; do run rot_delta_${E}_seed$S $S $E gym.reward_terms.object_rot_delta.activate=True; done ;;
   solver) E=${3:-3200}                       # does the solver residual matter for what is learned?  dense term on, 16 sweeps / temporal Gauss-Seidel against the shipped 8 sweeps
     run rot_delta_16_sweeps_seed11 11 $E gym.reward_terms.object_rot_delta.activate=True gym.sim.physx.num_position_iterations=16
     run rot_delta_16_sweeps_seed23 23 $E gym.reward_terms.object_rot_delta.activate=True gym.sim.physx.num_position_iterations=16
