@@ -23,7 +23,10 @@ overrides = sys.argv[6:]
 cfg = compose([f"gym=trifinger_difficulty_{difficulty}", f"args.num_envs={n}", "args.headless=True"] + overrides)
 if overrides:
     print("overrides:", " ".join(overrides), flush=True)
-env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False)
+_variant = os.environ.get("TF_LIB")                           # a developer build of the product library (A/B of a physics change through the learner)
+env = TrifingerEnv(config=cfg["gym"], device="cuda:0", verbose=False, **({"lib": capi.TfLib(os.path.abspath(_variant))} if _variant else {}))
+if _variant:
+    print("library:", _variant, flush=True)
 tr = PPOTrainer(RlGamesGpuEnvAdapter("rlgpu", n, env=VecTaskPython(env, rl_device="cuda:0")), env.get_obs_dim(), env.get_state_dim(),
                 env.get_action_dim(), PPOConfig.from_rlg(cfg["rlg"], num_envs=n, seed=seed, fused_kernels=fused), device="cuda:0")
 t0 = time.perf_counter()
