@@ -329,6 +329,15 @@ int tf_set_gravity(tf_handle h, const float g[3]);
 int tf_set_clipping(tf_handle h, float clip_obs, float clip_actions);
 int64_t tf_frame_count(tf_handle h);
 int tf_set_frame_count(tf_handle h, int64_t frames);
+/* The fused step exists in two instantiations with the SAME arithmetic (identical results, bit for bit): a 128-register one that puts four
+ * workgroups on a CU (populations that fill the chip) and a 256-register one without spills or LDS parking for populations that never put more
+ * than two workgroups on a CU (num_envs <= TF_WIDE_MAX_ENVS: shorter latency per step).  tf_create picks by num_envs (TF_KERNEL_AUTO); the parity
+ * tests and the benchmarks force one or the other.  The oracle accepts and ignores the call.  tf_kernel_variant returns what the launches use
+ * (TF_KERNEL_NARROW / TF_KERNEL_WIDE). */
+enum { TF_KERNEL_AUTO = 0, TF_KERNEL_NARROW = 1, TF_KERNEL_WIDE = 2 };
+#define TF_WIDE_MAX_ENVS 32768
+int tf_set_kernel_variant(tf_handle h, int32_t variant);
+int tf_kernel_variant(tf_handle h);
 
 /* The hot path: one control step for every env of the handle, fused, on `stream` (hipStream_t). */
 int tf_step(tf_handle h, const float* action /* [N][A] row-major, device */, void* stream);

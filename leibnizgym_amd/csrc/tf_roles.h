@@ -342,9 +342,11 @@ struct TipContact {            // fingertip sphere against one feature of the ar
     float arm[3];             // contact point relative to the tip-link origin (fingertip wrench sensor)
 };
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, int X>
+template <int A, bool IS_RESET, bool ASYM, int MODE, int X, bool WIDE>
 DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
     constexpr bool EXT = X != 0;      // X: 0 the headline kernels, 1 extended domain randomisation, 2 the same with the general box object
+    // WIDE: the 256-register instantiation (2 wavefronts per SIMD) launched for populations that never put more than two workgroups on a
+    // CU (num_envs <= 32768): nothing is parked in LDS or re-read from the state rows between substeps.  Same arithmetic, bit for bit.
     constexpr bool BOXK = X == 2;
     const TfModel& m = P.m;
     const int f = cx.role, lane = cx.lane;
@@ -383,6 +385,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     BAR();                                                      // #1: action tile in LDS, flag loads have returned
 #pragma unroll
     for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LD(L_DR0 + j) : TF_DR_NEUTRAL(j);
+    // L_DR0 aliases finger 1's record: in the fused modes barriers #2a / #2b stand between these reads and the first physics write; a launch
+    // without them (the split path's tf_simulate / tf_post_step) closes the hand-over with a barrier of its own
+    if (!(MODE & (M_ACT_IN | M_RESETS))) BAR();                 // #1b
     STAMP(1);
     // The warm-start rows are first needed when the contact rows are built, a free-motion phase later: issued here, behind the
     // barrier, they stay out of the load burst every workgroup of the launch starts with.
@@ -500,9 +505,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     // A launch that simulates AND emits the observations (the fused step) hands the fingertip wrench of the step from its last substep to
     // the post phase in registers: the TF_S_FT rows ("split path only") are neither written nor read by it.
     constexpr bool FT_IN_REGS = ((MODE & M_SIM) != 0) && ((MODE & M_POST) != 0);      // (in LDS, to be exact: the parking slots of the last substep)
+    float k_ft[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // WIDE: the fingertip wrench accumulator, carried in registers through the substeps into the post phase
     if (MODE & M_SIM) {
         const float h = P.hsub, inv_h = 1.0f / h;
         const int nsub = sa.nsim * P.substeps;
+        float k_lam_fc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, k_fc_link = 0.0f, k_lam_tf[3] = {0.0f, 0.0f, 0.0f}, k_lam_tw[3] = {0.0f, 0.0f, 0.0f};   // WIDE: carried in registers between substeps
         for (int s = 0; s < nsub; ++s) {
             const int sb_ = 4 + 12 * (s & 1);
             // Values that are cold through the sweeps (torque, last substep's impulses, wrench accumulator) do not occupy registers the
@@ -523,6 +530,18 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 if (ASYM) {
 #pragma unroll
                     for (int j = 0; j < 6; ++j) ft_run[j] = (MODE & M_TORQUE) ? 0.0f : LDST(TF_S_FT + 6 * f + j);
+                }
+            } else if (WIDE) {
+#pragma unroll
+                for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = dr[j];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { taus[j] = tau[j]; lam_tf[j] = k_lam_tf[j]; lam_tw[j] = k_lam_tw[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lam_fc[j] = k_lam_fc[j];
+                fc_link = k_fc_link;
+                if (ASYM) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) ft_run[j] = k_ft[j];
                 }
             } else {
 #pragma unroll
@@ -932,6 +951,12 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                     for (int d = 0; d < 3; ++d) STST(TF_S_LAM_TW + 3 * f + d, tc[1].lam[d]);
                 }
+            } else if (WIDE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k_lam_fc[j] = lam_fc[j];
+                k_fc_link = (float)cur_link;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { k_lam_tf[d] = tc[0].lam[d]; k_lam_tw[d] = tc[1].lam[d]; }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) LD(L_PARK(f) + PK_FC + j) = lam_fc[j];
@@ -964,10 +989,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
                 if (last_sub) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) { if (FT_IN_REGS) LD(L_PARK(f) + PK_FT + j) = ft[j]; else STST(TF_S_FT + 6 * f + j, ft[j]); }
+                    for (int j = 0; j < 6; ++j) { if (FT_IN_REGS) { if (WIDE) k_ft[j] = ft[j]; else LD(L_PARK(f) + PK_FT + j) = ft[j]; } else STST(TF_S_FT + 6 * f + j, ft[j]); }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) LD(L_PARK(f) + PK_FT + j) = ft[j];
+                    for (int j = 0; j < 6; ++j) { if (WIDE) k_ft[j] = ft[j]; else LD(L_PARK(f) + PK_FT + j) = ft[j]; }
                 }
             }
 #pragma unroll
@@ -995,7 +1020,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         for (int j = 0; j < 3; ++j) { tip_prev[j] = LDST(TF_S_TIP_P + 3 * f + j); tau_p[j] = LDST(TF_S_TAU + 3 * f + j); }
         if (ASYM) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ft[j] = FT_IN_REGS ? LD(L_PARK(f) + PK_FT + j) : LDST(TF_S_FT + 6 * f + j);   // (own slots, untouched until the tile is written behind P1)
+            for (int j = 0; j < 6; ++j) ft[j] = FT_IN_REGS ? (WIDE ? k_ft[j] : LD(L_PARK(f) + PK_FT + j)) : LDST(TF_S_FT + 6 * f + j);   // (own slots, untouched until the tile is written behind P1)
         }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {         // the last command, as _action_buf holds it (written above by this workgroup)
@@ -1231,7 +1256,7 @@ DEV void wall_arms(bool box, const float* lds, int lane, const float r[3], const
     }
 }
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, int X>
+template <int A, bool IS_RESET, bool ASYM, int MODE, int X, bool WIDE>
 DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
     constexpr bool EXT = X != 0;
     constexpr bool BOXK = X == 2;
@@ -1269,6 +1294,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         for (int j = 0; j < NDR; ++j) LD(L_DR0 + j) = dr[j];
     }
     BAR();                                                      // #1
+    if (!(MODE & (M_ACT_IN | M_RESETS))) BAR();                 // #1b: the finger roles have read L_DR0 (split path only; see the finger role)
     STAMP(1);
     if (MODE & (M_SIM | M_RESETS)) {                            // warm-start rows: behind the barrier, out of the launch's first load burst
         cf_face = LDST(TF_S_CF_FACE); cw_face = LDST(TF_S_CW_FACE);
@@ -1371,7 +1397,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             const int sb_ = 4 + 12 * (s & 1);
             float drs[TF_NUM_DR];                               // cold through the sweeps: re-read for every substep but the first
 #pragma unroll
-            for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (j >= NDR || s == 0 || !P.dr_enable) ? dr[j] : LDST(TF_S_DR + j);
+            for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (WIDE || j >= NDR || s == 0 || !P.dr_enable) ? dr[j] : LDST(TF_S_DR + j);
             const float* dr = drs;
             const float cube_mass = m.cube_mass * dr[0];
             const float cube_inertia = m.cube_inertia * dr[0] * dr[1] * dr[1];
@@ -1480,6 +1506,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             }
             bool wall_lane = false;
             bool slot_any[4] = {false, false, false, false};     // wave-uniform: a lane of this wavefront has a live corner in slot c
+            // WIDE (cube kernels): the rows of corner slots 0 and 1 stay in registers through the sweeps - normal, arms, 1/D, bias, impulses; LDS only
+            // keeps their impulses between substeps (slots 2 and 3, practically never live, go through LDS as in the 128-register build)
+            constexpr bool WREG = WIDE && !BOXK;
+            float w_r[6], w_n[4], w_D[6], w_bias[2], w_lam[6], w_a[6], w_b[6];
             {   // cube vs boundary wall: the four corners of the face that points outward most; rows go to LDS
                 const float cx_ = EXT ? cp[0] - soff[0] : cp[0], cy_ = EXT ? cp[1] - soff[1] : cp[1];      // relative to the stage centre
                 float rc2 = FMA(cx_, cx_, cy_ * cy_);
@@ -1562,9 +1592,17 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                             for (int d = 0; d < 3; ++d) lam[d] = ((c < 2) ? (((c ^ swap01) == 0) ? lam_old[d] : lam_old[3 + d]) : LD(wb + 9 + d)) * keep;
                         }
                     }
+                    if (WREG && c < 2) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { w_r[3 * c + j] = r[j]; w_D[3 * c + j] = Dinv[j]; w_lam[3 * c + j] = lam[j]; LD(wb + 9 + j) = lam[j]; }
+                        w_n[2 * c] = n[0]; w_n[2 * c + 1] = n[1]; w_bias[c] = bias;
+                        wall_arm_n(r, n, &w_a[3 * c]);
+                        wall_arm_t(r, n, &w_b[3 * c]);
+                    } else {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { LD(wb + j) = r[j]; LD(wb + 5 + j) = Dinv[j]; LD(wb + 9 + j) = lam[j]; }
                     LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
+                    }
                     wall_lane = wall_lane || (Dinv[0] > 0.0f);
                     slot_any[c] = __builtin_amdgcn_ballot_w64(Dinv[0] > 0.0f) != 0ull;
                 }
@@ -1641,6 +1679,20 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             STAMP(sb_ + 5);
             // ---- seeded impulses of the finger contacts (1/D, bias and impulses stay in registers through the sweeps) ----
             float cDinv[9], cbias[3], clam[9];
+            // WIDE: the contact-space records (A, directions, arms) are read ONCE per substep and stay in registers through the sweeps; only the
+            // contact-point velocity u, which the finger role republishes in every sweep, still comes through LDS (a dead slot's record is stale
+            // LDS content: loaded, never used - its rows sit behind the 1/D > 0 branch)
+            constexpr int NRR = WIDE ? 27 : 1, NRA = WIDE ? 18 : 1;
+            float rA[NRA], rDir[NRR], rRxd[NRR];
+            if (WIDE) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) rA[(6 * f + j) % NRA] = LD(L_REC(f) + R_A + j);
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) { rDir[(9 * f + j) % NRR] = LD(L_REC(f) + R_DIR + j); rRxd[(9 * f + j) % NRR] = LD(L_REC(f) + R_RXD + j); }
+                }
+            }
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
                 const int rb = L_REC(f);
@@ -1652,7 +1704,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     for (int d = 0; d < 3; ++d) {
                         float dir[3], rxd[3];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) { dir[j] = LD(rb + R_DIR + 3 * d + j); rxd[j] = LD(rb + R_RXD + 3 * d + j); }
+                        for (int j = 0; j < 3; ++j) { dir[j] = WIDE ? rDir[(9 * f + 3 * d + j) % NRR] : LD(rb + R_DIR + 3 * d + j); rxd[j] = WIDE ? rRxd[(9 * f + 3 * d + j) % NRR] : LD(rb + R_RXD + 3 * d + j); }
                         float sc = clam[3 * f + d] * inv_m, qq = clam[3 * f + d] * inv_I;
 #pragma unroll
                         for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
@@ -1684,6 +1736,13 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int wb = L_WALL + 12 * c;
+                if (WREG && c < 2) {
+                    if (slot_any[c] && w_D[3 * c] > 0.0f) {
+                        wn_apply(&w_n[2 * c], &w_a[3 * c], w_lam[3 * c], inv_m, inv_I, v, w);
+                        wt_apply(&w_n[2 * c], &w_b[3 * c], w_lam[3 * c + 1], inv_m, inv_I, v, w);
+                        cz_apply(&w_r[3 * c], w_lam[3 * c + 2], inv_m, inv_I, v, w);
+                    }
+                } else
                 if (slot_any[c] && LD(wb + 5) > 0.0f) {
                     float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
                     float a[3], b[3], c3[3];
@@ -1701,6 +1760,14 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int it = 0; it < P.iters; ++it) {
                 const uint32_t tf0_ = NOW();
                 const bool last = it == P.iters - 1;
+                float uu[9];                                    // WIDE: the nine contact-point velocities of the sweep, requested together
+                if (WIDE) {
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) uu[3 * f + j] = LD(L_REC(f) + R_U + j);
+                    }
+                }
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {                   // finger-cube rows in contact space
                     const int rb = L_REC(f);
@@ -1708,11 +1775,11 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     if (cDinv[3 * f] > 0.0f) {
                         float Am[6], u[3], dirs[9], rxds[9];
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) Am[j] = LD(rb + R_A + j);
+                        for (int j = 0; j < 6; ++j) Am[j] = WIDE ? rA[(6 * f + j) % NRA] : LD(rb + R_A + j);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) u[j] = LD(rb + R_U + j);
+                        for (int j = 0; j < 3; ++j) u[j] = WIDE ? uu[3 * f + j] : LD(rb + R_U + j);
 #pragma unroll
-                        for (int j = 0; j < 9; ++j) { dirs[j] = LD(rb + R_DIR + j); rxds[j] = LD(rb + R_RXD + j); }
+                        for (int j = 0; j < 9; ++j) { dirs[j] = WIDE ? rDir[(9 * f + j) % NRR] : LD(rb + R_DIR + j); rxds[j] = WIDE ? rRxd[(9 * f + j) % NRR] : LD(rb + R_RXD + j); }
 #pragma unroll
                         for (int d = 0; d < 3; ++d) {
                             const float* dir = &dirs[3 * d];
@@ -1780,7 +1847,18 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 for (int c = 0; c < 4; ++c) {                   // cube - wall: rows n (normal), t, +z
                     if (!slot_any[c]) continue;                 // wave-uniform
                     const int wb = L_WALL + 12 * c;
-                    {   // No per-lane branch around the rows: a lane whose corner in this slot is not live holds n = 0, 1/D = 0, bias = 0 and
+                    if (WREG && c < 2) {                        // the same rows on the register copies (dead lanes: n = 0, 1/D = 0, zero impulses, as below)
+                        float dl = solve_normal(w_lam[3 * c], w_D[3 * c], wn_vrel(&w_n[2 * c], &w_a[3 * c], v, w), w_bias[c]);
+                        wn_apply(&w_n[2 * c], &w_a[3 * c], dl, inv_m, inv_I, v, w);
+                        dl = solve_tangent(w_lam[3 * c + 1], w_D[3 * c + 1], wt_vrel(&w_n[2 * c], &w_b[3 * c], v, w), mu_cw * w_lam[3 * c]);
+                        wt_apply(&w_n[2 * c], &w_b[3 * c], dl, inv_m, inv_I, v, w);
+                        dl = solve_tangent(w_lam[3 * c + 2], w_D[3 * c + 2], cz_vrel(&w_r[3 * c], v, w), mu_cw * w_lam[3 * c]);
+                        cz_apply(&w_r[3 * c], dl, inv_m, inv_I, v, w);
+                        if (last && w_D[3 * c] > 0.0f) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = w_lam[3 * c + d];
+                        }
+                    } else {   // No per-lane branch around the rows: a lane whose corner in this slot is not live holds n = 0, 1/D = 0, bias = 0 and
                         // zero impulses there, so its rows come out as dl = +-0 and leave v, w as they are (they are never -0: they start at +0
                         // and only ever pass through additions) - one LDS round trip per block instead of two, no exec-mask juggling; only the
                         // impulses are stored per lane (a clamp to +-0 can yield -0, which must not reach the state row of a dead slot).

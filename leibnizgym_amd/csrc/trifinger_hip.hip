@@ -34,8 +34,11 @@
 #define SCR_STRIDE TF_SCR_STRIDE
 
 // One launch = one or more hooks of the reference step (MODE) for every env of the handle.
-template <int A, bool IS_RESET, bool ASYM, int MODE, int EXT>
-__global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
+// WIDE = false: 128 registers, 4 workgroups per CU (4 wavefronts per SIMD) - populations that fill the chip; WIDE = true: 256 registers, no spills,
+// nothing parked in LDS between substeps, the cube role's contact-space records in registers - populations of at most 32768 envs, which never put
+// more than two workgroups on a CU, so the occupancy the narrow build buys is not used (tf_create picks).  Same arithmetic.
+template <int A, bool IS_RESET, bool ASYM, int MODE, int EXT, bool WIDE>
+__global__ void __launch_bounds__(NT, WIDE ? 2 : 4) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
     __shared__ __attribute__((aligned(16))) float lds[((EXT == 2) ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
     const DevParams& P = *Pp;
     {   // Warm the scalar cache with the parameter block (one dword per 64-byte line) BEFORE the state loads of every workgroup of the
@@ -61,12 +64,12 @@ __global__ void __launch_bounds__(NT, 4) k_env(const DevParams* __restrict__ Pp,
     cx.i = cx.valid ? i_raw : (P.N - 1);
     cx.n_valid = (P.N - cx.wave_first < WAVE) ? (P.N - cx.wave_first) : WAVE;
 #if defined(TF_ONLY_FINGER)      // developer builds for per-role resource analysis (make resource-usage-roles)
-    finger_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
+    finger_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
 #elif defined(TF_ONLY_CUBE)
-    cube_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
+    cube_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
 #else
-    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
-    else finger_role<A, IS_RESET, ASYM, MODE, EXT>(P, sa, action, lds, cx);
+    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
+    else finger_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
 #endif
 }
 
@@ -146,6 +149,8 @@ struct TfHandle_ {
     int bound;
     int64_t frame_count;
     int action_dim;
+    int variant;             // TF_KERNEL_AUTO / NARROW / WIDE as asked for (tf_set_kernel_variant)
+    bool wide;               // what the launches use
     // optional kernel timing (bench.py): event pairs around the fused step kernel
     hipEvent_t* ev;          // [2 * ev_cap]
     int ev_cap, ev_used;
@@ -379,6 +384,8 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     h->ev_stride = 1;
     if (h->cfg.global_num_envs <= 0) h->cfg.global_num_envs = cfg->num_envs;
     h->action_dim = tf_action_dim(cfg->command_mode);
+    h->variant = TF_KERNEL_AUTO;
+    h->wide = cfg->num_envs <= TF_WIDE_MAX_ENVS;
     int od = 0, sd = 0;
     DevParams& P = h->dp;
     build_tables(&h->cfg, h->action_dim, P.tables, &od, &sd);
@@ -478,6 +485,13 @@ int tf_set_gravity(tf_handle h, const float g[3]) {
     HIP_TRY(push_params(h));
     return TF_OK;
 }
+int tf_set_kernel_variant(tf_handle h, int32_t variant) {
+    if (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE) return TF_ERR_INVALID_ARG;
+    h->variant = variant;
+    h->wide = (variant == TF_KERNEL_AUTO) ? (h->cfg.num_envs <= TF_WIDE_MAX_ENVS) : (variant == TF_KERNEL_WIDE);
+    return TF_OK;
+}
+int tf_kernel_variant(tf_handle h) { return h ? (h->wide ? TF_KERNEL_WIDE : TF_KERNEL_NARROW) : TF_ERR_INVALID_ARG; }
 int64_t tf_frame_count(tf_handle h) { return h ? h->frame_count : -1; }
 int tf_set_frame_count(tf_handle h, int64_t f) { if (!h) return TF_ERR_INVALID_ARG; h->frame_count = f; return TF_OK; }
 
@@ -525,17 +539,24 @@ static inline int n_waves(const TfHandle_* h) { return (h->cfg.num_envs + WAVE -
         if (e_ != hipSuccess) return hip_fail(e_, what);           \
     } while (0)
 
-template <int MODE, bool IS_RESET, int EXT>
-static void launch_env_obj(TfHandle_* h, const float* action, hipStream_t s) {
+template <int MODE, bool IS_RESET, int EXT, bool WIDE>
+static void launch_env_w(TfHandle_* h, const float* action, hipStream_t s) {
     dim3 grid(n_waves(h)), block(NT);
     const bool asym = h->cfg.asymmetric_obs != 0;
     if (h->action_dim == 9) {
-        if (asym) hipLaunchKernelGGL((k_env<9, IS_RESET, true, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<9, IS_RESET, false, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
+        if (asym) hipLaunchKernelGGL((k_env<9, IS_RESET, true, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
+        else hipLaunchKernelGGL((k_env<9, IS_RESET, false, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
     } else {
-        if (asym) hipLaunchKernelGGL((k_env<18, IS_RESET, true, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE, EXT>), grid, block, 0, s, h->d_params, h->sa, action);
+#if !defined(TF_DEV_MIN)
+        if (asym) hipLaunchKernelGGL((k_env<18, IS_RESET, true, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
+        else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
+#endif
     }
+}
+template <int MODE, bool IS_RESET, int EXT>
+static void launch_env_obj(TfHandle_* h, const float* action, hipStream_t s) {
+    if (h->wide) launch_env_w<MODE, IS_RESET, EXT, true>(h, action, s);
+    else launch_env_w<MODE, IS_RESET, EXT, false>(h, action, s);
 }
 // The extended domain randomisation (robot base / stage position, per-body friction) and the general box object (TfModel.box) live in
 // their own instantiations (EXT = 1, 2): the kernels of the headline path stay exactly what they were - a run-time flag for either cost
@@ -553,9 +574,14 @@ static int ext_kind(const TfConfig& c) {
 template <int MODE, bool IS_RESET>
 static void launch_env(TfHandle_* h, const float* action, hipStream_t s) {
     const int k = ext_kind(h->cfg);
+#if defined(TF_DEV_MIN)      // developer builds (tools/ab_bench.py): the headline kernels only
+    (void)k;
+    launch_env_obj<MODE, IS_RESET, 0>(h, action, s);
+#else
     if (k == 2) launch_env_obj<MODE, IS_RESET, 2>(h, action, s);
     else if (k == 1) launch_env_obj<MODE, IS_RESET, 1>(h, action, s);
     else launch_env_obj<MODE, IS_RESET, 0>(h, action, s);
+#endif
 }
 
 static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStream_t s, bool random_actions = false) {
@@ -638,14 +664,22 @@ int tf_kernel_time_ms(tf_handle h, double* total_ms, int64_t* launches) {
 // ---- split path: one hook of the reference step per launch (parity tests) ----
 int tf_apply_resets(tf_handle h, void* stream) {
     CHECK_HANDLE(h)
+#if defined(TF_DEV_MIN)
+    return TF_ERR_UNSUPPORTED;
+#else
     launch_env<M_RESETS, false>(h, nullptr, (hipStream_t)stream);
+#endif
     LAUNCH_CHECK("k_env<resets>");
     return TF_OK;
 }
 int tf_pre_step(tf_handle h, void* stream) {
     CHECK_HANDLE(h)
     h->sa.frame0 = (uint32_t)h->frame_count;
+#if defined(TF_DEV_MIN)
+    return TF_ERR_UNSUPPORTED;
+#else
     launch_env<M_TORQUE, false>(h, nullptr, (hipStream_t)stream);
+#endif
     LAUNCH_CHECK("k_env<torque>");
     return TF_OK;
 }
@@ -653,7 +687,11 @@ int tf_simulate(tf_handle h, void* stream) {
     CHECK_HANDLE(h)
     h->frame_count += 1;
     h->sa.nsim = 1;
+#if defined(TF_DEV_MIN)
+    return TF_ERR_UNSUPPORTED;
+#else
     launch_env<M_SIM, false>(h, nullptr, (hipStream_t)stream);
+#endif
     LAUNCH_CHECK("k_env<simulate>");
     return TF_OK;
 }
@@ -661,13 +699,21 @@ int tf_post_step(tf_handle h, void* stream) {
     CHECK_HANDLE(h)
     reward_coefs(h);
     h->sa.frame = (uint32_t)h->frame_count;
+#if defined(TF_DEV_MIN)
+    return TF_ERR_UNSUPPORTED;
+#else
     launch_env<M_POST, false>(h, nullptr, (hipStream_t)stream);
+#endif
     LAUNCH_CHECK("k_env<post>");
     return TF_OK;
 }
 int tf_finish_step(tf_handle h, void* stream) {
     CHECK_HANDLE(h)
+#if defined(TF_DEV_MIN)
+    return TF_ERR_UNSUPPORTED;
+#else
     launch_env<M_FINISH, false>(h, nullptr, (hipStream_t)stream);
+#endif
     LAUNCH_CHECK("k_env<finish>");
     return TF_OK;
 }

@@ -272,6 +272,20 @@ class TrifingerEngine:
     def frame_count(self, v):
         check(self.lib, self.lib.tf_set_frame_count(self._handle, int(v)), "tf_set_frame_count")
 
+    KERNEL_VARIANTS = {"auto": 0, "narrow": 1, "wide": 2}       # TF_KERNEL_* of include/trifinger.h
+
+    @property
+    def kernel_variant(self):
+        """which instantiation of the fused step the launches use: 'narrow' (128 registers, four workgroups per CU) or 'wide' (256
+        registers, picked for num_envs <= 32768); same results bit for bit"""
+        v = int(self.lib.tf_kernel_variant(self._handle))
+        check(self.lib, min(v, 0), "tf_kernel_variant")
+        return {1: "narrow", 2: "wide"}[v]
+
+    @kernel_variant.setter
+    def kernel_variant(self, name):
+        check(self.lib, self.lib.tf_set_kernel_variant(self._handle, self.KERNEL_VARIANTS[name]), "tf_set_kernel_variant")
+
     # -- checkpoint / exact replay (SURVEY.md section 5: the reference never checkpoints env state; optional here) -----------------
     _CHECKPOINT_BUFFERS = ("state", "action_buf", "obs", "states", "reward", "reset_buf", "goal_reset_buf", "successes", "dones",
                            "steps", "reset_count", "info")

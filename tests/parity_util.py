@@ -81,12 +81,29 @@ def actions_for(step, n, a, seed):
     return (torch.rand(n, a, generator=g) * 2 - 1).contiguous()
 
 
-def rollout(lib, device, n, steps, cfg_name, seed=3, episode_length=40, extra=None):
+VARIANTS = ("narrow", "wide")     # the two instantiations of the fused step (include/trifinger.h: tf_set_kernel_variant); at the sizes of
+                                  # these tests tf_create would always pick "wide", so the parity tests force each in turn
+
+_ORACLE_ROLLOUTS = {}
+
+
+def oracle_rollout(oracle, n, steps, cfg_name, **kw):
+    """the oracle's rollout, computed once per argument set (several product variants are compared with it)"""
+    key = (n, steps, cfg_name, repr(sorted(kw.items(), key=lambda kv: kv[0])))
+    if key not in _ORACLE_ROLLOUTS:
+        _ORACLE_ROLLOUTS[key] = rollout(oracle, "cpu", n, steps, cfg_name, **kw)
+    return _ORACLE_ROLLOUTS[key]
+
+
+def rollout(lib, device, n, steps, cfg_name, seed=3, episode_length=40, extra=None, variant=None):
     kw = dict(CONFIGS[cfg_name])
     kw.update(extra or {})
     clipping = kw.pop("_clipping", None)
     cfg = make_config(lib, n, seed=seed, episode_length=episode_length, **kw)
     eng = TrifingerEngine(cfg, device=device, lib=lib)
+    if variant is not None:
+        eng.kernel_variant = variant
+        assert eng.kernel_variant == variant
     if clipping:
         eng.set_clipping(*clipping)
     eng.reset()

@@ -10,17 +10,33 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("variant", pu.VARIANTS)
 @pytest.mark.parametrize("cfg_name", list(pu.CONFIGS))
-def test_rollout_bit_exact(hip, oracle, cfg_name):
+def test_rollout_bit_exact(hip, oracle, cfg_name, variant):
     n, steps = 1000, 130          # 1000 = 15 full waves + a ragged one; 130 steps > 3 episodes of 40
-    got = pu.rollout(hip, DEV, n, steps, cfg_name)
-    want = pu.rollout(oracle, "cpu", n, steps, cfg_name)
+    got = pu.rollout(hip, DEV, n, steps, cfg_name, variant=variant)
+    want = pu.oracle_rollout(oracle, n, steps, cfg_name)
     for t, (a, b) in enumerate(zip(got, want)):
-        pu.assert_bit_equal(a, b, f"{cfg_name} step {t}")
+        pu.assert_bit_equal(a, b, f"{cfg_name} [{variant}] step {t}")
 
 
-@pytest.mark.parametrize("cfg_name,fused_actions", [("d4_torque_asym", False), ("d4_domain_randomization", False), ("d4_torque_asym", True)])
-def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_name, fused_actions):
+def test_kernel_variant_follows_the_population(hip):
+    """tf_create picks the 256-register instantiation up to TF_WIDE_MAX_ENVS envs and the 128-register one above (what bench.py's headline size
+    runs); the override is what the tests above use."""
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    for n, want in ((64, "wide"), (32768, "wide"), (32769, "narrow"), (65536, "narrow")):
+        e = TrifingerEngine(make_config(hip, n, **{k: v for k, v in pu.CONFIGS["d4_torque_asym"].items()}), device=DEV, lib=hip)
+        assert e.kernel_variant == want, (n, e.kernel_variant)
+        e.kernel_variant = "narrow"
+        assert e.kernel_variant == "narrow"
+        e.kernel_variant = "auto"
+        assert e.kernel_variant == want
+        e.close()
+
+
+@pytest.mark.parametrize("cfg_name,fused_actions,variant", [("d4_torque_asym", False, "narrow"), ("d4_domain_randomization", False, "narrow"), ("d4_torque_asym", True, "narrow"),
+                                                            ("d4_torque_asym", False, "wide"), ("d4_domain_randomization", True, "wide")])
+def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_name, fused_actions, variant):
     """The 40-step episodes above never let a cube reach the boundary of the arena.  With 750-step episodes under random actions the
     rollout arrives at the steady state of the bench workload - a third of the envs with a live boundary contact - which is where the slot
     order of the boundary corners, the per-slot flags and the branch-free boundary block of the sweeps do their work: HIP and oracle side by
@@ -35,6 +51,7 @@ def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_na
         kw = dict(pu.CONFIGS[cfg_name])
         kw.pop("_clipping", None)
         engs.append(TrifingerEngine(make_config(lib, n, seed=21, episode_length=750, **kw), device=dev, lib=lib))
+    engs[0].kernel_variant = variant
     for e in engs:
         e.reset()
     live, compared = 0.0, 0
@@ -62,10 +79,11 @@ def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_na
 def test_solver_and_stepping_settings(hip, oracle, extra):
     """Loop bounds and stepping parameters other than the Hydra defaults (the env's own default dict asks for 4 position
     iterations; the reference's tests use control_decimation 5): still bit for bit."""
-    got = pu.rollout(hip, DEV, 300, 50, "envdefault_position", extra=extra)
-    want = pu.rollout(oracle, "cpu", 300, 50, "envdefault_position", extra=extra)
-    for t, (a, b) in enumerate(zip(got, want)):
-        pu.assert_bit_equal(a, b, f"{extra} step {t}")
+    want = pu.oracle_rollout(oracle, 300, 50, "envdefault_position", extra=extra)
+    for variant in pu.VARIANTS:
+        got = pu.rollout(hip, DEV, 300, 50, "envdefault_position", extra=extra, variant=variant)
+        for t, (a, b) in enumerate(zip(got, want)):
+            pu.assert_bit_equal(a, b, f"{extra} [{variant}] step {t}")
 
 
 @pytest.mark.parametrize("difficulty", [-1, 2, 5, 6])
@@ -103,14 +121,16 @@ def test_gravity_setter_takes_effect(hip, oracle):
 
 @pytest.mark.parametrize("n", [1, 4, 63, 64, 65])
 def test_ragged_sizes(hip, oracle, n):
-    got = pu.rollout(hip, DEV, n, 45, "d4_torque_asym")
-    want = pu.rollout(oracle, "cpu", n, 45, "d4_torque_asym")
-    for t, (a, b) in enumerate(zip(got, want)):
-        pu.assert_bit_equal(a, b, f"N={n} step {t}")
+    want = pu.oracle_rollout(oracle, n, 45, "d4_torque_asym")
+    for variant in pu.VARIANTS:
+        got = pu.rollout(hip, DEV, n, 45, "d4_torque_asym", variant=variant)
+        for t, (a, b) in enumerate(zip(got, want)):
+            pu.assert_bit_equal(a, b, f"N={n} [{variant}] step {t}")
 
 
+@pytest.mark.parametrize("variant", pu.VARIANTS)
 @pytest.mark.parametrize("cfg_name", ["envdefault_position", "d4_domain_randomization"])
-def test_split_path_equals_fused(hip, cfg_name):
+def test_split_path_equals_fused(hip, cfg_name, variant):
     """tf_apply_resets/pre_step/simulate/post_step/finish_step == tf_step on the GPU (also with every
     domain-randomisation feature on: the frame-keyed draws must agree between the two paths)."""
     from leibnizgym_amd.engine import TrifingerEngine, make_config
@@ -119,6 +139,7 @@ def test_split_path_equals_fused(hip, cfg_name):
     engs = [TrifingerEngine(make_config(hip, n, seed=5, episode_length=30, **kw), device=DEV, lib=hip)
             for _ in range(2)]
     for e in engs:
+        e.kernel_variant = variant
         e.reset()
     for t in range(70):
         act = pu.actions_for(t, n, 9, 5).to(DEV)

@@ -1,0 +1,37 @@
+"""Developer tool (GPU box): fused-step time (HIP events) of the headline workload for the two instantiations of the step kernel
+(tf_set_kernel_variant) over a range of population sizes, with a state checksum (identical between the variants: same arithmetic).
+    python tools/variant_sweep.py [lib.so] [N ...]"""
+import sys, os
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+import bench
+from leibnizgym_amd.engine import TrifingerEngine, make_config
+from leibnizgym_amd import _capi
+
+args = sys.argv[1:]
+lib = _capi.load_hip_library()
+if args and args[0].endswith(".so"):
+    lib = _capi.TfLib(os.path.abspath(args.pop(0)))
+sizes = [int(a) for a in args] or [8192, 16384, 32768, 65536]
+SETTLE = int(os.environ.get("SETTLE", "400"))
+for asym in (True, False):
+    for n in sizes:
+        for variant in ("narrow", "wide"):
+            eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym)), device="cuda:0", lib=lib)
+            eng.kernel_variant = variant
+            eng.reset()
+            eng.steps.copy_(torch.randint(0, 750, (n,), device="cuda:0"))      # spread the time-outs, as bench.py does
+            for k in range(SETTLE):
+                eng.step_random()
+            best = 1e9
+            for rep in range(3):
+                eng.enable_kernel_timing(64, window=8)
+                for k in range(512):
+                    eng.step_random()
+                torch.cuda.synchronize()
+                ms, cnt = eng.kernel_time_ms()
+                best = min(best, ms / cnt * 1e3)
+            chk = float(eng.state.double().abs().sum())
+            print(f"N={n:6d} asym={int(asym)} {variant:6s}: k_env {best:7.2f} us   {n / best:8.1f} env-steps/us   state checksum {chk:.9e}", flush=True)
+            eng.close()
