@@ -4,9 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`:
-one process per GPU, envs sharded with no data-path collective (weak scaling: every rank steps
-`--envs` environments; RNG is keyed by global env id).  RCCL is used only for the timing barrier and the
-max-over-ranks reduction of the elapsed time.
+one process per GPU, envs sharded with no data-path collective; RNG is keyed by global env id.  RCCL is used only for the
+timing barrier and the max-over-ranks reduction of the elapsed time.  `value` is the WEAK-scaling figure (every rank steps
+`--envs` environments: 65536 per GPU); beside it the same line carries the STRONG-scaling reading of the metric
+("@65536 envs, 1/2/4/8 GPUs"): `value_strong_65536_total` = a second timed leg in which the 65536 envs of the headline are
+partitioned over the ranks (shard_range: 65536 / N each, the step kernel's 256-register instantiation below 32768 per GPU).
 
 A "step" is one control step (tf_step: masked resets, torque law, decimation x substeps of physics,
 obs/states/rewards/termination) over the rank's whole batch, with synthetic random actions
@@ -49,13 +51,13 @@ BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symm
 FLOPS_PER_ENV_STEP = 19.7e3
 
 
-def load_pmc_profile(n, asym, ext=False):
+def load_pmc_profile(n, asym, ext=False, wide=False):
     """Per-launch counters of the fused step kernel from the newest profiles/r*_pmc.txt whose header names this workload
     (written by tools/profile_round.sh; rocprofv3 --pmc passes, raw counter expressions).  Returns (dict, path) or
     (None, None): nothing is hard-coded here, a profile of another N / kernel is not used."""
     import glob
     import re
-    kname = kernel_name(asym, 9, ext)
+    kname = kernel_name(asym, 9, ext, True, wide)
     want = f"# workload: N={n} asym={asym} kernel={kname}"
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.txt")), reverse=True):
         text = open(path).read()
@@ -125,10 +127,11 @@ FULL_DR = {"activate": True, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "
            "friction_robot": (0.8, 1.2), "friction_object": (0.8, 1.2), "friction_stage": (0.8, 1.2)}
 
 
-def kernel_name(asym, action_dim=9, ext=False, fused_actions=True):
+def kernel_name(asym, action_dim=9, ext=False, fused_actions=True, wide=False):
     """rocprofv3's name of the fused-step instantiation a workload launches (EXT: extended DR or the box object; MODE 127 = the step
-    with the action source fused in - tf_step_random, what `value` times -, 63 = the step that reads a resident action tensor)."""
-    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, {127 if fused_actions else 63}, {int(ext)}>"
+    with the action source fused in - tf_step_random, what `value` times -, 63 = the step that reads a resident action tensor; the last
+    argument: the 256-register instantiation tf_create picks up to 32768 envs per handle)."""
+    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, {127 if fused_actions else 63}, {int(ext)}, {'true' if wide else 'false'}>"
 
 
 def workload_kwargs(asym, difficulty=4, dr=False):
@@ -238,6 +241,8 @@ def main():
                          "taken.  Default: one episode length (750), so that every env has gone through a time-out reset.  0: none - the timed "
                          "region then starts --warmup steps after a reset of ALL envs (a correlated transient: "
                          "profiles/r4_a_driver_repro.txt)")
+    ap.add_argument("--strong-total", type=int, default=-1,
+                    help="global env count of the strong-scaling leg (partitioned over the ranks); default: --envs (65536), 0: no such leg")
     ap.add_argument("--time-window", type=int, default=8,
                     help="one HIP event pair per window of W consecutive k_step launches of the timed region (an event "
                          "pair costs ~3 us of stream time: per launch it would slow the region it measures and read "
@@ -355,13 +360,53 @@ def main():
     # sanity on what was just timed: finite state, resets happened if steps crossed an episode boundary
     assert torch.isfinite(eng.state).all(), "non-finite state after the timed region"
 
+    # ---- the STRONG-scaling reading of the metric ("@65536 envs, 1/2/4/8 GPUs"; SURVEY 8e partitions N over G): the same workload with
+    # --strong-total envs IN TOTAL, rank r stepping shard_range(total, r, world) of them (global env ids and the reward schedule as in one
+    # 65536-env engine: the union of the shards is bit-identical to it, tests/test_multi_rank.py).  Same prelude, same warm-up, same number
+    # of timed steps, same barriers and max over ranks.  At one rank it is the weak leg itself and is not run twice.
+    strong_total = args.strong_total if args.strong_total >= 0 else n
+    strong = None
+    if strong_total > 0 and (world > 1 or strong_total != n):
+        from leibnizgym_amd.sharding import shard_range
+        off, cnt = shard_range(strong_total, rank, world)
+        cfg_s = make_config(lib, cnt, seed=7, env_id_offset=off, global_num_envs=strong_total,
+                            model=lib.box_model((0.02, 0.08, 0.02), 500.0) if args.box else None,
+                            **workload_kwargs(asym, args.difficulty, args.dr))
+        eng_s = TrifingerEngine(cfg_s, device=dev, lib=lib)
+        eng_s.reset()
+        if settle > 0 and ep_len > 0:
+            eng_s.steps.copy_(torch.randint(0, ep_len, (cnt,), device=dev, generator=gen, dtype=torch.int64))
+            for k in range(settle):
+                eng_s.step_random()
+        for k in range(args.warmup):
+            eng_s.step_random()
+        eng_s.enable_kernel_timing(8192 if args.time_window > 0 else 0, max(1, args.time_window))
+        barrier()
+        t3 = time.perf_counter()
+        for k in range(args.steps):
+            eng_s.step_random()
+        barrier()
+        elapsed_s = time.perf_counter() - t3
+        ks_ms, ks_n = eng_s.kernel_time_ms()
+        assert torch.isfinite(eng_s.state).all(), "non-finite state after the strong-scaling leg"
+        if distributed:
+            t = torch.tensor([elapsed_s], device=dev if not one_device else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_s = float(t[0].item())
+        strong = {"global_envs": strong_total, "envs_per_gpu": cnt, "ms_per_step": elapsed_s / args.steps * 1e3,
+                  "value": strong_total * args.steps / elapsed_s, "kernel_variant": eng_s.kernel_variant,
+                  "kernel": kernel_name(asym, eng_s.action_dim, 2 if args.box else (1 if args.dr else 0), True, eng_s.kernel_variant == "wide"),
+                  "kernel_avg_us_rank0": (ks_ms / max(ks_n, 1)) * 1e3}
+        eng_s.close()
+
     total_env_steps = world * n * args.steps
     value = total_env_steps / elapsed
     kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
     bytes_per_launch = BYTES_PER_ENV_STEP[asym] * n
     achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
     ext = 2 if args.box else (1 if args.dr else 0)     # extended DR -> EXT = 1, box object -> EXT = 2 instantiation of the fused step
-    pmc, pmc_path = load_pmc_profile(n, asym, ext) if (headline or ext) else (None, None)      # counters of the kernel `value` launches
+    wide = eng.kernel_variant == "wide"
+    pmc, pmc_path = load_pmc_profile(n, asym, ext, wide) if (headline or ext) else (None, None)      # counters of the kernel `value` launches
     traffic = traffic_raw = issue = None
     traffic_how = None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -404,6 +449,10 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
+        # the strong-scaling reading of the metric: 65536 envs IN TOTAL partitioned over the ranks (at one rank: the weak figure itself)
+        "value_strong_65536_total": (strong["value"] if strong else (value if strong_total == n else None)) if strong_total == 65536 else None,
+        "strong_scaling": strong if strong else ({"global_envs": n, "envs_per_gpu": n, "ms_per_step": elapsed / args.steps * 1e3, "value": value,
+                                                  "same_as": "value (one rank: the weak and the strong partition coincide)"} if strong_total == n else None),
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -425,6 +474,8 @@ def main():
                         f"control_decimation 1 (BASELINE.json configs[{2 if headline else (3 if args.dr else 1)}]{'' if not args.box else ' with the object swapped'})",
             "envs_per_gpu": n,
             "global_envs": world * n,
+            "strong_scaling_workload": (f"the same workload with {strong_total} envs in total, {strong_total // world} per GPU x {world} GPU "
+                                        f"(`value_strong_65536_total` / `strong_scaling`)") if strong_total > 0 else None,
             "asymmetric_obs": asym,
             "parallelism": f"env-shard x{world} (no data-path collective"
                            + (f"; episode statistics all-reduced every {args.stats_every} steps on a side stream)" if reducer else ")"),
@@ -440,7 +491,8 @@ def main():
             "traffic": traffic,
             "traffic_raw": traffic_raw,
             "traffic_source": traffic_how,
-            "kernel": kernel_name(asym, eng.action_dim, ext),
+            "kernel": kernel_name(asym, eng.action_dim, ext, True, wide),
+            "kernel_variant": eng.kernel_variant,
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,
             "kernel_timing": f"one HIP event pair on the launch stream around every window of {max(1, args.time_window)} "

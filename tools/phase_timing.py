@@ -8,7 +8,7 @@ import bench
 from leibnizgym_amd.engine import TrifingerEngine, make_config
 from leibnizgym_amd import _capi
 
-lib = _capi.TfLib(os.path.join(REPO, "leibnizgym_amd", "csrc", "libtrifinger_hip_timing.so"))
+lib = _capi.TfLib(os.environ.get("TF_LIB") or os.path.join(REPO, "leibnizgym_amd", "csrc", "libtrifinger_hip_timing.so"))     # TF_LIB: another -DTF_PHASE_TIMING build
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 asym = True
 dr = len(sys.argv) > 3 and sys.argv[3] == "dr"          # phase_timing.py N WARMUP dr: every domain-randomisation feature (the EXT kernel)
@@ -16,6 +16,8 @@ eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym, 
 g = torch.Generator(device="cuda:0").manual_seed(1)
 ring = [(torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1) for _ in range(8)]
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 10      # steps after the reset before sampling starts (600: the cubes have reached the boundary)
+if os.environ.get("VARIANT"):                             # narrow / wide: force one instantiation of the step kernel (default: what tf_create picks for N)
+    eng.kernel_variant = os.environ["VARIANT"]
 eng.reset()
 acc = []
 for k in range(warm + 30):
@@ -31,6 +33,7 @@ def d(a, b, role):                # median over steps and workgroups of stamp[b]
 def v(a, role):
     sel = S[:, :, role, :] if role == 3 else S[:, :, 0:3, :].reshape(S.shape[0], -1, 64)
     return np.median(sel[..., a])
+print(f"kernel variant: {eng.kernel_variant}")
 print(f"N={n} asym={asym}{' + every DR feature (EXT kernel)' if dr else ''}, sampled {warm}..{warm + 29} steps after the reset: median s_memtime ticks; finger role | cube role")
 rows = [("loads + action tile (to #1)", 0, 1), ("resets, action_buf, torque", 1, 2)]
 for s in (0, 1):

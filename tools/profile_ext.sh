@@ -6,8 +6,8 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}; O=gpurun_out
 mkdir -p $O
 for W in dr box; do
-  K="k_env<9, false, true, 127, $([ $W = box ] && echo 2 || echo 1)>"
   for N in 16384 65536; do
+    K="k_env<9, false, true, 127, $([ $W = box ] && echo 2 || echo 1), $([ $N -le 32768 ] && echo true || echo false)>"      # <= 32768 envs: the 256-register instantiation
     B="python3 bench.py --$W --envs $N --no-cpu-baseline"
     P=$O/${T}_ext_${W}_${N}
     rocprofv3 --kernel-trace --stats -d $O/prof_$T/trace -o r -- $B --steps 300 --warmup 5 > /dev/null 2>&1

@@ -21,7 +21,7 @@ for asym in (True, False):
             eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym)), device="cuda:0", lib=lib)
             eng.kernel_variant = variant
             eng.reset()
-            eng.steps.copy_(torch.randint(0, 750, (n,), device="cuda:0"))      # spread the time-outs, as bench.py does
+            eng.steps.copy_(torch.randint(0, 750, (n,), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(11)))      # spread the time-outs, as bench.py does
             for k in range(SETTLE):
                 eng.step_random()
             best = 1e9
