@@ -273,3 +273,64 @@ DEV void wt_apply(const float n[2], const float b[3], float dl, float inv_m, flo
     v[1] = FMA(n[0], s, v[1]);
     w[0] = FMA(b[0], q, w[0]); w[1] = FMA(b[1], q, w[1]); w[2] = FMA(b[2], q, w[2]);
 }
+
+// ---- the same rows on a PACKED twist: p[j] = (v_j, w_j) as a register pair, so that the general rows of the cube role's 256-register instantiation
+// run as v_pk_mul_f32 / v_pk_fma_f32 (a lone wavefront issues a packed fp32 instruction in the same ~5 cycles as a scalar one: tools/microbench/
+// valu_pk.hip - with one wavefront per SIMD the step is bound by issue slots, not by the vector ALU).  Every lane-operation is the one the scalar
+// form performs, in the same order: bit-identical results.
+typedef float float2v __attribute__((ext_vector_type(2)));
+struct Twist { float2v p[3]; };
+DEV float2v pk_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+DEV float2v pk_splat(float x) { float2v r = {x, x}; return r; }
+// dot3(dir, v) + dot3(rxd, w) with rec[j] = (dir_j, rxd_j)
+DEV float pk_row_vel(const float2v rec[3], const Twist& t) {
+    float2v p = rec[0] * t.p[0];
+    p = pk_fma(rec[1], t.p[1], p);
+    p = pk_fma(rec[2], t.p[2], p);
+    return p.x + p.y;
+}
+// v -= dir dl / m, w -= rxd dl / I with mI = (1/m, 1/I)
+DEV void pk_row_apply_neg(const float2v rec[3], float dl, float2v mI, Twist& t) {
+    const float2v s = pk_splat(dl) * mI;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t.p[j] = pk_fma(-rec[j], s, t.p[j]);
+}
+DEV float cz_vrel(const float r[3], const Twist& t) { return FMA(r[1], t.p[0].y, FMA(-r[0], t.p[1].y, t.p[2].x)); }
+DEV void cz_apply(const float r[3], float dl, float2v mI, Twist& t) {
+    const float2v s = pk_splat(dl) * mI;
+    t.p[2].x = t.p[2].x + s.x;
+    t.p[0].y = FMA(r[1], s.y, t.p[0].y);
+    t.p[1].y = FMA(-r[0], s.y, t.p[1].y);
+}
+DEV float cx_vrel(const float r[3], const Twist& t) { return FMA(r[2], t.p[1].y, FMA(-r[1], t.p[2].y, t.p[0].x)); }
+DEV void cx_apply(const float r[3], float dl, float2v mI, Twist& t) {
+    const float2v s = pk_splat(dl) * mI;
+    t.p[0].x = t.p[0].x + s.x;
+    t.p[1].y = FMA(r[2], s.y, t.p[1].y);
+    t.p[2].y = FMA(-r[1], s.y, t.p[2].y);
+}
+DEV float cy_vrel(const float r[3], const Twist& t) { return FMA(-r[2], t.p[0].y, FMA(r[0], t.p[2].y, t.p[1].x)); }
+DEV void cy_apply(const float r[3], float dl, float2v mI, Twist& t) {
+    const float2v s = pk_splat(dl) * mI;
+    t.p[1].x = t.p[1].x + s.x;
+    t.p[0].y = FMA(-r[2], s.y, t.p[0].y);
+    t.p[2].y = FMA(r[0], s.y, t.p[2].y);
+}
+DEV float wn_vrel(const float n[2], const float a[3], const Twist& t) {
+    return FMA(a[2], t.p[2].y, FMA(a[1], t.p[1].y, FMA(a[0], t.p[0].y, FMA(n[1], t.p[1].x, n[0] * t.p[0].x))));
+}
+DEV void wn_apply(const float n[2], const float a[3], float dl, float2v mI, Twist& t) {
+    const float2v s = pk_splat(dl) * mI;
+    t.p[0].x = FMA(n[0], s.x, t.p[0].x);
+    t.p[1].x = FMA(n[1], s.x, t.p[1].x);
+    t.p[0].y = FMA(a[0], s.y, t.p[0].y); t.p[1].y = FMA(a[1], s.y, t.p[1].y); t.p[2].y = FMA(a[2], s.y, t.p[2].y);
+}
+DEV float wt_vrel(const float n[2], const float b[3], const Twist& t) {
+    return FMA(b[2], t.p[2].y, FMA(b[1], t.p[1].y, FMA(b[0], t.p[0].y, FMA(n[0], t.p[1].x, -(n[1] * t.p[0].x)))));
+}
+DEV void wt_apply(const float n[2], const float b[3], float dl, float2v mI, Twist& t) {
+    const float2v s = pk_splat(dl) * mI;
+    t.p[0].x = FMA(-n[1], s.x, t.p[0].x);
+    t.p[1].x = FMA(n[0], s.x, t.p[1].x);
+    t.p[0].y = FMA(b[0], s.y, t.p[0].y); t.p[1].y = FMA(b[1], s.y, t.p[1].y); t.p[2].y = FMA(b[2], s.y, t.p[2].y);
+}

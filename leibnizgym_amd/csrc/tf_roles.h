@@ -29,7 +29,8 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 // ---- LDS map: float slots of 64 lanes each, lds[slot * 64 + lane] --------------------------------------------------
 // physics phase
 #define L_REC(f) (30 * (f))             // contact-space record of finger f
-#define R_A 0                           //   6  A = J M^-1 J^T (00 01 02 11 12 22)
+#define R_A 0                           //   6  slots 0..2: K01 K02 K12, the off-diagonal part of the block-local Delassus matrix K = A + D D^T / m + R R^T / I
+                                        //      (A = J M^-1 J^T); after the last sweep the six slots carry the friction impulse and the force to the finger role
 #define R_DIR 6                         //   9  world directions n, t1, t2
 #define R_RXD 15                        //   9  cube arms r x d
 #define R_U 24                          //   3  contact-point velocity of the finger side
@@ -512,6 +513,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         float k_lam_fc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, k_fc_link = 0.0f, k_lam_tf[3] = {0.0f, 0.0f, 0.0f}, k_lam_tw[3] = {0.0f, 0.0f, 0.0f};   // WIDE: carried in registers between substeps
         for (int s = 0; s < nsub; ++s) {
             const int sb_ = 4 + 12 * (s & 1);
+            (void)sb_;
             // Values that are cold through the sweeps (torque, last substep's impulses, wrench accumulator) do not occupy registers the
             // sweeps need: between two substeps of a launch they are parked in the first slots of this finger's own record in LDS
             // (L_PARK: dead from the last sweep of a substep until the finger publishes its free motion in the next one; nobody else
@@ -759,9 +761,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     for (int j = 0; j < 9; ++j) { fcJ[j] = J[j]; LD(rb + R_DIR + j) = dir[j]; LD(rb + R_RXD + j) = rxd[j]; }
 #pragma unroll
                     for (int d = 0; d < 3; ++d) LD(L_VQFF + 3 * f + d) = f_rcp2(FMA(dot3(&rxd[3 * d], &rxd[3 * d]), inv_I, Dd[d] + inv_m));
-                    LD(rb + R_A + 0) = Dd[0]; LD(rb + R_A + 1) = dot3(&J[0], &W[3]); LD(rb + R_A + 2) = dot3(&J[0], &W[6]);
-                    LD(rb + R_A + 3) = Dd[1]; LD(rb + R_A + 4) = dot3(&J[3], &W[6]);
-                    LD(rb + R_A + 5) = Dd[2];
+                    LD(rb + R_A + 0) = FMA(dot3(&rxd[0], &rxd[3]), inv_I, dot3(&J[0], &W[3]));
+                    LD(rb + R_A + 1) = FMA(dot3(&rxd[0], &rxd[6]), inv_I, dot3(&J[0], &W[6]));
+                    LD(rb + R_A + 2) = FMA(dot3(&rxd[3], &rxd[6]), inv_I, dot3(&J[3], &W[6]));
                     if (link == 3) {
 #pragma unroll
                         for (int j = 0; j < 3; ++j) fc_arm[j] = Pw[j] - Tw[j];
@@ -883,11 +885,6 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 float dl[3];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) dl[d] = LD(rb + R_DL + d);
-                if (it == P.iters - 1) {                        // impulses of the finger-cube contact after the last sweep
-                    lam_fc[0] = LD(L_INIT + f);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { lam_fc[1 + j] = LD(rb + R_A + j); Fc[j] = LD(rb + R_A + 3 + j); }
-                }
                 if (cur_link != 0) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
@@ -934,6 +931,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
                 { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W2: contact-point velocities published
             }
+            // impulses of the finger-cube contact after the last sweep (the cube role left them behind barrier W2 of that sweep; nobody touches
+            // these slots again before this finger's own next publication)
+            lam_fc[0] = LD(L_INIT + f);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { lam_fc[1 + j] = LD(rb + R_A + j); Fc[j] = LD(rb + R_A + 3 + j); }
             STAMP(sb_ + 6);
             STAMPV(sb_ + 8, t_wait);
             // ---- impulses kept for the next substep (state rows), fingertip wrench sensor, integration ----
@@ -1395,6 +1397,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         }
         for (int s = 0; s < nsub; ++s) {
             const int sb_ = 4 + 12 * (s & 1);
+            (void)sb_;
             float drs[TF_NUM_DR];                               // cold through the sweeps: re-read for every substep but the first
 #pragma unroll
             for (int j = 0; j < TF_NUM_DR; ++j) drs[j] = (WIDE || j >= NDR || s == 0 || !P.dr_enable) ? dr[j] : LDST(TF_S_DR + j);
@@ -1677,18 +1680,189 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             STAMP(sb_ + 4);
             BAR();                                              // S3: records published by the finger roles
             STAMP(sb_ + 5);
+            if constexpr (WIDE && !BOXK) {
+            // ---- the 256-register instantiation of the cube kernels: contact-space records as (direction, arm) register pairs read once per
+            // substep, the twist as three (v_j, w_j) pairs, the general rows as packed fp32 (tf_contact.h: the same lane-operations in the
+            // same order as the form below); with one wavefront per SIMD the sweep is bound by issue slots, and this is half of them ----
+            Twist tw;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { tw.p[j].x = v[j]; tw.p[j].y = w[j]; }
+            float2v mI; mI.x = inv_m; mI.y = inv_I;
+            float cDinv[9], cbias[3], clam[9], Km[9];
+            float2v rec[27];                                    // rec[9 f + 3 d + j] = (dir_d[j], (r x dir_d)[j]) of finger f (a dead slot's record is stale LDS content:
+#pragma unroll                                                  //  loaded, never used - its rows sit behind the 1/D > 0 branch)
+            for (int f = 0; f < 3; ++f) {
+                const int rb = L_REC(f);
+                cbias[f] = LD(L_INIT + f);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { cDinv[3 * f + d] = LD(L_VQFF + 3 * f + d); clam[3 * f + d] = LD(rb + R_DL + d); Km[3 * f + d] = LD(rb + R_A + d); }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { rec[9 * f + j].x = LD(rb + R_DIR + j); rec[9 * f + j].y = LD(rb + R_RXD + j); }
+                if (cDinv[3 * f] > 0.0f) {                       // seeded impulses of a live contact
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) pk_row_apply_neg(&rec[9 * f + 3 * d], clam[3 * f + d], mI, tw);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (fDinv[3 * c] > 0.0f) {
+                    cz_apply(&fr_[3 * c], flam[3 * c], mI, tw);
+                    cx_apply(&fr_[3 * c], flam[3 * c + 1], mI, tw);
+                    cy_apply(&fr_[3 * c], flam[3 * c + 2], mI, tw);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int wb = L_WALL + 12 * c;
+                if (c < 2) {
+                    if (slot_any[c] && w_D[3 * c] > 0.0f) {
+                        wn_apply(&w_n[2 * c], &w_a[3 * c], w_lam[3 * c], mI, tw);
+                        wt_apply(&w_n[2 * c], &w_b[3 * c], w_lam[3 * c + 1], mI, tw);
+                        cz_apply(&w_r[3 * c], w_lam[3 * c + 2], mI, tw);
+                    }
+                } else if (slot_any[c] && LD(wb + 5) > 0.0f) {
+                    float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
+                    float a[3], b[3];
+                    wall_arm_n(r, n, a);
+                    wall_arm_t(r, n, b);
+                    wn_apply(n, a, LD(wb + 9), mI, tw);
+                    wt_apply(n, b, LD(wb + 10), mI, tw);
+                    cz_apply(r, LD(wb + 11), mI, tw);
+                }
+            }
+            uint32_t t_wait = 0u, t_fc = 0u, t_floor = 0u;
+            STAMP(sb_ + 9);
+            for (int it = 0; it < P.iters; ++it) {
+                const uint32_t tf0_ = NOW();
+                const bool last = it == P.iters - 1;
+                float uu[9];                                    // the nine contact-point velocities of the sweep, requested together
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) uu[3 * f + j] = LD(L_REC(f) + R_U + j);
+                }
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {                   // finger-cube rows in contact space (block form with K: see the general path below)
+#ifdef TF_DIAG_NO_FC
+                    if (false) {
+#else
+                    if (cDinv[3 * f] > 0.0f) {
+#endif
+                        const int rb = L_REC(f);
+                        const float2v* R = &rec[9 * f];
+                        float vr[3], dl[3];
+                        {   // the three rows side by side (no packed instruction waits for the one before it)
+                            float2v p0 = R[0] * tw.p[0], p1 = R[3] * tw.p[0], p2 = R[6] * tw.p[0];
+                            p0 = pk_fma(R[1], tw.p[1], p0); p1 = pk_fma(R[4], tw.p[1], p1); p2 = pk_fma(R[7], tw.p[1], p2);
+                            p0 = pk_fma(R[2], tw.p[2], p0); p1 = pk_fma(R[5], tw.p[2], p1); p2 = pk_fma(R[8], tw.p[2], p2);
+                            vr[0] = uu[3 * f] - (p0.x + p0.y); vr[1] = uu[3 * f + 1] - (p1.x + p1.y); vr[2] = uu[3 * f + 2] - (p2.x + p2.y);
+                        }
+                        dl[0] = solve_normal(clam[3 * f], cDinv[3 * f], vr[0], cbias[f]);
+                        vr[1] = FMA(Km[3 * f], dl[0], vr[1]);
+                        dl[1] = solve_tangent(clam[3 * f + 1], cDinv[3 * f + 1], vr[1], mu_fc * clam[3 * f]);
+                        vr[2] = FMA(Km[3 * f + 2], dl[1], FMA(Km[3 * f + 1], dl[0], vr[2]));
+                        dl[2] = solve_tangent(clam[3 * f + 2], cDinv[3 * f + 2], vr[2], mu_fc * clam[3 * f]);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) {
+                            LD(rb + R_DL + d) = dl[d];
+                            pk_row_apply_neg(&R[3 * d], dl[d], mI, tw);
+                        }
+                    }
+                }
+                t_fc += NOW() - tf0_;
+                { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W1
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                   // cube - floor: rows +z (normal), +x, +y
+                    const float* r = &fr_[3 * c];
+#ifdef TF_DIAG_NO_FLOOR
+                    if (false) {
+#else
+                    if (fDinv[3 * c] > 0.0f) {
+#endif
+                        float dl = solve_normal(flam[3 * c], fDinv[3 * c], cz_vrel(r, tw), fbias[c]);
+                        cz_apply(r, dl, mI, tw);
+                        dl = solve_tangent(flam[3 * c + 1], fDinv[3 * c + 1], cx_vrel(r, tw), mu_cf * flam[3 * c]);
+                        cx_apply(r, dl, mI, tw);
+                        dl = solve_tangent(flam[3 * c + 2], fDinv[3 * c + 2], cy_vrel(r, tw), mu_cf * flam[3 * c]);
+                        cy_apply(r, dl, mI, tw);
+                    }
+                }
+                t_floor += NOW() - tf0_;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                   // cube - wall: rows n (normal), t, +z (dead lanes: n = 0, 1/D = 0, zero impulses; see below)
+#ifdef TF_DIAG_NO_WALL
+                    continue;
+#endif
+                    if (!slot_any[c]) continue;                 // wave-uniform
+                    const int wb = L_WALL + 12 * c;
+                    if (c < 2) {
+                        float dl = solve_normal(w_lam[3 * c], w_D[3 * c], wn_vrel(&w_n[2 * c], &w_a[3 * c], tw), w_bias[c]);
+                        wn_apply(&w_n[2 * c], &w_a[3 * c], dl, mI, tw);
+                        dl = solve_tangent(w_lam[3 * c + 1], w_D[3 * c + 1], wt_vrel(&w_n[2 * c], &w_b[3 * c], tw), mu_cw * w_lam[3 * c]);
+                        wt_apply(&w_n[2 * c], &w_b[3 * c], dl, mI, tw);
+                        dl = solve_tangent(w_lam[3 * c + 2], w_D[3 * c + 2], cz_vrel(&w_r[3 * c], tw), mu_cw * w_lam[3 * c]);
+                        cz_apply(&w_r[3 * c], dl, mI, tw);
+                        if (last && w_D[3 * c] > 0.0f) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = w_lam[3 * c + d];
+                        }
+                    } else {
+                        float r[3] = {LD(wb), LD(wb + 1), LD(wb + 2)}, n[2] = {LD(wb + 3), LD(wb + 4)};
+                        float Dinv[3] = {LD(wb + 5), LD(wb + 6), LD(wb + 7)}, bias = LD(wb + 8);
+                        float lam[3] = {LD(wb + 9), LD(wb + 10), LD(wb + 11)};
+                        float a[3], b[3];
+                        wall_arm_n(r, n, a);
+                        wall_arm_t(r, n, b);
+                        float dl = solve_normal(lam[0], Dinv[0], wn_vrel(n, a, tw), bias);
+                        wn_apply(n, a, dl, mI, tw);
+                        dl = solve_tangent(lam[1], Dinv[1], wt_vrel(n, b, tw), mu_cw * lam[0]);
+                        wt_apply(n, b, dl, mI, tw);
+                        dl = solve_tangent(lam[2], Dinv[2], cz_vrel(r, tw), mu_cw * lam[0]);
+                        cz_apply(r, dl, mI, tw);
+                        if (Dinv[0] > 0.0f) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) LD(wb + 9 + d) = lam[d];
+                        }
+                    }
+                }
+                if (last) {                                     // what the finger roles keep: normal impulse, world friction impulse, force (read behind W2)
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        const int rb = L_REC(f);
+                        float ftv[3] = {0.0f, 0.0f, 0.0f}, Fc[3] = {0.0f, 0.0f, 0.0f};
+                        if (cDinv[3 * f] > 0.0f) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                ftv[j] = FMA(rec[9 * f + 6 + j].x, clam[3 * f + 2], rec[9 * f + 3 + j].x * clam[3 * f + 1]);
+                                Fc[j] = FMA(rec[9 * f + j].x, clam[3 * f], ftv[j]) * inv_h;
+                            }
+                        }
+                        LD(L_INIT + f) = clam[3 * f];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { LD(rb + R_A + j) = ftv[j]; LD(rb + R_A + 3 + j) = Fc[j]; }
+                    }
+                }
+                { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W2
+            }
+            STAMP(sb_ + 6);
+            STAMPV(sb_ + 8, t_wait);
+            STAMPV(sb_ + 10, t_fc);
+            STAMPV(sb_ + 11, t_floor);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { v[j] = tw.p[j].x; w[j] = tw.p[j].y; }
+            } else {
             // ---- seeded impulses of the finger contacts (1/D, bias and impulses stay in registers through the sweeps) ----
             float cDinv[9], cbias[3], clam[9];
             // WIDE: the contact-space records (A, directions, arms) are read ONCE per substep and stay in registers through the sweeps; only the
             // contact-point velocity u, which the finger role republishes in every sweep, still comes through LDS (a dead slot's record is stale
             // LDS content: loaded, never used - its rows sit behind the 1/D > 0 branch)
-            constexpr int NRR = WIDE ? 27 : 1, NRA = WIDE ? 18 : 1;
+            constexpr int NRR = WIDE ? 27 : 1, NRA = WIDE ? 9 : 1;
             float rA[NRA], rDir[NRR], rRxd[NRR];
             if (WIDE) {
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) rA[(6 * f + j) % NRA] = LD(L_REC(f) + R_A + j);
+                    for (int j = 0; j < 3; ++j) rA[(3 * f + j) % NRA] = LD(L_REC(f) + R_A + j);
 #pragma unroll
                     for (int j = 0; j < 9; ++j) { rDir[(9 * f + j) % NRR] = LD(L_REC(f) + R_DIR + j); rRxd[(9 * f + j) % NRR] = LD(L_REC(f) + R_RXD + j); }
                 }
@@ -1771,43 +1945,29 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {                   // finger-cube rows in contact space
                     const int rb = L_REC(f);
-                    float ftv[3] = {0.0f, 0.0f, 0.0f}, Fc[3] = {0.0f, 0.0f, 0.0f};
                     if (cDinv[3 * f] > 0.0f) {
-                        float Am[6], u[3], dirs[9], rxds[9];
+                        // The three rows of the block from the relative velocities at the INCOMING twist (independent of each other), the later
+                        // rows corrected with the off-diagonal entries of the block-local Delassus matrix K: the iterate of the row-by-row
+                        // Gauss-Seidel form in exact arithmetic, with the twist updates off the dependency chain (oracle: same order).
+                        float Km[3], u[3], dirs[9], rxds[9], vr[3], dl[3];
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) Am[j] = WIDE ? rA[(6 * f + j) % NRA] : LD(rb + R_A + j);
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) u[j] = WIDE ? uu[3 * f + j] : LD(rb + R_U + j);
+                        for (int j = 0; j < 3; ++j) { Km[j] = WIDE ? rA[(3 * f + j) % NRA] : LD(rb + R_A + j); u[j] = WIDE ? uu[3 * f + j] : LD(rb + R_U + j); }
 #pragma unroll
                         for (int j = 0; j < 9; ++j) { dirs[j] = WIDE ? rDir[(9 * f + j) % NRR] : LD(rb + R_DIR + j); rxds[j] = WIDE ? rRxd[(9 * f + j) % NRR] : LD(rb + R_RXD + j); }
 #pragma unroll
+                        for (int d = 0; d < 3; ++d) vr[d] = u[d] - (dot3(&dirs[3 * d], v) + dot3(&rxds[3 * d], w));
+                        dl[0] = solve_normal(clam[3 * f], cDinv[3 * f], vr[0], cbias[f]);
+                        vr[1] = FMA(Km[0], dl[0], vr[1]);
+                        dl[1] = solve_tangent(clam[3 * f + 1], cDinv[3 * f + 1], vr[1], mu_fc * clam[3 * f]);
+                        vr[2] = FMA(Km[2], dl[1], FMA(Km[1], dl[0], vr[2]));
+                        dl[2] = solve_tangent(clam[3 * f + 2], cDinv[3 * f + 2], vr[2], mu_fc * clam[3 * f]);
+#pragma unroll
                         for (int d = 0; d < 3; ++d) {
-                            const float* dir = &dirs[3 * d];
-                            const float* rxd = &rxds[3 * d];
-                            float vrel = u[d] - (dot3(dir, v) + dot3(rxd, w));
-                            float dl = (d == 0) ? solve_normal(clam[3 * f], cDinv[3 * f], vrel, cbias[f])
-                                                : solve_tangent(clam[3 * f + d], cDinv[3 * f + d], vrel, mu_fc * clam[3 * f]);
-                            LD(rb + R_DL + d) = dl;
-                            const int i0 = (d == 0) ? 0 : ((d == 1) ? 1 : 2), i1 = (d == 0) ? 1 : ((d == 1) ? 3 : 4), i2 = (d == 0) ? 2 : ((d == 1) ? 4 : 5);
-                            u[0] = FMA(Am[i0], dl, u[0]);
-                            u[1] = FMA(Am[i1], dl, u[1]);
-                            u[2] = FMA(Am[i2], dl, u[2]);
-                            float sc = dl * inv_m, qq = dl * inv_I;
+                            LD(rb + R_DL + d) = dl[d];
+                            const float sc = dl[d] * inv_m, qq = dl[d] * inv_I;
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) { v[j] = FMA(-dir[j], sc, v[j]); w[j] = FMA(-rxd[j], qq, w[j]); }
+                            for (int j = 0; j < 3; ++j) { v[j] = FMA(-dirs[3 * d + j], sc, v[j]); w[j] = FMA(-rxds[3 * d + j], qq, w[j]); }
                         }
-                        if (last) {                             // what the finger role keeps: world friction impulse, force
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                ftv[j] = FMA(dirs[6 + j], clam[3 * f + 2], dirs[3 + j] * clam[3 * f + 1]);
-                                Fc[j] = FMA(dirs[j], clam[3 * f], ftv[j]) * inv_h;
-                            }
-                        }
-                    }
-                    if (last) {
-                        LD(L_INIT + f) = clam[3 * f];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) { LD(rb + R_A + j) = ftv[j]; LD(rb + R_A + 3 + j) = Fc[j]; }
                     }
                 }
                 t_fc += NOW() - tf0_;
@@ -1887,12 +2047,33 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     }
                 }
                 }
+                if (last) {                                     // what the finger roles keep: normal impulse, world friction impulse, force (read behind W2)
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        const int rb = L_REC(f);
+                        float ftv[3] = {0.0f, 0.0f, 0.0f}, Fc[3] = {0.0f, 0.0f, 0.0f};
+                        if (cDinv[3 * f] > 0.0f) {
+                            float dirs[9];
+#pragma unroll
+                            for (int j = 0; j < 9; ++j) dirs[j] = WIDE ? rDir[(9 * f + j) % NRR] : LD(rb + R_DIR + j);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                ftv[j] = FMA(dirs[6 + j], clam[3 * f + 2], dirs[3 + j] * clam[3 * f + 1]);
+                                Fc[j] = FMA(dirs[j], clam[3 * f], ftv[j]) * inv_h;
+                            }
+                        }
+                        LD(L_INIT + f) = clam[3 * f];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { LD(rb + R_A + j) = ftv[j]; LD(rb + R_A + 3 + j) = Fc[j]; }
+                    }
+                }
                 { const uint32_t t0_ = NOW(); BAR(); t_wait += NOW() - t0_; }   // W2
             }
             STAMP(sb_ + 6);
             STAMPV(sb_ + 8, t_wait);
             STAMPV(sb_ + 10, t_fc);
             STAMPV(sb_ + 11, t_floor);
+            }
             // ---- impulses kept for the next substep, integration ----
 #pragma unroll
             for (int j = 0; j < 12; ++j) lam_cf[j] = flam[j];

@@ -33,45 +33,7 @@
 
 #define SCR_STRIDE TF_SCR_STRIDE
 
-// One launch = one or more hooks of the reference step (MODE) for every env of the handle.
-// WIDE = false: 128 registers, 4 workgroups per CU (4 wavefronts per SIMD) - populations that fill the chip; WIDE = true: 256 registers, no spills,
-// nothing parked in LDS between substeps, the cube role's contact-space records in registers - populations of at most 32768 envs, which never put
-// more than two workgroups on a CU, so the occupancy the narrow build buys is not used (tf_create picks).  Same arithmetic.
-template <int A, bool IS_RESET, bool ASYM, int MODE, int EXT, bool WIDE>
-__global__ void __launch_bounds__(NT, WIDE ? 2 : 4) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
-    __shared__ __attribute__((aligned(16))) float lds[((EXT == 2) ? LDS_SLOTS_BOX : LDS_SLOTS) * WAVE];
-    const DevParams& P = *Pp;
-    {   // Warm the scalar cache with the parameter block (one dword per 64-byte line) BEFORE the state loads of every workgroup of the
-        // launch saturate the L2: the model constants the free motion needs then come out of the constant cache instead of queueing
-        // behind that burst.
-        const unsigned* pw = reinterpret_cast<const unsigned*>(Pp);
-        unsigned touch = 0u;
-#pragma unroll
-        for (unsigned k = 0; k < sizeof(DevParams) / 64u; ++k) touch |= pw[16u * k];
-        asm volatile("" ::"s"(touch));
-    }
-    Ctx cx;
-    cx.tid = (int)threadIdx.x;
-    cx.lane = (int)threadIdx.x & (WAVE - 1);
-#if defined(TF_ROLE_ROT)         // developer variant: which wavefront of the workgroup takes which role rotates with the workgroup index
-    cx.role = __builtin_amdgcn_readfirstlane((((int)threadIdx.x >> 6) + ((int)blockIdx.x >> TF_ROLE_ROT)) & 3);
-#else
-    cx.role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#endif
-    cx.wave_first = (int)blockIdx.x * WAVE;
-    const int i_raw = cx.wave_first + cx.lane;
-    cx.valid = i_raw < P.N;
-    cx.i = cx.valid ? i_raw : (P.N - 1);
-    cx.n_valid = (P.N - cx.wave_first < WAVE) ? (P.N - cx.wave_first) : WAVE;
-#if defined(TF_ONLY_FINGER)      // developer builds for per-role resource analysis (make resource-usage-roles)
-    finger_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
-#elif defined(TF_ONLY_CUBE)
-    cube_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
-#else
-    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
-    else finger_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
-#endif
-}
+#include "tf_launch.h"
 
 // ---- leaf kernels for the golden tests ----
 __global__ void k_test_quat_diff(const float* a, const float* b, float* out, int n) {
@@ -539,29 +501,11 @@ static inline int n_waves(const TfHandle_* h) { return (h->cfg.num_envs + WAVE -
         if (e_ != hipSuccess) return hip_fail(e_, what);           \
     } while (0)
 
-template <int MODE, bool IS_RESET, int EXT, bool WIDE>
-static void launch_env_w(TfHandle_* h, const float* action, hipStream_t s) {
-    dim3 grid(n_waves(h)), block(NT);
-    const bool asym = h->cfg.asymmetric_obs != 0;
-    if (h->action_dim == 9) {
-        if (asym) hipLaunchKernelGGL((k_env<9, IS_RESET, true, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<9, IS_RESET, false, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
-    } else {
-#if !defined(TF_DEV_MIN)
-        if (asym) hipLaunchKernelGGL((k_env<18, IS_RESET, true, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
-        else hipLaunchKernelGGL((k_env<18, IS_RESET, false, MODE, EXT, WIDE>), grid, block, 0, s, h->d_params, h->sa, action);
-#endif
-    }
-}
-template <int MODE, bool IS_RESET, int EXT>
-static void launch_env_obj(TfHandle_* h, const float* action, hipStream_t s) {
-    if (h->wide) launch_env_w<MODE, IS_RESET, EXT, true>(h, action, s);
-    else launch_env_w<MODE, IS_RESET, EXT, false>(h, action, s);
-}
-// The extended domain randomisation (robot base / stage position, per-body friction) and the general box object (TfModel.box) live in
-// their own instantiations (EXT = 1, 2): the kernels of the headline path stay exactly what they were - a run-time flag for either cost
-// 9 to 26 us per step through register pressure - and the extended randomisation with the cube (BASELINE configs[3]) does not carry the
-// box code either (round 3: with both behind one template flag the cube role of that kernel spilled 95 registers on its serial chain).
+// The fused step kernel k_env<A, IS_RESET, ASYM, MODE, EXT, WIDE> lives in tf_env_kernels.hip, compiled once per (EXT, WIDE) pair so that the six
+// translation units build in parallel (tf_launch.h).  The extended domain randomisation (robot base / stage position, per-body friction) and the
+// general box object (TfModel.box) are their own instantiations (EXT = 1, 2): the kernels of the headline path stay exactly what they were - a
+// run-time flag for either cost 9 to 26 us per step through register pressure - and the extended randomisation with the cube (BASELINE configs[3])
+// does not carry the box code either (round 3: with both behind one template flag the cube role of that kernel spilled 95 registers on its serial chain).
 static int ext_kind(const TfConfig& c) {
     if (c.model.box) return 2;
     if (!c.dr_enable) return 0;
@@ -571,16 +515,17 @@ static int ext_kind(const TfConfig& c) {
     for (int b = 0; b < 3; ++b) if (f[b][0] != 1.0f || f[b][1] != 1.0f) return 1;
     return 0;
 }
-template <int MODE, bool IS_RESET>
-static void launch_env(TfHandle_* h, const float* action, hipStream_t s) {
-    const int k = ext_kind(h->cfg);
-#if defined(TF_DEV_MIN)      // developer builds (tools/ab_bench.py): the headline kernels only
-    (void)k;
-    launch_env_obj<MODE, IS_RESET, 0>(h, action, s);
+static void launch_env(TfHandle_* h, int lm, const float* action, hipStream_t s) {
+    EnvLaunch a;
+    a.grid = (unsigned)n_waves(h); a.action_dim = h->action_dim; a.asym = h->cfg.asymmetric_obs != 0;
+    a.d_params = h->d_params; a.sa = h->sa; a.action = action; a.stream = s;
+#if defined(TF_DEV_MIN)      // developer builds (tools/ab_bench.py, tools/variant_sweep.py): the headline kernels only
+    if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a);
 #else
-    if (k == 2) launch_env_obj<MODE, IS_RESET, 2>(h, action, s);
-    else if (k == 1) launch_env_obj<MODE, IS_RESET, 1>(h, action, s);
-    else launch_env_obj<MODE, IS_RESET, 0>(h, action, s);
+    const int k = ext_kind(h->cfg);
+    if (k == 2) { if (h->wide) tf_launch_env_2_1(lm, a); else tf_launch_env_2_0(lm, a); }
+    else if (k == 1) { if (h->wide) tf_launch_env_1_1(lm, a); else tf_launch_env_1_0(lm, a); }
+    else { if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a); }
 #endif
 }
 
@@ -596,9 +541,7 @@ static int launch_step(TfHandle_* h, const float* action, bool is_reset, hipStre
     if (is_reset) HIP_TRY(hipMemsetAsync((void*)h->dp.tickets, 0, STAT_WORDS * sizeof(unsigned long long), s));
     const bool timing = !is_reset && h->ev && h->ev_used < h->ev_cap;
     if (timing && h->ev_phase == 0) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], s));      // window opens
-    if (is_reset) launch_env<M_FUSED_RESET, true>(h, action, s);
-    else if (random_actions) launch_env<M_FUSED_STEP_RAND, false>(h, nullptr, s);
-    else launch_env<M_FUSED_STEP, false>(h, action, s);
+    launch_env(h, is_reset ? TF_LM_RESET : (random_actions ? TF_LM_STEP_RAND : TF_LM_STEP), random_actions ? nullptr : action, s);
     LAUNCH_CHECK("k_env");
     if (timing) {
         h->ev_phase += 1;
@@ -667,7 +610,7 @@ int tf_apply_resets(tf_handle h, void* stream) {
 #if defined(TF_DEV_MIN)
     return TF_ERR_UNSUPPORTED;
 #else
-    launch_env<M_RESETS, false>(h, nullptr, (hipStream_t)stream);
+    launch_env(h, TF_LM_RESETS, nullptr, (hipStream_t)stream);
 #endif
     LAUNCH_CHECK("k_env<resets>");
     return TF_OK;
@@ -678,7 +621,7 @@ int tf_pre_step(tf_handle h, void* stream) {
 #if defined(TF_DEV_MIN)
     return TF_ERR_UNSUPPORTED;
 #else
-    launch_env<M_TORQUE, false>(h, nullptr, (hipStream_t)stream);
+    launch_env(h, TF_LM_TORQUE, nullptr, (hipStream_t)stream);
 #endif
     LAUNCH_CHECK("k_env<torque>");
     return TF_OK;
@@ -690,7 +633,7 @@ int tf_simulate(tf_handle h, void* stream) {
 #if defined(TF_DEV_MIN)
     return TF_ERR_UNSUPPORTED;
 #else
-    launch_env<M_SIM, false>(h, nullptr, (hipStream_t)stream);
+    launch_env(h, TF_LM_SIM, nullptr, (hipStream_t)stream);
 #endif
     LAUNCH_CHECK("k_env<simulate>");
     return TF_OK;
@@ -702,7 +645,7 @@ int tf_post_step(tf_handle h, void* stream) {
 #if defined(TF_DEV_MIN)
     return TF_ERR_UNSUPPORTED;
 #else
-    launch_env<M_POST, false>(h, nullptr, (hipStream_t)stream);
+    launch_env(h, TF_LM_POST, nullptr, (hipStream_t)stream);
 #endif
     LAUNCH_CHECK("k_env<post>");
     return TF_OK;
@@ -712,7 +655,7 @@ int tf_finish_step(tf_handle h, void* stream) {
 #if defined(TF_DEV_MIN)
     return TF_ERR_UNSUPPORTED;
 #else
-    launch_env<M_FINISH, false>(h, nullptr, (hipStream_t)stream);
+    launch_env(h, TF_LM_FINISH, nullptr, (hipStream_t)stream);
 #endif
     LAUNCH_CHECK("k_env<finish>");
     return TF_OK;

@@ -1153,11 +1153,15 @@ typedef struct {
     float vlo[3], vhi[3], lim_dinv[3], lim_lam[3];
 } FingerRole;
 
-/* Contact-space record of one finger-cube contact, handed to the cube role (LDS in the HIP kernel): the 3x3 block
- * A = J M^-1 J^T of the finger side, the cube-side directions and arms, and the running contact-point velocity u. */
+/* Contact-space record of one finger-cube contact, handed to the cube role (LDS in the HIP kernel): the off-diagonal part of the
+ * block-local Delassus matrix K = A + D D^T / m + R R^T / I of the three rows (A = J M^-1 J^T the finger side, D the orthonormal
+ * directions - D D^T = 1 -, R the cube arms r x d), the cube-side directions and arms, and the contact-point velocity u of the finger
+ * side at the start of the sweep.  With K the three rows of a block are solved from the relative velocities at the INCOMING twist:
+ * row 1 is corrected by K01 dl0, row 2 by K02 dl0 + K12 dl1 - the Gauss-Seidel iterate of the row-by-row form, with a dependency
+ * chain a third as long (the twist and u updates leave the chain). */
 typedef struct {
     int active;
-    float A[6];                   /* 00 01 02 11 12 22 */
+    float K[3];                   /* 01 02 12 */
     float Dinv[3], bias, lam[3];
     float dir[3][3], rxd[3][3];
     float u[3], dl[3];
@@ -1497,9 +1501,9 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                     g->fcJ[d][j] = J[d][j]; g->fcW[d][j] = W[d][j]; rc_->dir[d][j] = dir[d][j]; rc_->rxd[d][j] = rxd[d][j];
                 }
                 for (int d = 0; d < 3; ++d) rc_->Dinv[d] = f_rcp2(FMA(dot3(rxd[d], rxd[d]), inv_I, Dd[d] + inv_m));
-                rc_->A[0] = Dd[0];                        rc_->A[1] = dot3(J[0], W[1]); rc_->A[2] = dot3(J[0], W[2]);
-                rc_->A[3] = Dd[1];                        rc_->A[4] = dot3(J[1], W[2]);
-                rc_->A[5] = Dd[2];
+                rc_->K[0] = FMA(dot3(rxd[0], rxd[1]), inv_I, dot3(J[0], W[1]));
+                rc_->K[1] = FMA(dot3(rxd[0], rxd[2]), inv_I, dot3(J[0], W[2]));
+                rc_->K[2] = FMA(dot3(rxd[1], rxd[2]), inv_I, dot3(J[1], W[2]));
                 if (link == 3) for (int i = 0; i < 3; ++i) g->fc_arm[i] = Pw[i] - g->Tw[i];
                 rc_->bias = contact_bias(m, gap, vn0, inv_h, rest_f);
                 if ((float)link == e->fc_link[f]) {          /* same link as in the last substep: seed the impulses */
@@ -1608,16 +1612,15 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int f = 0; f < 3; ++f) {
             FcRecord* c = &rec[f];
             if (!c->active) continue;
+            float vr[3];
+            for (int d = 0; d < 3; ++d) vr[d] = c->u[d] - (dot3(c->dir[d], v) + dot3(c->rxd[d], w));      /* all three at the incoming twist */
+            c->dl[0] = solve_normal(&c->lam[0], c->Dinv[0], vr[0], c->bias);
+            vr[1] = FMA(c->K[0], c->dl[0], vr[1]);
+            c->dl[1] = solve_tangent(&c->lam[1], c->Dinv[1], vr[1], mu_fc * c->lam[0]);
+            vr[2] = FMA(c->K[2], c->dl[1], FMA(c->K[1], c->dl[0], vr[2]));
+            c->dl[2] = solve_tangent(&c->lam[2], c->Dinv[2], vr[2], mu_fc * c->lam[0]);
             for (int d = 0; d < 3; ++d) {
-                float vrel = c->u[d] - (dot3(c->dir[d], v) + dot3(c->rxd[d], w));
-                float dl = (d == 0) ? solve_normal(&c->lam[0], c->Dinv[0], vrel, c->bias)
-                                    : solve_tangent(&c->lam[d], c->Dinv[d], vrel, mu_fc * c->lam[0]);
-                c->dl[d] = dl;
-                const int i0 = (d == 0) ? 0 : ((d == 1) ? 1 : 2), i1 = (d == 0) ? 1 : ((d == 1) ? 3 : 4), i2 = (d == 0) ? 2 : ((d == 1) ? 4 : 5);
-                c->u[0] = FMA(c->A[i0], dl, c->u[0]);
-                c->u[1] = FMA(c->A[i1], dl, c->u[1]);
-                c->u[2] = FMA(c->A[i2], dl, c->u[2]);
-                float sc = dl * inv_m, q = dl * inv_I;
+                float sc = c->dl[d] * inv_m, q = c->dl[d] * inv_I;
                 for (int j = 0; j < 3; ++j) { v[j] = FMA(-c->dir[d][j], sc, v[j]); w[j] = FMA(-c->rxd[d][j], q, w[j]); }
             }
         }

@@ -23,7 +23,7 @@ def declared_functions():
 def hip_lib():
     path = capi.hip_library_path()
     if not os.path.isfile(path):
-        subprocess.check_call(["make", "-C", os.path.dirname(path), "-s"])
+        subprocess.check_call(["make", "-j8", "-C", os.path.dirname(path), "-s"])
     return capi.TfLib(path)
 
 
