@@ -2131,6 +2131,21 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int j = 0; j < 4; ++j) acc = acc + cq[j] * 0.0f;
             LD(L_NAN + 3) = (acc == 0.0f) ? 0.0f : 1.0f;
         }
+        // The object terms of the reward (distance kernel, rotation terms, object motion: everything that needs no fingertip) depend on what this role
+        // already holds.  The 256-register instantiation evaluates them HERE, in the window in which it otherwise waits for the finger roles at P1 and P3
+        // (the 128-register one has no room to carry the six results across the two barriers: it evaluates them behind P3); same operations either way.
+        float o_dist = 0.0f, o_ang = 0.0f, o_r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto object_terms = [&]() __attribute__((always_inline)) {
+            const RewardCoef& rc = sa.rc;
+            o_dist = norm3d(cp, gp);
+            o_r[0] = rc.c_dist * lgsk(o_dist, 50.0f);
+            o_ang = quat_diff_rad(cq, gq);
+            o_r[1] = rc.w_rot * (rc.rot_num / (rc.rot_scale * f_abs(o_ang) + rc.rot_scale));
+            const float ang_prev = quat_diff_rad(&prev_obj[3], gq);
+            o_r[2] = rc.w_rot_delta * (rc.rot_delta_sched * (f_abs(o_ang) - f_abs(ang_prev)));
+            o_r[3] = rc.w_move * (o_dist - norm3d(prev_obj, gp));
+        };
+        if (WIDE && !IS_RESET) object_terms();
         STAMP(31);
         BAR();                                                  // P1
         STAMP(32);
@@ -2143,6 +2158,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             if (cx.valid) P.reset_buf[(unsigned)cx.i] = 1;
             c_reset = true;
             st.nonfinite += cx.valid ? 1.0f : 0.0f;
+            if (WIDE && !IS_RESET) object_terms();      // (the terms of the parked pose: what the evaluation behind P3 sees)
         }
         const float co = P.clip_obs;
         const bool nrm = P.normalize_obs != 0;
@@ -2189,13 +2205,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 for (int j = 0; j < 9; ++j) { float vel = (tips[j] - tip_prev[j]) / rc.dt; s = s + vel * vel; }
                 r[1] = rc.c_move_pen * s;
             }
-            float dist = norm3d(cp, gp);
-            r[2] = rc.c_dist * lgsk(dist, 50.0f);
-            float ang = quat_diff_rad(cq, gq);
-            r[3] = rc.w_rot * (rc.rot_num / (rc.rot_scale * f_abs(ang) + rc.rot_scale));
-            float ang_prev = quat_diff_rad(&prev_obj[3], gq);
-            r[4] = rc.w_rot_delta * (rc.rot_delta_sched * (f_abs(ang) - f_abs(ang_prev)));
-            r[5] = rc.w_move * (dist - norm3d(prev_obj, gp));
+            if (!WIDE) object_terms();
+            const float dist = o_dist, ang = o_ang;
+            r[2] = o_r[0]; r[3] = o_r[1]; r[4] = o_r[2]; r[5] = o_r[3];
             float total = 0.0f;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
