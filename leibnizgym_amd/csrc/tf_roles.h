@@ -1624,7 +1624,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
                 for (int j = 0; j < 3; ++j) LD(L_VQFF + 3 * f + j) = LD(L_REC(f) + P_VQ + j);
             }
-#pragma unroll 1
+#pragma unroll 1                                                // (unrolling the three pairs in the 256-register build changes nothing: measured)
             for (int p = 0; p < 3; ++p) {
                 const int fa = p, fb = (p == 2) ? 0 : p + 1;
                 float Pa[3], Pb[3];

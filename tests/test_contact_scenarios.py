@@ -584,3 +584,97 @@ def test_chain_steady_states_press_down_and_push(oracle):
 def test_chain_steady_states_press_down_and_push_gpu(hip):
     _check_press_down(hip, "cuda:0")
     _check_push_and_slide(hip, "cuda:0")
+
+
+# ---- the boundary as the cube's corners see it ------------------------------------------------------------------------------------------
+# The stage is a bowl (high_table_boundary.urdf:20-259): a vertical ring up to 32 mm, above it a cone that leans outward by 29-35 degrees.  The FINGERTIP
+# contact follows the tilted surface normal (test above).  The CUBE CORNERS keep the horizontal normal of the ring at every height, with the radius of
+# the profile at the corner's height (include/trifinger.h: TfModel.wall_r) - that is the model, and these two tests say what it
+# costs: (i) the deviation itself, pinned: a corner that meets the cone is stopped radially and gets NO vertical deflection, where the surface normal
+# would turn cos(a) sin(a) of the radial speed into upward speed; (ii) how often the workload puts a pushing corner on the cone at all: a cube that
+# lies on the table touches the boundary with its lower corners, 32 mm below the first knot, so only a lifted or tumbling cube at the boundary is affected.
+def _flying_cube_hits_the_cone(lib, device, v_r=0.3):
+    """a cube without weight, 110 mm up, flies outward: its two lower outward corners (77.5 mm: second segment of the cone) meet the boundary"""
+    def edit(m):
+        m.cube_linear_damping = 0.0
+        m.cube_angular_damping = 0.0
+        m.mu_cube_wall = 0.0                                   # the normal row alone (the friction rows act along the tangent and the vertical)
+    eng = T.engine(lib, device=device, model_edit=edit, gravity=(0.0, 0.0, 0.0), **T.HOLD)
+    m = lib.default_model()
+    f32 = dict(dtype=torch.float32, device=device)
+    r_at = T.wall_radius_at(0.11 - 0.0325, m)
+    eng.cube[0:3, 0] = torch.tensor([r_at - 0.0325 - 0.004, 0.0, 0.11], **f32)      # the corners 4 mm inside the profile: they arrive within the step
+    eng.cube[7, 0] = v_r
+    act = torch.tensor([[0.0, 0.9, -1.7] * 3], **f32)
+    before = eng.cube[:, 0].cpu().numpy().astype(np.float64)
+    eng.step(act)
+    after = eng.cube[:, 0].cpu().numpy().astype(np.float64)
+    lam = eng.state[capi.S_LAM_CW:capi.S_LAM_CW + 12, 0].cpu().numpy().astype(np.float64)
+    eng.close()
+    return before, after, lam, m
+
+
+def _check_corner_on_cone(lib, device):
+    v_r = 0.3
+    before, after, lam, m = _flying_cube_hits_the_cone(lib, device, v_r)
+    assert (lam[0::3] > 0).sum() == 2, lam                                 # the two lower outward corners pushed
+    dv = after[7:10] - before[7:10]
+    # the model: the boundary pushes HORIZONTALLY - the cube loses radial speed (and starts to pitch about the corners, which sit below its centre) ...
+    assert dv[0] < -0.3 * v_r and abs(dv[1]) < 1e-5, dv
+    # ... and gets no vertical impulse at all, where the tilted surface normal (c n_h, s) would give dv_z = -(s / c) dv_x: THE deviation of this model
+    assert abs(dv[2]) < 1e-6, dv
+    assert after[11] != 0.0                                                # pitch rate about y
+    sl = (float(m.wall_r[2]) - float(m.wall_r[1])) / (float(m.wall_z[2]) - float(m.wall_z[1]))
+    assert 0.5 < sl < 0.62                                                 # tan of the lean of this segment: the missing dv_z is 0.57 |dv_x|
+    zc = before[2] - 0.0325
+    assert float(m.wall_z[1]) < zc < float(m.wall_z[2])
+
+
+def test_cube_corner_on_the_cone_keeps_the_horizontal_normal(oracle):
+    _check_corner_on_cone(oracle, "cpu")
+
+
+@pytest.mark.gpu
+def test_cube_corner_on_the_cone_keeps_the_horizontal_normal_gpu(hip):
+    _check_corner_on_cone(hip, "cuda:0")
+
+
+def cone_corner_census(eng, m, steps, every, step_fn):
+    """share of (env, sample) pairs with a boundary corner that pushes (normal impulse > 0) and of those whose pushing corner sits ABOVE the vertical ring"""
+    corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64) * float(m.cube_half)
+    wz, wr = np.array(m.wall_z[:], dtype=np.float64), np.array(m.wall_r[:], dtype=np.float64)
+    n_samples = n_push = n_cone = 0
+    for k in range(steps):
+        step_fn(k)
+        if k % every:
+            continue
+        st = eng.state.cpu().numpy().astype(np.float64)
+        lam = st[capi.S_LAM_CW:capi.S_LAM_CW + 12:3]                       # normal impulses of the four corner slots
+        push = (st[capi.S_CW_FACE] != 0) & (lam > 0).any(0)
+        n_samples += st.shape[1]
+        n_push += int(push.sum())
+        for i in np.nonzero(push)[0]:
+            c = st[capi.S_CUBE_P:capi.S_CUBE_P + 7, i]
+            pts = c[0:3] + corners @ PR.quat_rot(c[3:7]).T
+            rho = np.hypot(pts[:, 0], pts[:, 1])
+            r_at = np.interp(pts[:, 2], wz, wr, left=wr[0])
+            near = (r_at - rho) < 1.5e-3                                   # corners at the surface (the pushing ones are among them)
+            n_cone += int((near & (pts[:, 2] > wz[0])).any())
+    return n_samples, n_push, n_cone
+
+
+def test_random_actions_rarely_put_a_pushing_corner_on_the_cone(oracle):
+    """Census of the bench workload (difficulty 4, random actions, 750-step episodes) on the oracle: cubes do reach the boundary (a few per cent of the
+    envs have a pushing corner at any time), and they do it lying on the table - the share of env-steps in which a pushing corner sits on the cone, where
+    the horizontal-normal model deviates from the surface, is below 0.3 % of all env-steps (measured 0.0-0.1 %; tools/wall_census.py prints the same
+    figure for 65536 envs on the GPU)."""
+    import parity_util as pu
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    n = 384
+    kw = dict(pu.CONFIGS["d4_torque_asym"])
+    eng = TrifingerEngine(make_config(oracle, n, seed=5, episode_length=750, **kw), device="cpu", lib=oracle)
+    eng.reset()
+    n_samples, n_push, n_cone = cone_corner_census(eng, oracle.default_model(), 900, 20, lambda k: eng.step_random())
+    eng.close()
+    assert n_push > 0.005 * n_samples, (n_push, n_samples)                 # the rollout did reach the boundary
+    assert n_cone < 0.003 * n_samples, (n_cone, n_push, n_samples)
