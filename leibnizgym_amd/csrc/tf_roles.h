@@ -1269,16 +1269,16 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
     constexpr int NDR = EXT ? TF_NUM_DR : TF_DR_BASE_POS;
     const uint32_t gid = (uint32_t)(P.env_id_offset + cx.i);
     // ---- loads ----
-    float cp[3], cq[4], cv[3], cw[3], gp[3], gq[4], gw[3], dr[TF_NUM_DR];
+    float cp[3], cq[4], cv[3], cw[3], dr[TF_NUM_DR];
     float lam_cf[12], lam_cw[12], cf_face = 0.0f, cw_face = 0.0f;
     uint8_t fl_reset = 0, fl_goal_reset = 0, fl_successes = 0;
     int fl_steps = 0;
     uint32_t fl_count = 0;
     STAMP(0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { cp[j] = LDST(TF_S_CUBE_P + j); cv[j] = LDST(TF_S_CUBE_V + j); cw[j] = LDST(TF_S_CUBE_W + j); gp[j] = 0.0f; gw[j] = 0.0f; }
+    for (int j = 0; j < 3; ++j) { cp[j] = LDST(TF_S_CUBE_P + j); cv[j] = LDST(TF_S_CUBE_V + j); cw[j] = LDST(TF_S_CUBE_W + j); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { cq[j] = LDST(TF_S_CUBE_Q + j); gq[j] = 0.0f; }      // (the goal rows are only WRITTEN here, by a reset; the post phase reads them)
+    for (int j = 0; j < 4; ++j) cq[j] = LDST(TF_S_CUBE_Q + j);
 #pragma unroll
     for (int j = 0; j < TF_NUM_DR; ++j) dr[j] = (j < NDR && P.dr_enable) ? LDST(TF_S_DR + j) : TF_DR_NEUTRAL(j);   // rows are read only when the feature is on
     if (MODE & (M_RESETS | M_POST | M_FINISH)) {
@@ -1318,6 +1318,8 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         const bool rflag = IS_RESET || (fl_reset != 0);
         const bool gflag = !IS_RESET && (fl_goal_reset != 0);
         uint32_t count = fl_count;
+        // the goal rows are only WRITTEN here (sample_goal fills every component; stored under rflag || gflag); the post phase reads them back
+        float gp[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gw[3] = {0.0f, 0.0f, 0.0f};
         if (rflag) {
             if (P.dr_enable) draw_dr<EXT>(P, gid, count, dr);
             if (P.object_reset_type == TF_RESET_DEFAULT) {

@@ -21,6 +21,7 @@ eng.reset()
 nonfinite = torch.zeros((), device="cuda:0"); resets = torch.zeros((), device="cuda:0")
 t0 = time.perf_counter()
 deep_box = []
+soft_box = []
 for k in range(steps):
     eng.step(ring[k % 32])
     nonfinite += eng.info[capi.INFO_NUM_NONFINITE]; resets += eng.info[capi.INFO_NUM_RESETS]
@@ -39,9 +40,15 @@ for k in range(steps):
         # solver), a centre below 2 mm fails
         if box and zmin < 0.006:
             deep_box.append((k + 1, zmin))
+        # the round-3 bound (centre above 4 mm) stays as a COUNTED soft failure: more than 2 % of the samples below it fails the soak, so that a
+        # regression of the penetration it was written for is still caught; a centre below 2 mm fails at once
+        if box and zmin <= 0.004:
+            soft_box.append((k + 1, zmin))
+            assert len(soft_box) <= max(2, (steps // 1000) // 50), ("bar pressed more than 6 mm into the table too often", soft_box[-5:])
         assert ok and rmax < 0.27 and zmin > (0.002 if box else 0.02) and zmax < 1.0 and vmax < 20.0 and tipz > -0.003, (zmin, zmax, rmax, vmax, tipz)
 torch.cuda.synchronize()
 print(f"{n} envs x {steps} steps in {time.perf_counter()-t0:.1f} s; non-finite envs caught: {float(nonfinite):.0f}")
 if box:
     print(f"samples (every 1000 steps, minimum over the envs) with the bar's centre below 6 mm (4 mm into the table): {len(deep_box)} of {steps // 1000}"
-          + (f"; deepest: centre at {min(z for _, z in deep_box) * 1e3:.1f} mm (step {min(deep_box, key=lambda t: t[1])[0]})" if deep_box else ""))
+          + (f"; deepest: centre at {min(z for _, z in deep_box) * 1e3:.1f} mm (step {min(deep_box, key=lambda t: t[1])[0]})" if deep_box else "")
+          + f"; below 4 mm (the counted soft bound, at most {max(2, (steps // 1000) // 50)} allowed): {len(soft_box)}")

@@ -9,4 +9,4 @@ for sym in (False, True):
         out = subprocess.run(cmd, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         d = json.loads(out)
         rows.append((n, not sym, d["value"], d["ms_per_step"], d["roofline"]["kernel_avg_us"], d["roofline"]["frac"]))
-        print(f"N={n:7d} asym={not sym!s:5s} {d['value']:.4e} env-steps/s  {d['ms_per_step']*1e3:8.1f} us/step  k_step {d['roofline']['kernel_avg_us']:7.1f} us  hbm frac {d['roofline']['frac']:.4f}", flush=True)
+        print(f"N={n:7d} asym={not sym!s:5s} {d['value']:.4e} env-steps/s  {d['ms_per_step']*1e3:8.1f} us/step  k_env {d['roofline']['kernel_avg_us']:7.1f} us ({d['roofline'].get('kernel_variant', '?'):6s})  hbm frac {d['roofline']['frac']:.4f}", flush=True)
