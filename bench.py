@@ -210,8 +210,23 @@ def cpu_baseline(asym, budget_s=12.0):
         eng.close()
         return n_small * k / el
     v_small = run_small(used, 1.5)
+    # beside the bit-exact oracle: the same source built for THIS host (-O3 -march=native, contraction allowed; oracle/Makefile `fast`): not a
+    # checker, only the CPU's best effort at the same algorithm
+    v_fast = None
+    try:
+        subprocess.check_call(["make", "-B", "-C", os.path.join(REPO, "oracle"), "-s", "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)      # -B: -march=native is THIS host's
+        bitexact = lib
+        lib = _capi.TfLib(os.path.join(REPO, "oracle", "_build", "libtrifinger_oracle_fast.so"))
+        lib.dll.tfo_omp_threads.argtypes = [ctypes.c_int]
+        lib.dll.tfo_omp_threads.restype = ctypes.c_int
+        v_fast = run(used, budget_s * 0.2)[3]
+        lib = bitexact
+    except Exception:
+        v_fast = None
     return {"value": va, "unit": "env-steps/s", "cores": used, "kind": "port",
             "single_thread_value": v1, "value_at_8192_envs": v_small,
+            "best_effort_value": v_fast,
+            "best_effort_is": "the same source compiled -O3 -march=native -ffp-contract=fast on this host (not bit-identical to the product: timed only)",
             "sample": f"{n} envs x {sa} steps of the same workload on {used} OpenMP threads (static schedule over envs, "
                       f"{ea:.1f} s) and x {s1} steps on 1 thread ({e1:.1f} s); reference IsaacGym CPU pipeline not "
                       f"available, baseline is this repo's CPU oracle (oracle/tf_oracle.c)"}

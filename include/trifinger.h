@@ -327,6 +327,9 @@ int tf_set_gravity(tf_handle h, const float g[3]);
  * task receives the clamped tensor), every emitted obs / states value to +-clip_obs (after scaling and after the
  * observation noise).  A bound <= 0 switches that clamp off (the default).  Cold path (blocking parameter copy). */
 int tf_set_clipping(tf_handle h, float clip_obs, float clip_actions);
+/* The frame count is kept as int64 (reward schedules: env_steps_count = frame count x global_num_envs, in double).  The counter-based draws that
+ * are keyed by it - fused action source, observation noise, action repeat - use its LOW 32 BITS as the Philox counter word: their sequences repeat
+ * after 2^32 frames (3.5 days at 14 000 steps/s; resets are keyed by the per-env reset count and are not affected). */
 int64_t tf_frame_count(tf_handle h);
 int tf_set_frame_count(tf_handle h, int64_t frames);
 /* The fused step exists in two instantiations with the SAME arithmetic (identical results, bit for bit): a 128-register one that puts four

@@ -86,7 +86,8 @@ struct DevParams {
 struct StepArgs {
     RewardCoef rc;
     int32_t nsim;
-    uint32_t frame;          // frame count after this launch (counter of the observation-noise draws)
+    uint32_t frame;          // frame count after this launch (counter of the observation-noise draws); the LOW 32 bits of the handle's int64 count:
+                             // frame-keyed draws repeat after 2^32 frames (include/trifinger.h)
     uint32_t frame0;         // frame count at the start of the control step (counter of the action-repeat draw)
 };
 
