@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TF_API_VERSION 5
+#define TF_API_VERSION 6
 
 typedef enum TfStatus {
     TF_OK = 0,
@@ -262,6 +262,10 @@ typedef struct TfConfig {
     float dt;                     /* seconds per simulate() call                                     */
     int32_t substeps;             /* solver substeps per simulate()                                  */
     int32_t solver_iterations;    /* num_position_iterations                                         */
+    int32_t solver_inner;         /* >= 1 (API 6; default 1).  n > 1: every sweep visits the block of ALL rows that touch the cube (finger-cube, cube-floor,
+                                   * cube-boundary, the fingers following through their contact-point velocities) n times before the finger-only rows
+                                   * (fingertip-floor, fingertip-boundary, joint limits) get their turn: the block 8 sweeps leave unresolved (INTEGRATION.md
+                                   * "what 8 sweeps leave").  Costs what solver_iterations x n sweeps cost. */
     float gravity[3];
     /* Domain randomisation (build-defined: the reference has none, leibnizgym/dr/__init__.py is empty; the intent
      * list is the comment block at trifinger_env.py:385-393).  Scale factors ~ U[lo, hi], drawn per env at reset. */

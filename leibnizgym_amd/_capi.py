@@ -11,7 +11,7 @@ same binding at the CPU oracle; nothing in this package ever does.
 import ctypes as C
 import os
 
-TF_API_VERSION = 5
+TF_API_VERSION = 6
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
 TF_STATE_ROWS = 157
@@ -108,7 +108,7 @@ class TfConfig(C.Structure):
         ("finger_reach_norm_p", C.c_int32), ("object_rot_scale", C.c_float),
         ("success_activate", C.c_int32), ("success_bonus", C.c_float),
         ("position_tolerance", C.c_float), ("orientation_tolerance", C.c_float),
-        ("dt", C.c_float), ("substeps", C.c_int32), ("solver_iterations", C.c_int32),
+        ("dt", C.c_float), ("substeps", C.c_int32), ("solver_iterations", C.c_int32), ("solver_inner", C.c_int32),
         ("gravity", C.c_float * 3),
         ("dr_enable", C.c_int32),
         ("dr_cube_mass", C.c_float * 2), ("dr_cube_size", C.c_float * 2),

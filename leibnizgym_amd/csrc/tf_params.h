@@ -69,7 +69,7 @@ struct DevParams {
     int32_t success_activate;
     float success_bonus, pos_tol, ori_tol;
     // stepping
-    int32_t substeps, iters, control_decimation;
+    int32_t substeps, iters, inner, control_decimation;      // iters = solver_iterations x solver_inner passes; the finger-only rows run on every inner-th
     float dt, hsub;
     float grav[3];
     TfModel m;

@@ -894,10 +894,13 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                         for (int j = 0; j < 3; ++j) vq[j] = FMA(Wd[j], dl[d], vq[j]);
                     }
                 }
+                // TfConfig.solver_inner > 1: the finger-only rows get their turn on every inner-th pass only (the passes in between visit the block of all
+                // rows that touch the cube; this finger follows them through its contact-point velocity)
+                const bool own_rows = (P.inner == 1) || (((it + 1) % P.inner) == 0);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {                   // fingertip - floor, fingertip - wall
                     TipContact& c = tc[t];
-                    if (c.active) {
+                    if (c.active && own_rows) {
 #pragma unroll
                         for (int d = 0; d < 3; ++d) {
                             float vrel = dot3(&c.J[3 * d], vq);
@@ -910,6 +913,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                         }
                     }
                 }
+                if (own_rows) {
 #pragma unroll
                 for (int jj = 0; jj < 3; ++jj) {                // joint limits + velocity limit
                     const int dg = (jj == 0) ? 0 : ((jj == 1) ? 3 : 5);
@@ -924,6 +928,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     vq[0] = FMA(k.Minv[c0], dlj, vq[0]);
                     vq[1] = FMA(k.Minv[c1], dlj, vq[1]);
                     vq[2] = FMA(k.Minv[c2], dlj, vq[2]);
+                }
                 }
                 if (cur_link != 0) {
 #pragma unroll

@@ -331,7 +331,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     int d = cfg->task_difficulty;
     if (!(d == -1 || (d >= 1 && d <= 6))) return TF_ERR_DIFFICULTY;
     if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
-    if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
+    if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->solver_inner <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
     /* boundary profile (TfModel.wall_z / wall_r, knots of a piecewise-linear r(z) since API 4 - before that: steps of a staircase): the
      * knots must rise strictly and be finite, or the slopes between them are not defined */
@@ -376,7 +376,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     for (int t = 0; t < 6; ++t) P.rew_active[t] = cfg->reward[t].activate;
     P.success_activate = cfg->success_activate; P.success_bonus = cfg->success_bonus;
     P.pos_tol = cfg->position_tolerance; P.ori_tol = cfg->orientation_tolerance;
-    P.substeps = cfg->substeps; P.iters = cfg->solver_iterations; P.control_decimation = cfg->control_decimation;
+    P.substeps = cfg->substeps; P.iters = cfg->solver_iterations * cfg->solver_inner; P.inner = cfg->solver_inner; P.control_decimation = cfg->control_decimation;
     P.dt = cfg->dt; P.hsub = cfg->dt / (float)cfg->substeps;
     for (int i = 0; i < 3; ++i) P.grav[i] = cfg->gravity[i];
     P.m = cfg->model;

@@ -68,7 +68,7 @@ def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, co
                 enable_ft_sensors=False, task_difficulty=1, episode_length=750, control_decimation=1,
                 robot_reset="default", dof_pos_stddev=0.4, dof_vel_stddev=0.2, object_reset="random",
                 goal_rotation=False, goal_rotation_rate=0.5, reward_terms=None, success=None,
-                dt=0.02, substeps=2, solver_iterations=8, gravity=(0.0, 0.0, -9.81), model=None,
+                dt=0.02, substeps=2, solver_iterations=8, solver_inner=1, gravity=(0.0, 0.0, -9.81), model=None,
                 domain_randomization=None):
     """Build a TfConfig.  String options are validated here with the reference's ValueErrors."""
     if command_mode not in capi.COMMAND_MODES:
@@ -111,6 +111,7 @@ def make_config(lib, num_envs, *, seed=0, env_id_offset=0, global_num_envs=0, co
     cfg.dt = float(dt)
     cfg.substeps = int(substeps)
     cfg.solver_iterations = int(solver_iterations)
+    cfg.solver_inner = int(solver_inner)
     for i in range(3):
         cfg.gravity[i] = float(gravity[i])
     dr = {"activate": False, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "friction": (0.7, 1.3),

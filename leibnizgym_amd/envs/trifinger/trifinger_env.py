@@ -165,6 +165,8 @@ class TrifingerEnv(IsaacEnvBase):
             # with gymapi's default of 2.  "native.substeps" overrides it explicitly.
             substeps=substeps,
             solver_iterations=iterations,
+            # "native.solver_inner" (default 1): passes over the block of all rows that touch the cube per sweep (include/trifinger.h: TfConfig.solver_inner)
+            solver_inner=int(native.get("solver_inner", 1)),
             gravity=c["sim"]["gravity"], domain_randomization=c.get("domain_randomization"),
             # "native.object_size" (x, y, z in metres) / "native.object_density": a general box instead of the 65 mm cube,
             # e.g. [0.02, 0.08, 0.02] / 500 for objects/urdf/cube_multicolor_rrc_phase3.urdf of the reference's assets

@@ -518,7 +518,7 @@ int tf_create(const TfConfig* cfg, tf_handle* out) {
     int d = cfg->task_difficulty;
     if (!(d == -1 || (d >= 1 && d <= 6))) return TF_ERR_DIFFICULTY;
     if (cfg->finger_reach_norm_p != TF_NORM_INF && (cfg->finger_reach_norm_p < 1 || cfg->finger_reach_norm_p > 16)) return TF_ERR_UNSUPPORTED;
-    if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
+    if (cfg->substeps <= 0 || cfg->solver_iterations <= 0 || cfg->solver_inner <= 0 || cfg->control_decimation <= 0 || !(cfg->dt > 0.0f))
         return TF_ERR_INVALID_ARG;
     /* boundary profile (TfModel.wall_z / wall_r, knots of a piecewise-linear r(z) since API 4 - before that: steps of a staircase): the
      * knots must rise strictly and be finite, or the slopes between them are not defined */
@@ -1607,7 +1607,9 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         else cz_apply(cwl[i].r, cwl[i].lam[2], inv_m, inv_I, v, w);
     }
     /* ---- projected Gauss-Seidel ---- */
-    for (int it = 0; it < cfg->solver_iterations; ++it) {
+    /* solver_inner > 1: the block of all rows that touch the cube is visited solver_inner times per sweep, the finger-only rows once (on the last pass) */
+    for (int it = 0; it < cfg->solver_iterations * cfg->solver_inner; ++it) {
+        const int own_rows = ((it + 1) % cfg->solver_inner) == 0;
         /* cube role: finger-cube rows in contact space */
         for (int f = 0; f < 3; ++f) {
             FcRecord* c = &rec[f];
@@ -1630,7 +1632,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             FcRecord* c = &rec[f];
             float* vf = g->vq;
             if (c->active) for (int d = 0; d < 3; ++d) for (int j = 0; j < 3; ++j) vf[j] = FMA(g->fcW[d][j], c->dl[d], vf[j]);
-            for (int t = 0; t < 2; ++t) {             /* fingertip - floor, fingertip - wall */
+            for (int t = 0; t < 2 && own_rows; ++t) { /* fingertip - floor, fingertip - wall */
                 TipContact* tcn = &g->tc[t];
                 if (!tcn->active) continue;
                 for (int d = 0; d < 3; ++d) {
@@ -1640,7 +1642,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                     for (int j = 0; j < 3; ++j) vf[j] = FMA(tcn->W[d][j], dl, vf[j]);
                 }
             }
-            for (int jj = 0; jj < 3; ++jj) {          /* joint limits + velocity limit */
+            for (int jj = 0; jj < 3 && own_rows; ++jj) {   /* joint limits + velocity limit */
                 static const int col[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
                 static const int diag[3] = {0, 3, 5};
                 const float* Mi = g->k.Minv;

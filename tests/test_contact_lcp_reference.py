@@ -287,8 +287,9 @@ def test_truncation_residual_of_the_shipped_sweeps_on_many_states(oracle):
     cases = [make_case(rng) for _ in range(n)]
     f32 = dict(dtype=torch.float32)
     res = {}
-    for sweeps in (8, 16):
-        eng = T.engine(oracle, n=n, dt=H, substeps=1, solver_iterations=sweeps)
+    for sweeps in (8, 16, (8, 2)):                       # (8, 2): solver_iterations 8 with solver_inner 2 - the cube block twice per sweep (API 6)
+        it, inner = sweeps if isinstance(sweeps, tuple) else (sweeps, 1)
+        eng = T.engine(oracle, n=n, dt=H, substeps=1, solver_iterations=it, solver_inner=inner)
         ref = T.engine(oracle, n=n, dt=H, substeps=1, solver_iterations=2048)
         for k, name in enumerate(("q", "qd", "cube", "tau")):
             getattr(eng, name).copy_(torch.tensor(np.array([c[k] for c in cases]).T, **f32))
@@ -310,3 +311,6 @@ def test_truncation_residual_of_the_shipped_sweeps_on_many_states(oracle):
     assert len(res[8]) >= 80
     assert np.median(res[8]) < 5e-3 and np.percentile(res[8], 90) < 8e-2 and res[8].max() < 1.0
     assert np.median(res[16]) < np.median(res[8]) and np.percentile(res[16], 90) < np.percentile(res[8], 90)     # more sweeps, less residual
+    # solver_inner = 2 (what the block study of round 4 pointed at: the unresolved part is the block of all rows that touch the cube): well below the 8 plain
+    # sweeps - and no better than 16 plain sweeps, which cost the same in this kernel (every pass is an exchange between the cube role and the finger roles)
+    assert np.percentile(res[(8, 2)], 90) < 0.6 * np.percentile(res[8], 90) and np.median(res[(8, 2)]) < np.median(res[8])

@@ -75,7 +75,8 @@ def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_na
 
 @pytest.mark.parametrize("extra", [dict(substeps=1, solver_iterations=4), dict(substeps=3, solver_iterations=1),
                                    dict(dt=0.01, solver_iterations=12, control_decimation=3),
-                                   dict(gravity=(0.3, -0.2, -3.7)), dict(normalize_action=False, apply_safety_damping=False)])
+                                   dict(gravity=(0.3, -0.2, -3.7)), dict(normalize_action=False, apply_safety_damping=False),
+                                   dict(solver_inner=2), dict(solver_iterations=3, solver_inner=3, substeps=1)])
 def test_solver_and_stepping_settings(hip, oracle, extra):
     """Loop bounds and stepping parameters other than the Hydra defaults (the env's own default dict asks for 4 position
     iterations; the reference's tests use control_decimation 5): still bit for bit."""

@@ -15,10 +15,13 @@ if args and args[0].endswith(".so"):
     lib = _capi.TfLib(os.path.abspath(args.pop(0)))
 sizes = [int(a) for a in args] or [8192, 16384, 32768, 65536]
 SETTLE = int(os.environ.get("SETTLE", "400"))
+SOLVER = [int(x) for x in os.environ.get("SOLVER", "8,1").split(",")]      # SOLVER=16,1 / SOLVER=8,2: solver_iterations, solver_inner
 for asym in (True, False):
     for n in sizes:
         for variant in ("narrow", "wide"):
-            eng = TrifingerEngine(make_config(lib, n, seed=7, **bench.workload_kwargs(asym)), device="cuda:0", lib=lib)
+            kw = bench.workload_kwargs(asym)
+            kw.update(solver_iterations=SOLVER[0], solver_inner=SOLVER[1])
+            eng = TrifingerEngine(make_config(lib, n, seed=7, **kw), device="cuda:0", lib=lib)
             eng.kernel_variant = variant
             eng.reset()
             eng.steps.copy_(torch.randint(0, 750, (n,), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(11)))      # spread the time-outs, as bench.py does
