@@ -204,7 +204,11 @@ typedef struct TfModel {
      * a vertical ring below wall_z[0], the flaring cone of the stage between the knots, nothing above wall_z[3]; from the 40 convex
      * pieces of meshes/convex_table_boundary/convex_*.obj (high_table_boundary.urdf:20-259) via tests/golden/model.npz: mid-way
      * between the chords and the corners of the polygonal inner surface.  The FINGERTIP contact follows the tilt of the surface (normal (c n_h, s) with
-     * c, s the cosine and sine of the slope angle of the segment, gap = distance to the tilted surface); the cube corners keep the horizontal normal. */
+     * c, s the cosine and sine of the slope angle of the segment, gap = distance to the tilted surface).  The CUBE CORNERS see the same profile - the radius
+     * at the corner's height - with the HORIZONTAL normal at every height: THIS IS THE MODEL, not an omission pending repair.  A cube that lies on the table
+     * meets the boundary with its lower corners, below the first knot, where the two normals coincide; a corner on the cone (a lifted or tumbling cube at the
+     * boundary: 0.007 % of the env-steps of the bench workload) is stopped radially and gets no vertical impulse where the surface normal would give
+     * 0.57 |dv_r| (tests/test_contact_scenarios.py: test_cube_corner_on_the_cone_keeps_the_horizontal_normal, test_random_actions_rarely_put_...). */
     float wall_r[4], wall_z[4];
     /* materials: PhysX "average" combine of trifinger_env.py:364-365,876-878,914-915,934-936 */
     float mu_finger_cube, mu_cube_floor, mu_tip_floor, mu_cube_wall, mu_tip_wall, mu_finger_finger;
