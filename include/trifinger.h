@@ -112,7 +112,15 @@ enum {
     TF_S_LAM_CW = 144,   /* 12 cube corner i against the boundary wall at [3i..3i+2]: normal, tangent, +z          */
     TF_S_CW_FACE = 156,  /*  1 feature those rows belong to: cube face 1..6 + 8 x which pair of its corners is the lower one (0..3) + 32 x order
                           *    inside that pair (nearer corner first); 0 while no corner touches the boundary (TF_S_LAM_CW then undefined) */
-    TF_STATE_ROWS = 157
+    /* Samples of the env's NEXT reset (API 6; an implementation choice like the warm start, not algorithmic traffic).  The step that flags an env for
+     * reset (time-out, non-finite state) draws the object pose and the goal of that reset at its END - on the finger wavefronts, which have finished by
+     * then - and the reset, which sits at the start of every launch's critical path, only loads them.  The draws are functions of (seed, global env id,
+     * reset count), so the values are the ones the reset would have drawn itself: TF_S_NEXT_TAG holds reset count + 1 as an integer bit pattern
+     * (0: nothing stored), and a reset whose count does not match (goal resets in between, a reset flagged from outside) draws as before. */
+    TF_S_NEXT_OBJ = 157, /*  4 object of the next reset: x, y relative to the stage centre, yaw quaternion z, w      */
+    TF_S_NEXT_GOAL = 161,/* 10 goal of the next reset: position relative to the stage centre (3), orientation (4), angular velocity (3) */
+    TF_S_NEXT_TAG = 171, /*  1 reset count + 1 the two were drawn for, as a uint32 bit pattern                       */
+    TF_STATE_ROWS = 172
 };
 #define TF_NUM_DR 14
 enum { TF_DR_CUBE_MASS = 0, TF_DR_CUBE_SIZE = 1, TF_DR_FRICTION = 2, TF_DR_MOTOR = 3, TF_DR_LINK_MASS = 4, TF_DR_RESTITUTION = 5,
@@ -122,7 +130,7 @@ enum { TF_DR_CUBE_MASS = 0, TF_DR_CUBE_SIZE = 1, TF_DR_FRICTION = 2, TF_DR_MOTOR
 #define TF_DR_NEUTRAL(j) (((j) >= TF_DR_BASE_POS && (j) < TF_DR_FRICTION_ROBOT) ? 0.0f : 1.0f)
 #define TF_NORM_INF (-1)      /* finger_reach_norm_p: the maximum norm */
 /* Largest num_envs of one handle: the kernels address state[TF_STATE_ROWS][num_envs] with 32-bit byte offsets
- * (157 * 2 Mi * 4 B = 1.3 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
+ * (172 * 2 Mi * 4 B = 1.4 GB).  Larger populations are sharded over several handles / GPUs (env_id_offset). */
 #define TF_MAX_ENVS 2097152
 
 #define TF_OBS_DIM_BASE 32    /* 9 + 9 + 7 + 7; the action slot (9 or 18) follows  trifinger_env.py:280-286 */

@@ -14,7 +14,7 @@ import os
 TF_API_VERSION = 6
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
-TF_STATE_ROWS = 157
+TF_STATE_ROWS = 172
 TF_NUM_DR = 14
 DR_BASE_POS, DR_STAGE_POS, DR_FRICTION_ROBOT, DR_FRICTION_OBJECT, DR_FRICTION_STAGE = 6, 9, 11, 12, 13
 
@@ -46,6 +46,7 @@ S_GOAL_P, S_GOAL_Q, S_GOAL_W, S_TIP_P, S_TAU = 31, 34, 38, 41, 50
 S_PREV_OBJ_P, S_PREV_OBJ_Q, S_FT, S_DR = 59, 62, 66, 84
 # warm-start rows of the contact solver
 S_LAM_FC, S_FC_LINK, S_LAM_TF, S_LAM_TW, S_LAM_CF, S_CF_FACE, S_LAM_CW, S_CW_FACE = 98, 110, 113, 122, 131, 143, 144, 156
+S_NEXT_OBJ, S_NEXT_GOAL, S_NEXT_TAG = 157, 161, 171
 
 INFO_POS_COUNT, INFO_ORI_COUNT, INFO_SUCCESS_MEAN, INFO_NUM_RESETS, INFO_NUM_NONFINITE = 6, 7, 8, 9, 10
 

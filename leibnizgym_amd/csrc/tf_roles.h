@@ -60,13 +60,14 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 #define L_INIT 147                      //   3: bias of finger f; after the last sweep the normal impulse of finger f
 #define L_DR0 32                        //  14: launch prologue only (behind the action tile, before any physics slot is live): the domain-randomisation rows of the
                                         //      env, loaded once by the cube role and handed to the three finger roles through barrier #1
-#define LDS_SLOTS 150
+#define LDS_SLOTS 153                   //   (4 workgroups x 153 x 256 B = 153 KB of the CU's 160 KB)
 #define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
 #define LDS_SLOTS_BOX 156
 // post phase (aliases the above)
 #define L_XCH (MAX_STATES)              //  18: fingertip position (3) and previous fingertip position (3) of finger f at 6 f
 #define L_NAN (MAX_STATES + 18)         //   4: non-finite flag of each role
-static_assert(MAX_STATES + 22 <= LDS_SLOTS, "post-phase LDS map");
+#define L_VSQ (MAX_STATES + 22)         //   9: squared fingertip speed components of finger f at 3 f (finger_move_penalty: formed where the fingertips are)
+static_assert(MAX_STATES + 31 <= LDS_SLOTS, "post-phase LDS map");
 #define LD(slot) lds[(slot) * WAVE + lane]
 
 struct Ctx {
@@ -101,17 +102,20 @@ struct Ctx {
 // ---- cooperative tile moves by the whole workgroup -----------------------------------------------------------------
 // store a [n_valid][W] tile staged in LDS as lds[env * W + j] to dst[(wave_first + env) * W + j]: dwordx4, coalesced; the tile
 // is a raw buffer of total4 * 16 bytes, so the hardware range check drops the lanes past its end
-template <int W>
+// NTH: the threads that take part - all four wavefronts (NT), or the three finger wavefronts (NT_F: threads 0..191; the tiles of the post phase,
+// which the cube wavefront - the last to finish, it evaluates the rewards - leaves to the fingers)
+#define NT_F 192
+template <int W, int NTH = NT>
 DEV void coop_store_tile(gfloat* __restrict__ dst, const float* lds, const Ctx& cx) {
     const unsigned total = (unsigned)(cx.n_valid * W);
     gfloat* base = dst + (size_t)cx.wave_first * (size_t)W;
     const unsigned total4 = total >> 2;
     const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(total4 * 16u), 0x00020000);
-    constexpr int ITER = (16 * W + NT - 1) / NT;
+    constexpr int ITER = (16 * W + NTH - 1) / NTH;
     const unsigned last4 = total4 - 1u;
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
-        const unsigned idx = (unsigned)cx.tid + (unsigned)(NT * k);
+        const unsigned idx = (unsigned)cx.tid + (unsigned)(NTH * k);
         const unsigned src = (idx < last4) ? idx : last4;
         u32x4 vv = *reinterpret_cast<const u32x4*>(&lds[src * 4u]);
         __builtin_amdgcn_raw_buffer_store_b128(vv, tile, idx * 16u, 0, 0);
@@ -120,17 +124,17 @@ DEV void coop_store_tile(gfloat* __restrict__ dst, const float* lds, const Ctx& 
     if (tail < total) base[tail] = lds[tail];
 }
 // the same for a [n_valid][W] global tile whose rows sit in LDS with row stride LS >= W (obs = first columns of states)
-template <int W, int LS>
+template <int W, int LS, int NTH = NT>
 DEV void coop_store_tile_strided(gfloat* __restrict__ dst, const float* lds, const Ctx& cx) {
     const unsigned total = (unsigned)(cx.n_valid * W);
     gfloat* base = dst + (size_t)cx.wave_first * (size_t)W;
     const unsigned total4 = total >> 2;
     const __amdgpu_buffer_rsrc_t tile = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(total4 * 16u), 0x00020000);
-    constexpr int ITER = (16 * W + NT - 1) / NT;
+    constexpr int ITER = (16 * W + NTH - 1) / NTH;
     const unsigned lastf = total - 1u;
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
-        const unsigned idx = (unsigned)cx.tid + (unsigned)(NT * k);
+        const unsigned idx = (unsigned)cx.tid + (unsigned)(NTH * k);
         u32x4 vv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -202,20 +206,25 @@ DEV void normalize_quat(const float n[4], float q[4]) {                         
 }
 // the CuboidalObject numbers of the reference (envs/trifinger/utils.py:122-131) come with the model: TfModel.obj_*
 
-template <bool EXT>
-DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, const float dr[TF_NUM_DR], float gp[3], float gq[4], float gw[3]) {   // trifinger_env.py:1194-1265
-    int d = P.task_difficulty;
+// the goal of a reset in two independent halves (trifinger_env.py:1194-1265): position relative to the stage centre + the yaw quaternion of difficulty -1
+// (identity otherwise) from the RNG_GOAL_POS block; the orientation of difficulties 4..6 and the angular velocity from their own blocks
+DEV void sample_goal_pos(const DevParams& P, uint32_t gid, uint32_t count, float xyz[3], float quat[4]) {
+    const int d = P.task_difficulty;
     float u[4];
     rng4(P, gid, count, RNG_GOAL_POS, u);
     float x = 0.0f, y = 0.0f, z;
-    float quat[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    quat[0] = 0.0f; quat[1] = 0.0f; quat[2] = 0.0f; quat[3] = 1.0f;
     if (d == -1 || d == 1 || d == 3 || d == 4 || d == 5) sample_xy(u[0], u[1], P.m.obj_max_com_dist, x, y);
     if (d == -1 || d == 1) z = P.m.obj_min_height;
     else if (d == 2 || d == 6) z = P.m.obj_min_height + 0.05f;
     else if (d == 3) z = P.m.obj_span_min_height * u[2] + P.m.obj_min_height;
     else z = P.m.obj_span_radius * u[2] + P.m.obj_radius_3d;
     if (d == -1) sample_yaw_quat(u[3], quat);
-    if (d == 4 || d == 5 || d == 6) {
+    xyz[0] = x; xyz[1] = y; xyz[2] = z;
+}
+DEV bool goal_has_random_quat(const DevParams& P) { const int d = P.task_difficulty; return d == 4 || d == 5 || d == 6; }
+DEV void sample_goal_rot(const DevParams& P, uint32_t gid, uint32_t count, float quat[4], float gw[3]) {      // quat: written for difficulties 4..6 only
+    if (goal_has_random_quat(P)) {
         float v[4], n[4];
         rng4(P, gid, count, RNG_GOAL_QUAT, v);
         box_muller(v[0], v[1], n[0], n[1]);
@@ -234,9 +243,22 @@ DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, const flo
     } else {
         gw[0] = 0.0f; gw[1] = 0.0f; gw[2] = 0.0f;
     }
-    gp[0] = EXT ? x + dr[TF_DR_STAGE_POS] : x; gp[1] = EXT ? y + dr[TF_DR_STAGE_POS + 1] : y; gp[2] = z;      // goals move with the stage
+}
+// raw[0..2] position relative to the stage centre, raw[3..6] orientation, raw[7..9] angular velocity -> the goal rows (goals move with the stage)
+template <bool EXT>
+DEV void goal_from_raw(const float raw[10], const float dr[TF_NUM_DR], float gp[3], float gq[4], float gw[3]) {
+    gp[0] = EXT ? raw[0] + dr[TF_DR_STAGE_POS] : raw[0]; gp[1] = EXT ? raw[1] + dr[TF_DR_STAGE_POS + 1] : raw[1]; gp[2] = raw[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gq[i] = quat[i];
+    for (int i = 0; i < 4; ++i) gq[i] = raw[3 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gw[i] = raw[7 + i];
+}
+template <bool EXT>
+DEV void sample_goal(const DevParams& P, uint32_t gid, uint32_t count, const float dr[TF_NUM_DR], float gp[3], float gq[4], float gw[3]) {
+    float raw[10];
+    sample_goal_pos(P, gid, count, &raw[0], &raw[3]);
+    sample_goal_rot(P, gid, count, &raw[3], &raw[7]);
+    goal_from_raw<EXT>(raw, dr, gp, gq, gw);
 }
 
 // per-env domain-randomisation factors drawn at a reset (build-defined): scale = lo + (hi - lo) u
@@ -380,6 +402,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     float fc_code = 0.0f;
     if (MODE & M_SIM) fc_code = LDST(TF_S_FC_LINK + f);
     if (MODE & M_RESETS) { fl_reset = P.reset_buf[(unsigned)cx.i]; fl_count = P.reset_count[(unsigned)cx.i]; }
+    // the fused step draws the samples of an env's NEXT reset at its end (last block of this role): what it needs to know which envs will be flagged
+    constexpr bool PRESAMPLE = !IS_RESET && (MODE & M_RESETS) && (MODE & M_SIM) && (MODE & M_POST) && (MODE & M_FINISH);
+    int fl_steps = 0;
+    uint8_t fl_goal_reset = 0;
+    if (PRESAMPLE) { fl_steps = (int)P.steps[(unsigned)cx.i]; fl_goal_reset = P.goal_reset_buf[(unsigned)cx.i]; }
     if (MODE & M_ACT_RAND) draw_action_tile<A>(P, sa, lds, cx);
     else if (MODE & M_ACT_IN) coop_load_tile<A>(action, lds, cx);
     else if (MODE & (M_RESETS | M_TORQUE | M_POST)) coop_load_tile<A>((const float*)P.action_buf, lds, cx);
@@ -1014,6 +1041,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     // =================================================================================================================
     // post: fingertip state, observation slots of this finger
     // =================================================================================================================
+    bool f_guarded = false;                                    // NaN guard of the env (set in the post phase; read by the presampler below)
     if (MODE & M_POST) {
         FK pk;
         float tips[13];
@@ -1044,6 +1072,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         BAR();                                                  // P1
         STAMP(32);
         const bool guarded = (LD(L_NAN) + LD(L_NAN + 1) + LD(L_NAN + 2) + LD(L_NAN + 3)) != 0.0f;
+        f_guarded = guarded;
         if (__builtin_expect(guarded, 0)) {                     // park the env at the default pose (it is flagged for reset)
 #pragma unroll
             for (int j = 0; j < 3; ++j) { q[j] = m.q_default[j]; qd[j] = 0.0f; }
@@ -1061,6 +1090,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
         const bool nrm = P.normalize_obs != 0;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { LD(L_XCH + 6 * f + j) = tips[j]; LD(L_XCH + 6 * f + 3 + j) = tip_prev[j]; }
+        if (!IS_RESET) {                                        // this finger's terms of the finger_move_penalty sum (rewards.py:165-184): the cube role adds them up in order
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const float vel = (tips[j] - tip_prev[j]) / sa.rc.dt; LD(L_VSQ + 3 * f + j) = vel * vel; }
+        }
         float* row = &lds[lane * TW];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1093,7 +1126,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             STAMP(33);
             BAR();                                              // P3: states tile complete
             STAMP(34);
-            coop_store_tile<SD>(P.states, lds, cx);
+            coop_store_tile<SD, NT_F>(P.states, lds, cx);
             if (P.dr_obs_noise > 0.0f) {
                 BAR();                                          // P4: states tile stored; obs noise goes on top of slots 0..24
                 float nz[28];
@@ -1112,7 +1145,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
                 BAR();                                          // P5
             }
-            coop_store_tile_strided<OD, SD>(P.obs, lds, cx);
+            coop_store_tile_strided<OD, SD, NT_F>(P.obs, lds, cx);
         } else {
             if (P.dr_obs_noise > 0.0f) {
                 float nz[28];
@@ -1131,13 +1164,55 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
             }
             BAR();                                              // P3
-            coop_store_tile<OD>(P.obs, lds, cx);
+            coop_store_tile<OD, NT_F>(P.obs, lds, cx);
         }
     }
     // ---- state rows of this finger ----
     if (MODE & (M_RESETS | M_SIM | M_POST)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { STST(TF_S_Q + 3 * f + j, q[j]); STST(TF_S_QD + 3 * f + j, qd[j]); }
+    }
+    // ---- the samples of the NEXT reset of an env this step flags (time-out, non-finite state): drawn HERE, where the finger wavefronts have finished and
+    // the cube wavefront still evaluates rewards and statistics - one third each: finger 0 the object pose and the tag, finger 1 the goal position,
+    // finger 2 the goal orientation and angular velocity (include/trifinger.h: TF_S_NEXT_*; the cube role's reset block loads them) ----
+    if (PRESAMPLE) {
+        const int steps_now = (rflag ? 0 : fl_steps) + 1;                                        // what the cube role writes to steps[] at the end of this step
+        const bool will_reset = f_guarded || (P.episode_length > 0 && steps_now >= P.episode_length);    // = reset_buf after this step
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(will_reset) != 0ull, 0)) {
+            const uint32_t count = fl_count + (rflag ? 1u : 0u) + ((fl_goal_reset != 0) ? 1u : 0u);         // reset_count after this step's resets
+            if (f == 0) {
+                if (P.object_reset_type == TF_RESET_RANDOM) {
+                    float u[4], ox, oy, oq[4];
+                    rng4(P, gid, count, RNG_OBJECT, u);
+                    sample_xy(u[0], u[1], m.obj_max_com_dist, ox, oy);
+                    sample_yaw_quat(u[2], oq);
+                    if (will_reset) { STST(TF_S_NEXT_OBJ + 0, ox); STST(TF_S_NEXT_OBJ + 1, oy); STST(TF_S_NEXT_OBJ + 2, oq[2]); STST(TF_S_NEXT_OBJ + 3, oq[3]); }
+                }
+                if (will_reset) STST(TF_S_NEXT_TAG, __builtin_bit_cast(float, count + 1u));
+            } else if (f == 1) {
+                float xyz[3], yq[4];
+                sample_goal_pos(P, gid, count, xyz, yq);
+                if (will_reset) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) STST(TF_S_NEXT_GOAL + j, xyz[j]);
+                    if (!goal_has_random_quat(P)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) STST(TF_S_NEXT_GOAL + 3 + j, yq[j]);
+                    }
+                }
+            } else {
+                float rq[4] = {0.0f, 0.0f, 0.0f, 1.0f}, gwn[3];
+                sample_goal_rot(P, gid, count, rq, gwn);
+                if (will_reset) {
+                    if (goal_has_random_quat(P)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) STST(TF_S_NEXT_GOAL + 3 + j, rq[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) STST(TF_S_NEXT_GOAL + 7 + j, gwn[j]);
+                }
+            }
+        }
     }
     STAMP(35);
     STAMPV(40, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID
@@ -1325,6 +1400,21 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         uint32_t count = fl_count;
         // the goal rows are only WRITTEN here (sample_goal fills every component; stored under rflag || gflag); the post phase reads them back
         float gp[3] = {0.0f, 0.0f, 0.0f}, gq[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gw[3] = {0.0f, 0.0f, 0.0f};
+        // The samples of this reset were drawn at the END of the step that flagged it, by the finger wavefronts (TF_S_NEXT_*; the finger role's last
+        // block): when the tag says they belong to this reset count they are loaded, and the ~600 instructions of Philox rounds, Box-Muller and
+        // sine / cosine polynomials stay off the critical path of the launch (a launch ends with its slowest workgroup, and at any size some
+        // workgroup holds a time-out: 1.4 us at 8192 envs, 2.5 us at 65536).  Same values either way: the draws are functions of (seed, env, count).
+        float nx_obj[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nx_goal[10] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        bool have = false;
+        if (!IS_RESET && __builtin_amdgcn_ballot_w64(rflag) != 0ull) {      // wave-uniform: rows are read by the wavefronts that hold a reset
+            const uint32_t tag = __builtin_bit_cast(uint32_t, LDST(TF_S_NEXT_TAG));
+            have = rflag && (tag == count + 1u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nx_obj[j] = LDST(TF_S_NEXT_OBJ + j);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) nx_goal[j] = LDST(TF_S_NEXT_GOAL + j);
+        }
+        const bool draw_now = __builtin_amdgcn_ballot_w64(rflag && !have) != 0ull;      // wave-uniform: some lane's reset has no stored samples
         if (rflag) {
             if (P.dr_enable) draw_dr<EXT>(P, gid, count, dr);
             if (P.object_reset_type == TF_RESET_DEFAULT) {
@@ -1333,16 +1423,29 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
             } else if (P.object_reset_type == TF_RESET_RANDOM) {
-                float u[4];
-                rng4(P, gid, count, RNG_OBJECT, u);
-                sample_xy(u[0], u[1], m.obj_max_com_dist, cp[0], cp[1]);
-                if (EXT) { cp[0] = cp[0] + dr[TF_DR_STAGE_POS]; cp[1] = cp[1] + dr[TF_DR_STAGE_POS + 1]; }     // spawn relative to the stage
+                float ox = nx_obj[0], oy = nx_obj[1], oq[4] = {0.0f, 0.0f, nx_obj[2], nx_obj[3]};
+                if (draw_now) {
+                    float u[4], tx, ty, tq[4];
+                    rng4(P, gid, count, RNG_OBJECT, u);
+                    sample_xy(u[0], u[1], m.obj_max_com_dist, tx, ty);
+                    sample_yaw_quat(u[2], tq);
+                    ox = have ? ox : tx; oy = have ? oy : ty; oq[2] = have ? oq[2] : tq[2]; oq[3] = have ? oq[3] : tq[3];
+                }
+                cp[0] = EXT ? ox + dr[TF_DR_STAGE_POS] : ox; cp[1] = EXT ? oy + dr[TF_DR_STAGE_POS + 1] : oy;      // spawn relative to the stage
                 cp[2] = m.obj_min_height * dr[1];
-                sample_yaw_quat(u[2], cq);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cq[k] = oq[k];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { cv[k] = 0.0f; cw[k] = 0.0f; }
             }
-            sample_goal<EXT>(P, gid, count, dr, gp, gq, gw);
+            if (draw_now) {
+                float raw[10];
+                sample_goal_pos(P, gid, count, &raw[0], &raw[3]);
+                sample_goal_rot(P, gid, count, &raw[3], &raw[7]);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) nx_goal[j] = have ? nx_goal[j] : raw[j];
+            }
+            goal_from_raw<EXT>(nx_goal, dr, gp, gq, gw);
             count = count + 1u;
 #pragma unroll
             for (int j = 0; j < 12; ++j) { lam_cf[j] = 0.0f; lam_cw[j] = 0.0f; }
@@ -2209,7 +2312,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             {
                 float s = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) { float vel = (tips[j] - tip_prev[j]) / rc.dt; s = s + vel * vel; }
+                for (int j = 0; j < 9; ++j) s = s + LD(L_VSQ + j);      // ((tips[j] - tip_prev[j]) / dt)^2, formed by the finger roles
                 r[1] = rc.c_move_pen * s;
             }
             if (!WIDE) object_terms();
@@ -2245,17 +2348,13 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             }
             st.succ += (cx.valid && succ) ? 1.0f : 0.0f;
         }
+        STAMP(36);
         stats_begin(P, st, lane, tk);
-        if (ASYM) {
-            coop_store_tile<SD>(P.states, lds, cx);
-            if (P.dr_obs_noise > 0.0f) {
-                BAR();                                          // P4
-                add_noise();
-                BAR();                                          // P5
-            }
-            coop_store_tile_strided<OD, SD>(P.obs, lds, cx);
-        } else {
-            coop_store_tile<OD>(P.obs, lds, cx);
+        STAMP(37);
+        if (ASYM && P.dr_obs_noise > 0.0f) {                    // (the tiles themselves leave through the three finger wavefronts: NT_F)
+            BAR();                                              // P4
+            add_noise();
+            BAR();                                              // P5
         }
     }
     // ---- state rows of the cube role; the moving goal advances AFTER the step's observations and rewards used its pose
@@ -2286,6 +2385,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) STST(TF_S_GOAL_Q + j, gq2[j]);
     }
+    STAMP(38);
     if (MODE & M_FINISH) {                                      // env_base.py:391-399
         if (cx.valid) {
             int sN = c_steps + 1;
@@ -2295,6 +2395,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             P.dones[(unsigned)cx.i] = (uint8_t)(rb && c_goal_reset);
         }
     }
+    STAMP(39);
     if (MODE & M_POST) stats_end(P, lane, tk);
     STAMP(35);
     STAMPV(40, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID

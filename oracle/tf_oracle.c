@@ -1844,8 +1844,8 @@ static void normalize_quat(const float n[4], float q[4]) {
 #define CUBE_MIN_HEIGHT 0.0325f
 #define CUBE_MAX_HEIGHT 0.1f
 
-/* trifinger_env.py:1194-1265 */
-static void sample_goal(const struct TfHandle_* h, uint32_t gid, uint32_t count, Env* e) {
+/* trifinger_env.py:1194-1265; the position relative to the stage centre (raw[0..2]), orientation (raw[3..6]), angular velocity (raw[7..9]) */
+static void sample_goal_raw(const struct TfHandle_* h, uint32_t gid, uint32_t count, float raw[10]) {
     const TfConfig* c = &h->cfg;
     int d = c->task_difficulty;
     float u[4];
@@ -1872,12 +1872,37 @@ static void sample_goal(const struct TfHandle_* h, uint32_t gid, uint32_t count,
         box_muller(v[2], v[3], &n[2], &n[3]);
         float nrm = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
         float mag = n[3] * c->goal_rotation_rate_magnitude;
-        for (int i = 0; i < 3; ++i) e->gw[i] = mag * (n[i] / nrm);
+        for (int i = 0; i < 3; ++i) raw[7 + i] = mag * (n[i] / nrm);
     } else {
-        e->gw[0] = 0.0f; e->gw[1] = 0.0f; e->gw[2] = 0.0f;
+        raw[7] = 0.0f; raw[8] = 0.0f; raw[9] = 0.0f;
     }
-    e->gp[0] = h->ext ? x + e->dr[TF_DR_STAGE_POS] : x; e->gp[1] = h->ext ? y + e->dr[TF_DR_STAGE_POS + 1] : y; e->gp[2] = z;   /* goals move with the stage */
-    for (int i = 0; i < 4; ++i) e->gq[i] = quat[i];
+    raw[0] = x; raw[1] = y; raw[2] = z;
+    for (int i = 0; i < 4; ++i) raw[3 + i] = quat[i];
+}
+static void sample_goal(const struct TfHandle_* h, uint32_t gid, uint32_t count, Env* e) {
+    float raw[10];
+    sample_goal_raw(h, gid, count, raw);
+    e->gp[0] = h->ext ? raw[0] + e->dr[TF_DR_STAGE_POS] : raw[0]; e->gp[1] = h->ext ? raw[1] + e->dr[TF_DR_STAGE_POS + 1] : raw[1]; e->gp[2] = raw[2];   /* goals move with the stage */
+    for (int i = 0; i < 4; ++i) e->gq[i] = raw[3 + i];
+    for (int i = 0; i < 3; ++i) e->gw[i] = raw[7 + i];
+}
+/* The samples of the env's NEXT reset, formed at the end of the fused step that flags it (include/trifinger.h: TF_S_NEXT_*).  The kernels load them at the
+ * reset when the tag matches; the values are what the reset draws itself, so this restatement only has to WRITE the same rows at the same time. */
+static void presample_next_reset(const struct TfHandle_* h, int i) {
+    const TfConfig* c = &h->cfg;
+    const uint32_t gid = (uint32_t)(c->env_id_offset + i), count = h->buf.reset_count[i];
+    if (c->object_reset_type == TF_RESET_RANDOM) {
+        float u[4], xy[2], q[4];
+        rng4(c->seed, gid, count, RNG_OBJECT, u);
+        sample_xy(u[0], u[1], c->model.obj_max_com_dist, &xy[0], &xy[1]);
+        sample_yaw_quat(u[2], q);
+        ST(h, TF_S_NEXT_OBJ + 0, i) = xy[0]; ST(h, TF_S_NEXT_OBJ + 1, i) = xy[1]; ST(h, TF_S_NEXT_OBJ + 2, i) = q[2]; ST(h, TF_S_NEXT_OBJ + 3, i) = q[3];
+    }
+    float raw[10];
+    sample_goal_raw(h, gid, count, raw);
+    for (int j = 0; j < 10; ++j) ST(h, TF_S_NEXT_GOAL + j, i) = raw[j];
+    const uint32_t tag = count + 1u;
+    memcpy(&ST(h, TF_S_NEXT_TAG, i), &tag, sizeof(tag));
 }
 
 /* masked _reset_impl then _goal_reset_impl (env_base.py:370-379; trifinger_env.py:373-440).
@@ -2295,7 +2320,10 @@ static int run_step(tf_handle h, const float* action, int is_reset, int random_a
             post_step_env(h, i, &e, prev_obj, &rc, !is_reset, &local);
             goal_advance(h, &e, nsim * c->substeps, hsub);
             env_store(h, i, &e, 0);          /* the fused step keeps the fingertip wrench of the step to itself: TF_S_FT is split-path state */
-            if (!is_reset) finish_env(h, i);
+            if (!is_reset) {
+                finish_env(h, i);
+                if (h->buf.reset_buf[i]) presample_next_reset(h, i);
+            }
         }
 #pragma omp critical
         stats_add(&total, &local);

@@ -153,11 +153,11 @@ def test_split_path_equals_fused(hip, cfg_name, variant):
         e.post_step()
         e.finish_step()
         torch.cuda.synchronize()
-        # rows 66.. (wrench accumulators) are written by the split path only;
+        # rows 66.. (wrench accumulators) are written by the split path only, rows 157.. (samples of the next reset) by the fused step only;
         # info[9] (number of resets) is only counted by the fused kernel
         a, b = pu.snapshot(engs[0]), pu.snapshot(engs[1])
         a["info"][9] = b["info"][9] = 0.0
-        pu.assert_bit_equal(a, b, f"split vs fused step {t}", skip_rows=slice(66, 84))
+        pu.assert_bit_equal(a, b, f"split vs fused step {t}", skip_rows=[slice(66, 84), slice(157, 172)])
 
 
 def test_full_size_properties(hip):

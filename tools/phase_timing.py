@@ -45,6 +45,8 @@ for s in (0, 1):
 rows += [("to post start", 4 + 12 + 7, 30), ("tip FK / nan flags", 30, 31), ("P1 wait", 31, 32), ("emit tile", 32, 33), ("P3 wait", 33, 34), ("rewards, stores, finish", 34, 35), ("TOTAL", 0, 35)]
 for lab, a, b in rows:
     print(f"  {lab:55s} {d(a, b, 0):9.0f} | {d(a, b, 3):9.0f}")
+print(f"  cube role behind P3: rewards {d(34, 36, 3):.0f} | statistics fold issued {d(36, 37, 3):.0f} | state rows {d(37, 38, 3):.0f} | counters, time-out, dones {d(38, 39, 3):.0f} | "
+      f"statistics fold consumed, end {d(39, 35, 3):.0f}")
 for s in (0, 1):
     b = 4 + 12 * s
     print(f"  sub{s}: barrier wait inside sweeps: finger {v(b + 8, 0):.0f} | cube {v(b + 8, 3):.0f};  cube finger-cube rows {v(b + 10, 3):.0f}; up to the end of the floor rows (incl. W1) {v(b + 11, 3):.0f}")

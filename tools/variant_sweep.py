@@ -21,6 +21,8 @@ for asym in (True, False):
         for variant in ("narrow", "wide"):
             kw = bench.workload_kwargs(asym)
             kw.update(solver_iterations=SOLVER[0], solver_inner=SOLVER[1])
+            if os.environ.get("NO_TIMEOUT"):                  # diagnostic: no time-out resets inside the timed steps (what the reset path of a launch costs)
+                kw.update(episode_length=0)
             eng = TrifingerEngine(make_config(lib, n, seed=7, **kw), device="cuda:0", lib=lib)
             eng.kernel_variant = variant
             eng.reset()
