@@ -1565,57 +1565,13 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             for (int j = 0; j < 3; ++j) { LD(L_POSE_A + j) = cp[j]; LD(L_POSE_B + j) = v[j]; LD(L_POSE_B + 3 + j) = w[j]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) LD(L_POSE_A + 3 + j) = cq[j];
-            // ---- corner contacts of the cube against the arena: built BEFORE S1, in the window in which the finger roles compute their
-            // free motion and this role would only wait ----
+            // ---- corner contacts of the cube against the arena: built here, before S1, in the window in which the finger roles compute their free
+            // motion and this role would only wait.  The 256-register build, whose fingers' free motion is short (one wavefront per SIMD), builds the
+            // FLOOR corners behind S1b instead, in the window in which the finger roles build their records and this role waits again: there it was
+            // the last to arrive at S1 in every substep (-1.0 us at 8192 envs; the 128-register build at 65536: +0.6 us, it keeps them here) ----
             float fr_[12], fDinv[12], fbias[4], flam[12];       // floor corners: arm, 1/D, bias, impulses of rows +z, +x, +y
-            {   // cube vs floor: the four corners of the face that points down most
-                int k = 0;
-                float down[3] = {f_abs(R[6]), f_abs(R[7]), f_abs(R[8])};
-                if (__builtin_expect(box, 0)) {                 // the four lowest corners of a box
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) down[j] = down[j] * hc[j];
-                }
-                float best = down[0];
-                if (down[1] > best) { best = down[1]; k = 1; }
-                if (down[2] > best) { best = down[2]; k = 2; }
-                float rk = (k == 0) ? R[6] : ((k == 1) ? R[7] : R[8]);
-                float sk = (rk > 0.0f) ? -1.0f : 1.0f;
-                const float face = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0));
-                const float keep = (face == cf_face) ? ws : 0.0f;
-                cf_face = face;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float* r = &fr_[3 * c];
-                    cube_corner(R, hc, k, sk, c, r);
-                    float gap = cp[2] + r[2];
-                    fDinv[3 * c] = 0.0f; fDinv[3 * c + 1] = 0.0f; fDinv[3 * c + 2] = 0.0f;
-                    fbias[c] = 0.0f;
-                    flam[3 * c] = 0.0f; flam[3 * c + 1] = 0.0f; flam[3 * c + 2] = 0.0f;
-                    float vn0, barm[9];
-                    if (__builtin_expect(box, 0)) {
-                        float S[6];
-#pragma unroll
-                        for (int e = 0; e < 6; ++e) S[e] = LD(L_POSE_S + e);
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) { float n[3]; box_axis(d, n); box_arm(S, r, n, &barm[3 * d]); }
-                        float n0[3];
-                        box_axis(0, n0);
-                        vn0 = g_vrel(n0, &barm[0], v, w);
-                    } else vn0 = cz_vrel(r, v, w);
-                    if (__builtin_expect(contact_live(m, gap, vn0, h), 1)) {
-                        if (__builtin_expect(box, 0)) {
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) fDinv[3 * c + d] = f_rcp2(FMA(dot3(&barm[3 * d], &barm[3 * d]), inv_I, inv_m));
-                        } else {
-                            fDinv[3 * c] = f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
-                            fDinv[3 * c + 1] = f_rcp2(FMA(FMA(r[2], r[2], r[1] * r[1]), inv_I, inv_m));
-                            fDinv[3 * c + 2] = f_rcp2(FMA(FMA(r[2], r[2], r[0] * r[0]), inv_I, inv_m));
-                        }
-                        fbias[c] = contact_bias(m, gap, vn0, inv_h, 0.0f);
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) flam[3 * c + d] = lam_cf[3 * c + d] * keep;
-                    }
-                }
+            if constexpr (!WIDE) {
+#include "tf_floor_corners.inc"
             }
             bool wall_lane = false;
             bool slot_any[4] = {false, false, false, false};     // wave-uniform: a lane of this wavefront has a live corner in slot c
@@ -1787,6 +1743,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             STAMP(sb_ + 2);
             BAR();                                              // S1b: finger-finger pass done
             STAMP(sb_ + 3);
+            if constexpr (WIDE) {
+#include "tf_floor_corners.inc"
+            }
             STAMP(sb_ + 4);
             BAR();                                              // S3: records published by the finger roles
             STAMP(sb_ + 5);
