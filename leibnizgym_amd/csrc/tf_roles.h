@@ -60,14 +60,15 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 #define L_INIT 147                      //   3: bias of finger f; after the last sweep the normal impulse of finger f
 #define L_DR0 32                        //  14: launch prologue only (behind the action tile, before any physics slot is live): the domain-randomisation rows of the
                                         //      env, loaded once by the cube role and handed to the three finger roles through barrier #1
-#define LDS_SLOTS 153                   //   (4 workgroups x 153 x 256 B = 153 KB of the CU's 160 KB)
+#define LDS_SLOTS 159                   //   (4 workgroups x 159 x 256 B = 159 KB of the CU's 160 KB)
 #define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
-#define LDS_SLOTS_BOX 156
+#define LDS_SLOTS_BOX 159
 // post phase (aliases the above)
 #define L_XCH (MAX_STATES)              //  18: fingertip position (3) and previous fingertip position (3) of finger f at 6 f
 #define L_NAN (MAX_STATES + 18)         //   4: non-finite flag of each role
 #define L_VSQ (MAX_STATES + 22)         //   9: squared fingertip speed components of finger f at 3 f (finger_move_penalty: formed where the fingertips are)
-static_assert(MAX_STATES + 31 <= LDS_SLOTS, "post-phase LDS map");
+#define L_OTERM (MAX_STATES + 31)       //   6: object terms of the reward, parked by the 128-register cube role across P1 / P3 (the 256-register one keeps them in registers)
+static_assert(MAX_STATES + 37 <= LDS_SLOTS, "post-phase LDS map");
 #define LD(slot) lds[(slot) * WAVE + lane]
 
 struct Ctx {
@@ -2201,8 +2202,8 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             LD(L_NAN + 3) = (acc == 0.0f) ? 0.0f : 1.0f;
         }
         // The object terms of the reward (distance kernel, rotation terms, object motion: everything that needs no fingertip) depend on what this role
-        // already holds.  The 256-register instantiation evaluates them HERE, in the window in which it otherwise waits for the finger roles at P1 and P3
-        // (the 128-register one has no room to carry the six results across the two barriers: it evaluates them behind P3); same operations either way.
+        // already holds.  They are evaluated HERE, in the window in which this role otherwise waits for the finger roles at P1 and P3; the 256-register
+        // instantiation carries the six results in registers, the 128-register one parks them in LDS (L_OTERM).
         float o_dist = 0.0f, o_ang = 0.0f, o_r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto object_terms = [&]() __attribute__((always_inline)) {
             const RewardCoef& rc = sa.rc;
@@ -2214,7 +2215,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             o_r[2] = rc.w_rot_delta * (rc.rot_delta_sched * (f_abs(o_ang) - f_abs(ang_prev)));
             o_r[3] = rc.w_move * (o_dist - norm3d(prev_obj, gp));
         };
-        if (WIDE && !IS_RESET) object_terms();
+        if (!IS_RESET) {
+            object_terms();
+            if (!WIDE) { LD(L_OTERM) = o_dist; LD(L_OTERM + 1) = o_ang; LD(L_OTERM + 2) = o_r[0]; LD(L_OTERM + 3) = o_r[1]; LD(L_OTERM + 4) = o_r[2]; LD(L_OTERM + 5) = o_r[3]; }
+        }
         STAMP(31);
         BAR();                                                  // P1
         STAMP(32);
@@ -2227,7 +2231,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             if (cx.valid) P.reset_buf[(unsigned)cx.i] = 1;
             c_reset = true;
             st.nonfinite += cx.valid ? 1.0f : 0.0f;
-            if (WIDE && !IS_RESET) object_terms();      // (the terms of the parked pose: what the evaluation behind P3 sees)
+            if (!IS_RESET) {                                  // (the terms of the parked pose: what an evaluation behind P3 would see)
+                object_terms();
+                if (!WIDE) { LD(L_OTERM) = o_dist; LD(L_OTERM + 1) = o_ang; LD(L_OTERM + 2) = o_r[0]; LD(L_OTERM + 3) = o_r[1]; LD(L_OTERM + 4) = o_r[2]; LD(L_OTERM + 5) = o_r[3]; }
+            }
         }
         const float co = P.clip_obs;
         const bool nrm = P.normalize_obs != 0;
@@ -2274,7 +2281,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                 for (int j = 0; j < 9; ++j) s = s + LD(L_VSQ + j);      // ((tips[j] - tip_prev[j]) / dt)^2, formed by the finger roles
                 r[1] = rc.c_move_pen * s;
             }
-            if (!WIDE) object_terms();
+            if (!WIDE) { o_dist = LD(L_OTERM); o_ang = LD(L_OTERM + 1); o_r[0] = LD(L_OTERM + 2); o_r[1] = LD(L_OTERM + 3); o_r[2] = LD(L_OTERM + 4); o_r[3] = LD(L_OTERM + 5); }
             const float dist = o_dist, ang = o_ang;
             r[2] = o_r[0]; r[3] = o_r[1]; r[4] = o_r[2]; r[5] = o_r[3];
             float total = 0.0f;
