@@ -345,7 +345,9 @@ __device__ unsigned long long g_wg[2048 * 2];     // [workgroup][start, end] in 
 #endif
 #ifndef GEMM_WPE
 #define GEMM_WPE 4       // wavefronts per SIMD the register allocation must leave room for: two workgroups of 8 wavefronts per CU (the k-contiguous scalar-load
-                         // instantiations - first layers, K = 41 / 113 - took 146 registers and ran ONE workgroup per CU: 20.7 -> 16.0 us, 29.2 -> 24.0 us)
+                         // instantiations - first layers, K = 41 / 113 - took 146 registers and ran ONE workgroup per CU: 20.7 -> 16.0 us, 29.2 -> 24.0 us;
+                         // under the hint exactly these two forward instantiations spill 6 registers (28 B of scratch per lane, `make resource-usage-ppo`) and
+                         // are still the faster form; every other instantiation is below 128 registers by itself and is not affected)
 #endif
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
