@@ -50,6 +50,18 @@ int tfp_gemm_tn_partials(const float* A, const float* Y, const float* B, float* 
 int tfp_sum_partials_multi(const void* const* part, void* const* gw, void* const* gb, const int32_t* splits, const int32_t* n1,
                            const int32_t* n2, int32_t n, void* stream);
 
+/* The three products above for n <= 8 INDEPENDENT problems in ONE launch (host arrays of n device pointers / sizes): the layers of the actor and of the
+ * central value network side by side, the eight weight gradients of a minibatch step together.  Each of these products takes 5 - 25 us on its own, of
+ * which the dispatch, the cold first loads and the tail are a third; packed into one grid the next problem's workgroups fill them.  All problems of a call
+ * must be of one kind - the same alignment class (K % 4 == 0 with 16-byte aligned operands, or not), one activation, Y given for all or for none:
+ * otherwise -4, and the caller launches them one by one.  Results are bit-identical to the single-problem entry points (same tiles, same order). */
+int tfp_linear_fwd_group(const void* const* A, const void* const* W, const void* const* bias, void* const* C, const int32_t* M, const int32_t* N,
+                         const int32_t* K, int32_t act, int32_t n, void* stream);
+int tfp_gemm_nn_group(const void* const* A, const void* const* Y /* may be NULL */, const void* const* B, void* const* C, const int32_t* M, const int32_t* N,
+                      const int32_t* K, int32_t n, void* stream);
+int tfp_gemm_tn_partials_group(const void* const* A, const void* const* Y /* may be NULL */, const void* const* B, void* const* part, const int32_t* rows,
+                               const int32_t* N1, const int32_t* N2, int32_t chunk, int32_t n, void* stream);
+
 /* Minibatch gather: dst[k][i, :] = src[k][idx[i], :] for n <= 8 float arrays of widths[k] columns (host arrays of n device pointers);
  * idx: int64 [rows] on the device */
 int tfp_gather_rows(const void* const* src, void* const* dst, const int32_t* widths, int32_t n, const void* idx, int32_t rows, void* stream);

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
+#include <string.h>
 
 #define MAX_A 18
 
@@ -349,23 +350,26 @@ __device__ unsigned long long g_wg[2048 * 2];     // [workgroup][start, end] in 
                          // under the hint exactly these two forward instantiations spill 6 registers (28 B of scratch per lane, `make resource-usage-ppo`) and
                          // are still the faster form; every other instantiation is below 128 registers by itself and is not affected)
 #endif
+// The body of one 64 x 64 output tile: workgroup (bx0, by0, bz0) of an (nx, ny, nz) grid of ONE product.  k_gemm launches a product on its own grid;
+// k_gemm_group packs the grids of up to 8 independent products of the same kind (the two networks' layers; the eight weight gradients of a
+// minibatch step) into one launch: these products are 5 - 25 us each, and a launch costs its dispatch, its cold first loads and its tail, all of
+// which the next product's workgroups now fill.
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
-                                              const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk) {
+__device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                          const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk,
+                                          int bx0, int by0, int bz0, int nx, int ny, int nz) {
     // Role-specialised wavefronts: waves 0-3 multiply (one 32 x 32 accumulator each: LDS reads and MFMAs, nothing else), waves 4-7 stage
     // (global loads, the fix-ups, LDS writes).  A SIMD hosts one of each per workgroup, so the staging instructions of the producers issue
     // in the shadow of the consumers' MFMAs instead of between them; tile t is multiplied out of LDS buffer t & 1 while tile t + 1 is
     // written into the other one, one workgroup barrier per tile.
-    __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];   // [buffer][operand]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave >= 4;
     const int tid = threadIdx.x & 255;                               // index inside the role
     const int wr = (wave & 3) >> 1, wc = wave & 1;
     // Workgroups are handed to the 8 XCDs round-robin in launch order; each XCD has its own L2.  The workgroups that share operand rows
     // (the column blocks of one row block; for the split form: every tile of one row chunk) are renumbered onto ONE XCD.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    int bx = bx0, by = by0, bz = bz0;
     {
-        const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
         const int L = bx + nx * (by + ny * bz), xcd = L & 7, idx = L >> 3;
         if (SPLIT) {
             if ((nz & 7) == 0) { const int w = nx * ny, in = idx % w; bz = (idx / w) * 8 + xcd; by = in / nx; bx = in - by * nx; }
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_W
     const int ntiles = (kend - kbeg + GK - 1) / GK;
     unsigned t_bar = 0u; const unsigned t_start = TNOW(); (void)t_bar; (void)t_start;
 #ifdef GEMM_TIMING
-    const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int wg_lin = bx0 + nx * (by0 + ny * bz0);
     if (threadIdx.x == 0 && wg_lin < 2048) g_wg[2 * wg_lin] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (producer) {
@@ -497,6 +501,43 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_W
 #endif
 }
 
+template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                              const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk) {
+    __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];   // [buffer][operand]
+    gemm_tile<AK, BK, AVEC, BVEC, ACT, DZ, ONES, SPLIT>(S, A, B, bias, Y, C, M, N, K, lda, ldb, chunk, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
+                                                         (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
+}
+
+// up to 8 products of one kind in one launch: workgroup L of the launch belongs to product p = the last one with first[p] <= L; every product's share is
+// padded to a multiple of 8 workgroups so that its tiles meet the XCDs as they do in a launch of their own (the padding workgroups leave at once)
+struct GemmGroup {
+    const float* A[8]; const float* B[8]; const float* bias[8]; const float* Y[8]; float* C[8];
+    int M[8], N[8], K[8], lda[8], ldb[8], chunk[8], nx[8], ny[8], nz[8], first[9], n;
+};
+template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm_group(const GemmGroup g) {
+    __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];
+    const int L = (int)blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) p = (j < g.n && L >= g.first[j]) ? j : p;
+    const int l = L - g.first[p], nx = g.nx[p], ny = g.ny[p], nz = g.nz[p];
+    if (l >= nx * ny * nz) return;                                   // padding (uniform over the workgroup)
+    const int bx = l % nx, t = l / nx, by = t % ny, bz = t / ny;
+    gemm_tile<AK, BK, AVEC, BVEC, ACT, DZ, ONES, SPLIT>(S, g.A[p], g.B[p], g.bias[p], g.Y[p], g.C[p], g.M[p], g.N[p], g.K[p], g.lda[p], g.ldb[p], g.chunk[p],
+                                                         bx, by, bz, nx, ny, nz);
+}
+// host side: append product (grid nx x ny x nz) to the group
+static void group_add(GemmGroup& g, int& total, const float* A, const float* B, const float* bias, const float* Y, float* C, int M, int N, int K, int lda, int ldb,
+                      int chunk, int nx, int ny, int nz) {
+    const int p = g.n;
+    g.A[p] = A; g.B[p] = B; g.bias[p] = bias; g.Y[p] = Y; g.C[p] = C; g.M[p] = M; g.N[p] = N; g.K[p] = K; g.lda[p] = lda; g.ldb[p] = ldb; g.chunk[p] = chunk;
+    g.nx[p] = nx; g.ny[p] = ny; g.nz[p] = nz; g.first[p] = total;
+    total += (nx * ny * nz + 7) & ~7;
+    g.n = p + 1;
+}
+
 // gw[N1, N2] and gb[N1] from `splits` slabs of [N1, N2 + 1] (fixed summation order: deterministic)
 __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int splits,
                                                       int N1, int N2) {
@@ -546,6 +587,70 @@ int tfp_gemm_tn_bias(const float* A, const float* Y, const float* B, float* part
     else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk);
     const int tot = N1 * (N2 + 1);
     hipLaunchKernelGGL(k_sum_partials, dim3((tot + 255) / 256), dim3(256), 0, s, part, gw, gb, splits, N1, N2);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// ---- the same three products for n <= 8 independent problems in ONE launch (host arrays of n device pointers / sizes).  All problems of a call must be of
+// one kind - the same alignment class (K % 4 == 0 and 16-byte aligned operands, or not), the same activation, Y given for all or for none: -4 otherwise
+// (the caller then launches them one by one) ----
+int tfp_linear_fwd_group(const void* const* A, const void* const* W, const void* const* bias, void* const* C, const int32_t* M, const int32_t* N, const int32_t* K,
+                         int32_t act, int32_t n, void* stream) {
+    if (n <= 0 || n > 8) return -1;
+    GemmGroup g; memset(&g, 0, sizeof(g));
+    int total = 0, nvec = 0;
+    for (int p = 0; p < n; ++p) {
+        if (M[p] <= 0 || N[p] <= 0 || K[p] <= 0) return -1;
+        nvec += ((K[p] & 3) == 0 && (((uintptr_t)A[p] | (uintptr_t)W[p]) & 15) == 0) ? 1 : 0;
+        group_add(g, total, (const float*)A[p], (const float*)W[p], (const float*)bias[p], nullptr, (float*)C[p], M[p], N[p], K[p], K[p], K[p], 0,
+                  (N[p] + GT - 1) / GT, (M[p] + GT - 1) / GT, 1);
+    }
+    for (int p = n; p < 9; ++p) g.first[p] = total;
+    if (nvec != 0 && nvec != n) return -4;
+    hipStream_t s = (hipStream_t)stream;
+#define FWDG(V, ACT_) hipLaunchKernelGGL((k_gemm_group<false, false, V, V, ACT_, false, false, false>), dim3(total), dim3(512), 0, s, g)
+    if (nvec) { if (act) FWDG(true, 1); else FWDG(true, 0); }
+    else { if (act) FWDG(false, 1); else FWDG(false, 0); }
+#undef FWDG
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int tfp_gemm_nn_group(const void* const* A, const void* const* Y, const void* const* B, void* const* C, const int32_t* M, const int32_t* N, const int32_t* K,
+                      int32_t n, void* stream) {
+    if (n <= 0 || n > 8) return -1;
+    GemmGroup g; memset(&g, 0, sizeof(g));
+    int total = 0, nvec = 0, ny_ = 0;
+    for (int p = 0; p < n; ++p) {
+        if (M[p] <= 0 || N[p] <= 0 || K[p] <= 0) return -1;
+        const float* y = Y ? (const float*)Y[p] : nullptr;
+        nvec += ((K[p] & 3) == 0 && (((uintptr_t)A[p] | (uintptr_t)y) & 15) == 0) ? 1 : 0;
+        ny_ += y ? 1 : 0;
+        group_add(g, total, (const float*)A[p], (const float*)B[p], nullptr, y, (float*)C[p], M[p], N[p], K[p], K[p], N[p], 0,
+                  (N[p] + GT - 1) / GT, (M[p] + GT - 1) / GT, 1);
+    }
+    for (int p = n; p < 9; ++p) g.first[p] = total;
+    if ((nvec != 0 && nvec != n) || (ny_ != 0 && ny_ != n)) return -4;
+    hipStream_t s = (hipStream_t)stream;
+#define NNG(V, DZ_) hipLaunchKernelGGL((k_gemm_group<false, true, V, false, -1, DZ_, false, false>), dim3(total), dim3(512), 0, s, g)
+    if (nvec) { if (ny_) NNG(true, true); else NNG(true, false); }
+    else { if (ny_) NNG(false, true); else NNG(false, false); }
+#undef NNG
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int tfp_gemm_tn_partials_group(const void* const* A, const void* const* Y, const void* const* B, void* const* part, const int32_t* rows, const int32_t* N1,
+                               const int32_t* N2, int32_t chunk, int32_t n, void* stream) {
+    if (n <= 0 || n > 8 || chunk <= 0 || (chunk % GK) != 0) return -1;
+    GemmGroup g; memset(&g, 0, sizeof(g));
+    int total = 0, ny_ = 0;
+    for (int p = 0; p < n; ++p) {
+        if (rows[p] <= 0 || N1[p] <= 0 || N2[p] <= 0) return -1;
+        const float* y = Y ? (const float*)Y[p] : nullptr;
+        ny_ += y ? 1 : 0;
+        group_add(g, total, (const float*)A[p], (const float*)B[p], nullptr, y, (float*)part[p], N1[p], N2[p] + 1, rows[p], N1[p], N2[p], chunk,
+                  (N2[p] + 1 + GT - 1) / GT, (N1[p] + GT - 1) / GT, (rows[p] + chunk - 1) / chunk);
+    }
+    for (int p = n; p < 9; ++p) g.first[p] = total;
+    if (ny_ != 0 && ny_ != n) return -4;
+    hipStream_t s = (hipStream_t)stream;
+    if (ny_) hipLaunchKernelGGL((k_gemm_group<true, true, false, false, -1, true, true, true>), dim3(total), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm_group<true, true, false, false, -1, false, true, true>), dim3(total), dim3(512), 0, s, g);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 #ifdef GEMM_TIMING

@@ -508,15 +508,13 @@ class PPOTrainer:
         with torch.no_grad():
             la, lc = self.net.actor.layer_list(), self.net.critic.layer_list()
             xc = states if self.net.central else obs
-            ya = pk.mlp_forward(obs, la)
-            yc = pk.mlp_forward(xc, lc)
+            ya, yc = pk.mlp_forward_pair(obs, la, xc, lc)        # layer k of both networks in one launch
             mu, v = ya[-1], yc[-1].squeeze(-1)
             v_coef = 1.0 if self.net.central else 0.5 * c.critic_coef
             _, d_mu, d_v, _ = pk.ppo_loss_and_grads(mu, self.net.log_std, v, act, old_nlp, adv, ret, old_mu, acc["_fused"], c.e_clip, v_coef,
                                                     c.entropy_coef, c.bounds_loss_coef, d_ls_out=self.flat_opt.grad_view(self.net.log_std))
             try:
-                pk.mlp_backward(obs, ya, d_mu, la)
-                pk.mlp_backward(xc, yc, d_v.unsqueeze(-1), lc)
+                pk.mlp_backward_pair(obs, ya, d_mu, la, xc, yc, d_v.unsqueeze(-1), lc)
                 pk.flush_partial_sums()
             finally:
                 pk.discard_partial_sums()                  # nothing stale survives a launch that raised

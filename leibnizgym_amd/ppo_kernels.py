@@ -39,6 +39,12 @@ def load():
         lib.tfp_gemm_tn_bias.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p]
         lib.tfp_gemm_tn_partials.restype = C.c_int
         lib.tfp_gemm_tn_partials.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
+        lib.tfp_linear_fwd_group.restype = C.c_int
+        lib.tfp_linear_fwd_group.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p]
+        lib.tfp_gemm_nn_group.restype = C.c_int
+        lib.tfp_gemm_nn_group.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]
+        lib.tfp_gemm_tn_partials_group.restype = C.c_int
+        lib.tfp_gemm_tn_partials_group.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p]
         lib.tfp_sum_partials_multi.restype = C.c_int
         lib.tfp_sum_partials_multi.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]
         lib.tfp_gather_rows.restype = C.c_int
@@ -253,6 +259,57 @@ def gemm_tn_bias(a, b, y=None, chunk=256, out=None, defer=False):
     return gw, gb
 
 
+# ---- the same products for several independent problems in one launch (tfp_*_group) -------------------------------------------------
+def _vp(ts):
+    return (C.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+def _ip(vals):
+    return (C.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def linear_fwd_group(xs, ws, bs, act):
+    """[act(x @ w.T + b)] for up to 8 independent (x, w, b) in ONE launch; None when the problems are not of one kind (the caller falls back)"""
+    n = len(xs)
+    ys = [torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=torch.float32) for x, w in zip(xs, ws)]
+    rc = load().tfp_linear_fwd_group(_vp(xs), _vp(ws), _vp(bs), _vp(ys), _ip([x.shape[0] for x in xs]), _ip([w.shape[0] for w in ws]),
+                                     _ip([x.shape[1] for x in xs]), int(act), n, _stream(xs[0]))
+    if rc == -4:
+        return None
+    _chk(rc, "tfp_linear_fwd_group")
+    return ys
+
+
+def gemm_nn_group(as_, bs, ys=None):
+    """[(a * elu'(y)) @ b] for up to 8 independent problems in ONE launch (ys: all given or None); None when they are not of one kind"""
+    n = len(as_)
+    cs = [torch.empty(a.shape[0], b.shape[1], device=a.device, dtype=torch.float32) for a, b in zip(as_, bs)]
+    rc = load().tfp_gemm_nn_group(_vp(as_), _vp(ys) if ys is not None else None, _vp(bs), _vp(cs), _ip([a.shape[0] for a in as_]),
+                                  _ip([b.shape[1] for b in bs]), _ip([a.shape[1] for a in as_]), n, _stream(as_[0]))
+    if rc == -4:
+        return None
+    _chk(rc, "tfp_gemm_nn_group")
+    return cs
+
+
+def gemm_tn_bias_group(as_, bs, ys, outs, chunk=256):
+    """the chunk products of up to 8 weight / bias gradients in ONE launch, their sums deferred to flush_partial_sums() (as gemm_tn_bias(defer=True));
+    ys: all given or None.  Returns False when the problems are not of one kind (nothing is queued then)"""
+    n = len(as_)
+    rows = [a.shape[0] for a in as_]
+    n1 = [a.shape[1] for a in as_]
+    n2 = [b.shape[1] for b in bs]
+    parts = [torch.empty(((r + chunk - 1) // chunk) * a1 * (b2 + 1), device=as_[0].device, dtype=torch.float32) for r, a1, b2 in zip(rows, n1, n2)]
+    rc = load().tfp_gemm_tn_partials_group(_vp(as_), _vp(ys) if ys is not None else None, _vp(bs), _vp(parts), _ip(rows), _ip(n1), _ip(n2), int(chunk), n,
+                                           _stream(as_[0]))
+    if rc == -4:
+        return False
+    _chk(rc, "tfp_gemm_tn_partials_group")
+    for k in range(n):
+        _PENDING_SUMS.append((parts[k], outs[k][0], outs[k][1], (rows[k] + chunk - 1) // chunk, n1[k], n2[k]))
+    return True
+
+
 class _MfmaLinear(torch.autograd.Function):
     """act(x W^T + b) with every matrix product on the hand-written fp32 MFMA kernels: forward with bias and ELU fused into the
     store; backward with the ELU derivative formed in the operand loads and the bias gradient as an extra column of the weight
@@ -307,3 +364,51 @@ def mlp_backward(x, ys, gy, layers):
         gemm_tn_bias(gy, inp, yy, out=grad_out, defer=True)
         if k > 0:
             gy = gemm_nn(gy, w, yy)
+
+
+# ---- the actor and the central value network side by side: layer k of both in one launch, all weight gradients in two ----------------------
+def _pairable(la, lc):
+    return len(la) == len(lc) and all(a[2] == c[2] for a, c in zip(la, lc))
+
+
+def mlp_forward_pair(xa, la, xc, lc):
+    """mlp_forward of two networks of the same depth and activations, one grouped launch per layer (4 launches instead of 8 for the trainer's MLPs)"""
+    if not _pairable(la, lc):
+        return mlp_forward(xa, la), mlp_forward(xc, lc)
+    ya, yc = [], []
+    for (wa, ba, act, _), (wc, bc, _, _) in zip(la, lc):
+        out = linear_fwd_group([xa, xc], [wa, wc], [ba, bc], act)
+        if out is None:
+            out = [linear_fwd(xa, wa, ba, act), linear_fwd(xc, wc, bc, act)]
+        xa, xc = out
+        ya.append(xa); yc.append(xc)
+    return ya, yc
+
+
+def mlp_backward_pair(xa, ya, gya, la, xc, yc, gyc, lc):
+    """mlp_backward of both networks: the input-gradient products of layer k of both in one launch, and ALL weight / bias gradient products of the
+    step in two launches (layers with an ELU, layers without) behind them - 5 launches instead of 14 for the trainer's MLPs.  Chunk sums deferred
+    as in mlp_backward: call flush_partial_sums() afterwards."""
+    if not _pairable(la, lc):
+        mlp_backward(xa, ya, gya, la)
+        mlp_backward(xc, yc, gyc, lc)
+        return
+    dw = {True: ([], [], [], []), False: ([], [], [], [])}          # has ELU -> (gy, input, y, grad_out)
+    for k in range(len(la) - 1, -1, -1):
+        act = la[k][2]
+        for net_x, net_y, gy, layers in ((xa, ya, gya, la), (xc, yc, gyc, lc)):
+            inp = net_y[k - 1] if k > 0 else net_x
+            slot = dw[bool(act)]
+            slot[0].append(gy); slot[1].append(inp); slot[2].append(net_y[k] if act else None); slot[3].append(layers[k][3])
+        if k > 0:
+            yy = [ya[k], yc[k]] if act else None
+            out = gemm_nn_group([gya, gyc], [la[k][0], lc[k][0]], yy)
+            if out is None:
+                out = [gemm_nn(gya, la[k][0], ya[k] if act else None), gemm_nn(gyc, lc[k][0], yc[k] if act else None)]
+            gya, gyc = out
+    for has_elu, (gys, inps, ys, outs) in dw.items():
+        for i in range(0, len(gys), 8):
+            sl = slice(i, i + 8)
+            if not gemm_tn_bias_group(gys[sl], inps[sl], ys[sl] if has_elu else None, outs[sl]):
+                for g, x, y, o in zip(gys[sl], inps[sl], ys[sl], outs[sl]):
+                    gemm_tn_bias(g, x, y, out=o, defer=True)

@@ -172,3 +172,78 @@ def test_gather_rows_and_deferred_chunk_sums(hip):
     pk.flush_partial_sums()
     for (gw0, gb0), (gw1, gb1) in zip(direct, deferred):
         assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
+
+
+@pytest.mark.gpu
+def test_grouped_launches_equal_the_single_products_bit_for_bit(hip):
+    """tfp_linear_fwd_group / tfp_gemm_nn_group / tfp_gemm_tn_partials_group (several independent products in ONE launch: the trainer's two networks side
+    by side, all weight gradients of a step together) against the single-product entry points: the same tiles in the same order, so the results are
+    identical bit for bit - at the trainer's layer shapes (minibatch 8192, obs 41 / states 113, MLP [400, 200, 100], 9 actions / 1 value) and ragged
+    ones; a mixed-kind group is refused (the Python wrapper then falls back)."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(17)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+    M = 8192
+    # forward: layer k of actor and critic
+    for (ka, kc, n_a, n_c, act) in ((41, 113, 400, 400, 1), (400, 400, 200, 200, 1), (100, 100, 9, 1, 0), (200, 200, 100, 100, 1)):
+        xs, ws, bs = [r(M, ka), r(M, kc)], [r(n_a, ka), r(n_c, kc)], [r(n_a), r(n_c)]
+        got = pk.linear_fwd_group(xs, ws, bs, act)
+        assert got is not None
+        for y, x, w, b in zip(got, xs, ws, bs):
+            assert torch.equal(y, pk.linear_fwd(x, w, b, act))
+    assert pk.linear_fwd_group([r(64, 41), r(64, 400)], [r(8, 41), r(8, 400)], [r(8), r(8)], 1) is None          # scalar-load and vector-load kinds do not mix
+    # input gradients: dZ W for both networks, with and without the ELU derivative; a ragged pair
+    for (ka, kc, n_a, n_c, elu) in ((200, 200, 400, 400, True), (9, 1, 100, 100, False), (100, 100, 200, 200, True)):
+        as_, bs = [r(M, ka), r(M, kc)], [r(ka, n_a), r(kc, n_c)]
+        ys = [torch.rand(M, ka, device=dev, generator=g) - 0.3, torch.rand(M, kc, device=dev, generator=g) - 0.3] if elu else None
+        got = pk.gemm_nn_group(as_, bs, ys)
+        assert got is not None
+        for k in range(2):
+            assert torch.equal(got[k], pk.gemm_nn(as_[k], bs[k], ys[k] if elu else None))
+    # weight / bias gradients: the six hidden-layer products of a step in one launch, the two output-layer ones in another
+    hidden = [(400, 41), (200, 400), (100, 200), (400, 113), (200, 400), (100, 200)]
+    as_, bs = [r(M, n1) for n1, _ in hidden], [r(M, n2) for _, n2 in hidden]
+    ys = [torch.rand(M, n1, device=dev, generator=g) - 0.3 for n1, _ in hidden]
+    outs = [(torch.empty(n1, n2, device=dev), torch.empty(n1, device=dev)) for n1, n2 in hidden]
+    assert pk.gemm_tn_bias_group(as_, bs, ys, outs)
+    pk.flush_partial_sums()
+    for a, b, y, (gw, gb) in zip(as_, bs, ys, outs):
+        gw0, gb0 = pk.gemm_tn_bias(a, b, y)
+        assert torch.equal(gw, gw0) and torch.equal(gb, gb0)
+    outl = [(9, 100), (1, 100)]
+    as_, bs = [r(777, n1) for n1, _ in outl], [r(777, n2) for _, n2 in outl]
+    outs = [(torch.empty(n1, n2, device=dev), torch.empty(n1, device=dev)) for n1, n2 in outl]
+    assert pk.gemm_tn_bias_group(as_, bs, None, outs)
+    pk.flush_partial_sums()
+    for a, b, (gw, gb) in zip(as_, bs, outs):
+        gw0, gb0 = pk.gemm_tn_bias(a, b, None)
+        assert torch.equal(gw, gw0) and torch.equal(gb, gb0)
+
+
+@pytest.mark.gpu
+def test_paired_network_walks_equal_the_separate_ones(hip):
+    """mlp_forward_pair / mlp_backward_pair (what the trainer's minibatch step runs) against mlp_forward / mlp_backward network by network: identical
+    outputs and identical gradients in the caller's buffers."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(23)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+
+    def net(k_in, n_out):
+        dims = [k_in, 400, 200, 100, n_out]
+        return [(r(dims[i + 1], dims[i]) * dims[i] ** -0.5, r(dims[i + 1]), 1 if i < 3 else 0,
+                 (torch.zeros(dims[i + 1], dims[i], device=dev), torch.zeros(dims[i + 1], device=dev))) for i in range(4)]
+    la, lc = net(41, 9), net(113, 1)
+    xa, xc, gya, gyc = r(8192, 41), r(8192, 113), r(8192, 9), r(8192, 1)
+    ya, yc = pk.mlp_forward_pair(xa, la, xc, lc)
+    for got, want in zip(ya + yc, pk.mlp_forward(xa, la) + pk.mlp_forward(xc, lc)):
+        assert torch.equal(got, want)
+    pk.mlp_backward_pair(xa, ya, gya, la, xc, yc, gyc, lc)
+    pk.flush_partial_sums()
+    paired = [(gw.clone(), gb.clone()) for _, _, _, (gw, gb) in la + lc]
+    for _, _, _, (gw, gb) in la + lc:
+        gw.zero_(); gb.zero_()
+    pk.mlp_backward(xa, ya, gya, la)
+    pk.mlp_backward(xc, yc, gyc, lc)
+    pk.flush_partial_sums()
+    for (gw0, gb0), (_, _, _, (gw, gb)) in zip(paired, la + lc):
+        assert torch.equal(gw0, gw) and torch.equal(gb0, gb)
