@@ -357,6 +357,10 @@ enum { TF_KERNEL_AUTO = 0, TF_KERNEL_NARROW = 1, TF_KERNEL_WIDE = 2 };
 #define TF_WIDE_MAX_ENVS 32768
 int tf_set_kernel_variant(tf_handle h, int32_t variant);
 int tf_kernel_variant(tf_handle h);
+/* Workgroups of the handle's fused step that fit one CU at once, as the HIP runtime computes it from the kernel's registers and LDS (diagnostic; -1 if
+ * the query fails, 0 from the oracle).  The 128-register instantiation is built to fit FOUR (its LDS is 4 x 39.75 KB of the CU's 160 KB, to the
+ * byte): anything below that - another toolchain, a runtime that reserves LDS - costs the headline a quarter; tests/test_env_api.py holds it. */
+int tf_kernel_occupancy(tf_handle h);
 
 /* The hot path: one control step for every env of the handle, fused, on `stream` (hipStream_t). */
 int tf_step(tf_handle h, const float* action /* [N][A] row-major, device */, void* stream);

@@ -148,6 +148,7 @@ SYMBOLS = {
     "tf_set_frame_count": (C.c_int, [_P, C.c_int64]),
     "tf_set_kernel_variant": (C.c_int, [_P, C.c_int32]),
     "tf_kernel_variant": (C.c_int, [_P]),
+    "tf_kernel_occupancy": (C.c_int, [_P]),
     "tf_step": (C.c_int, [_P, _P, _P]),
     "tf_step_random": (C.c_int, [_P, C.c_void_p]),
     "tf_reset": (C.c_int, [_P, _P]),

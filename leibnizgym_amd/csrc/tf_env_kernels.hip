@@ -86,3 +86,20 @@ void TF_CAT3(tf_launch_env_, TF_EXT, TF_WIDE)(int lm, const EnvLaunch& a) {
     default: break;
     }
 }
+
+int TF_CAT3(tf_occupancy_env_, TF_EXT, TF_WIDE)(int action_dim, bool asym) {
+    constexpr int EXT = TF_EXT;
+    constexpr bool WIDE = TF_WIDE != 0;
+    int n = -1;
+    hipError_t e = hipSuccess;
+    if (action_dim == 9) {
+        if (asym) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_env<9, false, true, M_FUSED_STEP_RAND, EXT, WIDE>, NT, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_env<9, false, false, M_FUSED_STEP_RAND, EXT, WIDE>, NT, 0);
+    } else {
+#if !defined(TF_DEV_MIN)
+        if (asym) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_env<18, false, true, M_FUSED_STEP_RAND, EXT, WIDE>, NT, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_env<18, false, false, M_FUSED_STEP_RAND, EXT, WIDE>, NT, 0);
+#endif
+    }
+    return e == hipSuccess ? n : -1;
+}

@@ -21,6 +21,13 @@ struct EnvLaunch {
 // which hooks of the reference step a launch performs (MODE of tf_roles.h)
 enum { TF_LM_STEP = 0, TF_LM_STEP_RAND, TF_LM_RESET, TF_LM_RESETS, TF_LM_TORQUE, TF_LM_SIM, TF_LM_POST, TF_LM_FINISH };
 
+// workgroups of the fused step (actions drawn in the launch) that fit a CU at once, as the HIP runtime computes it from registers and LDS
+int tf_occupancy_env_0_0(int action_dim, bool asym);
+int tf_occupancy_env_0_1(int action_dim, bool asym);
+int tf_occupancy_env_1_0(int action_dim, bool asym);
+int tf_occupancy_env_1_1(int action_dim, bool asym);
+int tf_occupancy_env_2_0(int action_dim, bool asym);
+int tf_occupancy_env_2_1(int action_dim, bool asym);
 void tf_launch_env_0_0(int lm, const EnvLaunch& a);      // tf_launch_env_<EXT>_<WIDE>
 void tf_launch_env_0_1(int lm, const EnvLaunch& a);
 void tf_launch_env_1_0(int lm, const EnvLaunch& a);

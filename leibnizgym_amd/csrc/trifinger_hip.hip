@@ -447,6 +447,7 @@ int tf_set_gravity(tf_handle h, const float g[3]) {
     HIP_TRY(push_params(h));
     return TF_OK;
 }
+static int ext_kind(const TfConfig& c);
 int tf_set_kernel_variant(tf_handle h, int32_t variant) {
     if (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE) return TF_ERR_INVALID_ARG;
     h->variant = variant;
@@ -454,6 +455,18 @@ int tf_set_kernel_variant(tf_handle h, int32_t variant) {
     return TF_OK;
 }
 int tf_kernel_variant(tf_handle h) { return h ? (h->wide ? TF_KERNEL_WIDE : TF_KERNEL_NARROW) : TF_ERR_INVALID_ARG; }
+int tf_kernel_occupancy(tf_handle h) {
+    if (!h) return TF_ERR_INVALID_ARG;
+    const bool asym = h->cfg.asymmetric_obs != 0;
+#if defined(TF_DEV_MIN)
+    return h->wide ? tf_occupancy_env_0_1(h->action_dim, asym) : tf_occupancy_env_0_0(h->action_dim, asym);
+#else
+    const int k = ext_kind(h->cfg);
+    if (k == 2) return h->wide ? tf_occupancy_env_2_1(h->action_dim, asym) : tf_occupancy_env_2_0(h->action_dim, asym);
+    if (k == 1) return h->wide ? tf_occupancy_env_1_1(h->action_dim, asym) : tf_occupancy_env_1_0(h->action_dim, asym);
+    return h->wide ? tf_occupancy_env_0_1(h->action_dim, asym) : tf_occupancy_env_0_0(h->action_dim, asym);
+#endif
+}
 int64_t tf_frame_count(tf_handle h) { return h ? h->frame_count : -1; }
 int tf_set_frame_count(tf_handle h, int64_t f) { if (!h) return TF_ERR_INVALID_ARG; h->frame_count = f; return TF_OK; }
 

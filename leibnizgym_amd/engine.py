@@ -283,6 +283,11 @@ class TrifingerEngine:
         check(self.lib, min(v, 0), "tf_kernel_variant")
         return {1: "narrow", 2: "wide"}[v]
 
+    @property
+    def kernel_occupancy(self):
+        """workgroups of the fused step per CU (HIP runtime's figure for the instantiation this engine launches; 0 from the oracle)"""
+        return int(self.lib.tf_kernel_occupancy(self._handle))
+
     @kernel_variant.setter
     def kernel_variant(self, name):
         check(self.lib, self.lib.tf_set_kernel_variant(self._handle, self.KERNEL_VARIANTS[name]), "tf_set_kernel_variant")

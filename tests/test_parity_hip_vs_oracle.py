@@ -20,6 +20,20 @@ def test_rollout_bit_exact(hip, oracle, cfg_name, variant):
         pu.assert_bit_equal(a, b, f"{cfg_name} [{variant}] step {t}")
 
 
+def test_both_instantiations_get_the_occupancy_they_are_built_for(hip):
+    """The 128-register instantiation is built to put FOUR workgroups on a CU (its LDS is 4 x 39.75 KB of the CU's 160 KB, to the byte), the
+    256-register one two: what the HIP runtime computes for the kernels this engine launches - headline, extended DR and box object."""
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    kw = {k: v for k, v in pu.CONFIGS["d4_torque_asym"].items()}
+    for extra in ({}, {"domain_randomization": pu.CONFIGS["d4_domain_randomization_extended"]["domain_randomization"]}, {"model": hip.box_model((0.02, 0.08, 0.02), 500.0)}):
+        e = TrifingerEngine(make_config(hip, 4096, **{**kw, **extra}), device=DEV, lib=hip)
+        e.kernel_variant = "narrow"
+        assert e.kernel_occupancy == 4, (extra.keys(), e.kernel_occupancy)
+        e.kernel_variant = "wide"
+        assert e.kernel_occupancy == 2, (extra.keys(), e.kernel_occupancy)
+        e.close()
+
+
 def test_kernel_variant_follows_the_population(hip):
     """tf_create picks the 256-register instantiation up to TF_WIDE_MAX_ENVS envs and the 128-register one above (what bench.py's headline size
     runs); the override is what the tests above use."""
