@@ -144,10 +144,11 @@ def test_ragged_sizes(hip, oracle, n):
 
 
 @pytest.mark.parametrize("variant", pu.VARIANTS)
-@pytest.mark.parametrize("cfg_name", ["envdefault_position", "d4_domain_randomization"])
+@pytest.mark.parametrize("cfg_name", ["envdefault_position", "d4_domain_randomization", "d4_domain_randomization_extended"])
 def test_split_path_equals_fused(hip, cfg_name, variant):
     """tf_apply_resets/pre_step/simulate/post_step/finish_step == tf_step on the GPU (also with every
-    domain-randomisation feature on: the frame-keyed draws must agree between the two paths)."""
+    domain-randomisation feature on: the frame-keyed draws must agree between the two paths, and the hand-over of the DR rows from the cube role to the
+    finger roles through LDS must hold in a launch that only simulates - barrier #1b of tf_roles.h)."""
     from leibnizgym_amd.engine import TrifingerEngine, make_config
     n = 777
     kw = dict(pu.CONFIGS[cfg_name])
