@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TF_API_VERSION 6
+#define TF_API_VERSION 7
 
 typedef enum TfStatus {
     TF_OK = 0,
@@ -243,6 +243,11 @@ typedef struct TfModel {
     float obj_min_height;         /* size_z / 2                                  0.0325                  */
     float obj_span_min_height;    /* max_height (0.1) - min_height               0.0675   (difficulty 3) */
     float obj_span_radius;        /* max_height - radius_3d                      0.04370835 (difficulty 4, 5) */
+    /* API 7.  Finger-finger contacts beyond the three distal pairs: != 0 adds the MIDDLE link of every finger (shape2) against the fingertip capsule
+     * of each other finger - six ordered pairs, one frictionless normal row each, visited after the distal pairs in the finger-finger pass (the
+     * reference keeps all robot links in one self-colliding group, trifinger_env.py:811-812; uniformly drawn joint positions overlap in a
+     * middle-distal pair 1.4 % of the time, in a distal pair 1.7 %).  0 (default): the three distal pairs only.  Cost: INTEGRATION.md. */
+    int32_t ff_middle_pairs;
 } TfModel;
 
 /* Fill the box fields of `m` for an object of `size` (x, y, z, metres) and `density` (kg/m^3): mass, principal moments,

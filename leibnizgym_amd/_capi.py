@@ -11,7 +11,7 @@ same binding at the CPU oracle; nothing in this package ever does.
 import ctypes as C
 import os
 
-TF_API_VERSION = 6
+TF_API_VERSION = 7
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
 TF_STATE_ROWS = 172
@@ -91,6 +91,7 @@ class TfModel(C.Structure):
         ("box", C.c_int32), ("box_gyroscopic", C.c_int32), ("box_half", C.c_float * 3), ("box_inertia", C.c_float * 3),
         ("obj_radius_3d", C.c_float), ("obj_max_com_dist", C.c_float), ("obj_min_height", C.c_float),
         ("obj_span_min_height", C.c_float), ("obj_span_radius", C.c_float),
+        ("ff_middle_pairs", C.c_int32),
     ]
 
 

@@ -158,6 +158,24 @@ DEV void seg_seg(const float p1[3], const float q1[3], const float p2[3], const 
     for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
 }
 
+// the same with the parameter s of the closest point on the first segment (the cross-section of a link shape depends on it)
+DEV void seg_seg_s(const float p1[3], const float q1[3], const float p2[3], const float q2[3], float c1[3], float c2[3], float& s_out) {
+    float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]};
+    float d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
+    float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2);
+    float denom = FMA(a, e, -(b * b));
+    float ia = f_rcp(a), ie = f_rcp(e);
+    float s = 0.0f;
+    if (denom > 1e-12f) s = f_clamp(FMA(b, f, -(c * e)) * f_rcp(denom), 0.0f, 1.0f);
+    float t = FMA(b, s, f) * ie;
+    if (t < 0.0f) { t = 0.0f; s = f_clamp(-c * ia, 0.0f, 1.0f); }
+    else if (t > 1.0f) { t = 1.0f; s = f_clamp((b - c) * ia, 0.0f, 1.0f); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
+    s_out = s;
+}
+
 // inner radius of the boundary at height z: the piecewise-linear profile through the knots (wall_z[i], wall_r[i]) - a vertical ring below
 // the first knot, the flaring cone of the stage above it (slopes wall_s precomputed at tf_create), nothing above the last knot (1e3)
 DEV float wall_radius_at(const DevParams& P, float z) {

@@ -1741,6 +1741,98 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     }
                 }
             }
+            // ---- FF, second part (TfModel.ff_middle_pairs, off by default; wave-uniform): the middle link of finger fm (shape2) against the distal
+            // capsule of each other finger - six ordered pairs on the same velocities.  The middle frame is rebuilt from what finger fm publishes:
+            // e_x = (c1, 0, -s1), g = (p3 - p2) - j3_x e_x = j3_y e_y + j3_z e_z, e_x x g = j3_y e_z - j3_z e_y (oracle/tf_oracle.c, the same lines). ----
+            if (__builtin_expect(m.ff_middle_pairs != 0, 0)) {
+                const TfLinkShape& sh = m.shape2;
+                const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
+                const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
+#pragma unroll 1
+                for (int fm = 0; fm < 3; ++fm) {
+                    FingerPubRegs pm;
+                    read_pub(lds, lane, fm, pm);
+                    const Yaw ym = {m.base_yaw_cos[fm], m.base_yaw_sin[fm], 0.0f, 0.0f, m.base_height};
+                    const float ex[3] = {pm.k.c1, 0.0f, -pm.k.s1};
+                    float ey[3], aw[3], bw[3];
+                    {
+                        float g[3], xg[3], ez[3], ab[3], bb[3];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) g[i] = FMA(-jx, ex[i], pm.k.p3[i] - pm.k.p2[i]);
+                        cross3(ex, g, xg);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { ey[i] = FMA(jy, g[i], -(jz * xg[i])) * inv_j; ez[i] = FMA(jz, g[i], jy * xg[i]) * inv_j; }
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            ab[i] = FMA(sh.a[2], ez[i], FMA(sh.a[1], ey[i], FMA(sh.a[0], ex[i], pm.k.p2[i])));
+                            bb[i] = FMA(sh.b[2], ez[i], FMA(sh.b[1], ey[i], FMA(sh.b[0], ex[i], pm.k.p2[i])));
+                        }
+                        base_to_world(ym, ab, aw);
+                        base_to_world(ym, bb, bw);
+                    }
+#pragma unroll 1
+                    for (int o = 1; o <= 2; ++o) {
+                        const int fd = (fm + o >= 3) ? fm + o - 3 : fm + o;
+                        float Pm[3], Pd[3], sp;
+                        {
+                            float Ad[3], Bd[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) { Ad[j] = LD(L_REC(fd) + P_AW + j); Bd[j] = LD(L_REC(fd) + P_BW + j); }
+                            seg_seg_s(aw, bw, Ad, Bd, Pm, Pd, sp);
+                        }
+                        const float dv[3] = {Pd[0] - Pm[0], Pd[1] - Pm[1], Pd[2] - Pm[2]};
+                        const float dist2 = dot3(dv, dv);
+                        const float inv = f_rsqrt(f_max(dist2, 1e-12f));
+                        const float dist = dist2 * inv;
+                        const float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};      // from the middle link to the distal capsule
+                        float nm[3];
+                        dir_world_to_base(ym, n, nm);
+                        const float u1 = dot3(nm, ex), u2 = dot3(nm, ey);
+                        const float rho = FMA(sp, sh.rho[1] - sh.rho[0], sh.rho[0]);
+                        const float h1 = FMA(sp, sh.w1[1] - sh.w1[0], sh.w1[0]) - rho, h2 = FMA(sp, sh.w2[1] - sh.w2[0], sh.w2[0]) - rho;
+                        const float o1 = FMA(sp, sh.o1[1] - sh.o1[0], sh.o1[0]), o2 = FMA(sp, sh.o2[1] - sh.o2[0], sh.o2[0]);
+                        const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
+                        const float gap = dist - ext - m.cap_radius;
+                        if ((dist2 > 1e-12f) && (gap < m.contact_margin)) {
+                            float Jd[3], Wd[3], Jm[3], Wm[3], vd[3], vm[3];
+                            {   // distal side: the point of the capsule surface that faces the middle link
+                                const Yaw yd = {m.base_yaw_cos[fd], m.base_yaw_sin[fd], 0.0f, 0.0f, m.base_height};
+                                FingerPubRegs pd;
+                                read_pub(lds, lane, fd, pd);
+                                float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) C[j] = FMA(-m.cap_radius, n[j], Pd[j]);
+                                world_to_base(yd, C, Cb_);
+                                levers(pd.k, Cb_, L1, L2, L3);
+                                dir_world_to_base(yd, n, nb);
+                                Jd[0] = dot3(L1, nb); Jd[1] = dot3(L2, nb); Jd[2] = dot3(L3, nb);
+                                sym3_mul(pd.k.Minv, Jd, Wd);
+                            }
+                            {   // middle side: joints 1 and 2 move it, joint 3 does not
+                                float C[3], Cb_[3], L1[3], L2[3], L3[3];
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) C[j] = FMA(ext, n[j], Pm[j]);
+                                world_to_base(ym, C, Cb_);
+                                levers(pm.k, Cb_, L1, L2, L3);
+                                Jm[0] = dot3(L1, nm); Jm[1] = dot3(L2, nm); Jm[2] = 0.0f;
+                                sym3_mul(pm.k.Minv, Jm, Wm);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) { vd[j] = LD(L_VQFF + 3 * fd + j); vm[j] = LD(L_VQFF + 3 * fm + j); }
+                            const float vn0 = dot3(Jd, vd) - dot3(Jm, vm);
+                            if (contact_live(m, gap, vn0, h)) {
+                                const float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+                                const float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Jd, Wd) + dot3(Jm, Wm)), 0.0f);
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) {
+                                    LD(L_VQFF + 3 * fd + j) = FMA(Wd[j], lam, vd[j]);
+                                    LD(L_VQFF + 3 * fm + j) = FMA(-Wm[j], lam, vm[j]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
             STAMP(sb_ + 2);
             BAR();                                              // S1b: finger-finger pass done
             STAMP(sb_ + 3);

@@ -146,6 +146,13 @@ class TrifingerEnv(IsaacEnvBase):
             substeps = int(native.get("substeps", 2))
         else:
             raise ValueError(f"native.solver: 'pgs' or 'tgs', got {solver!r}")
+        model = (lib.box_model(native["object_size"], native.get("object_density", 500.0))
+                 if native.get("object_size") is not None else None)
+        # "native.ff_middle_pairs" (default False): finger-finger contacts between the middle link of a finger and the distal link of another, beyond
+        # the three distal pairs (include/trifinger.h: TfModel.ff_middle_pairs; the reference keeps all robot links in one self-colliding group, :811-812)
+        if native.get("ff_middle_pairs", False):
+            model = model if model is not None else lib.default_model()
+            model.ff_middle_pairs = 1
         cfg = make_config(
             lib, int(c["num_instances"]), seed=int(c["seed"]), env_id_offset=self._env_id_offset,
             global_num_envs=self._global_num_instances(), command_mode=c["command_mode"],
@@ -170,8 +177,7 @@ class TrifingerEnv(IsaacEnvBase):
             gravity=c["sim"]["gravity"], domain_randomization=c.get("domain_randomization"),
             # "native.object_size" (x, y, z in metres) / "native.object_density": a general box instead of the 65 mm cube,
             # e.g. [0.02, 0.08, 0.02] / 500 for objects/urdf/cube_multicolor_rrc_phase3.urdf of the reference's assets
-            model=(lib.box_model(native["object_size"], native.get("object_density", 500.0))
-                   if native.get("object_size") is not None else None))
+            model=model)
         return TrifingerEngine(cfg, device=self.device, lib=lib)
 
     def _configure_mdp_spaces(self):

@@ -413,6 +413,7 @@ void tf_default_model(TfModel* m) {
     m->obj_min_height = 0.0325f;
     m->obj_span_min_height = 0.0675f;
     m->obj_span_radius = 0.04370835f;
+    m->ff_middle_pairs = 0;
 }
 
 /* The object as a general box: mass, principal moments about the body axes, reference inertia of the scaled solve (the mean
@@ -994,6 +995,23 @@ static void seg_seg(const float p1[3], const float q1[3], const float p2[3], con
     for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
 }
 
+/* the same with the parameter s of the closest point on the first segment (the cross-section of a link shape depends on it) */
+static void seg_seg_s(const float p1[3], const float q1[3], const float p2[3], const float q2[3], float c1[3], float c2[3], float* s_out) {
+    float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]};
+    float d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
+    float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    float a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2);
+    float denom = FMA(a, e, -(b * b));
+    float ia = f_rcp(a), ie = f_rcp(e);
+    float s = 0.0f;
+    if (denom > 1e-12f) s = f_clamp(FMA(b, f, -(c * e)) * f_rcp(denom), 0.0f, 1.0f);
+    float t = FMA(b, s, f) * ie;
+    if (t < 0.0f) { t = 0.0f; s = f_clamp(-c * ia, 0.0f, 1.0f); }
+    else if (t > 1.0f) { t = 1.0f; s = f_clamp((b - c) * ia, 0.0f, 1.0f); }
+    for (int i = 0; i < 3; ++i) { c1[i] = FMA(s, d1[i], p1[i]); c2[i] = FMA(t, d2[i], p2[i]); }
+    *s_out = s;
+}
+
 /* inner radius of the boundary at height z: piecewise-linear profile through the knots (wall_z[i], wall_r[i]); a vertical ring below
  * the first knot, nothing above the last (1e3) */
 static float wall_radius_at(const struct TfHandle_* H, float z) {
@@ -1463,6 +1481,77 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
         float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja, Wa) + dot3(Jb, Wb)), 0.0f);
         for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[j], lam, va[j]); vb[j] = FMA(-Wb[j], lam, vb[j]); }
+    }
+    /* ---- FF, second part (TfModel.ff_middle_pairs, off by default): the MIDDLE link of finger fm against the distal capsule of each other
+     * finger fd - the six ordered pairs (0;1) (0;2) (1;2) (1;0) (2;0) (2;1), visited after the three distal pairs on the same velocities.
+     * The reference leaves every robot link in one collision group with self-collision on (trifinger_env.py:811-812).  The middle link is
+     * its finger-cube shape (shape2: tapered rounded box about the axis a -> b of the middle frame), the distal link the fingertip capsule
+     * as in the distal pairs.  The cube role of the kernels sees of a finger what it publishes (p2, p3, sin / cos of joint 1, M^-1): the
+     * middle frame is rebuilt from those - e_x = (c1, 0, -s1) is the axis of joints 2 and 3, g = (p3 - p2) - j3_x e_x = j3_y e_y + j3_z e_z
+     * and e_x x g = j3_y e_z - j3_z e_y give e_y and e_z - and this restatement does it the same way. ---- */
+    if (m->ff_middle_pairs) {
+        const TfLinkShape* sh = &m->shape2;
+        const float jx = m->j3_origin[0], jy = m->j3_origin[1], jz = m->j3_origin[2];
+        const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
+        for (int fm = 0; fm < 3; ++fm) {
+            const FK* km = &fr[fm].k;
+            const float ex[3] = {km->c1, 0.0f, -km->s1};
+            float g[3], xg[3], ey[3], ez[3], ab[3], bb[3], aw[3], bw[3];
+            for (int i = 0; i < 3; ++i) g[i] = FMA(-jx, ex[i], km->p3[i] - km->p2[i]);
+            cross3(ex, g, xg);
+            for (int i = 0; i < 3; ++i) { ey[i] = FMA(jy, g[i], -(jz * xg[i])) * inv_j; ez[i] = FMA(jz, g[i], jy * xg[i]) * inv_j; }
+            for (int i = 0; i < 3; ++i) {
+                ab[i] = FMA(sh->a[2], ez[i], FMA(sh->a[1], ey[i], FMA(sh->a[0], ex[i], km->p2[i])));
+                bb[i] = FMA(sh->b[2], ez[i], FMA(sh->b[1], ey[i], FMA(sh->b[0], ex[i], km->p2[i])));
+            }
+            base_to_world(m, fm, ab, aw);
+            base_to_world(m, fm, bb, bw);
+            for (int o = 1; o <= 2; ++o) {
+                const int fd = (fm + o) % 3;
+                float Pm[3], Pd[3], sp;
+                seg_seg_s(aw, bw, fr[fd].Aw, fr[fd].Bw, Pm, Pd, &sp);
+                float dv[3] = {Pd[0] - Pm[0], Pd[1] - Pm[1], Pd[2] - Pm[2]};
+                float dist2 = dot3(dv, dv);
+                if (!(dist2 > 1e-12f)) continue;
+                float inv = f_rsqrt(dist2);
+                float dist = dist2 * inv;
+                float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};      /* from the middle link to the distal capsule */
+                float nm[3];
+                dir_world_to_base(m, fm, n, nm);
+                const float u1 = dot3(nm, ex), u2 = dot3(nm, ey);
+                const float rho = FMA(sp, sh->rho[1] - sh->rho[0], sh->rho[0]);
+                const float h1 = FMA(sp, sh->w1[1] - sh->w1[0], sh->w1[0]) - rho, h2 = FMA(sp, sh->w2[1] - sh->w2[0], sh->w2[0]) - rho;
+                const float o1 = FMA(sp, sh->o1[1] - sh->o1[0], sh->o1[0]), o2 = FMA(sp, sh->o2[1] - sh->o2[0], sh->o2[0]);
+                const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
+                float gap = dist - ext - m->cap_radius;
+                if (!(gap < m->contact_margin)) continue;
+                float Jd[3], Wd[3], Jm[3], Wm[3];
+                {   /* distal side: the point of the capsule surface that faces the middle link */
+                    float C[3], Cb[3], L1[3], L2[3], L3[3], nb[3];
+                    for (int i = 0; i < 3; ++i) C[i] = FMA(-m->cap_radius, n[i], Pd[i]);
+                    world_to_base(m, fd, C, Cb);
+                    levers(&fr[fd].k, Cb, L1, L2, L3);
+                    dir_world_to_base(m, fd, n, nb);
+                    Jd[0] = dot3(L1, nb); Jd[1] = dot3(L2, nb); Jd[2] = dot3(L3, nb);
+                    sym3_mul(fr[fd].k.Minv, Jd, Wd);
+                }
+                {   /* middle side: joints 1 and 2 move it, joint 3 does not */
+                    float C[3], Cb[3], L1[3], L2[3], L3[3];
+                    for (int i = 0; i < 3; ++i) C[i] = FMA(ext, n[i], Pm[i]);
+                    world_to_base(m, fm, C, Cb);
+                    levers(km, Cb, L1, L2, L3);
+                    Jm[0] = dot3(L1, nm); Jm[1] = dot3(L2, nm); Jm[2] = 0.0f;
+                    sym3_mul(km->Minv, Jm, Wm);
+                }
+                float* vd = vq_ff[fd];
+                float* vm = vq_ff[fm];
+                float vn0 = dot3(Jd, vd) - dot3(Jm, vm);
+                if (!contact_live(m, gap, vn0, h)) continue;
+                float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+                float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Jd, Wd) + dot3(Jm, Wm)), 0.0f);
+                for (int j = 0; j < 3; ++j) { vd[j] = FMA(Wd[j], lam, vd[j]); vm[j] = FMA(-Wm[j], lam, vm[j]); }
+            }
+        }
     }
     /* ---- F2: contacts of each finger ---- */
     float cube_top_check = cpr[2];

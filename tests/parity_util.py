@@ -64,6 +64,11 @@ CONFIGS = {
                                     normalize_obs=False,
                                     success={"activate": True, "bonus": 100.0, "position_tolerance": 0.04,
                                              "orientation_tolerance": 3.2}),
+    # the opt-in middle-distal finger-finger pairs (TfModel.ff_middle_pairs) with robot resets that spread the joints widely: fingers meet
+    # at resets and under random torques (tests/test_ff_middle_pairs.py: the switch changes this very rollout)
+    "ff_middle_pairs": dict(_model_edit=dict(ff_middle_pairs=1), command_mode="torque", task_difficulty=1, asymmetric_obs=True,
+                            robot_reset="random", dof_pos_stddev=1.2, dof_vel_stddev=0.5, reward_terms=D1_REWARDS,
+                            success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.01, "orientation_tolerance": 0.1}),
 }
 
 PER_ENV_FIELDS = ("state", "action_buf", "obs", "states", "reward", "reset_buf", "goal_reset_buf", "successes",
@@ -99,6 +104,11 @@ def rollout(lib, device, n, steps, cfg_name, seed=3, episode_length=40, extra=No
     kw = dict(CONFIGS[cfg_name])
     kw.update(extra or {})
     clipping = kw.pop("_clipping", None)
+    model_edit = kw.pop("_model_edit", None)
+    if model_edit:                                   # fields of the default TfModel to overwrite
+        kw["model"] = lib.default_model()
+        for name, value in model_edit.items():
+            setattr(kw["model"], name, value)
     cfg = make_config(lib, n, seed=seed, episode_length=episode_length, **kw)
     eng = TrifingerEngine(cfg, device=device, lib=lib)
     if variant is not None:

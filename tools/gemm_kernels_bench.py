@@ -24,7 +24,9 @@ def t_us(f, n=20, reps=5):
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 CH = int(os.environ.get("CHUNK", "512"))
 tot = [0.0, 0.0]
-for K, N in ((41, 400), (113, 400), (400, 200), (200, 100), (100, 9), (100, 1)):
+SHAPES = ((41, 400), (113, 400), (400, 200), (200, 100), (100, 9), (100, 1))
+if os.environ.get("SHAPES"): SHAPES = tuple(tuple(int(v) for v in sh.split("x")) for sh in os.environ["SHAPES"].split(","))   # e.g. SHAPES=400x200
+for K, N in SHAPES:
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
     gy = torch.randn(M, N, device=dev); y = torch.randn(M, N, device=dev)
     fl = 2.0 * M * N * K * 1e-6

@@ -18,3 +18,7 @@ print("start us: min %.2f median %.2f max %.2f" % (st.min(), np.median(st), st.m
 print("end   us: min %.2f median %.2f max %.2f" % (en.min(), np.median(en), en.max()))
 print("duration us: min %.2f median %.2f max %.2f" % ((en-st).min(), np.median(en-st), (en-st).max()))
 print("histogram of start times (us):", np.histogram(st, bins=8)[0], np.histogram(st, bins=8)[1].round(1))
+dbg = (C.c_uint * 64)(); pk.load().tfp_debug_read(dbg)
+d = np.array(list(dbg), dtype=np.int64).reshape(8, 8)
+for wv in range(8):
+    print("wave %d (%s): total %6d cycles, in barriers %6d, tiles %d" % (wv, "multiplies" if wv < 4 else "stages", d[wv, 0], d[wv, 1], d[wv, 2]))

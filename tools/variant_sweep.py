@@ -1,6 +1,6 @@
 """Developer tool (GPU box): fused-step time (HIP events) of the headline workload for the two instantiations of the step kernel
 (tf_set_kernel_variant) over a range of population sizes, with a state checksum (identical between the variants: same arithmetic).
-    python tools/variant_sweep.py [lib.so] [N ...]"""
+    python tools/variant_sweep.py [lib.so] [N ...]      env: SETTLE, SOLVER=iterations,inner, NO_TIMEOUT=1, FF_MIDDLE=1, ASYM=0|1 (default: both)"""
 import sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -16,11 +16,14 @@ if args and args[0].endswith(".so"):
 sizes = [int(a) for a in args] or [8192, 16384, 32768, 65536]
 SETTLE = int(os.environ.get("SETTLE", "400"))
 SOLVER = [int(x) for x in os.environ.get("SOLVER", "8,1").split(",")]      # SOLVER=16,1 / SOLVER=8,2: solver_iterations, solver_inner
-for asym in (True, False):
+for asym in ([bool(int(os.environ["ASYM"]))] if os.environ.get("ASYM") else (True, False)):
     for n in sizes:
         for variant in ("narrow", "wide"):
             kw = bench.workload_kwargs(asym)
             kw.update(solver_iterations=SOLVER[0], solver_inner=SOLVER[1])
+            if os.environ.get("FF_MIDDLE"):                   # FF_MIDDLE=1: the opt-in middle-distal finger-finger pairs (TfModel.ff_middle_pairs)
+                kw["model"] = lib.default_model()
+                kw["model"].ff_middle_pairs = 1
             if os.environ.get("NO_TIMEOUT"):                  # diagnostic: no time-out resets inside the timed steps (what the reset path of a launch costs)
                 kw.update(episode_length=0)
             eng = TrifingerEngine(make_config(lib, n, seed=7, **kw), device="cuda:0", lib=lib)
