@@ -317,7 +317,8 @@ __device__ __forceinline__ void stage_store(float* S, int tid, const float (&v)[
 }
 
 #ifndef GEMM_DBG
-#define GEMM_DBG 0        // developer builds: 1 = no MFMAs, 2 = no loads inside the loop (tools/gemm_kernels_bench.py)
+#define GEMM_DBG 0        // developer builds (timing only, wrong results): 1 = no MFMAs and no LDS reads, 2 = no global loads inside the loop, 4 = no LDS reads,
+                          // 5 = no global loads and no LDS writes inside the loop: the staging wavefronts only keep the barriers (tools/gemm_decompose.sh)
 #endif
 #ifndef GEMM_SCHED
 #define GEMM_SCHED 1
@@ -401,12 +402,16 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
             const int k0 = kbeg + t * GK;
             stage_fix<AK, AVEC, DZ, false>(M, r0, k0, kend, tid, ra[d], ry[DZ ? d : 0]);
             stage_fix<BK, BVEC, false, ONES>(N, c0, k0, kend, tid, rb[d], rb[d]);
-            stage_store<AK, AVEC>(S[t & 1][0], tid, ra[d]);
-            stage_store<BK, BVEC>(S[t & 1][1], tid, rb[d]);
+            if (GEMM_DBG != 5) {
+                stage_store<AK, AVEC>(S[t & 1][0], tid, ra[d]);
+                stage_store<BK, BVEC>(S[t & 1][1], tid, rb[d]);
+            }
             const int kn = kbeg + min(t + GD, ntiles - 1) * GK;
-            stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[d]);
-            if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[DZ ? d : 0]);
-            stage_load<BK, BVEC, ONES>(B, ldb, N, c0, GEMM_DBG == 3 ? kbeg : kn, kend, tid, rb[d]);   // (3: developer build, B re-read from L1)
+            if (GEMM_DBG != 2 && GEMM_DBG != 5) {
+                stage_load<AK, AVEC, false>(A, lda, M, r0, kn, kend, tid, ra[d]);
+                if (DZ) stage_load<AK, AVEC, false>(Y, lda, M, r0, kn, kend, tid, ry[DZ ? d : 0]);
+                stage_load<BK, BVEC, ONES>(B, ldb, N, c0, GEMM_DBG == 3 ? kbeg : kn, kend, tid, rb[d]);   // (3: developer build, B re-read from L1)
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         stage(std::integral_constant<int, 0>{}, 0);
