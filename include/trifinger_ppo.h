@@ -37,6 +37,10 @@ int tfp_linear_fwd(const float* A, const float* W, const float* bias, float* C, 
 
 /* Input gradient: C[M, N] = dZ[M, K] . B[K, N], dZ = A, or A * elu'(Y) when Y (the layer's ELU output, [M, K]) is not NULL */
 int tfp_gemm_nn(const float* A, const float* Y, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
+/* ... the same product leaving as the dZ of the layer BELOW: C[M, N] = (dZ . B) * elu'(Yout[M, N]) with Yout that layer's ELU output (NULL: no factor).
+ * A backward walk that chains these (A = the dZ the call above produced, Y = NULL) multiplies every activation gradient once, where the product is
+ * stored, instead of in the operand loads of the two products that consume it; same bits.  N % 4 == 0 needs Yout 16-byte aligned. */
+int tfp_gemm_nn_dz(const float* A, const float* Y, const float* B, const float* Yout, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 
 /* Weight and bias gradient: gw[N1, N2] = dZ^T B, gb[N1] = column sums of dZ, for dZ[rows, N1] (as above), B[rows, N2].
  * `part` is scratch for ceil(rows / chunk) slabs of N1 * (N2 + 1) floats; chunk must be a multiple of 32.  The sum over the row
@@ -59,6 +63,8 @@ int tfp_linear_fwd_group(const void* const* A, const void* const* W, const void*
                          const int32_t* K, int32_t act, int32_t n, void* stream);
 int tfp_gemm_nn_group(const void* const* A, const void* const* Y /* may be NULL */, const void* const* B, void* const* C, const int32_t* M, const int32_t* N,
                       const int32_t* K, int32_t n, void* stream);
+int tfp_gemm_nn_dz_group(const void* const* A, const void* const* Y /* may be NULL */, const void* const* B, const void* const* Yout /* may be NULL */,
+                         void* const* C, const int32_t* M, const int32_t* N, const int32_t* K, int32_t n, void* stream);
 int tfp_gemm_tn_partials_group(const void* const* A, const void* const* Y /* may be NULL */, const void* const* B, void* const* part, const int32_t* rows,
                                const int32_t* N1, const int32_t* N2, int32_t chunk, int32_t n, void* stream);
 

@@ -358,7 +358,7 @@ __device__ unsigned long long g_wg[2048 * 2];     // [workgroup][start, end] in 
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
 __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                           const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk,
-                                          int bx0, int by0, int bz0, int nx, int ny, int nz) {
+                                          int bx0, int by0, int bz0, int nx, int ny, int nz, const float* __restrict__ E = nullptr) {
     // Role-specialised wavefronts: waves 0-3 multiply (one 32 x 32 accumulator each: LDS reads and MFMAs, nothing else), waves 4-7 stage
     // (global loads, the fix-ups, LDS writes).  A SIMD hosts one of each per workgroup, so the staging instructions of the producers issue
     // in the shadow of the consumers' MFMAs instead of between them; tile t is multiplied out of LDS buffer t & 1 while tile t + 1 is
@@ -387,6 +387,10 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
 #endif
     if (producer) {
         __builtin_amdgcn_s_setprio(GEMM_PRIO);                      // staging instructions go first whenever they are ready: they are few, the
+        // wave-uniform: can a tile of this workgroup hold values that stage_fix must replace?  The loads are clamped into the matrix, so an interior
+        // tile (all 64 rows / columns inside, the K tile below kend) is staged as loaded: a staging wavefront's vector instructions do not overlap
+        // with the MFMAs of the multiplying wavefront on its SIMD (tools/microbench/mfma_valu_overlap.hip)
+        const bool a_edge = r0 + GT > M, b_edge = c0 + GT > (ONES ? N - 1 : N);
         float ra[GD][8], rb[GD][8], ry[DZ ? GD : 1][8];
 #pragma unroll
         for (int d = 0; d < GD; ++d) {                              // tiles past the end are re-reads of the last one, never used
@@ -400,8 +404,9 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
         auto stage = [&](auto dc, int t) __attribute__((always_inline)) {
             constexpr int d = decltype(dc)::value;
             const int k0 = kbeg + t * GK;
-            stage_fix<AK, AVEC, DZ, false>(M, r0, k0, kend, tid, ra[d], ry[DZ ? d : 0]);
-            stage_fix<BK, BVEC, false, ONES>(N, c0, k0, kend, tid, rb[d], rb[d]);
+            const bool k_edge = k0 + GK > kend;
+            if (DZ || a_edge || k_edge) stage_fix<AK, AVEC, DZ, false>(M, r0, k0, kend, tid, ra[d], ry[DZ ? d : 0]);
+            if (b_edge || k_edge) stage_fix<BK, BVEC, false, ONES>(N, c0, k0, kend, tid, rb[d], rb[d]);
             if (GEMM_DBG != 5) {
                 stage_store<AK, AVEC>(S[t & 1][0], tid, ra[d]);
                 stage_store<BK, BVEC>(S[t & 1][1], tid, rb[d]);
@@ -488,7 +493,15 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int rr = (t >> 4) + 16 * it, cc = (t & 15) * 4;
-            if (r0 + rr < M && c0 + cc < N) *(f32x4*)(C + (size_t)(r0 + rr) * N + c0 + cc) = *(const f32x4*)(T + rr * GTP + cc);
+            if (r0 + rr < M && c0 + cc < N) {
+                f32x4 v = *(const f32x4*)(T + rr * GTP + cc);
+                if (E) {                                            // the product leaves as dZ of the layer below: times elu'(its output)
+                    const f32x4 y = *(const f32x4*)(E + (size_t)(r0 + rr) * N + c0 + cc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] *= elu_grad_from_out(y[c]);
+                }
+                *(f32x4*)(C + (size_t)(r0 + rr) * N + c0 + cc) = v;
+            }
         }
     } else if (live && col < N) {
 #pragma unroll
@@ -497,6 +510,7 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
             if (row < M) {
                 float v = acc[reg] + bv;
                 if (ACT == 1) v = v > 0.0f ? v : expm1f(v);          // ELU, alpha = 1
+                if (E) v *= elu_grad_from_out(E[(size_t)row * N + col]);
                 C[(size_t)row * N + col] = v;
             }
         }
@@ -508,16 +522,17 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
 
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
-                                              const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk) {
+                                              const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk,
+                                              const float* __restrict__ E) {
     __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];   // [buffer][operand]
     gemm_tile<AK, BK, AVEC, BVEC, ACT, DZ, ONES, SPLIT>(S, A, B, bias, Y, C, M, N, K, lda, ldb, chunk, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
-                                                         (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
+                                                         (int)gridDim.x, (int)gridDim.y, (int)gridDim.z, SPLIT ? nullptr : E);
 }
 
 // up to 8 products of one kind in one launch: workgroup L of the launch belongs to product p = the last one with first[p] <= L; every product's share is
 // padded to a multiple of 8 workgroups so that its tiles meet the XCDs as they do in a launch of their own (the padding workgroups leave at once)
 struct GemmGroup {
-    const float* A[8]; const float* B[8]; const float* bias[8]; const float* Y[8]; float* C[8];
+    const float* A[8]; const float* B[8]; const float* bias[8]; const float* Y[8]; const float* E[8]; float* C[8];
     int M[8], N[8], K[8], lda[8], ldb[8], chunk[8], nx[8], ny[8], nz[8], first[9], n;
 };
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
@@ -531,12 +546,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_W
     if (l >= nx * ny * nz) return;                                   // padding (uniform over the workgroup)
     const int bx = l % nx, t = l / nx, by = t % ny, bz = t / ny;
     gemm_tile<AK, BK, AVEC, BVEC, ACT, DZ, ONES, SPLIT>(S, g.A[p], g.B[p], g.bias[p], g.Y[p], g.C[p], g.M[p], g.N[p], g.K[p], g.lda[p], g.ldb[p], g.chunk[p],
-                                                         bx, by, bz, nx, ny, nz);
+                                                         bx, by, bz, nx, ny, nz, SPLIT ? nullptr : g.E[p]);
 }
 // host side: append product (grid nx x ny x nz) to the group
 static void group_add(GemmGroup& g, int& total, const float* A, const float* B, const float* bias, const float* Y, float* C, int M, int N, int K, int lda, int ldb,
-                      int chunk, int nx, int ny, int nz) {
+                      int chunk, int nx, int ny, int nz, const float* E = nullptr) {
     const int p = g.n;
+    g.E[p] = E;
     g.A[p] = A; g.B[p] = B; g.bias[p] = bias; g.Y[p] = Y; g.C[p] = C; g.M[p] = M; g.N[p] = N; g.K[p] = K; g.lda[p] = lda; g.ldb[p] = ldb; g.chunk[p] = chunk;
     g.nx[p] = nx; g.ny[p] = ny; g.nz[p] = nz; g.first[p] = total;
     total += (nx * ny * nz + 7) & ~7;
@@ -562,23 +578,27 @@ int tfp_linear_fwd(const float* A, const float* W, const float* bias, float* C, 
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (K & 3) == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0;
-#define FWD(V, ACT_) hipLaunchKernelGGL((k_gemm<false, false, V, V, ACT_, false, false, false>), grid, block, 0, s, A, W, bias, nullptr, C, M, N, K, K, K, 0)
+#define FWD(V, ACT_) hipLaunchKernelGGL((k_gemm<false, false, V, V, ACT_, false, false, false>), grid, block, 0, s, A, W, bias, nullptr, C, M, N, K, K, K, 0, nullptr)
     if (vec) { if (act) FWD(true, 1); else FWD(true, 0); }
     else { if (act) FWD(false, 1); else FWD(false, 0); }
 #undef FWD
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-// C[M,N] = dZ[M,K] . B[K,N] with dZ = A (Y == NULL) or A * elu'(Y)
-int tfp_gemm_nn(const float* A, const float* Y, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
+// C[M,N] = (dZ[M,K] . B[K,N]) * elu'(Yout[M,N]) with dZ = A (Y == NULL) or A * elu'(Y); Yout == NULL: no factor
+int tfp_gemm_nn_dz(const float* A, const float* Y, const float* B, const float* Yout, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return -1;
+    if (Yout && (N & 3) == 0 && ((uintptr_t)Yout & 15) != 0) return -1;      // the vector epilogue reads Yout as it writes C
     dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (K & 3) == 0 && (((uintptr_t)A | (uintptr_t)Y) & 15) == 0;
-#define NN(V, DZ_) hipLaunchKernelGGL((k_gemm<false, true, V, false, -1, DZ_, false, false>), grid, block, 0, s, A, B, nullptr, Y, C, M, N, K, K, N, 0)
+#define NN(V, DZ_) hipLaunchKernelGGL((k_gemm<false, true, V, false, -1, DZ_, false, false>), grid, block, 0, s, A, B, nullptr, Y, C, M, N, K, K, N, 0, Yout)
     if (vec) { if (Y) NN(true, true); else NN(true, false); }
     else { if (Y) NN(false, true); else NN(false, false); }
 #undef NN
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int tfp_gemm_nn(const float* A, const float* Y, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
+    return tfp_gemm_nn_dz(A, Y, B, nullptr, C, M, N, K, stream);
 }
 // gw[N1, N2] = dZ^T B, gb[N1] = column sums of dZ, for dZ[rows, N1] = A or A * elu'(Y), B[rows, N2]; `part` is scratch for
 // ceil(rows / chunk) slabs of [N1, N2 + 1] floats
@@ -588,8 +608,8 @@ int tfp_gemm_tn_bias(const float* A, const float* Y, const float* B, float* part
     const int splits = (rows + chunk - 1) / chunk;
     dim3 grid((N2 + 1 + GT - 1) / GT, (N1 + GT - 1) / GT, splits), block(512);
     hipStream_t s = (hipStream_t)stream;
-    if (Y) hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, true, true, true>), grid, block, 0, s, A, B, nullptr, Y, part, N1, N2 + 1, rows, N1, N2, chunk);
-    else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk);
+    if (Y) hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, true, true, true>), grid, block, 0, s, A, B, nullptr, Y, part, N1, N2 + 1, rows, N1, N2, chunk, nullptr);
+    else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk, nullptr);
     const int tot = N1 * (N2 + 1);
     hipLaunchKernelGGL(k_sum_partials, dim3((tot + 255) / 256), dim3(256), 0, s, part, gw, gb, splits, N1, N2);
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -617,8 +637,8 @@ int tfp_linear_fwd_group(const void* const* A, const void* const* W, const void*
 #undef FWDG
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-int tfp_gemm_nn_group(const void* const* A, const void* const* Y, const void* const* B, void* const* C, const int32_t* M, const int32_t* N, const int32_t* K,
-                      int32_t n, void* stream) {
+int tfp_gemm_nn_dz_group(const void* const* A, const void* const* Y, const void* const* B, const void* const* Yout, void* const* C, const int32_t* M,
+                         const int32_t* N, const int32_t* K, int32_t n, void* stream) {
     if (n <= 0 || n > 8) return -1;
     GemmGroup g; memset(&g, 0, sizeof(g));
     int total = 0, nvec = 0, ny_ = 0;
@@ -627,8 +647,10 @@ int tfp_gemm_nn_group(const void* const* A, const void* const* Y, const void* co
         const float* y = Y ? (const float*)Y[p] : nullptr;
         nvec += ((K[p] & 3) == 0 && (((uintptr_t)A[p] | (uintptr_t)y) & 15) == 0) ? 1 : 0;
         ny_ += y ? 1 : 0;
+        const float* e = Yout ? (const float*)Yout[p] : nullptr;
+        if (e && (N[p] & 3) == 0 && ((uintptr_t)e & 15) != 0) return -1;
         group_add(g, total, (const float*)A[p], (const float*)B[p], nullptr, y, (float*)C[p], M[p], N[p], K[p], K[p], N[p], 0,
-                  (N[p] + GT - 1) / GT, (M[p] + GT - 1) / GT, 1);
+                  (N[p] + GT - 1) / GT, (M[p] + GT - 1) / GT, 1, e);
     }
     for (int p = n; p < 9; ++p) g.first[p] = total;
     if ((nvec != 0 && nvec != n) || (ny_ != 0 && ny_ != n)) return -4;
@@ -638,6 +660,10 @@ int tfp_gemm_nn_group(const void* const* A, const void* const* Y, const void* co
     else { if (ny_) NNG(false, true); else NNG(false, false); }
 #undef NNG
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int tfp_gemm_nn_group(const void* const* A, const void* const* Y, const void* const* B, void* const* C, const int32_t* M, const int32_t* N, const int32_t* K,
+                      int32_t n, void* stream) {
+    return tfp_gemm_nn_dz_group(A, Y, B, nullptr, C, M, N, K, n, stream);
 }
 int tfp_gemm_tn_partials_group(const void* const* A, const void* const* Y, const void* const* B, void* const* part, const int32_t* rows, const int32_t* N1,
                                const int32_t* N2, int32_t chunk, int32_t n, void* stream) {
@@ -733,8 +759,8 @@ int tfp_gemm_tn_partials(const float* A, const float* Y, const float* B, float* 
     const int splits = (rows + chunk - 1) / chunk;
     dim3 grid((N2 + 1 + GT - 1) / GT, (N1 + GT - 1) / GT, splits), block(512);
     hipStream_t s = (hipStream_t)stream;
-    if (Y) hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, true, true, true>), grid, block, 0, s, A, B, nullptr, Y, part, N1, N2 + 1, rows, N1, N2, chunk);
-    else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk);
+    if (Y) hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, true, true, true>), grid, block, 0, s, A, B, nullptr, Y, part, N1, N2 + 1, rows, N1, N2, chunk, nullptr);
+    else hipLaunchKernelGGL((k_gemm<true, true, false, false, -1, false, true, true>), grid, block, 0, s, A, B, nullptr, nullptr, part, N1, N2 + 1, rows, N1, N2, chunk, nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 }  // extern "C"

@@ -35,6 +35,10 @@ def load():
         lib.tfp_linear_fwd.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]
         lib.tfp_gemm_nn.restype = C.c_int
         lib.tfp_gemm_nn.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
+        lib.tfp_gemm_nn_dz.restype = C.c_int
+        lib.tfp_gemm_nn_dz.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]
+        lib.tfp_gemm_nn_dz_group.restype = C.c_int
+        lib.tfp_gemm_nn_dz_group.argtypes = [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
         lib.tfp_gemm_tn_bias.restype = C.c_int
         lib.tfp_gemm_tn_bias.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p]
         lib.tfp_gemm_tn_partials.restype = C.c_int
@@ -193,12 +197,14 @@ def linear_fwd(x, w, b, act):
     return y
 
 
-def gemm_nn(a, b, y=None):
-    """(a * elu'(y)) @ b  (y: the ELU output the gradient a belongs to, or None)"""
+def gemm_nn(a, b, y=None, y_out=None):
+    """((a * elu'(y)) @ b) * elu'(y_out)  (y: the ELU output the gradient a belongs to, or None; y_out: the ELU output of the layer the product is the
+    gradient of, or None - with it the result is that layer's dZ, ready for its own two products without a factor in their operand loads)"""
     M, K = a.shape
     N = b.shape[1]
     c = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    _chk(load().tfp_gemm_nn(a.data_ptr(), y.data_ptr() if y is not None else None, b.data_ptr(), c.data_ptr(), M, N, K, _stream(a)), "tfp_gemm_nn")
+    _chk(load().tfp_gemm_nn_dz(a.data_ptr(), y.data_ptr() if y is not None else None, b.data_ptr(), y_out.data_ptr() if y_out is not None else None,
+                               c.data_ptr(), M, N, K, _stream(a)), "tfp_gemm_nn_dz")
     return c
 
 
@@ -280,15 +286,19 @@ def linear_fwd_group(xs, ws, bs, act):
     return ys
 
 
-def gemm_nn_group(as_, bs, ys=None):
-    """[(a * elu'(y)) @ b] for up to 8 independent problems in ONE launch (ys: all given or None); None when they are not of one kind"""
+def gemm_nn_group(as_, bs, ys=None, y_outs=None):
+    """[((a * elu'(y)) @ b) * elu'(y_out)] for up to 8 independent problems in ONE launch (ys: all given or None; y_outs: a list with None entries
+    allowed, or None); None when they are not of one kind"""
     n = len(as_)
     cs = [torch.empty(a.shape[0], b.shape[1], device=a.device, dtype=torch.float32) for a, b in zip(as_, bs)]
-    rc = load().tfp_gemm_nn_group(_vp(as_), _vp(ys) if ys is not None else None, _vp(bs), _vp(cs), _ip([a.shape[0] for a in as_]),
-                                  _ip([b.shape[1] for b in bs]), _ip([a.shape[1] for a in as_]), n, _stream(as_[0]))
+    eo = None
+    if y_outs is not None and any(e is not None for e in y_outs):
+        eo = (C.c_void_p * n)(*[e.data_ptr() if e is not None else None for e in y_outs])
+    rc = load().tfp_gemm_nn_dz_group(_vp(as_), _vp(ys) if ys is not None else None, _vp(bs), eo, _vp(cs), _ip([a.shape[0] for a in as_]),
+                                     _ip([b.shape[1] for b in bs]), _ip([a.shape[1] for a in as_]), n, _stream(as_[0]))
     if rc == -4:
         return None
-    _chk(rc, "tfp_gemm_nn_group")
+    _chk(rc, "tfp_gemm_nn_dz_group")
     return cs
 
 
@@ -357,13 +367,18 @@ def mlp_forward(x, layers):
 def mlp_backward(x, ys, gy, layers):
     """gradients of every layer's weight and bias into its `grad_out` buffers (chunk sums deferred: call flush_partial_sums() after the
     last network), given the gradient `gy` of the network output; the input gradient of the first layer is not formed"""
+    # gy is the gradient of layer k's OUTPUT at the top of the walk and the dZ of layer k - already times elu'(ys[k]) - below it: every input-gradient
+    # product leaves multiplied by the activation derivative of the layer it is the gradient of (tfp_gemm_nn_dz), so the two products that consume it
+    # stage plain operands.  Same bits as multiplying in their operand loads (one fp32 product either way).
+    is_dz = False
     for k in range(len(layers) - 1, -1, -1):
         w, _, act, grad_out = layers[k]
         inp = ys[k - 1] if k > 0 else x
-        yy = ys[k] if act else None
+        yy = ys[k] if (act and not is_dz) else None
         gemm_tn_bias(gy, inp, yy, out=grad_out, defer=True)
         if k > 0:
-            gy = gemm_nn(gy, w, yy)
+            gy = gemm_nn(gy, w, yy, y_out=ys[k - 1] if layers[k - 1][2] else None)
+            is_dz = True
 
 
 # ---- the actor and the central value network side by side: layer k of both in one launch, all weight gradients in two ----------------------
@@ -393,19 +408,23 @@ def mlp_backward_pair(xa, ya, gya, la, xc, yc, gyc, lc):
         mlp_backward(xa, ya, gya, la)
         mlp_backward(xc, yc, gyc, lc)
         return
-    dw = {True: ([], [], [], []), False: ([], [], [], [])}          # has ELU -> (gy, input, y, grad_out)
+    dw = {True: ([], [], [], []), False: ([], [], [], [])}          # the operand load multiplies by elu' -> (gy, input, y, grad_out)
+    is_dz = False                                                    # as in mlp_backward: below the top layer gy arrives as dZ
     for k in range(len(la) - 1, -1, -1):
-        act = la[k][2]
+        act = la[k][2] and not is_dz
         for net_x, net_y, gy, layers in ((xa, ya, gya, la), (xc, yc, gyc, lc)):
             inp = net_y[k - 1] if k > 0 else net_x
             slot = dw[bool(act)]
             slot[0].append(gy); slot[1].append(inp); slot[2].append(net_y[k] if act else None); slot[3].append(layers[k][3])
         if k > 0:
             yy = [ya[k], yc[k]] if act else None
-            out = gemm_nn_group([gya, gyc], [la[k][0], lc[k][0]], yy)
+            eo = [ya[k - 1], yc[k - 1]] if la[k - 1][2] else None
+            out = gemm_nn_group([gya, gyc], [la[k][0], lc[k][0]], yy, eo)
             if out is None:
-                out = [gemm_nn(gya, la[k][0], ya[k] if act else None), gemm_nn(gyc, lc[k][0], yc[k] if act else None)]
+                out = [gemm_nn(gya, la[k][0], ya[k] if act else None, y_out=eo[0] if eo else None),
+                       gemm_nn(gyc, lc[k][0], yc[k] if act else None, y_out=eo[1] if eo else None)]
             gya, gyc = out
+            is_dz = True
     for has_elu, (gys, inps, ys, outs) in dw.items():
         for i in range(0, len(gys), 8):
             sl = slice(i, i + 8)

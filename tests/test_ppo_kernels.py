@@ -247,3 +247,40 @@ def test_paired_network_walks_equal_the_separate_ones(hip):
     pk.flush_partial_sums()
     for (gw0, gb0), (_, _, _, (gw, gb)) in zip(paired, la + lc):
         assert torch.equal(gw0, gw) and torch.equal(gb0, gb)
+
+
+@pytest.mark.gpu
+def test_activation_gradient_applied_where_the_product_is_stored(hip):
+    """tfp_gemm_nn_dz (an input-gradient product that leaves as the dZ of the layer below) against the product followed by the elementwise factor -
+    one fp32 multiply per element either way: identical bits, vector and scalar epilogue, ragged sizes; and the backward walk built on it
+    (mlp_backward: every product below the top layer stages plain operands) against the walk that multiplies in the operand loads of both
+    consumers, which is what the kernels did before: identical weight and bias gradients."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(29)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+    elu_grad = lambda y: torch.where(y > 0, torch.ones_like(y), y + 1.0)                      # noqa: E731
+    for (M, K, N, with_y) in ((8192, 200, 400, True), (8192, 9, 100, False), (777, 100, 200, True), (130, 36, 41, False), (64, 8, 3, True)):
+        a, b = r(M, K), r(K, N)
+        y = (torch.rand(M, K, device=dev, generator=g) - 0.3) if with_y else None
+        yo = torch.rand(M, N, device=dev, generator=g) - 0.3
+        assert torch.equal(pk.gemm_nn(a, b, y, y_out=yo), pk.gemm_nn(a, b, y) * elu_grad(yo))
+    got = pk.gemm_nn_group([r(8192, 200), r(8192, 200)], [r(200, 400), r(200, 400)], None, [None, None])
+    assert got is not None and len(got) == 2
+
+    def net(k_in, n_out):
+        dims = [k_in, 400, 200, 100, n_out]
+        return [(r(dims[i + 1], dims[i]) * dims[i] ** -0.5, r(dims[i + 1]), 1 if i < 3 else 0,
+                 (torch.zeros(dims[i + 1], dims[i], device=dev), torch.zeros(dims[i + 1], device=dev))) for i in range(4)]
+    layers = net(41, 9)
+    x, gy = r(8192, 41), r(8192, 9)
+    ys = pk.mlp_forward(x, layers)
+    pk.mlp_backward(x, ys, gy, layers)
+    pk.flush_partial_sums()
+    new = [(gw.clone(), gb.clone()) for _, _, _, (gw, gb) in layers]
+    for k in range(len(layers) - 1, -1, -1):                     # the former walk: gy stays the gradient of the layer OUTPUT all the way down
+        w, _, act, _ = layers[k]
+        yy = ys[k] if act else None
+        gw, gb = pk.gemm_tn_bias(gy, ys[k - 1] if k > 0 else x, yy)
+        assert torch.equal(gw, new[k][0]) and torch.equal(gb, new[k][1]), k
+        if k > 0:
+            gy = pk.gemm_nn(gy, w, yy)

@@ -30,10 +30,19 @@ for K, N in SHAPES:
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
     gy = torch.randn(M, N, device=dev); y = torch.randn(M, N, device=dev)
     fl = 2.0 * M * N * K * 1e-6
-    r = [("fwd ", t_us(lambda: pk.linear_fwd(x, w, b, 1)), t_us(lambda: torch.nn.functional.elu(torch.addmm(b, x, w.t())))),
-         ("dX  ", t_us(lambda: pk.gemm_nn(gy, w, y)), t_us(lambda: (gy * torch.where(y > 0, 1.0, y + 1.0)) @ w)),
-         ("dW+b", t_us(lambda: pk.gemm_tn_bias(gy, x, y, chunk=CH)), t_us(lambda: ((gy * torch.where(y > 0, 1.0, y + 1.0)).t() @ x, gy.sum(0))))]
-    dz = gy * torch.where(y > 0, 1.0, y + 1.0)
+    # the trainer's flow (ppo_kernels.mlp_backward): gy arrives as dZ of this layer (the product above multiplied it by elu'(y) where it was stored), the
+    # input gradient leaves as dZ of the layer below (times elu' of this layer's input x, itself an ELU output); OPERAND=1: the former flow, the factor
+    # elu'(y) formed in the operand loads of both products
+    eg = lambda t: torch.where(t > 0, 1.0, t + 1.0)           # noqa: E731
+    if os.environ.get("OPERAND"):
+        r = [("fwd ", t_us(lambda: pk.linear_fwd(x, w, b, 1)), t_us(lambda: torch.nn.functional.elu(torch.addmm(b, x, w.t())))),
+             ("dX  ", t_us(lambda: pk.gemm_nn(gy, w, y)), t_us(lambda: (gy * eg(y)) @ w)),
+             ("dW+b", t_us(lambda: pk.gemm_tn_bias(gy, x, y, chunk=CH)), t_us(lambda: ((gy * eg(y)).t() @ x, gy.sum(0))))]
+    else:
+        r = [("fwd ", t_us(lambda: pk.linear_fwd(x, w, b, 1)), t_us(lambda: torch.nn.functional.elu(torch.addmm(b, x, w.t())))),
+             ("dX  ", t_us(lambda: pk.gemm_nn(gy, w, None, y_out=x)), t_us(lambda: (gy @ w) * eg(x))),
+             ("dW+b", t_us(lambda: pk.gemm_tn_bias(gy, x, None, chunk=CH)), t_us(lambda: (gy.t() @ x, gy.sum(0))))]
+    dz = gy * eg(y)
     e = lambda u, v: float((u - v).abs().max() / v.abs().max())
     gw, gb = pk.gemm_tn_bias(gy, x, y)
     print(f"   rel err fwd {e(pk.linear_fwd(x, w, b, 1), torch.nn.functional.elu(torch.addmm(b, x, w.t()))):.1e} dX {e(pk.gemm_nn(gy, w, y), dz @ w):.1e} "
