@@ -495,7 +495,7 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
             const int rr = (t >> 4) + 16 * it, cc = (t & 15) * 4;
             if (r0 + rr < M && c0 + cc < N) {
                 f32x4 v = *(const f32x4*)(T + rr * GTP + cc);
-                if (E) {                                            // the product leaves as dZ of the layer below: times elu'(its output)
+                if (ACT < 0 && E) {                                 // (input-gradient kinds only) the product leaves as dZ of the layer below: times elu'(its output)
                     const f32x4 y = *(const f32x4*)(E + (size_t)(r0 + rr) * N + c0 + cc);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] *= elu_grad_from_out(y[c]);
@@ -510,7 +510,7 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
             if (row < M) {
                 float v = acc[reg] + bv;
                 if (ACT == 1) v = v > 0.0f ? v : expm1f(v);          // ELU, alpha = 1
-                if (E) v *= elu_grad_from_out(E[(size_t)row * N + col]);
+                if (ACT < 0 && E) v *= elu_grad_from_out(E[(size_t)row * N + col]);
                 C[(size_t)row * N + col] = v;
             }
         }
@@ -520,8 +520,12 @@ __device__ __forceinline__ void gemm_tile(float (&S)[2][2][GT * GP], const float
 #endif
 }
 
+// The vector-load forward kinds need 63 - 67 registers: held to 64, four workgroups of 8 wavefronts are resident per CU (LDS: 4 x 36 KB) and the 1024
+// workgroups of a grouped pair of 8192 x 400 -> 200 layers run as ONE round; at 67 registers three are resident and the fourth quarter of the grid runs as
+// a second round behind the first: 44 -> 54 us for that launch (tools/experiments/grp_bench.py).
+#define GEMM_WPE_OF(AVEC_, BVEC_, DZ_) (((AVEC_) && (BVEC_) && !(DZ_)) ? 8 : GEMM_WPE)     // (the other kinds below 70 registers held to 64 as well: no measurable change)
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE_OF(AVEC, BVEC, DZ)))) k_gemm(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                                               const float* __restrict__ Y, float* __restrict__ C, int M, int N, int K, int lda, int ldb, int chunk,
                                               const float* __restrict__ E) {
     __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];   // [buffer][operand]
@@ -536,7 +540,7 @@ struct GemmGroup {
     int M[8], N[8], K[8], lda[8], ldb[8], chunk[8], nx[8], ny[8], nz[8], first[9], n;
 };
 template <bool AK, bool BK, bool AVEC, bool BVEC, int ACT, bool DZ, bool ONES, bool SPLIT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE))) k_gemm_group(const GemmGroup g) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GEMM_WPE_OF(AVEC, BVEC, DZ)))) k_gemm_group(const GemmGroup g) {
     __shared__ __attribute__((aligned(16))) float S[2][2][GT * GP];
     const int L = (int)blockIdx.x;
     int p = 0;
