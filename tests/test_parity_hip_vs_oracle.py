@@ -101,6 +101,23 @@ def test_solver_and_stepping_settings(hip, oracle, extra):
             pu.assert_bit_equal(a, b, f"{extra} [{variant}] step {t}")
 
 
+@pytest.mark.parametrize("kind", ["box", "extended_dr"])
+def test_middle_distal_pairs_in_the_extended_kernels(hip, oracle, kind):
+    """TfModel.ff_middle_pairs through the other two kernel families (the box object: EXT-2; every DR feature: EXT-1), both instantiations"""
+    extra = {}
+    if kind == "box":
+        m = hip.box_model((0.02, 0.08, 0.02), 500.0)
+        m.ff_middle_pairs = 1
+        extra = {"_model_edit": None, "model": m}
+    else:
+        extra = {"domain_randomization": pu.CONFIGS["d4_domain_randomization_extended"]["domain_randomization"]}
+    want = pu.oracle_rollout(oracle, 300, 50, "ff_middle_pairs", extra=extra)
+    for variant in pu.VARIANTS:
+        got = pu.rollout(hip, DEV, 300, 50, "ff_middle_pairs", extra=extra, variant=variant)
+        for t, (a, b) in enumerate(zip(got, want)):
+            pu.assert_bit_equal(a, b, f"ff_middle_pairs + {kind} [{variant}] step {t}")
+
+
 @pytest.mark.parametrize("difficulty", [-1, 2, 5, 6])
 def test_remaining_difficulties_and_reset_modes(hip, oracle, difficulty):
     """Goal samplers of the difficulties the Hydra configs do not use (trifinger_env.py:1211-1243), with success goal

@@ -7,6 +7,7 @@ python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $O/$
 bash tools/profile_round.sh $T > $O/${T}_profile_log.txt 2>&1
 bash tools/profile_ext.sh $T > /dev/null 2>&1
 python3 tools/sweep.py 2>&1 | grep -v amdgpu.ids > $O/${T}_sweep.txt; cat $O/${T}_sweep.txt
+python3 -c "from leibnizgym_amd import _capi; _capi.TfLib('leibnizgym_amd/csrc/libtrifinger_hip_timing.so')" 2>/dev/null || echo "STALE timing build: run make -C leibnizgym_amd/csrc libtrifinger_hip_timing.so before this script (the phase tables below will be an error trace)"
 { python3 tools/phase_timing.py 65536 600; python3 tools/phase_timing.py 8192 600; } 2>&1 | grep -v amdgpu.ids > $O/${T}_phase_timing_steady.txt
 python3 tools/api_bench.py 2>&1 | grep -v amdgpu.ids > $O/${T}_api_layers.txt
 python3 bench.py --difficulty 1 --envs 8192 --no-cpu-baseline > $O/${T}_bench_config1.json 2>/dev/null
