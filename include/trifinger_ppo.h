@@ -68,6 +68,16 @@ int tfp_gemm_nn_dz_group(const void* const* A, const void* const* Y /* may be NU
 int tfp_gemm_tn_partials_group(const void* const* A, const void* const* Y /* may be NULL */, const void* const* B, void* const* part, const int32_t* rows,
                                const int32_t* N1, const int32_t* N2, int32_t chunk, int32_t n, void* stream);
 
+/* The rollout's bookkeeping of one environment step (leibnizgym_amd/ppo.py::PPOTrainer.rollout; RL-Games' a2c_common.play_steps does the same with
+ * PyTorch operators): one launch samples the action a = mu + sigma * eps (sigma = exp(log_std) [A] and eps ~ N(0, 1) [n, A] supplied by the caller), its negative log-likelihood, and files
+ * the step into slot t of the caller's buffers (b_*: pointers to that slot; states / b_states may be NULL with Ds = 0); one launch scales the reward and
+ * converts the done flags (one byte per env); one launch runs generalised advantage estimation over the horizon (adv, ret: [T, n]; val: [T + 1, n]).
+ * Every product and sum is rounded separately in the order of the PyTorch expressions they replace: the buffers hold the same bits. */
+int tfp_rollout_record(const float* obs, int32_t Do, const float* states, int32_t Ds, const float* mu, const float* log_std, const float* sigma, const float* eps,
+                       const float* val, int32_t n, int32_t A, float* b_obs, float* b_states, float* b_act, float* b_mu, float* b_nlp, float* b_val, void* stream);
+int tfp_rollout_reward(const float* r, const void* done_bytes, float scale, int32_t n, float* b_rew, float* b_done, void* stream);
+int tfp_gae(const float* rew, const float* done, const float* val, float gamma, float gamma_tau, int32_t T, int32_t n, float* adv, float* ret, void* stream);
+
 /* Minibatch gather: dst[k][i, :] = src[k][idx[i], :] for n <= 8 float arrays of widths[k] columns (host arrays of n device pointers);
  * idx: int64 [rows] on the device */
 int tfp_gather_rows(const void* const* src, void* const* dst, const int32_t* widths, int32_t n, const void* idx, int32_t rows, void* stream);

@@ -708,6 +708,62 @@ __global__ void __launch_bounds__(256) k_gather_rows(GatherArgs ga, const long l
     ga.dst[k][(size_t)r * ga.width[k] + cc] = ga.src[k][(size_t)idx[r] * ga.width[k] + cc];
 }
 
+// ---- the rollout's bookkeeping of one environment step in one launch each (they stand where ~25 elementwise / copy launches of 3 - 4 us were:
+// exp, mul, add, the negative log-likelihood chain, seven copies into the rollout buffers, clones of obs / states, reward scaling, the done cast) ----
+// One wavefront per env: a = mu + sigma * eps (sigma = exp(log_std), formed by the caller once per rollout; a product and a sum, rounded separately like
+// the two torch operators), nlp = sum over the actions of 0.5 ((a - mu) / sigma)^2 + log_std + 0.5 log(2 pi), and the row of the step filed into slot t of the buffers (obs, states, act, mu, nlp, val).
+__global__ void __launch_bounds__(256) k_rollout_record(const float* __restrict__ obs, int Do, const float* __restrict__ states, int Ds, const float* __restrict__ mu,
+                                                        const float* __restrict__ log_std, const float* __restrict__ sigma, const float* __restrict__ eps,
+                                                        const float* __restrict__ val, int n, int A,
+                                                        float* __restrict__ b_obs, float* __restrict__ b_states, float* __restrict__ b_act, float* __restrict__ b_mu,
+                                                        float* __restrict__ b_nlp, float* __restrict__ b_val) {
+#pragma clang fp contract(off)                               // no fused multiply-adds below (HIP's __fmul_rn / __fadd_rn are inline operators that carry the
+                                                             // translation unit's contraction mode with them: they do not prevent it)
+    const int env = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (env >= n) return;
+    for (int c = lane; c < Do; c += 64) b_obs[(size_t)env * Do + c] = obs[(size_t)env * Do + c];
+    for (int c = lane; c < Ds; c += 64) b_states[(size_t)env * Ds + c] = states[(size_t)env * Ds + c];
+    float part = 0.0f;
+    for (int c = lane; c < A; c += 64) {
+        const float m = mu[(size_t)env * A + c], ls = log_std[c], sd = sigma[c];
+        const float se = sd * eps[(size_t)env * A + c];
+        const float a = m + se;
+        b_act[(size_t)env * A + c] = a;
+        b_mu[(size_t)env * A + c] = m;
+        const float z = (a - m) / sd, zz = z * z, h = 0.5f * zz;
+        part += (h + ls) + 0.91893853320467274178f;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) { b_nlp[env] = part; b_val[env] = val[env]; }
+}
+// rew[t] = r * scale, done[t] = float(d != 0); d: one byte per env (torch.bool / uint8)
+__global__ void __launch_bounds__(256) k_rollout_reward(const float* __restrict__ r, const unsigned char* __restrict__ d, float scale, int n, float* __restrict__ b_rew,
+                                                        float* __restrict__ b_done) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    b_rew[i] = r[i] * scale;
+    b_done[i] = d[i] ? 1.0f : 0.0f;
+}
+// generalised advantage estimation, one thread per env walking its T steps backwards; every product and sum rounded separately in the order of the torch
+// loop it replaces (8 launches per step of the horizon): nd = 1 - done; delta = (rew + (gamma val[t+1]) nd) - val[t]; last = delta + ((gamma tau) nd) last
+__global__ void __launch_bounds__(256) k_gae(const float* __restrict__ rew, const float* __restrict__ done, const float* __restrict__ val, float gamma, float gamma_tau,
+                                             int T, int n, float* __restrict__ adv, float* __restrict__ ret) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float last = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float nd = 1.0f - done[(size_t)t * n + i], v0 = val[(size_t)t * n + i];
+        const float gv = gamma * val[(size_t)(t + 1) * n + i], gvn = gv * nd, s1 = rew[(size_t)t * n + i] + gvn, delta = s1 - v0;
+        const float gn = gamma_tau * nd, gl = gn * last;
+        last = delta + gl;
+        adv[(size_t)t * n + i] = last;
+        ret[(size_t)t * n + i] = last + v0;
+    }
+}
+
 // ---- one launch for the chunk sums of every layer of a backward pass ----
 struct SumArgs { const float* part[8]; float* gw[8]; float* gb[8]; int splits[8]; int n1[8]; int n2[8]; int first[9]; int n; };
 __global__ void __launch_bounds__(256) k_sum_partials_multi(SumArgs sa) {
@@ -739,6 +795,23 @@ int tfp_gather_rows(const void* const* src, void* const* dst, const int32_t* wid
     ga.n = n;
     const long long total = (long long)rows * tw;
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ga, (const long long*)idx, rows, tw);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int tfp_rollout_record(const float* obs, int32_t Do, const float* states, int32_t Ds, const float* mu, const float* log_std, const float* sigma, const float* eps,
+                       const float* val, int32_t n, int32_t A, float* b_obs, float* b_states, float* b_act, float* b_mu, float* b_nlp, float* b_val, void* stream) {
+    if (n <= 0 || A <= 0 || Do <= 0 || Ds < 0 || (Ds > 0 && (!states || !b_states))) return -1;
+    hipLaunchKernelGGL(k_rollout_record, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, obs, Do, states, Ds, mu, log_std, sigma, eps, val, n, A, b_obs, b_states,
+                       b_act, b_mu, b_nlp, b_val);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int tfp_rollout_reward(const float* r, const void* done_bytes, float scale, int32_t n, float* b_rew, float* b_done, void* stream) {
+    if (n <= 0) return -1;
+    hipLaunchKernelGGL(k_rollout_reward, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r, (const unsigned char*)done_bytes, scale, n, b_rew, b_done);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int tfp_gae(const float* rew, const float* done, const float* val, float gamma, float gamma_tau, int32_t T, int32_t n, float* adv, float* ret, void* stream) {
+    if (n <= 0 || T <= 0) return -1;
+    hipLaunchKernelGGL(k_gae, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rew, done, val, gamma, gamma_tau, T, n, adv, ret);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 // the products of tfp_gemm_tn_partials summed for n <= 8 layers in one launch (fixed order over the chunks: deterministic)

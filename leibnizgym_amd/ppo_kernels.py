@@ -51,6 +51,12 @@ def load():
         lib.tfp_gemm_tn_partials_group.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_void_p]
         lib.tfp_sum_partials_multi.restype = C.c_int
         lib.tfp_sum_partials_multi.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]
+        lib.tfp_rollout_record.restype = C.c_int
+        lib.tfp_rollout_record.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_int32] + [C.c_void_p] * 7
+        lib.tfp_rollout_reward.restype = C.c_int
+        lib.tfp_rollout_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.tfp_gae.restype = C.c_int
+        lib.tfp_gae.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.tfp_gather_rows.restype = C.c_int
         lib.tfp_gather_rows.argtypes = [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = lib
@@ -241,6 +247,35 @@ def gather_rows(srcs, idx, outs=None):
     _chk(load().tfp_gather_rows((C.c_void_p * n)(*[s.data_ptr() for s in srcs]), (C.c_void_p * n)(*[o.data_ptr() for o in outs]),
                                 (C.c_int32 * n)(*widths), n, idx.data_ptr(), rows, _stream(idx)), "tfp_gather_rows")
     return outs
+
+
+# ---- the rollout's bookkeeping (ppo.PPOTrainer.rollout) -----------------------------------------------------------------------------------
+def rollout_record(obs, states, mu, log_std, sigma, eps, val, buf, t):
+    """a = mu + sigma * eps (sigma = log_std.exp(), formed once per rollout), its negative log-likelihood, and the step filed into slot t of the rollout buffers (obs, states, act, mu, nlp, val) in
+    ONE launch; returns the action (a view of buf["act"][t])"""
+    n, A = mu.shape
+    f = lambda x: x if x.is_contiguous() else x.contiguous()          # noqa: E731
+    obs, mu, eps, val = f(obs), f(mu), f(eps), f(val)
+    states = f(states) if states is not None else None
+    _chk(load().tfp_rollout_record(obs.data_ptr(), obs.shape[1], states.data_ptr() if states is not None else None, states.shape[1] if states is not None else 0,
+                                   mu.data_ptr(), log_std.data_ptr(), sigma.data_ptr(), eps.data_ptr(), val.data_ptr(), n, A, buf["obs"][t].data_ptr(),
+                                   buf["states"][t].data_ptr() if states is not None else None, buf["act"][t].data_ptr(), buf["mu"][t].data_ptr(),
+                                   buf["nlp"][t].data_ptr(), buf["val"][t].data_ptr(), _stream(mu)), "tfp_rollout_record")
+    return buf["act"][t]
+
+
+def rollout_reward(r, d, scale, rew_t, done_t):
+    """rew_t = r * scale, done_t = float(d) in one launch; d: torch.bool / uint8"""
+    assert d.dtype in (torch.bool, torch.uint8) and d.is_contiguous() and r.is_contiguous() and r.dtype == torch.float32
+    _chk(load().tfp_rollout_reward(r.data_ptr(), d.data_ptr(), float(scale), r.numel(), rew_t.data_ptr(), done_t.data_ptr(), _stream(r)), "tfp_rollout_reward")
+
+
+def gae(rew, done, val, gamma, tau):
+    """(adv, ret) over the horizon in one launch: rew, done [T, n], val [T + 1, n] -> adv, ret [T, n]; the arithmetic of the backward loop it replaces"""
+    T, n = rew.shape
+    adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+    _chk(load().tfp_gae(rew.data_ptr(), done.data_ptr(), val.data_ptr(), float(gamma), float(gamma * tau), T, n, adv.data_ptr(), ret.data_ptr(), _stream(rew)), "tfp_gae")
+    return adv, ret
 
 
 def gemm_tn_bias(a, b, y=None, chunk=256, out=None, defer=False):

@@ -284,3 +284,45 @@ def test_activation_gradient_applied_where_the_product_is_stored(hip):
         assert torch.equal(gw, new[k][0]) and torch.equal(gb, new[k][1]), k
         if k > 0:
             gy = pk.gemm_nn(gy, w, yy)
+
+
+@pytest.mark.gpu
+def test_rollout_bookkeeping_kernels_hold_the_bits_of_the_torch_expressions(hip):
+    """tfp_rollout_record / tfp_rollout_reward / tfp_gae (the rollout's ~25 elementwise launches per environment step and 8 per step of the advantage
+    loop as three kernels) against the PyTorch expressions of PPOTrainer.rollout: every product and sum is rounded separately in the same order, so
+    actions, filed rows, rewards, done flags, advantages and returns are identical; the negative log-likelihood (a sum over the actions, in another
+    order) to rounding."""
+    from leibnizgym_amd.ppo import neglogp
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(31)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+    for n, A, Do, Ds in ((8192, 9, 41, 113), (1000, 18, 50, 0), (3, 9, 41, 113)):
+        T = 4
+        obs, states = r(n, Do), (r(n, Ds) if Ds else None)
+        mu, eps, val, ls = r(n, A), r(n, A), r(n), 0.3 * r(A)
+        buf = dict(obs=torch.zeros(T, n, Do, device=dev), states=torch.zeros(T, n, Ds, device=dev) if Ds else None, act=torch.zeros(T, n, A, device=dev),
+                   mu=torch.zeros(T, n, A, device=dev), nlp=torch.zeros(T, n, device=dev), val=torch.zeros(T + 1, n, device=dev))
+        a = pk.rollout_record(obs, states, mu, ls, ls.exp(), eps, val, buf, 2)
+        want = mu + ls.expand_as(mu).exp() * eps
+        assert torch.equal(a, want) and a.data_ptr() == buf["act"][2].data_ptr()
+        assert torch.equal(buf["obs"][2], obs) and torch.equal(buf["mu"][2], mu) and torch.equal(buf["val"][2], val)
+        assert Ds == 0 or torch.equal(buf["states"][2], states)
+        torch.testing.assert_close(buf["nlp"][2], neglogp(want, mu, ls.expand_as(mu)), rtol=2e-6, atol=2e-6)
+        assert float(buf["obs"][1].abs().max()) == 0.0 and float(buf["act"][3].abs().max()) == 0.0          # the other slots stay untouched
+    n, T = 8192, 32
+    rew_in, d = r(n), torch.rand(n, device=dev, generator=g) < 0.1
+    rew, done = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pk.rollout_reward(rew_in, d, 0.01, rew, done)
+    assert torch.equal(rew, rew_in * 0.01) and torch.equal(done, d.float())
+    pk.rollout_reward(rew_in, d.to(torch.uint8), 0.01, rew, done)
+    assert torch.equal(done, d.float())
+    rews, dones, vals = r(T, n), (torch.rand(T, n, device=dev, generator=g) < 0.05).float(), r(T + 1, n)
+    gamma, tau = 0.99, 0.95
+    adv, last = torch.zeros(T, n, device=dev), torch.zeros(n, device=dev)
+    for t in reversed(range(T)):                                       # the loop of PPOTrainer.rollout
+        nd = 1.0 - dones[t]
+        delta = rews[t] + gamma * vals[t + 1] * nd - vals[t]
+        last = delta + gamma * tau * nd * last
+        adv[t] = last
+    got_adv, got_ret = pk.gae(rews, dones, vals, gamma, tau)
+    assert torch.equal(got_adv, adv) and torch.equal(got_ret, adv + vals[:T])
