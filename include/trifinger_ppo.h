@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-int tfp_api_version(void);                                     /* 1 */
+int tfp_api_version(void);                                     /* 2 (sq [4] / step [2] of tfp_clip_adam) */
 
 /* The whole PPO objective of one minibatch, value and gradients, in one launch (B samples, A = 9 or 18 actions):
  *   loss = a_loss + v_coef c_loss - ent_coef entropy + bounds_coef b_loss   (formulas: csrc/ppo_kernels.hip header)
@@ -28,7 +28,8 @@ int tfp_ppo_loss(const float* mu, const float* log_std, const float* act, const 
                  float* d_mu, float* d_v, float* d_logstd, float* loss_out, float* stats, void* stream);
 
 /* Gradient-norm truncation + Adam for two parameter groups over one flat buffer: group 0 = [0, n0), group 1 = [n0, n1).
- * sq [2] scratch, step [1] step counter (device), lr [2] learning rates (device). */
+ * sq [4] scratch - all zero before the first step, never touched by the caller afterwards (the two launches of a step keep the half the next step sums
+ * into clear: no zeroing launch) -, step [2] = (this step, completed steps) on the device, both zero at the start, lr [2] learning rates (device). */
 int tfp_clip_adam(float* p, const float* g, float* m, float* v, int32_t n0, int32_t n1, float* sq, float* step, const float* lr,
                   float max_norm0, float max_norm1, float beta1, float beta2, float eps, void* stream);
 

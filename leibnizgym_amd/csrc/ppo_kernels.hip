@@ -28,6 +28,11 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// d_logstd and the loss are sums over the blocks.  They are accumulated in accumulators of the library that are ZERO between launches and handed to the
+// caller's buffers by the block that finishes last (a ticket), which also clears them again: the caller's outputs need no launch that zeroes them first.
+// One objective at a time per device (the trainer's single stream); results as before up to the order of the atomic sums.
+__device__ float g_loss_acc[24];
+__device__ unsigned g_loss_ticket;
 template <int A>
 __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, const float* __restrict__ log_std, const float* __restrict__ act,
                                                   const float* __restrict__ old_nlp, const float* __restrict__ adv,
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, 
         if (q < A) {
             float add = t;
             if (blockIdx.x == 0) add += -ent_coef;               // the batch-independent entropy term, once
-            if (add != 0.0f) atomicAdd(&d_logstd[q], add);
+            if (add != 0.0f) atomicAdd(&g_loss_acc[q], add);
         } else if (q == A) {
             // thread A also assembles the block's share of the loss (it needs the three other sums of the block)
             const float bsa = t;
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, 
             const float bsb = (red[0][A + 2] + red[1][A + 2]) + (red[2][A + 2] + red[3][A + 2]);
             float part = bsa + v_coef * bsc + bounds_coef * bsb;
             if (blockIdx.x == 0) part += -ent_coef * ent;
-            atomicAdd(&loss_out[0], part);
+            atomicAdd(&g_loss_acc[A], part);
             atomicAdd(&stats[0], part);
             atomicAdd(&stats[1], bsa);
         } else if (q == A + 1) {
@@ -114,6 +119,20 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, 
             atomicAdd(&stats[3], t);
         }
     }
+    // the last block to get here hands the sums over and restores the zero state
+    __shared__ unsigned last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(&g_loss_ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        if (threadIdx.x <= A) {
+            const float sum = atomicExch(&g_loss_acc[threadIdx.x], 0.0f);
+            if (threadIdx.x < A) d_logstd[threadIdx.x] = sum; else loss_out[0] = sum;
+        }
+        if (threadIdx.x == 0) g_loss_ticket = 0u;
+    }
 }
 
 // ---- gradient-norm truncation + Adam over FLAT buffers, two parameter groups (actor | central value network) ------------------
@@ -121,6 +140,10 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, 
 // the two groups plus the norm / scale launches); over one flat buffer of 264 k floats the same arithmetic is two 5 us launches.
 // Group 0 = elements [0, n0), group 1 = [n0, n1).  k_grad_sqnorms also advances the step counter (kernel boundary = ordering).
 __global__ void __launch_bounds__(256) k_grad_sqnorms(const float* __restrict__ g, int n0, int n1, float* __restrict__ sq, float* __restrict__ step) {
+    // step[1] is the count of COMPLETED steps (written by k_clip_adam, stable during this launch); this step is tn = step[1] + 1 and sums into the half
+    // of sq that belongs to its parity - the half k_clip_adam of the step before cleared (no launch that zeroes sq)
+    const float tn = step[1] + 1.0f;
+    const int par = (int)tn & 1;
     float a0 = 0.0f, a1 = 0.0f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += gridDim.x * blockDim.x) {
         const float x = g[i];
@@ -134,19 +157,22 @@ __global__ void __launch_bounds__(256) k_grad_sqnorms(const float* __restrict__ 
     if (threadIdx.x < 2) {
         const int q = threadIdx.x;
         const float t = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
-        if (t != 0.0f) atomicAdd(&sq[q], t);
+        if (t != 0.0f) atomicAdd(&sq[2 * par + q], t);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) step[0] += 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) step[0] = tn;
 }
 // torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (||g|| + 1e-6)) per group; then torch.optim.Adam (no weight decay, no
 // amsgrad): m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2, p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int n0, int n1, const float* __restrict__ sq,
-                                                   const float* __restrict__ step, const float* __restrict__ lr, float max0, float max1,
+                                                   float* __restrict__ v, int n0, int n1, float* __restrict__ sq,
+                                                   float* __restrict__ step, const float* __restrict__ lr, float max0, float max1,
                                                    float b1, float b2, float eps) {
-    const float t = step[0];
+    const float t = step[0];                                    // this step (written by k_grad_sqnorms, stable during this launch)
+    const int par = (int)t & 1;
     const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
-    const float c0 = fminf(max0 / (sqrtf(sq[0]) + 1e-6f), 1.0f), c1 = fminf(max1 / (sqrtf(sq[1]) + 1e-6f), 1.0f);
+    const float c0 = fminf(max0 / (sqrtf(sq[2 * par]) + 1e-6f), 1.0f), c1 = fminf(max1 / (sqrtf(sq[2 * par + 1]) + 1e-6f), 1.0f);
+    if (blockIdx.x == 0 && threadIdx.x < 2) sq[2 * (1 - par) + threadIdx.x] = 0.0f;      // the other half: the next step sums into it (nobody touches it now)
+    if (blockIdx.x == 0 && threadIdx.x == 0) step[1] = t;
     const float s0 = lr[0] / bc1, s1 = lr[1] / bc1;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += gridDim.x * blockDim.x) {
         const bool g0 = i < n0;
@@ -160,25 +186,18 @@ __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ p, const 
 
 extern "C" {
 
-int tfp_api_version(void) { return 1; }
+int tfp_api_version(void) { return 2; }
 
-// d_logstd [A] and loss_out [1] are zeroed here (on the stream); stats [4] (loss, a_loss, c_loss, kl) ACCUMULATE across calls.
+// d_logstd [A] and loss_out [1] are overwritten; stats [4] (loss, a_loss, c_loss, kl) ACCUMULATE across calls.
 }  // extern "C"
-// Small buffers are cleared by a kernel, not by hipMemsetAsync: inside a captured HIP graph the memset / memcpy NODES of this ROCm stack
-// proved unsafe (pointer-like garbage appeared in a 40-byte pool tensor between the graph that wrote it and the graph that read it; see
-// DESIGN.md section 8) - the trainer's graphs consist of kernel nodes only.
-__global__ void k_zero_f32(float* __restrict__ a, int na, float* __restrict__ b, int nb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < na) a[i] = 0.0f;
-    if (b && i < nb) b[i] = 0.0f;
-}
+// (No launch of this file zeroes a small buffer any more - the objective and the optimiser keep their accumulators clean themselves.  When one did, it was a
+// kernel and not hipMemsetAsync: inside a captured HIP graph the memset / memcpy NODES of this ROCm stack proved unsafe, docs/HISTORY.md section 8.)
 extern "C" {
 int tfp_ppo_loss(const float* mu, const float* log_std, const float* act, const float* old_nlp, const float* adv, const float* old_mu,
                  const float* v, const float* ret, int32_t B, int32_t A, float e_clip, float v_coef, float ent_coef, float bounds_coef,
                  float* d_mu, float* d_v, float* d_logstd, float* loss_out, float* stats, void* stream) {
     if (B <= 0 || (A != 9 && A != 18)) return -1;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_zero_f32, dim3(1), dim3(64), 0, s, d_logstd, A, loss_out, 1);
     dim3 grid((B + 255) / 256), block(256);
     if (A == 9)
         hipLaunchKernelGGL((k_ppo_loss<9>), grid, block, 0, s, mu, log_std, act, old_nlp, adv, old_mu, v, ret, B, e_clip, v_coef, ent_coef,
@@ -189,12 +208,12 @@ int tfp_ppo_loss(const float* mu, const float* log_std, const float* act, const 
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// One optimisation step over flat buffers: sq [2] is scratch (zeroed here), step [1] and lr [2] live on the device (graph capture).
+// One optimisation step over flat buffers: sq [4] is scratch (all zero before the first step; the launches keep the half of the next step zero), step [2]
+// = (this step, completed steps) and lr [2] live on the device (graph capture).
 int tfp_clip_adam(float* p, const float* g, float* m, float* v, int32_t n0, int32_t n1, float* sq, float* step, const float* lr,
                   float max_norm0, float max_norm1, float beta1, float beta2, float eps, void* stream) {
     if (n1 <= 0 || n0 < 0 || n0 > n1) return -1;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_zero_f32, dim3(1), dim3(64), 0, s, sq, 2, (float*)nullptr, 0);
     const int blocks = (n1 + 256 * 4 - 1) / (256 * 4);
     hipLaunchKernelGGL(k_grad_sqnorms, dim3(blocks), dim3(256), 0, s, g, n0, n1, sq, step);
     hipLaunchKernelGGL(k_clip_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, n0, n1, sq, step, lr, max_norm0, max_norm1, beta1, beta2, eps);

@@ -293,7 +293,7 @@ class PPOTrainer:
             for p, o in zip(fo.params, fo.offsets):
                 m[names[id(p)]] = fo.m[o:o + p.numel()].view_as(p).clone()
                 v[names[id(p)]] = fo.v[o:o + p.numel()].view_as(p).clone()
-            step = float(fo.step_count.item())
+            step = float(fo.step_count[1].item())             # completed steps
             lrs = [float(x) for x in fo.lr.tolist()]
         else:
             for g in self.opt.param_groups:
@@ -362,7 +362,7 @@ class PPOTrainer:
                 if n in m:
                     fo.m[o:o + p.numel()].copy_(m[n].reshape(-1).to(fo.m.device))
                     fo.v[o:o + p.numel()].copy_(v[n].reshape(-1).to(fo.v.device))
-            fo.step_count.fill_(step)
+            fo._set_step(torch.tensor([float(step)]))
             fo.set_lr(0, lr_actor)
             if lr_value is not None:
                 fo.set_lr(1, lr_value if self.net.central else lr_actor)

@@ -145,9 +145,9 @@ class FlatClipAdam:
             p.data = self.flat_p[o:o + p.numel()].view_as(p)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.m, self.v = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
-        self.step_count = torch.zeros(1, device=dev)
+        self.step_count = torch.zeros(2, device=dev)            # (this step, completed steps): include/trifinger_ppo.h
         self.lr = torch.tensor([float(lr0), float(lr1)], device=dev)
-        self.sq = torch.zeros(2, device=dev)
+        self.sq = torch.zeros(4, device=dev)                    # two halves used by alternate steps; the kernels keep the next one clear
         self.max_norms, self.betas, self.eps = (float(max_norm0), float(max_norm1)), betas, float(eps)
 
     def set_lr(self, group, value):
@@ -182,15 +182,20 @@ class FlatClipAdam:
         return self.m.clone(), self.v.clone(), self.step_count.clone()
 
     def restore_snapshot(self, snap):
-        self.m.copy_(snap[0]); self.v.copy_(snap[1]); self.step_count.copy_(snap[2])
+        self.m.copy_(snap[0]); self.v.copy_(snap[1]); self._set_step(snap[2])
 
     def state_dict(self):
-        return {"kind": "flat_clip_adam", "m": self.m.clone(), "v": self.v.clone(), "step": self.step_count.clone(), "lr": self.lr.clone()}
+        return {"kind": "flat_clip_adam", "m": self.m.clone(), "v": self.v.clone(), "step": self.step_count[1:2].clone(), "lr": self.lr.clone()}
+
+    def _set_step(self, t):
+        """continue from `t` completed steps (a 1-element tensor, or the two-slot counter of a snapshot)"""
+        self.step_count.fill_(float(t.reshape(-1)[-1]))
+        self.sq.zero_()
 
     def load_state_dict(self, sd):
         if sd.get("kind") != "flat_clip_adam" or sd["m"].numel() != self.m.numel():
             raise ValueError("optimizer state of another kind / size")
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count.copy_(sd["step"]); self.lr.copy_(sd["lr"])
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self._set_step(sd["step"]); self.lr.copy_(sd["lr"])
 
 
 # ---- fp32 MFMA GEMMs of the two MLPs (csrc/ppo_kernels.hip: k_gemm) --------------------------------------------------------------

@@ -153,7 +153,7 @@ def test_ppo_library_exports_every_symbol_its_header_declares():
     lib = C.CDLL(path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.tfp_api_version() == 1
+    assert lib.tfp_api_version() == 2
     bound = pk.load()                                   # the binding sets argtypes for every declared entry point
     for n in names:
         assert getattr(bound, n).restype is C.c_int, n

@@ -17,7 +17,7 @@ def test_ppo_library_loads_and_exports_its_symbols():
     for name in ("tfp_api_version", "tfp_ppo_loss", "tfp_clip_adam", "tfp_linear_fwd", "tfp_gemm_nn", "tfp_gemm_tn_bias", "tfp_gemm_tn_partials",
                  "tfp_sum_partials_multi", "tfp_gather_rows"):
         assert hasattr(lib, name), name
-    assert lib.tfp_api_version() == 1
+    assert lib.tfp_api_version() == 2
 
 
 def reference_loss(mu, ls, v, act, old_nlp, adv, ret, old_mu, e_clip, v_coef, ent_coef, bounds_coef):
@@ -121,7 +121,7 @@ def test_flat_clip_adam_matches_torch(hip):
     sd = flat.state_dict()
     flat2 = pk.FlatClipAdam([torch.nn.Parameter(t.clone()) for t in init[:4]], [torch.nn.Parameter(t.clone()) for t in init[4:]], 1.0, 1.0, 1.0, 0.5)
     flat2.load_state_dict(sd)
-    assert torch.equal(flat2.m, flat.m) and float(flat2.step_count) == 25.0 and torch.equal(flat2.lr, flat.lr)
+    assert torch.equal(flat2.m, flat.m) and flat2.step_count.tolist() == [25.0, 25.0] and torch.equal(flat2.lr, flat.lr)
 
 
 @pytest.mark.gpu
