@@ -135,6 +135,11 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, 
     }
 }
 
+__global__ void k_reset_loss_state() {
+    if (threadIdx.x < 24) g_loss_acc[threadIdx.x] = 0.0f;
+    if (threadIdx.x == 0) g_loss_ticket = 0u;
+}
+
 // ---- gradient-norm truncation + Adam over FLAT buffers, two parameter groups (actor | central value network) ------------------
 // torch's fused multi-tensor Adam and clip_grad_norm_ take ~110 us per step for these 32 small tensors (two 38 us launches for
 // the two groups plus the norm / scale launches); over one flat buffer of 264 k floats the same arithmetic is two 5 us launches.
@@ -142,7 +147,11 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mu, 
 __global__ void __launch_bounds__(256) k_grad_sqnorms(const float* __restrict__ g, int n0, int n1, float* __restrict__ sq, float* __restrict__ step) {
     // step[1] is the count of COMPLETED steps (written by k_clip_adam, stable during this launch); this step is tn = step[1] + 1 and sums into the half
     // of sq that belongs to its parity - the half k_clip_adam of the step before cleared (no launch that zeroes sq)
-    const float tn = step[1] + 1.0f;
+    // The counter is a float (it feeds powf) and must keep ALTERNATING for ever - its parity selects the half of sq -, so it does not count past 2^23 + 1: from
+    // there it swings between 2^23 (even) and 2^23 + 1 (odd), both exact in fp32 (at 2^24 a float + 1 rounds back onto itself and the parity would freeze: the
+    // squared norms would then pile up in one half and the truncation coefficient fall towards 0).  The bias corrections 1 - beta^t are 1.0f long before that.
+    const float tp = step[1];
+    const float tn = tp >= 8388609.0f ? 8388608.0f : tp + 1.0f;
     const int par = (int)tn & 1;
     float a0 = 0.0f, a1 = 0.0f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += gridDim.x * blockDim.x) {
@@ -186,7 +195,7 @@ __global__ void __launch_bounds__(256) k_clip_adam(float* __restrict__ p, const 
 
 extern "C" {
 
-int tfp_api_version(void) { return 2; }
+int tfp_api_version(void) { return 3; }
 
 // d_logstd [A] and loss_out [1] are overwritten; stats [4] (loss, a_loss, c_loss, kl) ACCUMULATE across calls.
 }  // extern "C"
@@ -205,6 +214,12 @@ int tfp_ppo_loss(const float* mu, const float* log_std, const float* act, const 
     else
         hipLaunchKernelGGL((k_ppo_loss<18>), grid, block, 0, s, mu, log_std, act, old_nlp, adv, old_mu, v, ret, B, e_clip, v_coef, ent_coef,
                            bounds_coef, d_mu, d_v, d_logstd, loss_out, stats);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// the zero state of tfp_ppo_loss's accumulators (after a launch that failed or was aborted; a completed launch leaves them clean itself)
+int tfp_reset_state(void* stream) {
+    hipLaunchKernelGGL(k_reset_loss_state, dim3(1), dim3(64), 0, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

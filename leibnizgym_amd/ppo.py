@@ -214,7 +214,7 @@ class ActorCritic(nn.Module):
         xc = states if self.central else obs
         if self.actor.mfma and self.critic.mfma and obs.is_cuda and obs.dtype == torch.float32 and not torch.is_grad_enabled():
             from . import ppo_kernels as pk
-            ya, yc = pk.mlp_forward_pair(obs.contiguous(), self.actor.layer_list(), xc.contiguous(), self.critic.layer_list())
+            ya, yc = pk.mlp_forward_pair(obs.contiguous(), self.actor.layer_list(), xc.contiguous(), self.critic.layer_list(), store_hidden=False)
             mu, v = ya[-1], yc[-1].squeeze(-1)
         else:
             mu, v = self.actor(obs), self.critic(xc).squeeze(-1)

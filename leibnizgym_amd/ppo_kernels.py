@@ -16,7 +16,8 @@ _F = C.POINTER(C.c_float)
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_ppo.so")
+    """TFP_LIB: a developer build of the same sources (tools/experiments/*: timing variants)"""
+    return os.environ.get("TFP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_ppo.so")
 
 
 def load():
@@ -59,6 +60,11 @@ def load():
         lib.tfp_gae.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.tfp_gather_rows.restype = C.c_int
         lib.tfp_gather_rows.argtypes = [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        lib.tfp_reset_state.restype = C.c_int
+        lib.tfp_reset_state.argtypes = [C.c_void_p]
+        for name in ("tfp_mlp_forward", "tfp_mlp_backward"):
+            getattr(lib, name).restype = C.c_int
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         _LIB = lib
     return _LIB
 
@@ -107,6 +113,11 @@ def ppo_loss_and_grads(mu, log_std, v, act, old_nlp, adv, ret, old_mu, stats, e_
                           v.data_ptr(), ret.data_ptr(), B, A, float(e_clip), float(v_coef), float(ent_coef), float(bounds_coef),
                           d_mu.data_ptr(), d_v.data_ptr(), d_ls.data_ptr(), loss.data_ptr(), stats.data_ptr(), _stream(mu)), "tfp_ppo_loss")
     return loss, d_mu, d_v, d_ls
+
+
+def reset_state(device="cuda:0"):
+    """the zero state of the objective kernel's accumulators (only after a launch of it was aborted: a completed one leaves them clean)"""
+    _chk(load().tfp_reset_state(C.c_void_p(torch.cuda.current_stream(torch.device(device)).cuda_stream)), "tfp_reset_state")
 
 
 def fused_ppo_loss(mu, log_std, v, act, old_nlp, adv, ret, old_mu, stats, e_clip, v_coef, ent_coef, bounds_coef):
@@ -421,13 +432,101 @@ def mlp_backward(x, ys, gy, layers):
             is_dz = True
 
 
+# ---- the network walk (csrc/ppo_mlp_walk.hip): all layers of up to two networks in ONE launch per direction ------------------------------------
+WALK_MAXL = 4
+
+
+class TfpMlp(C.Structure):
+    """include/trifinger_ppo.h: TfpMlp"""
+    _fields_ = [("x", C.c_void_p), ("W", C.c_void_p * WALK_MAXL), ("b", C.c_void_p * WALK_MAXL), ("yin", C.c_void_p * WALK_MAXL),
+                ("y", C.c_void_p * WALK_MAXL), ("dim", C.c_int32 * (WALK_MAXL + 1)), ("act", C.c_int32 * WALK_MAXL), ("n_layers", C.c_int32)]
+
+
+def _walk_struct(x, layers):
+    m = TfpMlp()
+    m.x = x.data_ptr()
+    m.n_layers = len(layers)
+    m.dim[0] = layers[0][0].shape[1]
+    for l, (w, b, act, _) in enumerate(layers):
+        m.W[l] = w.data_ptr()
+        m.b[l] = b.data_ptr() if b is not None else None
+        m.dim[l + 1] = w.shape[0]
+        m.act[l] = int(act)
+    return m
+
+
+def _walkable(nets):
+    return (0 < len(nets) <= 2 and all(0 < len(layers) <= WALK_MAXL for _, layers in nets)
+            and all(x.dim() == 2 and x.is_contiguous() and x.shape[0] == nets[0][0].shape[0] for x, _ in nets))
+
+
+def mlp_walk_forward(nets, store_hidden=True):
+    """nets: [(x, layers)] for one or two Linear / ELU stacks over the same rows (`layers` as in mlp_forward).  ONE launch; returns the list of layer
+    outputs per network (hidden outputs None with store_hidden = False: the rollout needs the network outputs only), or None when the shapes do not
+    fit the walk (the caller then runs the layers one by one)."""
+    if not _walkable(nets):
+        return None
+    M = nets[0][0].shape[0]
+    arr = (TfpMlp * len(nets))()
+    outs = []
+    for i, (x, layers) in enumerate(nets):
+        m = _walk_struct(x, layers)
+        ys = []
+        for l, (w, _, _, _) in enumerate(layers):
+            keep = store_hidden or l == len(layers) - 1
+            y = torch.empty(M, w.shape[0], device=x.device, dtype=torch.float32) if keep else None
+            m.y[l] = y.data_ptr() if keep else None
+            ys.append(y)
+        arr[i] = m
+        outs.append(ys)
+    rc = load().tfp_mlp_forward(C.cast(arr, C.c_void_p), len(nets), M, _stream(nets[0][0]))
+    if rc == -4:
+        return None
+    _chk(rc, "tfp_mlp_forward")
+    return outs
+
+
+def mlp_walk_backward(nets):
+    """nets: [(gy, ys, layers)]: gy = gradient of the network output, ys = the layer outputs the forward kept.  ONE launch for the whole input-gradient
+    chain; returns per network the list dz with dz[l] = gradient of layer l's pre-activation (dz[-1] is gy itself), or None when the shapes do not fit."""
+    if not (0 < len(nets) <= 2) or any(len(layers) > WALK_MAXL or any(y is None for y in ys) for _, ys, layers in nets):
+        return None
+    M = nets[0][0].shape[0]
+    arr = (TfpMlp * len(nets))()
+    outs = []
+    for i, (gy, ys, layers) in enumerate(nets):
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        m = _walk_struct(gy, layers)
+        dz = []
+        for l in range(len(layers) - 1):
+            d = torch.empty_like(ys[l])
+            m.y[l] = d.data_ptr()
+            m.yin[l] = ys[l].data_ptr()
+            dz.append(d)
+        dz.append(gy)
+        arr[i] = m
+        outs.append(dz)
+    rc = load().tfp_mlp_backward(C.cast(arr, C.c_void_p), len(nets), M, _stream(nets[0][0]))
+    if rc == -4:
+        return None
+    _chk(rc, "tfp_mlp_backward")
+    return outs
+
+
+USE_WALK = True       # tools / tests switch it off to time or check the per-layer launches
+
+
 # ---- the actor and the central value network side by side: layer k of both in one launch, all weight gradients in two ----------------------
 def _pairable(la, lc):
     return len(la) == len(lc) and all(a[2] == c[2] for a, c in zip(la, lc))
 
 
-def mlp_forward_pair(xa, la, xc, lc):
+def mlp_forward_pair(xa, la, xc, lc, store_hidden=True):
     """mlp_forward of two networks of the same depth and activations, one grouped launch per layer (4 launches instead of 8 for the trainer's MLPs)"""
+    if USE_WALK:
+        out = mlp_walk_forward([(xa, la), (xc, lc)], store_hidden)
+        if out is not None:
+            return out[0], out[1]
     if not _pairable(la, lc):
         return mlp_forward(xa, la), mlp_forward(xc, lc)
     ya, yc = [], []
@@ -444,6 +543,20 @@ def mlp_backward_pair(xa, ya, gya, la, xc, yc, gyc, lc):
     """mlp_backward of both networks: the input-gradient products of layer k of both in one launch, and ALL weight / bias gradient products of the
     step in two launches (layers with an ELU, layers without) behind them - 5 launches instead of 14 for the trainer's MLPs.  Chunk sums deferred
     as in mlp_backward: call flush_partial_sums() afterwards."""
+    if USE_WALK:
+        dz = mlp_walk_backward([(gya, ya, la), (gyc, yc, lc)])
+        if dz is not None:
+            # every dZ is in memory: all weight / bias gradients of the step are plain products dZ_l^T [input_l | 1] = one grouped launch
+            gys, inps, outs = [], [], []
+            for net_x, net_y, d, layers in ((xa, ya, dz[0], la), (xc, yc, dz[1], lc)):
+                for k in range(len(layers) - 1, -1, -1):
+                    gys.append(d[k]); inps.append(net_y[k - 1] if k > 0 else net_x); outs.append(layers[k][3])
+            for i in range(0, len(gys), 8):
+                sl = slice(i, i + 8)
+                if not gemm_tn_bias_group(gys[sl], inps[sl], None, outs[sl]):
+                    for g, x, o in zip(gys[sl], inps[sl], outs[sl]):
+                        gemm_tn_bias(g, x, None, out=o, defer=True)
+            return
     if not _pairable(la, lc):
         mlp_backward(xa, ya, gya, la)
         mlp_backward(xc, yc, gyc, lc)

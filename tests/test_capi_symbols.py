@@ -146,14 +146,14 @@ def test_ppo_library_exports_every_symbol_its_header_declares():
     src = open(os.path.join(REPO, "include", "trifinger_ppo.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(tfp_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 17, names
+    assert len(names) == 20, names
     path = pk.library_path()
     if not os.path.isfile(path):
         subprocess.check_call(["make", "-C", os.path.dirname(path), "-s"])
     lib = C.CDLL(path)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.tfp_api_version() == 2
+    assert lib.tfp_api_version() == 3
     bound = pk.load()                                   # the binding sets argtypes for every declared entry point
     for n in names:
         assert getattr(bound, n).restype is C.c_int, n

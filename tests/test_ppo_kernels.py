@@ -15,9 +15,9 @@ def test_ppo_library_loads_and_exports_its_symbols():
     assert os.path.isfile(pk.library_path()), "run `make -C leibnizgym_amd/csrc` (python __graft_entry__.py)"
     lib = C.CDLL(pk.library_path())
     for name in ("tfp_api_version", "tfp_ppo_loss", "tfp_clip_adam", "tfp_linear_fwd", "tfp_gemm_nn", "tfp_gemm_tn_bias", "tfp_gemm_tn_partials",
-                 "tfp_sum_partials_multi", "tfp_gather_rows"):
+                 "tfp_sum_partials_multi", "tfp_gather_rows", "tfp_mlp_forward", "tfp_mlp_backward"):
         assert hasattr(lib, name), name
-    assert lib.tfp_api_version() == 2
+    assert lib.tfp_api_version() == 3
 
 
 def reference_loss(mu, ls, v, act, old_nlp, adv, ret, old_mu, e_clip, v_coef, ent_coef, bounds_coef):
@@ -125,6 +125,45 @@ def test_flat_clip_adam_matches_torch(hip):
 
 
 @pytest.mark.gpu
+def test_step_counter_keeps_alternating_past_2_to_the_23(hip):
+    """The float step counter of tfp_clip_adam selects, by its parity, the half of sq a step sums its squared norms into (the other half is cleared for
+    the next step).  A float stops counting at 2^24; the counter therefore swings between 2^23 and 2^23 + 1 once it gets there.  Preset just below the
+    boundary: over eight steps every step must see the squared norm of ITS gradients only (nothing piles up) and leave the other half zero."""
+    dev = "cuda:0"
+    p0, p1 = torch.nn.Parameter(torch.ones(1000, device=dev)), torch.nn.Parameter(torch.ones(500, device=dev))
+    flat = pk.FlatClipAdam([p0], [p1], 1e-4, 1e-4, 1.0, 1.0)
+    flat._set_step(torch.tensor([8388606.0]))                                 # 2^23 - 2 completed steps
+    seen = []
+    for k in range(8):
+        g0, g1 = torch.full((1000,), 0.01 * (k + 1), device=dev), torch.full((500,), 0.02 * (k + 1), device=dev)
+        p0.grad, p1.grad = g0, g1
+        flat.step()
+        t = float(flat.step_count[0])
+        par = int(t) & 1
+        seen.append(t)
+        sq = flat.sq.tolist()
+        assert sq[2 * (1 - par)] == 0.0 and sq[2 * (1 - par) + 1] == 0.0, (k, sq)
+        assert abs(sq[2 * par] - float((g0 * g0).sum())) <= 1e-5 * float((g0 * g0).sum()), (k, sq)
+        assert abs(sq[2 * par + 1] - float((g1 * g1).sum())) <= 1e-5 * float((g1 * g1).sum()), (k, sq)
+    assert seen == [8388607.0, 8388608.0, 8388609.0, 8388608.0, 8388609.0, 8388608.0, 8388609.0, 8388608.0], seen
+    assert torch.isfinite(p0).all() and float((p0 - 1).abs().max()) > 0            # the parameters kept moving
+
+
+@pytest.mark.gpu
+def test_reset_state_restores_the_objective_accumulators(hip):
+    """tfp_reset_state: a no-op on a clean library - the objective gives the same loss before and after"""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+    mu, ls, v = r(300, 9), r(9) * 0.1, r(300)
+    args = (mu, ls, v, mu + r(300, 9), r(300), r(300), r(300), mu + 0.01 * r(300, 9))
+    a = pk.ppo_loss_and_grads(*args, torch.zeros(4, device=dev), 0.2, 1.0, 0.0, 1e-4)[0].clone()
+    pk.reset_state(dev)
+    b = pk.ppo_loss_and_grads(*args, torch.zeros(4, device=dev), 0.2, 1.0, 0.0, 1e-4)[0].clone()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N,act", [(8192, 41, 400, 1), (8192, 400, 200, 1), (8192, 100, 9, 0), (1000, 113, 400, 1), (777, 200, 100, 1),
                                       (65, 100, 1, 0), (64, 32, 64, 1), (3, 5, 7, 1)])
 def test_mfma_linear_matches_torch_fp32(hip, M, K, N, act):
@@ -221,7 +260,7 @@ def test_grouped_launches_equal_the_single_products_bit_for_bit(hip):
 
 
 @pytest.mark.gpu
-def test_paired_network_walks_equal_the_separate_ones(hip):
+def test_paired_network_walks_equal_the_separate_ones(hip, monkeypatch):
     """mlp_forward_pair / mlp_backward_pair (what the trainer's minibatch step runs) against mlp_forward / mlp_backward network by network: identical
     outputs and identical gradients in the caller's buffers."""
     dev = "cuda:0"
@@ -234,6 +273,7 @@ def test_paired_network_walks_equal_the_separate_ones(hip):
                  (torch.zeros(dims[i + 1], dims[i], device=dev), torch.zeros(dims[i + 1], device=dev))) for i in range(4)]
     la, lc = net(41, 9), net(113, 1)
     xa, xc, gya, gyc = r(8192, 41), r(8192, 113), r(8192, 9), r(8192, 1)
+    monkeypatch.setattr(pk, "USE_WALK", False)               # the per-layer grouped launches (what runs when the shapes do not fit the network walk)
     ya, yc = pk.mlp_forward_pair(xa, la, xc, lc)
     for got, want in zip(ya + yc, pk.mlp_forward(xa, la) + pk.mlp_forward(xc, lc)):
         assert torch.equal(got, want)
@@ -247,6 +287,79 @@ def test_paired_network_walks_equal_the_separate_ones(hip):
     pk.flush_partial_sums()
     for (gw0, gb0), (_, _, _, (gw, gb)) in zip(paired, la + lc):
         assert torch.equal(gw0, gw) and torch.equal(gb0, gb)
+
+
+def _walk_reference(x, layers, gy):
+    """float64 torch: the layer outputs, the dZ of every layer and the parameter gradients of one Linear / ELU stack"""
+    ws = [w.double().requires_grad_(True) for w, _, _, _ in layers]
+    bs = [b.double().requires_grad_(True) for _, b, _, _ in layers]
+    h, ys, zs = x.double(), [], []
+    for (w, b, (_, _, act, _)) in zip(ws, bs, layers):
+        z = torch.nn.functional.linear(h, w, b)
+        z.retain_grad()
+        zs.append(z)
+        h = torch.nn.functional.elu(z) if act else z
+        ys.append(h)
+    h.backward(gy.double())
+    return ys, [z.grad for z in zs], [w.grad for w in ws], [b.grad for b in bs]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,dims_a,dims_c", [(8192, [41, 400, 200, 100, 9], [113, 400, 200, 100, 1]),
+                                             (1000, [41, 400, 200, 100, 18], [113, 400, 200, 100, 1]),
+                                             (77, [7, 33, 64, 5], [20, 416, 17, 3]),
+                                             (64, [16, 16], [3, 1]),
+                                             (130, [41, 400, 200, 100, 9], None)])
+def test_network_walk_matches_torch(hip, M, dims_a, dims_c):
+    """csrc/ppo_mlp_walk.hip - all layers of one or two Linear / ELU stacks in ONE launch per direction (64-row blocks, activations in LDS,
+    v_mfma_f32_16x16x4_f32) - against float64 torch: every layer output, every dZ of the input-gradient chain, and the parameter gradients the
+    trainer forms from them; the trainer's shapes, ragged row counts, widths that are no multiple of 16, one network alone, one-layer networks."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(M + sum(dims_a))
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+
+    def net(dims):
+        n = len(dims) - 1
+        return [(r(dims[i + 1], dims[i]) * dims[i] ** -0.5, r(dims[i + 1]) * 0.3, 1 if i < n - 1 else 0,
+                 (torch.zeros(dims[i + 1], dims[i], device=dev), torch.zeros(dims[i + 1], device=dev))) for i in range(n)]
+    nets = [(r(M, d[0]), net(d), r(M, d[-1])) for d in (dims_a, dims_c) if d is not None]
+    outs = pk.mlp_walk_forward([(x, layers) for x, layers, _ in nets])
+    assert outs is not None
+    refs = [_walk_reference(x, layers, gy) for x, layers, gy in nets]
+    close = lambda got, want, what: torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5, msg=lambda m: f"{what}: {m}")   # noqa: E731
+    for (x, layers, gy), ys, (ys64, dz64, gw64, gb64) in zip(nets, outs, refs):
+        for l, (y, y64) in enumerate(zip(ys, ys64)):
+            close(y, y64, f"output of layer {l}")
+    last = pk.mlp_walk_forward([(x, layers) for x, layers, _ in nets], store_hidden=False)                 # the rollout's form: network outputs only
+    for ys, ys_last in zip(outs, last):
+        assert all(y is None for y in ys_last[:-1]) and torch.equal(ys_last[-1], ys[-1])
+    dzs = pk.mlp_walk_backward([(gy, ys, layers) for (x, layers, gy), ys in zip(nets, outs)])
+    assert dzs is not None
+    for (x, layers, gy), ys, dz, (ys64, dz64, gw64, gb64) in zip(nets, outs, dzs, refs):
+        for l, (d, d64) in enumerate(zip(dz, dz64)):
+            close(d, d64, f"dZ of layer {l}")
+    if len(nets) == 2:                                                                        # the trainer's backward on top of it: parameter gradients
+        (xa, la, gya), (xc, lc, gyc) = nets
+        pk.mlp_backward_pair(xa, outs[0], gya, la, xc, outs[1], gyc, lc)
+        pk.flush_partial_sums()
+        for (x, layers, gy), (ys64, dz64, gw64, gb64) in zip(nets, refs):
+            for l, (_, _, _, (gw, gb)) in enumerate(layers):
+                scale = float(gw64[l].abs().max()) + 1e-12
+                assert float((gw.double() - gw64[l]).abs().max()) <= 3e-5 * scale + 1e-6, f"dW of layer {l}"
+                assert float((gb.double() - gb64[l]).abs().max()) <= 3e-5 * (float(gb64[l].abs().max()) + 1e-12) + 1e-6, f"db of layer {l}"
+
+
+@pytest.mark.gpu
+def test_network_walk_declines_what_does_not_fit(hip):
+    """a layer wider than 416 (26 column tiles) or activations beyond the LDS budget: None, and the pair entry points fall back to the per-layer launches"""
+    dev = "cuda:0"
+    x = torch.randn(256, 64, device=dev)
+    wide = [(torch.randn(512, 64, device=dev) * 0.1, torch.zeros(512, device=dev), 1, None), (torch.randn(8, 512, device=dev) * 0.05, torch.zeros(8, device=dev), 0, None)]
+    assert pk.mlp_walk_forward([(x, wide)]) is None
+    ya, yc = pk.mlp_forward_pair(x, wide, x, wide)
+    want = torch.nn.functional.linear(torch.nn.functional.elu(torch.nn.functional.linear(x, wide[0][0], wide[0][1])), wide[1][0], wide[1][1])
+    torch.testing.assert_close(ya[-1], want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(yc[-1], want, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.gpu
