@@ -76,6 +76,15 @@ int tfp_gemm_nn_dz_group(const void* const* A, const void* const* Y /* may be NU
 int tfp_gemm_tn_partials_group(const void* const* A, const void* const* Y /* may be NULL */, const void* const* B, void* const* part, const int32_t* rows,
                                const int32_t* N1, const int32_t* N2, int32_t chunk, int32_t n, void* stream);
 
+/* The weight / bias gradients of n <= 8 problems in ONE launch without LDS staging (csrc/ppo_dw_direct.hip): 64 x 64 output blocks whose operands come
+ * straight from memory as interleaved MFMA fragments (one dwordx4 per operand and 4-k step feeds 16 MFMAs), a workgroup = four 256-row pieces of one
+ * chunk of tfp_gemm_tn_partials_direct_chunk() = 1024 rows, summed through LDS in a fixed order.  A[p] = dZ [rows, N1] (already times the activation derivative), B[p] = the layer input [rows, N2];
+ * part[p] receives ceil(rows / chunk) slabs of N1 * (N2 + 1) floats, [dW | db] per slab: sum them with tfp_sum_partials_multi (splits = ceil(rows / chunk)).
+ * -4: more than 160 blocks in the call or an operand beyond 4 GB (the caller uses tfp_gemm_tn_partials_group). */
+int tfp_gemm_tn_partials_direct_chunk(void);                    /* rows per slab of the build (1024) */
+int tfp_gemm_tn_partials_direct(const void* const* A, const void* const* B, void* const* part, const int32_t* rows, const int32_t* N1, const int32_t* N2,
+                                int32_t n, void* stream);
+
 /* The rollout's bookkeeping of one environment step (leibnizgym_amd/ppo.py::PPOTrainer.rollout; RL-Games' a2c_common.play_steps does the same with
  * PyTorch operators): one launch samples the action a = mu + sigma * eps (sigma = exp(log_std) [A] and eps ~ N(0, 1) [n, A] supplied by the caller), its negative log-likelihood, and files
  * the step into slot t of the caller's buffers (b_*: pointers to that slot; states / b_states may be NULL with Ds = 0); one launch scales the reward and

@@ -60,6 +60,10 @@ def load():
         lib.tfp_gae.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.tfp_gather_rows.restype = C.c_int
         lib.tfp_gather_rows.argtypes = [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        lib.tfp_gemm_tn_partials_direct_chunk.restype = C.c_int
+        lib.tfp_gemm_tn_partials_direct_chunk.argtypes = []
+        lib.tfp_gemm_tn_partials_direct.restype = C.c_int
+        lib.tfp_gemm_tn_partials_direct.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]
         lib.tfp_reset_state.restype = C.c_int
         lib.tfp_reset_state.argtypes = [C.c_void_p]
         for name in ("tfp_mlp_forward", "tfp_mlp_backward"):
@@ -371,6 +375,31 @@ def gemm_tn_bias_group(as_, bs, ys, outs, chunk=256):
     return True
 
 
+def gemm_tn_bias_direct(as_, bs, outs):
+    """the chunk slabs of up to 8 weight / bias gradients [a.T @ b | a.sum(0)] in ONE launch of the direct kernel (csrc/ppo_dw_direct.hip: 64 x 64 blocks,
+    operands straight from memory), their sums deferred to flush_partial_sums().  a: dZ [rows, N1] (plain: no activation factor), b: [rows, N2].
+    Returns False when the call does not fit (nothing is queued then)."""
+    n = len(as_)
+    as_ = [a if a.is_contiguous() else a.contiguous() for a in as_]
+    bs = [b if b.is_contiguous() else b.contiguous() for b in bs]
+    rows = [a.shape[0] for a in as_]
+    n1 = [a.shape[1] for a in as_]
+    n2 = [b.shape[1] for b in bs]
+    chunk = load().tfp_gemm_tn_partials_direct_chunk()          # rows per slab of the build
+    splits = [(r + chunk - 1) // chunk for r in rows]
+    parts = [torch.empty(sp * a1 * (b2 + 1), device=as_[0].device, dtype=torch.float32) for sp, a1, b2 in zip(splits, n1, n2)]
+    rc = load().tfp_gemm_tn_partials_direct(_vp(as_), _vp(bs), _vp(parts), _ip(rows), _ip(n1), _ip(n2), n, _stream(as_[0]))
+    if rc == -4:
+        return False
+    _chk(rc, "tfp_gemm_tn_partials_direct")
+    for k in range(n):
+        _PENDING_SUMS.append((parts[k], outs[k][0], outs[k][1], splits[k], n1[k], n2[k]))
+    return True
+
+
+USE_DIRECT_DW = True
+
+
 class _MfmaLinear(torch.autograd.Function):
     """act(x W^T + b) with every matrix product on the hand-written fp32 MFMA kernels: forward with bias and ELU fused into the
     store; backward with the ELU derivative formed in the operand loads and the bias gradient as an extra column of the weight
@@ -553,6 +582,8 @@ def mlp_backward_pair(xa, ya, gya, la, xc, yc, gyc, lc):
                     gys.append(d[k]); inps.append(net_y[k - 1] if k > 0 else net_x); outs.append(layers[k][3])
             for i in range(0, len(gys), 8):
                 sl = slice(i, i + 8)
+                if USE_DIRECT_DW and gemm_tn_bias_direct(gys[sl], inps[sl], outs[sl]):
+                    continue
                 if not gemm_tn_bias_group(gys[sl], inps[sl], None, outs[sl]):
                     for g, x, o in zip(gys[sl], inps[sl], outs[sl]):
                         gemm_tn_bias(g, x, None, out=o, defer=True)

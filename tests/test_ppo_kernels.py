@@ -15,7 +15,7 @@ def test_ppo_library_loads_and_exports_its_symbols():
     assert os.path.isfile(pk.library_path()), "run `make -C leibnizgym_amd/csrc` (python __graft_entry__.py)"
     lib = C.CDLL(pk.library_path())
     for name in ("tfp_api_version", "tfp_ppo_loss", "tfp_clip_adam", "tfp_linear_fwd", "tfp_gemm_nn", "tfp_gemm_tn_bias", "tfp_gemm_tn_partials",
-                 "tfp_sum_partials_multi", "tfp_gather_rows", "tfp_mlp_forward", "tfp_mlp_backward"):
+                 "tfp_sum_partials_multi", "tfp_gather_rows", "tfp_mlp_forward", "tfp_mlp_backward", "tfp_gemm_tn_partials_direct"):
         assert hasattr(lib, name), name
     assert lib.tfp_api_version() == 3
 
@@ -347,6 +347,34 @@ def test_network_walk_matches_torch(hip, M, dims_a, dims_c):
                 scale = float(gw64[l].abs().max()) + 1e-12
                 assert float((gw.double() - gw64[l]).abs().max()) <= 3e-5 * scale + 1e-6, f"dW of layer {l}"
                 assert float((gb.double() - gb64[l]).abs().max()) <= 3e-5 * (float(gb64[l].abs().max()) + 1e-12) + 1e-6, f"db of layer {l}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [8192, 1000, 77])
+def test_direct_weight_gradients_match_torch(hip, rows):
+    """csrc/ppo_dw_direct.hip - [dZ^T X | column sums of dZ] for the eight layers of a minibatch step in ONE launch, 64 x 64 blocks with both operands
+    straight from memory as interleaved MFMA fragments - against float64 torch: the trainer's shapes (widths that are no multiple of 4 or 64, a
+    one-column dZ), row counts that are no multiple of the 1024-row chunk or of 4; and the same twice: identical bits (fixed summation order)."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(rows)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                                   # noqa: E731
+    shapes = [(400, 41), (200, 400), (100, 200), (9, 100), (400, 113), (200, 400), (100, 200), (1, 100)]
+    as_ = [r(rows, n1) for n1, _ in shapes]
+    bs = [r(rows, n2) for _, n2 in shapes]
+    outs = [(torch.zeros(n1, n2, device=dev), torch.zeros(n1, device=dev)) for n1, n2 in shapes]
+    assert pk.gemm_tn_bias_direct(as_, bs, outs)
+    pk.flush_partial_sums()
+    first = [(gw.clone(), gb.clone()) for gw, gb in outs]
+    for (gw, gb), a, b in zip(outs, as_, bs):
+        want_w, want_b = a.double().t() @ b.double(), a.double().sum(0)
+        assert float((gw.double() - want_w).abs().max()) <= 2e-5 * float(want_w.abs().max()) + 1e-5
+        assert float((gb.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max()) + 1e-5
+    for gw, gb in outs:
+        gw.zero_(); gb.zero_()
+    assert pk.gemm_tn_bias_direct(as_, bs, outs)
+    pk.flush_partial_sums()
+    for (gw0, gb0), (gw, gb) in zip(first, outs):
+        assert torch.equal(gw0, gw) and torch.equal(gb0, gb)
 
 
 @pytest.mark.gpu

@@ -37,8 +37,8 @@ xa, xc, gya, gyc = torch.randn(M, 41, device=dev), torch.randn(M, 113, device=de
 flops_f = 2.0 * M * (41 * 400 + 113 * 400 + 2 * (400 * 200 + 200 * 100) + 100 * 10)
 flops_b = 2.0 * M * (2 * (400 * 200 + 200 * 100) + 100 * 10)
 out = {}
-for walk in (False, True):
-    pk.USE_WALK = walk
+for walk, direct in ((False, False), (True, False), (True, True)):
+    pk.USE_WALK, pk.USE_DIRECT_DW = walk, direct
     ya, yc = pk.mlp_forward_pair(xa, la, xc, lc)
     out[walk] = (ya, yc)
     f_train = t_us(lambda: pk.mlp_forward_pair(xa, la, xc, lc))
@@ -47,7 +47,7 @@ for walk in (False, True):
         pk.mlp_backward_pair(xa, ya, gya, la, xc, yc, gyc, lc); pk.flush_partial_sums()
     b_all = t_us(bwd)
     b_dx = t_us(lambda: pk.mlp_walk_backward([(gya, ya, la), (gyc, yc, lc)])) if walk else float("nan")
-    print(f"{'walk' if walk else 'per-layer grouped'}: forward (train) {f_train:.1f} us = {flops_f / f_train * 1e-6:.1f} TFLOP/s, forward (rollout) {f_roll:.1f} us, "
+    print(f"{'walk' if walk else 'per-layer grouped'}{' + direct dW' if direct else ''}: forward (train) {f_train:.1f} us = {flops_f / f_train * 1e-6:.1f} TFLOP/s, forward (rollout) {f_roll:.1f} us, "
           f"backward incl. dW {b_all:.1f} us, input-gradient walk {b_dx:.1f} us = {flops_b / b_dx * 1e-6 if walk else float('nan'):.1f} TFLOP/s, "
           f"minibatch GEMM total {f_train + b_all:.1f} us", flush=True)
 # error against float64
