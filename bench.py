@@ -44,12 +44,12 @@ VALU_CYCLES_PER_INST = 2.0       # a wave64 VALU instruction occupies a SIMD-32 
 TF_OBS_BASE, TF_STATES_EXTRA = 32, 72     # include/trifinger.h: obs = 32 + A values, states = obs + 72
 BYTES_PER_ENV_STEP = {False: 623, True: 1075}     # symmetric / asymmetric obs (algorithmic)
 ACTION_READ_BYTES = 36                            # ... of which the [N, 9] action read, which the instantiation with the fused action source does not perform
-# exact fp32 operation count of one env-step of this workload on a scalar machine (the oracle's instrumented build, oracle/tf_flops.h:
-# 2404 add + 4505 mul + 18 div + 12 sqrt + 6379 fma counted twice; beside them 3854 comparisons / min / max / abs and 112 conversions):
-# tests/test_flop_count.py holds this constant to the count, profiles/r3_l_flops.txt is its table.  It replaces SURVEY.md 8(d)'s 33 kFLOP
-# paper estimate.  The GPU executes more than this (a wavefront runs a contact row whenever one of its 64 envs needs it): that is
-# valu_lane_ops_per_env_step, from the counters.
-FLOPS_PER_ENV_STEP = 19.7e3
+# exact fp32 operation count of one env-step of this workload on a scalar machine (the oracle's instrumented build, oracle/tf_flops.h), default model of
+# API 8 (the six middle-distal finger-finger pairs included: their geometry runs for every env): 2722 add + 5039 mul + 18 div + 12 sqrt + 7390 fma counted
+# twice; beside them 3995 comparisons / min / max / abs and 116 conversions (the fast contact set of API <= 7: 19.7 kFLOP, profiles/r3_l_flops.txt).
+# tests/test_flop_count.py holds this constant to the count.  It replaces SURVEY.md 8(d)'s 33 kFLOP paper estimate.  The GPU executes more than this
+# (a wavefront runs a contact row whenever one of its 64 envs needs it): that is valu_lane_ops_per_env_step, from the counters.
+FLOPS_PER_ENV_STEP = 22.6e3
 
 
 def load_pmc_profile(n, asym, ext=False, wide=False):
@@ -257,6 +257,8 @@ def main():
                          "taken.  Default: one episode length (750), so that every env has gone through a time-out reset.  0: none - the timed "
                          "region then starts --warmup steps after a reset of ALL envs (a correlated transient: "
                          "profiles/r4_a_driver_repro.txt)")
+    ap.add_argument("--no-fast-contact-leg", action="store_true",
+                    help="skip the second timed leg on the contact set of API <= 7 (`value_fast_contact_set`)")
     ap.add_argument("--strong-total", type=int, default=-1,
                     help="global env count of the strong-scaling leg (partitioned over the ranks); default: --envs (65536), 0: no such leg")
     ap.add_argument("--time-window", type=int, default=8,
@@ -357,6 +359,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n = eng.kernel_time_ms()
     global_stats = reducer.result().cpu().tolist() if reducer is not None else None
+    local_stats = eng.info.cpu().tolist() if reducer is not None else None
     eng.enable_kernel_timing(0)
     # beside it, over the same number of steps: the step fed from a ring of 16 RESIDENT action tensors (what rounds 1-3 printed as
     # `value`) ...
@@ -402,6 +405,7 @@ def main():
                 eng_s.step_random()
         for k in range(args.warmup):
             eng_s.step_random()
+        eng_s.frame_count = frame_first              # the same reward-schedule window as the weak leg (its frame counter was set back too)
         eng_s.enable_kernel_timing(8192 if args.time_window > 0 else 0, max(1, args.time_window))
         barrier()
         t3 = time.perf_counter()
@@ -420,6 +424,41 @@ def main():
                   "kernel": kernel_name(asym, eng_s.action_dim, 2 if args.box else (1 if args.dr else 0), True, eng_s.kernel_variant == "wide"),
                   "kernel_avg_us_rank0": (ks_ms / max(ks_n, 1)) * 1e3}
         eng_s.close()
+
+    # ---- beside `value`: the same workload on the contact set of API <= 7.  Since API 8 the default model holds the reference's self-collision set
+    # (TfModel.ff_middle_pairs = 1: the middle link of a finger against the fingertip of another, trifinger_env.py:811-812) and `value` is timed on
+    # it; `native.ff_middle_pairs: false` restores the distal pairs only - the faster step every earlier round's `value` was.  Same prelude, same
+    # warm-up, same frame window, same number of timed steps, same barriers and max over ranks.
+    fast = None
+    if not args.no_fast_contact_leg:
+        model_f = lib.box_model((0.02, 0.08, 0.02), 500.0) if args.box else lib.default_model()
+        model_f.ff_middle_pairs = 0
+        cfg_f = make_config(lib, n, seed=7, env_id_offset=rank * n, global_num_envs=world * n, model=model_f, **workload_kwargs(asym, args.difficulty, args.dr))
+        eng_f = TrifingerEngine(cfg_f, device=dev, lib=lib)
+        eng_f.reset()
+        if settle > 0 and ep_len > 0:
+            eng_f.steps.copy_(torch.randint(0, ep_len, (n,), device=dev, generator=gen, dtype=torch.int64))
+            for k in range(settle):
+                eng_f.step_random()
+        for k in range(args.warmup):
+            eng_f.step_random()
+        eng_f.frame_count = frame_first
+        eng_f.enable_kernel_timing(8192 if args.time_window > 0 else 0, max(1, args.time_window))
+        barrier()
+        t4 = time.perf_counter()
+        for k in range(args.steps):
+            eng_f.step_random()
+        barrier()
+        elapsed_f = time.perf_counter() - t4
+        kf_ms, kf_n = eng_f.kernel_time_ms()
+        assert torch.isfinite(eng_f.state).all(), "non-finite state after the fast-contact-set leg"
+        if distributed:
+            t = torch.tensor([elapsed_f], device=dev if not one_device else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_f = float(t[0].item())
+        fast = {"value": world * n * args.steps / elapsed_f, "ms_per_step": elapsed_f / args.steps * 1e3, "kernel_avg_us_rank0": (kf_ms / max(kf_n, 1)) * 1e3,
+                "contact_set": "TfModel.ff_middle_pairs = 0 (`native.ff_middle_pairs: false`): finger-finger contacts between the three distal pairs only"}
+        eng_f.close()
 
     total_env_steps = world * n * args.steps
     value = total_env_steps / elapsed
@@ -478,6 +517,13 @@ def main():
         "value_strong_65536_total": (strong["value"] if strong else (value if strong_total == n else None)) if strong_total == 65536 else None,
         "strong_scaling": strong if strong else ({"global_envs": n, "envs_per_gpu": n, "ms_per_step": elapsed / args.steps * 1e3, "value": value,
                                                   "same_as": "value (one rank: the weak and the strong partition coincide)"} if strong_total == n else None),
+        # the default model = the reference's contact set since API 8; the opt-out (the step of every earlier round) beside it
+        "contact_set": "TfModel.ff_middle_pairs = 1 (default since API 8): every finger-finger pair the reference's self-collision group holds among the "
+                       "modelled shapes - the three distal pairs and the six middle-distal pairs (trifinger_env.py:811-812)",
+        "value_fast_contact_set": fast["value"] if fast else None,
+        "fast_contact_set": fast,
+        "comparability": "`value` of rounds 1-5 was timed on the fast contact set (compare their `value` with `value_fast_contact_set`); rounds 1-4 "
+                         "did not set the frame counter back after the prelude (reward-schedule switch outside their window)",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -541,12 +587,13 @@ def main():
             "valu_lane_ops_per_env_step": (pmc["SQ_INSTS_VALU"] * 64.0 / n) if (pmc and "SQ_INSTS_VALU" in pmc) else None,
             "valu_lane_ops_frac": (pmc["SQ_INSTS_VALU"] * 64.0 / kern_avg_s / (FP32_PEAK_TFLOPS * 0.5e12)) if (pmc and kern_n and "SQ_INSTS_VALU" in pmc) else None,
             "flops_per_env_step": FLOPS_PER_ENV_STEP,
-            "flops_source": "exact count of the oracle's instrumented build (tests/test_flop_count.py, profiles/r3_l_flops.txt)",
+            "flops_source": "exact count of the oracle's instrumented build on the default model of API 8 (tests/test_flop_count.py)",
             "fp32_frac": (FLOPS_PER_ENV_STEP * n / kern_avg_s / 1e12 / FP32_PEAK_TFLOPS) if kern_n else 0.0,
         },
     }
     if global_stats is not None:
         out["episode_stats_all_reduced"] = global_stats[:11]
+        out["episode_stats_rank0"] = local_stats[:11]          # this rank's own statistics of the same step (equal to the reduced ones in a world of one)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(asym)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TF_API_VERSION 7
+#define TF_API_VERSION 8
 
 typedef enum TfStatus {
     TF_OK = 0,
@@ -243,10 +243,11 @@ typedef struct TfModel {
     float obj_min_height;         /* size_z / 2                                  0.0325                  */
     float obj_span_min_height;    /* max_height (0.1) - min_height               0.0675   (difficulty 3) */
     float obj_span_radius;        /* max_height - radius_3d                      0.04370835 (difficulty 4, 5) */
-    /* API 7.  Finger-finger contacts beyond the three distal pairs: != 0 adds the MIDDLE link of every finger (shape2) against the fingertip capsule
+    /* API 7 / 8.  Finger-finger contacts beyond the three distal pairs: != 0 adds the MIDDLE link of every finger (shape2) against the fingertip capsule
      * of each other finger - six ordered pairs, one frictionless normal row each, visited after the distal pairs in the finger-finger pass (the
      * reference keeps all robot links in one self-colliding group, trifinger_env.py:811-812; uniformly drawn joint positions overlap in a
-     * middle-distal pair 1.4 % of the time, in a distal pair 1.7 %).  0 (default): the three distal pairs only.  Cost: INTEGRATION.md. */
+     * middle-distal pair 1.4 % of the time, in a distal pair 1.7 %).  API 8: tf_default_model sets 1 - the reference's contact set is the default;
+     * 0 = the three distal pairs only (`native.ff_middle_pairs: false`, the faster step of API 7).  Cost: INTEGRATION.md. */
     int32_t ff_middle_pairs;
 } TfModel;
 

@@ -11,7 +11,7 @@ same binding at the CPU oracle; nothing in this package ever does.
 import ctypes as C
 import os
 
-TF_API_VERSION = 7
+TF_API_VERSION = 8
 TF_NUM_REWARD_TERMS = 6
 TF_NUM_INFO = 16
 TF_STATE_ROWS = 172

@@ -1741,10 +1741,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                     }
                 }
             }
-            // ---- FF, second part (TfModel.ff_middle_pairs, off by default; wave-uniform): the middle link of finger fm (shape2) against the distal
+            // ---- FF, second part (TfModel.ff_middle_pairs, on by default since API 8; wave-uniform): the middle link of finger fm (shape2) against the distal
             // capsule of each other finger - six ordered pairs on the same velocities.  The middle frame is rebuilt from what finger fm publishes:
             // e_x = (c1, 0, -s1), g = (p3 - p2) - j3_x e_x = j3_y e_y + j3_z e_z, e_x x g = j3_y e_z - j3_z e_y (oracle/tf_oracle.c, the same lines). ----
-            if (__builtin_expect(m.ff_middle_pairs != 0, 0)) {
+            if (__builtin_expect(m.ff_middle_pairs != 0, 1)) {
                 const TfLinkShape& sh = m.shape2;
                 const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
                 const float inv_j = f_rcp(FMA(jy, jy, jz * jz));

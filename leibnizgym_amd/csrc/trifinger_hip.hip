@@ -241,7 +241,7 @@ void tf_default_model(TfModel* m) {
     m->obj_min_height = 0.0325f;
     m->obj_span_min_height = 0.0675f;
     m->obj_span_radius = 0.04370835f;
-    m->ff_middle_pairs = 0;
+    m->ff_middle_pairs = 1;                // API 8: the reference keeps every robot link in one self-colliding group (trifinger_env.py:811-812)
 }
 
 // The object as a general box: mass, principal moments about the body axes, reference inertia of the scaled solve (the mean

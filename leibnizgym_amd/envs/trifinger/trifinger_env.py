@@ -148,11 +148,12 @@ class TrifingerEnv(IsaacEnvBase):
             raise ValueError(f"native.solver: 'pgs' or 'tgs', got {solver!r}")
         model = (lib.box_model(native["object_size"], native.get("object_density", 500.0))
                  if native.get("object_size") is not None else None)
-        # "native.ff_middle_pairs" (default False): finger-finger contacts between the middle link of a finger and the distal link of another, beyond
-        # the three distal pairs (include/trifinger.h: TfModel.ff_middle_pairs; the reference keeps all robot links in one self-colliding group, :811-812)
-        if native.get("ff_middle_pairs", False):
+        # "native.ff_middle_pairs" (default True since API 8): finger-finger contacts between the middle link of a finger and the distal link of
+        # another, beyond the three distal pairs (include/trifinger.h: TfModel.ff_middle_pairs; the reference keeps all robot links in one
+        # self-colliding group, :811-812).  False: the distal pairs only - the faster step of the earlier API.
+        if not native.get("ff_middle_pairs", True):
             model = model if model is not None else lib.default_model()
-            model.ff_middle_pairs = 1
+            model.ff_middle_pairs = 0
         cfg = make_config(
             lib, int(c["num_instances"]), seed=int(c["seed"]), env_id_offset=self._env_id_offset,
             global_num_envs=self._global_num_instances(), command_mode=c["command_mode"],

@@ -226,7 +226,9 @@ def neglogp(x, mu, log_std):
 
 
 class PPOTrainer:
-    """`env` is an RlGamesGpuEnvAdapter-like object: reset() -> {"obs","states"} or obs; step(a) -> (same, r, d, info)."""
+    """`env` is an RlGamesGpuEnvAdapter-like object: reset() -> {"obs","states"} or obs; step(a) -> (same, r, d, info).  Contract on the tensors it
+    returns: with the attribute `buffers_stable_until_next_step = True` they may be the env's live buffers (valid until its next step / reset, on the
+    calling stream) and the fused rollout reads them in place; without it every step's observation is cloned before it is used."""
 
     def __init__(self, env, obs_dim, state_dim, act_dim, cfg: PPOConfig = None, device="cuda:0", group=None):
         self.env, self.cfg, self.device, self.group = env, cfg or PPOConfig(), torch.device(device), group
@@ -249,11 +251,14 @@ class PPOTrainer:
         self.fused_loss = fused and c.fused_kernels        # hand-written objective kernel (GPU only)
         self.net.actor.mfma = self.net.critic.mfma = bool(fused and c.fused_kernels)   # ... and the MFMA linear layers
         self.dist_on = False
+        self.n_grad_allreduce = self.n_kl_allreduce = 0       # collectives issued so far (what a test of the distributed path counts)
         rank = 0
         try:
             import torch.distributed as dist
             self.dist = dist
-            self.dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+            # a process group that exists is used - also a world of one (`torch.distributed.run --nproc-per-node 1`): the collectives then run exactly
+            # as in a multi-GPU job (that is how the RCCL path is exercised on a one-GPU box); without a group nothing is exchanged
+            self.dist_on = dist.is_available() and dist.is_initialized()
         except Exception:
             self.dist = None
         if self.dist_on:                       # identical initial weights on every rank
@@ -461,8 +466,11 @@ class PPOTrainer:
                 buf["val"][t] = val_t
             out, r, d, extra = self.env.step(a)
             last_step = t == T - 1
-            # the env may hand out its own buffers: they are read (filed above) before the next step overwrites them, so only what outlives the loop is cloned
-            obs, states = self._unpack(out) if (not fused or last_step) else ((out["obs"], out["states"]) if isinstance(out, dict) else (out, None))
+            # an env that DECLARES its buffers stable until its next step (`buffers_stable_until_next_step`: RlGamesGpuEnvAdapter hands out the
+            # engine's own tensors) is read in place - they are filed above before the next step overwrites them, only what outlives the loop is cloned;
+            # any other env gets a snapshot per step (it may refresh its observation asynchronously or on another stream)
+            live = fused and not last_step and getattr(self.env, "buffers_stable_until_next_step", False)
+            obs, states = ((out["obs"], out["states"]) if isinstance(out, dict) else (out, None)) if live else self._unpack(out)
             if isinstance(extra, (list, tuple)) and len(extra) > 1 and isinstance(extra[1], dict):
                 self.last_info = extra[1]                   # RL-Games convention: [[], info] (direct logging from the env)
             if fused and r.is_cuda and r.dtype == torch.float32 and r.is_contiguous() and d.is_cuda and d.dtype in (torch.bool, torch.uint8) and d.is_contiguous():
@@ -579,6 +587,7 @@ class PPOTrainer:
             off += p.numel()
 
     def _exchange(self, flat):
+        self.n_grad_allreduce += 1
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         flat /= self.dist.get_world_size(self.group)
 
@@ -615,6 +624,7 @@ class PPOTrainer:
             count += nmb
             kl = acc["kl"] / max(nmb, 1)
             if self.dist_on:
+                self.n_kl_allreduce += 1
                 self.dist.all_reduce(kl, op=self.dist.ReduceOp.SUM, group=self.group)
                 kl /= self.dist.get_world_size(self.group)
             kl = float(kl)                     # the one host sync per mini-epoch (adaptive learning rate)

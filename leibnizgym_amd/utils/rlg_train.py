@@ -92,6 +92,12 @@ class RlGamesGpuEnvAdapter(_IVecEnv):
     """`IVecEnv` over a `VecTaskPython`.  The observation handed to RL-Games is ONE dict object for the adapter's
     lifetime (RL-Games keeps a reference to it between calls); only its entries are replaced."""
 
+    # The tensors this adapter hands out are the env's OWN buffers: they hold the values of a step until the next `step` / `reset` call overwrites them, on
+    # the stream that call runs on.  A consumer that reads them before its next call (on that stream) needs no copy - leibnizgym_amd.ppo.PPOTrainer checks
+    # this attribute and files obs / states of a rollout step straight out of them; an env without it (buffers refreshed asynchronously or on a side stream)
+    # gets a clone per step.
+    buffers_stable_until_next_step = True
+
     def __init__(self, config_name: str, num_actors: int, env=None, **kwargs):
         self.env = env if env is not None else env_configurations.configurations[config_name]["env_creator"](**kwargs)
         self.use_global_obs = self.env.num_states > 0

@@ -413,7 +413,7 @@ void tf_default_model(TfModel* m) {
     m->obj_min_height = 0.0325f;
     m->obj_span_min_height = 0.0675f;
     m->obj_span_radius = 0.04370835f;
-    m->ff_middle_pairs = 0;
+    m->ff_middle_pairs = 1;                /* API 8: the reference keeps every robot link in one self-colliding group (trifinger_env.py:811-812) */
 }
 
 /* The object as a general box: mass, principal moments about the body axes, reference inertia of the scaled solve (the mean
@@ -1482,7 +1482,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja, Wa) + dot3(Jb, Wb)), 0.0f);
         for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[j], lam, va[j]); vb[j] = FMA(-Wb[j], lam, vb[j]); }
     }
-    /* ---- FF, second part (TfModel.ff_middle_pairs, off by default): the MIDDLE link of finger fm against the distal capsule of each other
+    /* ---- FF, second part (TfModel.ff_middle_pairs, on by default since API 8): the MIDDLE link of finger fm against the distal capsule of each other
      * finger fd - the six ordered pairs (0;1) (0;2) (1;2) (1;0) (2;0) (2;1), visited after the three distal pairs on the same velocities.
      * The reference leaves every robot link in one collision group with self-collision on (trifinger_env.py:811-812).  The middle link is
      * its finger-cube shape (shape2: tapered rounded box about the axis a -> b of the middle frame), the distal link the fingertip capsule

@@ -41,7 +41,10 @@ def main(argv):
         local = 0
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
-    if world > 1:
+    # launched by torch.distributed.run (RANK is set): a process group also for a world of ONE, so that `--nproc-per-node 1` runs the very code path of
+    # an 8-GPU job - RCCL initialisation, the gradient all-reduce of every minibatch, the KL all-reduce of every mini-epoch (tests/test_rccl_gpu.py)
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -71,7 +74,10 @@ def main(argv):
                   f"kl {st['kl']:.4f} lr {st['lr']:.2e} loss {st['loss']:.4f}  {st['frames'] * world / (now - t0):.3e} frames/s "
                   f"since start, {steady:.3e} over the last {min(len(marks) - 1, 10)} epochs", flush=True)
     tr.train(epochs, log, checkpoint_dir=save_dir if rank == 0 else None)
-    if world > 1:
+    if world > 1 or launched:
+        if rank == 0:
+            print(f"collectives: backend {dist.get_backend()}, world {dist.get_world_size()}, gradient all-reduces {tr.n_grad_allreduce}, "
+                  f"KL all-reduces {tr.n_kl_allreduce}", flush=True)
         dist.destroy_process_group()
 
 

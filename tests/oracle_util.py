@@ -14,6 +14,8 @@ _lib = None
 
 
 def build_oracle():
+    if os.environ.get("TF_ORACLE_SO"):          # another build of the same source (tests/test_oracle_sanitizer.py: the -fsanitize=address,undefined one)
+        return os.environ["TF_ORACLE_SO"]
     src = os.path.join(ORACLE_DIR, "tf_oracle.c")
     hdr = os.path.join(REPO, "include", "trifinger.h")
     if (not os.path.isfile(ORACLE_SO)

@@ -64,11 +64,15 @@ CONFIGS = {
                                     normalize_obs=False,
                                     success={"activate": True, "bonus": 100.0, "position_tolerance": 0.04,
                                              "orientation_tolerance": 3.2}),
-    # the opt-in middle-distal finger-finger pairs (TfModel.ff_middle_pairs) with robot resets that spread the joints widely: fingers meet
-    # at resets and under random torques (tests/test_ff_middle_pairs.py: the switch changes this very rollout)
-    "ff_middle_pairs": dict(_model_edit=dict(ff_middle_pairs=1), command_mode="torque", task_difficulty=1, asymmetric_obs=True,
+    # robot resets that spread the joints widely: fingers meet at resets and under random torques, so the middle-distal finger-finger pairs
+    # (TfModel.ff_middle_pairs, part of the default model since API 8) carry impulses (tests/test_ff_middle_pairs.py: the switch changes this very rollout)
+    "ff_middle_pairs": dict(command_mode="torque", task_difficulty=1, asymmetric_obs=True,
                             robot_reset="random", dof_pos_stddev=1.2, dof_vel_stddev=0.5, reward_terms=D1_REWARDS,
                             success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.01, "orientation_tolerance": 0.1}),
+    # the opt-out: the distal pairs only (`native.ff_middle_pairs: false`, what every earlier API stepped), on the headline workload
+    "fast_contact_set": dict(_model_edit=dict(ff_middle_pairs=0), command_mode="torque", task_difficulty=4, asymmetric_obs=True, reward_terms=D4_REWARDS,
+                             robot_reset="random", dof_pos_stddev=1.2, dof_vel_stddev=0.5,
+                             success={"activate": False, "bonus": 5000.0, "position_tolerance": 0.02, "orientation_tolerance": 0.25}),
 }
 
 PER_ENV_FIELDS = ("state", "action_buf", "obs", "states", "reward", "reset_buf", "goal_reset_buf", "successes",

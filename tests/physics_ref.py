@@ -10,7 +10,7 @@ approaches this solution as its sweep count grows, on random contact configurati
 What is restated from the spec (these are modelling choices, so they are part of what is compared): the collision
 primitives and their selection rules, the tangent basis of a normal, the speculative / Baumgarte / restitution bias of a
 normal row, the friction pyramid, the joint-limit box rows, the finger-finger pre-solve on the free
-velocities, damping factors and symplectic Euler.
+velocities (the three distal pairs, then the six middle-distal pairs of the default model), damping factors and symplectic Euler.
 """
 import numpy as np
 from scipy.optimize import minimize, minimize_scalar
@@ -220,7 +220,7 @@ def box_spec(size, density, gyroscopic=True):
     return {"half": size / 2.0, "mass": mass, "inertia": inertia, "gyroscopic": gyroscopic}
 
 
-def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_sweeps=200000, box=None):
+def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_sweeps=200000, box=None, ff_middle=True):
     """One substep of length h in fp64.  q, qd, tau: (9,), cube: (13,) [p, quat xyzw, v, w].  `box`: a `box_spec` for a
     general box object (full world-frame inertia tensor here - the product's inertia-scaled coordinates are not used).
     Returns (qd_new (9,), cube_v (3,), cube_w (3,), details)."""
@@ -254,7 +254,7 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
     vfree[9:12] = (cv + h * np.asarray(gravity)) * (1.0 - h * CUBE_LIN_DAMP)
     vfree[12:15] = w_free * (1.0 - h * CUBE_ANG_DAMP)
     rows = []
-    details = {"fc": [], "te": [], "ff": [], "n_floor": 0, "n_wall": 0}
+    details = {"fc": [], "te": [], "ff": [], "ffm": [], "n_floor": 0, "n_wall": 0}
 
     def add_contact(Jn_dofs, dirs, gap, restitution, mu, vref):
         """three rows for the 3x15 map `Jn_dofs` (velocity of body A minus body B at the contact, world) and dirs n,t1,t2"""
@@ -306,6 +306,37 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         lam_n = max(-(vn0 + contact_bias(gap, vn0, h, REST_FF)) / float(Jr @ Minv @ Jr), 0.0)     # frictionless: one row
         v_ff = v_ff + Minv @ Jr * lam_n
         details["ff"].append((fa, fb, gap, lam_n))
+    # ---- ... then the middle link of every finger against the fingertip capsule of each other finger (the default model since API 8: the reference
+    # keeps all robot links in one self-colliding group): six ordered pairs (fm; fm + 1), (fm; fm + 2), one frictionless row each on the same
+    # velocities.  The middle link is its finger-cube shape: closest points of its axis and the capsule's axis, its support function along the
+    # line between them; the row moves joints 1 and 2 of the middle finger (the point is a point of link 2) and all three of the distal one ----
+    if ff_middle:
+        sh2 = next(e[2] for e in SHAPES if e[0] == "shape" and e[1] == 2)
+        for fm in range(3):
+            qm = q[3 * fm:3 * fm + 3]
+            am, bm = link_point_world(fm, qm, 2, sh2["a"]), link_point_world(fm, qm, 2, sh2["b"])
+            for o in (1, 2):
+                fd = (fm + o) % 3
+                Pm, Pd = segment_segment(am, bm, distal[fd][0], distal[fd][1])
+                dist = np.linalg.norm(Pd - Pm)
+                if not dist > 1e-6:
+                    continue
+                n = (Pd - Pm) / dist                                    # from the middle link to the capsule
+                sp = float(np.clip((Pm - am) @ (bm - am) / ((bm - am) @ (bm - am)), 0.0, 1.0))
+                ext = MF.shape_extent(sh2, sp, link_rotation_world(fm, qm, 2).T @ n)
+                gap = dist - ext - TIP_CAP[3]
+                if not gap < MARGIN:
+                    continue
+                Jm_ = np.zeros((3, 15))
+                Jm_[:, 3 * fd:3 * fd + 3] = point_jacobian(fd, q[3 * fd:3 * fd + 3], 3, Pd - TIP_CAP[3] * n)
+                Jm_[:, 3 * fm:3 * fm + 3] = -point_jacobian(fm, qm, 2, Pm + ext * n)
+                Jr = n @ Jm_
+                vn0 = float(Jr @ v_ff)
+                if not contact_live(gap, vn0, h):
+                    continue
+                lam_n = max(-(vn0 + contact_bias(gap, vn0, h, REST_FF)) / float(Jr @ Minv @ Jr), 0.0)
+                v_ff = v_ff + Minv @ Jr * lam_n
+                details["ffm"].append((fm, fd, gap, lam_n))
     # ---- finger contacts ----
     for f in range(3):
         sl = slice(3 * f, 3 * f + 3)

@@ -1,10 +1,10 @@
-"""TfModel.ff_middle_pairs (API 7): the middle link of a finger against the distal capsule of another finger, beyond the three
+"""TfModel.ff_middle_pairs (API 7; the default model has it ON since API 8: VERDICT r5 item 2): the middle link of a finger against the distal capsule of another finger, beyond the three
 distal pairs.  The reference keeps every robot link in one collision group with self-collision on (trifinger_env.py:811-812).
 
 * scenario (oracle here, HIP under -m gpu): finger 2 is told to put its fingertip INSIDE the middle link of finger 0.  The gap between the two
   bodies - closest points of the middle link's axis and the fingertip capsule, the support function of the middle link's cross-section, the capsule
   radius: all from the independent fp64 model (tests/physics_ref.py, tests/model_fixture.py) - stays at zero with the pairs on and goes 4 cm
-  negative with them off (the default).
+  negative with them off (`native.ff_middle_pairs: false`, the opt-out).
 * the parity rollout of this switch (tests/parity_util.py CONFIGS["ff_middle_pairs"], compared bit for bit in test_parity_hip_vs_oracle.py) is one
   in which the switch matters: the same rollout without it ends elsewhere."""
 import numpy as np
@@ -73,7 +73,7 @@ def _check(lib, device):
     assert g[0] > 0.005 and g.min() > -4e-3, (g[0], g.min())        # approaches from outside, never deeper than a transient of a few mm
     assert np.abs(np.median(g[-60:])) < 1e-3, np.median(g[-60:])      # ... and stays pressed against the middle link: the gap is zero
     ghost = _run(lib, device, False)
-    assert ghost.min() < -0.03, ghost.min()                            # the default (distal pairs only): the fingertip goes 4 cm into the body
+    assert ghost.min() < -0.03, ghost.min()                            # the opt-out (distal pairs only): the fingertip goes 4 cm into the body
 
 
 def test_fingertip_stops_at_the_middle_link_of_another_finger(oracle):
@@ -91,3 +91,8 @@ def test_the_parity_rollout_of_the_switch_is_one_in_which_it_matters(oracle):
     off = pu.rollout(oracle, "cpu", n, steps, "ff_middle_pairs", extra={"_model_edit": dict(ff_middle_pairs=0)})
     changed = np.any(on[-1]["state"][0:18] != off[-1]["state"][0:18], axis=0)
     assert 0.02 < changed.mean() < 0.9, changed.mean()      # a share of the envs saw such a contact (the rest are bit-identical: the rows are only added)
+
+
+def test_the_default_model_holds_the_reference_contact_set(oracle):
+    """API 8: tf_default_model() has the middle-distal pairs on (the reference keeps every robot link in one self-colliding group, trifinger_env.py:811-812)"""
+    assert oracle.default_model().ff_middle_pairs == 1

@@ -91,6 +91,61 @@ def test_trainer_with_and_without_the_kernels(hip):
 
 
 @pytest.mark.gpu
+def test_rollout_snapshots_the_observation_of_an_env_that_does_not_promise_stable_buffers(hip):
+    """The fused rollout reads obs / states IN PLACE only from an env that declares `buffers_stable_until_next_step` (RlGamesGpuEnvAdapter: the engine's
+    own tensors, overwritten by the next step on the same stream).  An env without the attribute may refresh its buffers whenever it likes: the trainer
+    must have taken its snapshot when `step` returned.  Emulated here by an env that scribbles NaN over the tensors it handed out as soon as the policy
+    is evaluated the next time (i.e. after `step` returned, before the trainer files the step): same rollout as the well-behaved env, no NaN anywhere."""
+    from leibnizgym_amd.config import gym_config
+    from leibnizgym_amd.envs import TrifingerEnv
+    from leibnizgym_amd.ppo import PPOTrainer
+    from leibnizgym_amd.utils.rlg_train import RlGamesGpuEnvAdapter
+    from leibnizgym_amd.wrappers import VecTaskPython
+
+    class Unstable:
+        """hands out copies held in its own buffers and does NOT promise they stay put"""
+        def __init__(self, inner):
+            self.inner, self.handed = inner, None
+
+        def _own(self, out):
+            self.handed = {k: v.clone() for k, v in out.items()}
+            return self.handed
+
+        def reset(self):
+            return self._own(self.inner.reset())
+
+        def step(self, a):
+            out, r, d, info = self.inner.step(a)
+            return self._own(out), r, d, info
+
+        def scribble(self):
+            for v in self.handed.values():
+                v.fill_(float("nan"))
+
+    def run(unstable):
+        cfg = gym_config("trifinger_difficulty_4")
+        cfg.update(num_instances=256, seed=1, physics_engine="physx", asymmetric_obs=True, episode_length=20)
+        ad = RlGamesGpuEnvAdapter("rlgpu", 256, env=VecTaskPython(TrifingerEnv(config=cfg, device="cuda:0", verbose=False), rl_device="cuda:0"))
+        env = Unstable(ad) if unstable else ad
+        tr = PPOTrainer(env, 41, 113, 9, PPOConfig(horizon=6, minibatches=3, mini_epochs=1), device="cuda:0")
+        if unstable:
+            inner = tr.net.dist_and_value
+
+            def hooked(obs, states):
+                out = inner(obs, states)              # the trainer's own snapshot is what it passes in ...
+                env.scribble()                        # ... the env's buffers change under it right away
+                return out
+            tr.net.dist_and_value = hooked
+        torch.manual_seed(5)
+        return tr.rollout()
+    good, bad = run(False), run(True)
+    for k in ("obs", "states", "act", "rew", "val"):
+        assert torch.isfinite(bad[k]).all(), k
+        assert torch.equal(good[k], bad[k]), k
+    assert RlGamesGpuEnvAdapter.buffers_stable_until_next_step is True
+
+
+@pytest.mark.gpu
 def test_flat_clip_adam_matches_torch(hip):
     """gradient-norm truncation per group + Adam over the flat buffer == clip_grad_norm_ + torch.optim.Adam, 25 steps with
     gradients that exercise both the truncated and the untruncated case and two different learning rates"""
