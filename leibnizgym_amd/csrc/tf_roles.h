@@ -61,6 +61,15 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 #define L_DR0 32                        //  14: launch prologue only (behind the action tile, before any physics slot is live): the domain-randomisation rows of the
                                         //      env, loaded once by the cube role and handed to the three finger roles through barrier #1
 #define LDS_SLOTS 159                   //   (4 workgroups x 159 x 256 B = 159 KB of the CU's 160 KB)
+// Mailboxes of the middle-distal finger-finger rows built on the finger wavefronts (cube kernels only - the box kernels keep L_POSE_S at 150..155 and
+// leave these rows to the cube role): finger fd receives the velocity change of TWO rows, 2 x 3 floats.  Written between S1 and S1b by the finger that
+// owns the middle link, read by fd right behind S1b - so they must be slots nobody writes between S1b and S3 other than fd itself: fd's own L_INIT
+// slot, the free tail of its own record (the records are rewritten behind S1b, each by its owner), and the free slots 150..158.
+DEV constexpr int ffm_mbox(int fd, int k) {                  // k = 3 x message + component
+    return fd == 0 ? (k == 0 ? 147 : 149 + k)               //   finger 0: 147 (L_INIT + 0), 150 .. 154
+         : fd == 1 ? (k == 0 ? 148 : (k == 1 ? 59 : 153 + k))    //   finger 1: 148 (L_INIT + 1), 59 (tail of record 1), 155 .. 158
+                   : 83 + k;                                 //   finger 2: 83 .. 88 (tail of record 2)
+}
 #define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
 #define LDS_SLOTS_BOX 159
 // post phase (aliases the above)
@@ -360,6 +369,18 @@ DEV void tip_state(const TfModel& m, const Yaw& y, const FK& k, const float q[3]
 // =====================================================================================================================
 // FINGER ROLE
 // =====================================================================================================================
+// what a finger publishes after its free motion, as the registers of a reader (the finger-finger rows)
+struct FingerPubRegs { FK k; };
+DEV void read_pub(const float* lds, int lane, int f, FingerPubRegs& p) {
+    const int pb = L_REC(f);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { p.k.p2[j] = LD(pb + P_P2 + j); p.k.p3[j] = LD(pb + P_P3 + j); }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) p.k.Minv[j] = LD(pb + P_MINV + j);
+    p.k.s1 = LD(pb + P_S1); p.k.c1 = LD(pb + P_C1);
+    p.k.ax[0] = p.k.c1; p.k.ax[1] = 0.0f; p.k.ax[2] = -p.k.s1;
+}
+
 struct TipContact {            // fingertip sphere against one feature of the arena: finger-only rows
     bool active;
     float J[9], Dinv[3], bias, lam[3], mu;
@@ -742,6 +763,104 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     try_shape(L1{}, m.shape1, a, b, upper_ok);
                 }
             }
+            // ---- FF on the finger wavefronts (cube kernels; TfModel.ff_middle_pairs): the MIDDLE link of this finger against the distal capsule of
+            // each other finger.  Since API 8 these six rows are solved on the FREE velocities (oracle/tf_oracle.c: a Jacobi step), so a row needs only
+            // what the fingers published before S1: this wavefront builds the two rows of its own middle link - out of its own frames, where the cube
+            // role had to rebuild the middle frame from what is published - while the cube role runs the distal pairs, keeps its own velocity change
+            // and posts the other finger's (ffm_mbox).  The same lines as the cube role's placement, the same bits. ----
+            float ffm_own[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            // Placement is a choice per instantiation (same bits either way): the 256-register cube kernels build the rows HERE (8192 envs: 46.9 -> 43.1 us;
+            // one wavefront per SIMD, the cube wavefront is the long pole before the sweeps); the 128-register kernels keep them on the cube wavefront
+            // (65536 envs: 70.4 us there against 73.0 us here - this block costs the finger role registers it has to spill), and so do the box kernels.
+            const bool ffm_here = WIDE && !BOXK && m.ff_middle_pairs != 0;     // wave-uniform
+            if (ffm_here) {
+                const TfLinkShape& sh = m.shape2;
+                const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
+                const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
+                const float ex[3] = {k.c1, 0.0f, -k.s1};
+                float ey[3], aw[3], bw[3];
+                {
+                    float g[3], xg[3], ez[3], ab[3], bb[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) g[i] = FMA(-jx, ex[i], k.p3[i] - k.p2[i]);
+                    cross3(ex, g, xg);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { ey[i] = FMA(jy, g[i], -(jz * xg[i])) * inv_j; ez[i] = FMA(jz, g[i], jy * xg[i]) * inv_j; }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        ab[i] = FMA(sh.a[2], ez[i], FMA(sh.a[1], ey[i], FMA(sh.a[0], ex[i], k.p2[i])));
+                        bb[i] = FMA(sh.b[2], ez[i], FMA(sh.b[1], ey[i], FMA(sh.b[0], ex[i], k.p2[i])));
+                    }
+                    base_to_world(yw, ab, aw);
+                    base_to_world(yw, bb, bw);
+                }
+                const float rest_ff = m.restitution_ff * dr[5];
+#pragma unroll 1
+                for (int o = 1; o <= 2; ++o) {
+                    const int fd = (f + o >= 3) ? f + o - 3 : f + o;
+                    float dd[3] = {0.0f, 0.0f, 0.0f};
+                    float Pm[3], Pd[3], sp;
+                    {
+                        float Ad[3], Bd[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { Ad[j] = LD(L_REC(fd) + P_AW + j); Bd[j] = LD(L_REC(fd) + P_BW + j); }
+                        seg_seg_s(aw, bw, Ad, Bd, Pm, Pd, sp);
+                    }
+                    const float dv[3] = {Pd[0] - Pm[0], Pd[1] - Pm[1], Pd[2] - Pm[2]};
+                    const float dist2 = dot3(dv, dv);
+                    const float inv = f_rsqrt(f_max(dist2, 1e-12f));
+                    const float dist = dist2 * inv;
+                    const float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};      // from the middle link to the distal capsule
+                    float nm[3];
+                    dir_world_to_base(yw, n, nm);
+                    const float u1 = dot3(nm, ex), u2 = dot3(nm, ey);
+                    const float rho = FMA(sp, sh.rho[1] - sh.rho[0], sh.rho[0]);
+                    const float h1 = FMA(sp, sh.w1[1] - sh.w1[0], sh.w1[0]) - rho, h2 = FMA(sp, sh.w2[1] - sh.w2[0], sh.w2[0]) - rho;
+                    const float o1 = FMA(sp, sh.o1[1] - sh.o1[0], sh.o1[0]), o2 = FMA(sp, sh.o2[1] - sh.o2[0], sh.o2[0]);
+                    const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
+                    const float gap_ff = dist - ext - m.cap_radius;
+                    const bool near_ff = (dist2 > 1e-12f) && (gap_ff < m.contact_margin);
+                    if (__builtin_amdgcn_ballot_w64(near_ff) != 0ull) {
+                        float Jd[3], Wd[3], Jm[3], Wm[3], vd[3];
+                        {   // distal side: the point of the capsule surface that faces the middle link
+                            const Yaw yd = {m.base_yaw_cos[fd], m.base_yaw_sin[fd], 0.0f, 0.0f, m.base_height};
+                            FingerPubRegs pd;
+                            read_pub(lds, lane, fd, pd);
+                            float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) C[j] = FMA(-m.cap_radius, n[j], Pd[j]);
+                            world_to_base(yd, C, Cb_);
+                            levers(pd.k, Cb_, L1, L2, L3);
+                            dir_world_to_base(yd, n, nb);
+                            Jd[0] = dot3(L1, nb); Jd[1] = dot3(L2, nb); Jd[2] = dot3(L3, nb);
+                            sym3_mul(pd.k.Minv, Jd, Wd);
+                        }
+                        {   // middle side: joints 1 and 2 move it, joint 3 does not
+                            float C[3], Cb_[3], L1[3], L2[3], L3[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) C[j] = FMA(ext, n[j], Pm[j]);
+                            world_to_base(yw, C, Cb_);
+                            levers(k, Cb_, L1, L2, L3);
+                            Jm[0] = dot3(L1, nm); Jm[1] = dot3(L2, nm); Jm[2] = 0.0f;
+                            sym3_mul(k.Minv, Jm, Wm);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) vd[j] = LD(L_REC(fd) + P_VQ + j);          // free velocities on both sides
+                        const float vn0 = dot3(Jd, vd) - dot3(Jm, vq);
+                        if (near_ff && contact_live(m, gap_ff, vn0, h)) {
+                            const float bias = contact_bias(m, gap_ff, vn0, inv_h, rest_ff);
+                            const float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Jd, Wd) + dot3(Jm, Wm)), 0.0f);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) { dd[j] = Wd[j] * lam; ffm_own[o - 1][j] = Wm[j] * lam; }
+                        }
+                    }
+                    // fd's mailbox: its first message is the one of the owner with the smaller finger index (the order the rows are listed in)
+                    const int other = 3 - f - fd, msg = (f < other) ? 0 : 1;
+                    if (fd == 0) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(0, 3 * msg + j)) = dd[j]; }
+                    else if (fd == 1) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(1, 3 * msg + j)) = dd[j]; }
+                    else { for (int j = 0; j < 3; ++j) LD(ffm_mbox(2, 3 * msg + j)) = dd[j]; }
+                }
+            }
             STAMP(sb_ + 2);
             BAR();                                              // S1b: the finger-finger pass of the cube role is done
             STAMP(sb_ + 3);
@@ -749,6 +868,23 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             float vqf[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) vqf[j] = LD(L_VQFF + 3 * f + j);
+            if (ffm_here) {
+                // the velocity changes of the six rows in the order they are listed - (0;1) (0;2) (1;2) (1;0) (2;0) (2;1) - a zero component skipped:
+                // finger 0: own, own, mail, mail;  finger 1: mail, own, own, mail;  finger 2: mail, mail, own, own
+                float mail[2][3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    mail[0][j] = (f == 0) ? LD(ffm_mbox(0, j)) : ((f == 1) ? LD(ffm_mbox(1, j)) : LD(ffm_mbox(2, j)));
+                    mail[1][j] = (f == 0) ? LD(ffm_mbox(0, 3 + j)) : ((f == 1) ? LD(ffm_mbox(1, 3 + j)) : LD(ffm_mbox(2, 3 + j)));
+                }
+                auto take = [&](const float d[3], bool minus) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { const float t = minus ? vqf[j] - d[j] : vqf[j] + d[j]; vqf[j] = (d[j] != 0.0f) ? t : vqf[j]; }
+                };
+                if (f == 0) { take(ffm_own[0], true); take(ffm_own[1], true); take(mail[0], false); take(mail[1], false); }
+                else if (f == 1) { take(mail[0], false); take(ffm_own[0], true); take(ffm_own[1], true); take(mail[1], false); }
+                else { take(mail[0], false); take(mail[1], false); take(ffm_own[0], true); take(ffm_own[1], true); }
+            }
             // rows of the finger-cube contact; the contact-space record goes straight to LDS for the cube role
             const int rb = L_REC(f);
             float fcJ[9], fc_arm[3], rec_lam[3];
@@ -1312,16 +1448,6 @@ DEV void stats_zero(LaneStats& st) {
     st.pos_cnt = 0.0f; st.ori_cnt = 0.0f; st.succ = 0.0f; st.resets = 0.0f; st.nonfinite = 0.0f;
 }
 
-struct FingerPubRegs { FK k; };
-DEV void read_pub(const float* lds, int lane, int f, FingerPubRegs& p) {
-    const int pb = L_REC(f);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { p.k.p2[j] = LD(pb + P_P2 + j); p.k.p3[j] = LD(pb + P_P3 + j); }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) p.k.Minv[j] = LD(pb + P_MINV + j);
-    p.k.s1 = LD(pb + P_S1); p.k.c1 = LD(pb + P_C1);
-    p.k.ax[0] = p.k.c1; p.k.ax[1] = 0.0f; p.k.ax[2] = -p.k.s1;
-}
 
 // arms of the three rows of a wall corner: r x n, r x t and (box only) r x z, inertia-scaled for a box (S from LDS)
 DEV void wall_arms(bool box, const float* lds, int lane, const float r[3], const float n[2], float a[3], float b[3], float c3[3]) {
@@ -1744,7 +1870,9 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             // ---- FF, second part (TfModel.ff_middle_pairs, on by default since API 8; wave-uniform): the middle link of finger fm (shape2) against the distal
             // capsule of each other finger - six ordered pairs on the same velocities.  The middle frame is rebuilt from what finger fm publishes:
             // e_x = (c1, 0, -s1), g = (p3 - p2) - j3_x e_x = j3_y e_y + j3_z e_z, e_x x g = j3_y e_z - j3_z e_y (oracle/tf_oracle.c, the same lines). ----
-            if (__builtin_expect(m.ff_middle_pairs != 0, 1)) {
+            // (256-register cube kernels: built by the finger wavefronts - the block above their S1b; this placement serves the 128-register kernels and
+            // the box kernels, whose LDS has no room for the mailboxes)
+            if ((BOXK || !WIDE) && m.ff_middle_pairs != 0) {
                 const TfLinkShape& sh = m.shape2;
                 const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
                 const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
@@ -1818,15 +1946,16 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                                 sym3_mul(pm.k.Minv, Jm, Wm);
                             }
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) { vd[j] = LD(L_VQFF + 3 * fd + j); vm[j] = LD(L_VQFF + 3 * fm + j); }
+                            for (int j = 0; j < 3; ++j) { vd[j] = LD(L_REC(fd) + P_VQ + j); vm[j] = LD(L_REC(fm) + P_VQ + j); }      // the FREE velocities (API 8)
                             const float vn0 = dot3(Jd, vd) - dot3(Jm, vm);
                             if (contact_live(m, gap, vn0, h)) {
                                 const float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
                                 const float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Jd, Wd) + dot3(Jm, Wm)), 0.0f);
 #pragma unroll
                                 for (int j = 0; j < 3; ++j) {
-                                    LD(L_VQFF + 3 * fd + j) = FMA(Wd[j], lam, vd[j]);
-                                    LD(L_VQFF + 3 * fm + j) = FMA(-Wm[j], lam, vm[j]);
+                                    const float dd = Wd[j] * lam, dm = Wm[j] * lam;
+                                    if (dd != 0.0f) LD(L_VQFF + 3 * fd + j) = LD(L_VQFF + 3 * fd + j) + dd;
+                                    if (dm != 0.0f) LD(L_VQFF + 3 * fm + j) = LD(L_VQFF + 3 * fm + j) - dm;
                                 }
                             }
                         }

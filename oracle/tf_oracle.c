@@ -1483,7 +1483,12 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[j], lam, va[j]); vb[j] = FMA(-Wb[j], lam, vb[j]); }
     }
     /* ---- FF, second part (TfModel.ff_middle_pairs, on by default since API 8): the MIDDLE link of finger fm against the distal capsule of each other
-     * finger fd - the six ordered pairs (0;1) (0;2) (1;2) (1;0) (2;0) (2;1), visited after the three distal pairs on the same velocities.
+     * finger fd - the six ordered pairs (0;1) (0;2) (1;2) (1;0) (2;0) (2;1).  API 8: every one of these rows is solved on the FREE velocities (those
+     * before any finger-finger row - a Jacobi step: the rows do not see each other nor the distal pairs), and its two velocity changes d = W lambda
+     * (a product rounded on its own) are ADDED to the velocities the distal pairs left, in the order the pairs are listed, a zero component skipped.
+     * A row then depends on nothing but what the fingers publish after their free motion, so the three finger wavefronts of the kernels can build
+     * the rows of their own middle link side by side and hand the other finger's share over (csrc/tf_roles.h); visited in turn by the cube wavefront -
+     * the other placement - the same lines give the same bits.
      * The reference leaves every robot link in one collision group with self-collision on (trifinger_env.py:811-812).  The middle link is
      * its finger-cube shape (shape2: tapered rounded box about the axis a -> b of the middle frame), the distal link the fingertip capsule
      * as in the distal pairs.  The cube role of the kernels sees of a finger what it publishes (p2, p3, sin / cos of joint 1, M^-1): the
@@ -1543,13 +1548,17 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
                     Jm[0] = dot3(L1, nm); Jm[1] = dot3(L2, nm); Jm[2] = 0.0f;
                     sym3_mul(km->Minv, Jm, Wm);
                 }
-                float* vd = vq_ff[fd];
-                float* vm = vq_ff[fm];
+                const float* vd = fr[fd].vq;                        /* free velocities: not vq_ff */
+                const float* vm = fr[fm].vq;
                 float vn0 = dot3(Jd, vd) - dot3(Jm, vm);
                 if (!contact_live(m, gap, vn0, h)) continue;
                 float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
                 float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Jd, Wd) + dot3(Jm, Wm)), 0.0f);
-                for (int j = 0; j < 3; ++j) { vd[j] = FMA(Wd[j], lam, vd[j]); vm[j] = FMA(-Wm[j], lam, vm[j]); }
+                for (int j = 0; j < 3; ++j) {
+                    const float dd = Wd[j] * lam, dm = Wm[j] * lam;
+                    if (dd != 0.0f) vq_ff[fd][j] = vq_ff[fd][j] + dd;
+                    if (dm != 0.0f) vq_ff[fm][j] = vq_ff[fm][j] - dm;
+                }
             }
         }
     }

@@ -307,8 +307,9 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
         v_ff = v_ff + Minv @ Jr * lam_n
         details["ff"].append((fa, fb, gap, lam_n))
     # ---- ... then the middle link of every finger against the fingertip capsule of each other finger (the default model since API 8: the reference
-    # keeps all robot links in one self-colliding group): six ordered pairs (fm; fm + 1), (fm; fm + 2), one frictionless row each on the same
-    # velocities.  The middle link is its finger-cube shape: closest points of its axis and the capsule's axis, its support function along the
+    # keeps all robot links in one self-colliding group): six ordered pairs (fm; fm + 1), (fm; fm + 2), one frictionless row each, every one solved
+    # on the FREE velocities (a Jacobi step: the rows see neither each other nor the distal pairs) and its velocity changes added to what the distal
+    # pairs left.  The middle link is its finger-cube shape: closest points of its axis and the capsule's axis, its support function along the
     # line between them; the row moves joints 1 and 2 of the middle finger (the point is a point of link 2) and all three of the distal one ----
     if ff_middle:
         sh2 = next(e[2] for e in SHAPES if e[0] == "shape" and e[1] == 2)
@@ -331,7 +332,7 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
                 Jm_[:, 3 * fd:3 * fd + 3] = point_jacobian(fd, q[3 * fd:3 * fd + 3], 3, Pd - TIP_CAP[3] * n)
                 Jm_[:, 3 * fm:3 * fm + 3] = -point_jacobian(fm, qm, 2, Pm + ext * n)
                 Jr = n @ Jm_
-                vn0 = float(Jr @ v_ff)
+                vn0 = float(Jr @ vfree)
                 if not contact_live(gap, vn0, h):
                     continue
                 lam_n = max(-(vn0 + contact_bias(gap, vn0, h, REST_FF)) / float(Jr @ Minv @ Jr), 0.0)

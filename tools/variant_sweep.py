@@ -1,6 +1,6 @@
 """Developer tool (GPU box): fused-step time (HIP events) of the headline workload for the two instantiations of the step kernel
 (tf_set_kernel_variant) over a range of population sizes, with a state checksum (identical between the variants: same arithmetic).
-    python tools/variant_sweep.py [lib.so] [N ...]      env: SETTLE, SOLVER=iterations,inner, NO_TIMEOUT=1, FF_MIDDLE=1, ASYM=0|1 (default: both)"""
+    python tools/variant_sweep.py [lib.so] [N ...]      env: SETTLE, SOLVER=iterations,inner, NO_TIMEOUT=1, FF_MIDDLE=0|1, ASYM=0|1 (default: both)"""
 import sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -21,9 +21,9 @@ for asym in ([bool(int(os.environ["ASYM"]))] if os.environ.get("ASYM") else (Tru
         for variant in ("narrow", "wide"):
             kw = bench.workload_kwargs(asym)
             kw.update(solver_iterations=SOLVER[0], solver_inner=SOLVER[1])
-            if os.environ.get("FF_MIDDLE"):                   # FF_MIDDLE=1: the opt-in middle-distal finger-finger pairs (TfModel.ff_middle_pairs)
+            if os.environ.get("FF_MIDDLE"):                   # FF_MIDDLE=0: the fast contact set of API <= 7 (TfModel.ff_middle_pairs = 0; default model: 1)
                 kw["model"] = lib.default_model()
-                kw["model"].ff_middle_pairs = 1
+                kw["model"].ff_middle_pairs = int(os.environ["FF_MIDDLE"])
             if os.environ.get("NO_TIMEOUT"):                  # diagnostic: no time-out resets inside the timed steps (what the reset path of a launch costs)
                 kw.update(episode_length=0)
             eng = TrifingerEngine(make_config(lib, n, seed=7, **kw), device="cuda:0", lib=lib)
