@@ -7,11 +7,11 @@ T=${1:-rX}
 O=gpurun_out
 K='k_env<9, false, true, 127, 0, false>'
 mkdir -p $O
-CMD="python3 bench.py --steps 500 --warmup 5 --no-cpu-baseline"
+CMD="python3 bench.py --steps 500 --warmup 5 --no-cpu-baseline --no-fast-contact-leg"
 rocprofv3 --kernel-trace --stats -d $O/prof_$T/trace -o r -- $CMD > /dev/null 2>&1
 { echo "# command: rocprofv3 --kernel-trace --stats -- $CMD   (MI355X, 65536 envs, asymmetric obs)"
   python3 tools/rocprof_summary.py trace $(find $O/prof_$T/trace -name "*.db" | head -1); } > $O/${T}_kernel_trace_stats.txt
-CMD="python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline"
+CMD="python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-fast-contact-leg"
 { echo "# workload: N=65536 asym=True kernel=$K"; } > $O/${T}_pmc.txt
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_BRANCH"; do
   d=$O/prof_$T/pmc
