@@ -772,7 +772,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             // Placement is a choice per instantiation (same bits either way): the 256-register cube kernels build the rows HERE (8192 envs: 46.9 -> 43.1 us;
             // one wavefront per SIMD, the cube wavefront is the long pole before the sweeps); the 128-register kernels keep them on the cube wavefront
             // (65536 envs: 70.4 us there against 73.0 us here - this block costs the finger role registers it has to spill), and so do the box kernels.
-            const bool ffm_here = WIDE && !BOXK && m.ff_middle_pairs != 0;     // wave-uniform
+            // The 128-register kernels build only the SECOND group here (fd = f + 1: one row per finger wavefront) and leave the first to the cube role:
+            // all six on the fingers cost this role registers it has to spill (65536 envs: 73.0 us against 70.0 us with all six on the cube wavefront).
+            const bool ffm_here = !BOXK && m.ff_middle_pairs != 0;     // wave-uniform
+            constexpr int FFM_O_FIRST = WIDE ? 2 : 1;                  // this wavefront's groups: o = FFM_O_FIRST .. 1
             if (ffm_here) {
                 const TfLinkShape& sh = m.shape2;
                 const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
@@ -796,7 +799,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
                 const float rest_ff = m.restitution_ff * dr[5];
 #pragma unroll 1
-                for (int o = 1; o <= 2; ++o) {
+                for (int o = FFM_O_FIRST; o >= 1; --o) {
                     const int fd = (f + o >= 3) ? f + o - 3 : f + o;
                     float dd[3] = {0.0f, 0.0f, 0.0f};
                     float Pm[3], Pd[3], sp;
@@ -854,8 +857,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                             for (int j = 0; j < 3; ++j) { dd[j] = Wd[j] * lam; ffm_own[o - 1][j] = Wm[j] * lam; }
                         }
                     }
-                    // fd's mailbox: its first message is the one of the owner with the smaller finger index (the order the rows are listed in)
-                    const int other = 3 - f - fd, msg = (f < other) ? 0 : 1;
+                    // fd's mailbox: message 0 is the row of the first group (o = 2), message 1 the row of the second (o = 1)
+                    const int msg = 2 - o;
                     if (fd == 0) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(0, 3 * msg + j)) = dd[j]; }
                     else if (fd == 1) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(1, 3 * msg + j)) = dd[j]; }
                     else { for (int j = 0; j < 3; ++j) LD(ffm_mbox(2, 3 * msg + j)) = dd[j]; }
@@ -869,21 +872,24 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
             for (int j = 0; j < 3; ++j) vqf[j] = LD(L_VQFF + 3 * f + j);
             if (ffm_here) {
-                // the velocity changes of the six rows in the order they are listed - (0;1) (0;2) (1;2) (1;0) (2;0) (2;1) - a zero component skipped:
-                // finger 0: own, own, mail, mail;  finger 1: mail, own, own, mail;  finger 2: mail, mail, own, own
+                // the velocity changes of the rows in the order they are listed - first group (0;2) (1;0) (2;1), second group (0;1) (1;2) (2;0) - a zero
+                // component skipped.  Within a group the rows are ordered by the finger that owns the middle link: this finger's own row (fm = f) and the
+                // one it received (first group: fm = f + 1, second group: fm = f + 2, mod 3).  (128-register kernels: the first group is in L_VQFF already.)
                 float mail[2][3];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    mail[0][j] = (f == 0) ? LD(ffm_mbox(0, j)) : ((f == 1) ? LD(ffm_mbox(1, j)) : LD(ffm_mbox(2, j)));
+                    mail[0][j] = !WIDE ? 0.0f : ((f == 0) ? LD(ffm_mbox(0, j)) : ((f == 1) ? LD(ffm_mbox(1, j)) : LD(ffm_mbox(2, j))));
                     mail[1][j] = (f == 0) ? LD(ffm_mbox(0, 3 + j)) : ((f == 1) ? LD(ffm_mbox(1, 3 + j)) : LD(ffm_mbox(2, 3 + j)));
                 }
                 auto take = [&](const float d[3], bool minus) __attribute__((always_inline)) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { const float t = minus ? vqf[j] - d[j] : vqf[j] + d[j]; vqf[j] = (d[j] != 0.0f) ? t : vqf[j]; }
                 };
-                if (f == 0) { take(ffm_own[0], true); take(ffm_own[1], true); take(mail[0], false); take(mail[1], false); }
-                else if (f == 1) { take(mail[0], false); take(ffm_own[0], true); take(ffm_own[1], true); take(mail[1], false); }
-                else { take(mail[0], false); take(mail[1], false); take(ffm_own[0], true); take(ffm_own[1], true); }
+                if (WIDE) {                                          // first group: own row (f; f + 2), received row (f + 1; f)
+                    if (f == 2) { take(mail[0], false); take(ffm_own[1], true); } else { take(ffm_own[1], true); take(mail[0], false); }
+                }
+                if (f == 0) { take(ffm_own[0], true); take(mail[1], false); }      // second group: own row (f; f + 1), received row (f + 2; f)
+                else { take(mail[1], false); take(ffm_own[0], true); }
             }
             // rows of the finger-cube contact; the contact-space record goes straight to LDS for the cube role
             const int rb = L_REC(f);
@@ -1870,12 +1876,15 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             // ---- FF, second part (TfModel.ff_middle_pairs, on by default since API 8; wave-uniform): the middle link of finger fm (shape2) against the distal
             // capsule of each other finger - six ordered pairs on the same velocities.  The middle frame is rebuilt from what finger fm publishes:
             // e_x = (c1, 0, -s1), g = (p3 - p2) - j3_x e_x = j3_y e_y + j3_z e_z, e_x x g = j3_y e_z - j3_z e_y (oracle/tf_oracle.c, the same lines). ----
-            // (256-register cube kernels: built by the finger wavefronts - the block above their S1b; this placement serves the 128-register kernels and
-            // the box kernels, whose LDS has no room for the mailboxes)
+            // (placement per instantiation, same bits: the 256-register cube kernels build all six rows on the finger wavefronts - the block above
+            // their S1b; the 128-register cube kernels leave the FIRST group, fd = fm + 2, here and build the second on the finger wavefronts; the box
+            // kernels, whose LDS has no room for the mailboxes, visit both groups here)
             if ((BOXK || !WIDE) && m.ff_middle_pairs != 0) {
                 const TfLinkShape& sh = m.shape2;
                 const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
                 const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
+#pragma unroll 1
+                for (int o_ = 2; o_ >= (BOXK ? 1 : 2); --o_)
 #pragma unroll 1
                 for (int fm = 0; fm < 3; ++fm) {
                     FingerPubRegs pm;
@@ -1898,8 +1907,8 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
                         base_to_world(ym, ab, aw);
                         base_to_world(ym, bb, bw);
                     }
-#pragma unroll 1
-                    for (int o = 1; o <= 2; ++o) {
+                    {
+                        const int o = o_;
                         const int fd = (fm + o >= 3) ? fm + o - 3 : fm + o;
                         float Pm[3], Pd[3], sp;
                         {

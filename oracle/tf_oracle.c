@@ -1483,12 +1483,14 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         for (int j = 0; j < 3; ++j) { va[j] = FMA(Wa[j], lam, va[j]); vb[j] = FMA(-Wb[j], lam, vb[j]); }
     }
     /* ---- FF, second part (TfModel.ff_middle_pairs, on by default since API 8): the MIDDLE link of finger fm against the distal capsule of each other
-     * finger fd - the six ordered pairs (0;1) (0;2) (1;2) (1;0) (2;0) (2;1).  API 8: every one of these rows is solved on the FREE velocities (those
+     * finger fd - the six ordered pairs, listed as the three with fd = fm + 2 - (0;2) (1;0) (2;1) - and then the three with fd = fm + 1 - (0;1) (1;2)
+     * (2;0).  API 8: every one of these rows is solved on the FREE velocities (those
      * before any finger-finger row - a Jacobi step: the rows do not see each other nor the distal pairs), and its two velocity changes d = W lambda
      * (a product rounded on its own) are ADDED to the velocities the distal pairs left, in the order the pairs are listed, a zero component skipped.
      * A row then depends on nothing but what the fingers publish after their free motion, so the three finger wavefronts of the kernels can build
      * the rows of their own middle link side by side and hand the other finger's share over (csrc/tf_roles.h); visited in turn by the cube wavefront -
-     * the other placement - the same lines give the same bits.
+     * the other placement - the same lines give the same bits; and because the first group is complete before the second begins, a kernel may leave
+     * the first group to the cube wavefront and build the second on the finger wavefronts (the 128-register kernels do).
      * The reference leaves every robot link in one collision group with self-collision on (trifinger_env.py:811-812).  The middle link is
      * its finger-cube shape (shape2: tapered rounded box about the axis a -> b of the middle frame), the distal link the fingertip capsule
      * as in the distal pairs.  The cube role of the kernels sees of a finger what it publishes (p2, p3, sin / cos of joint 1, M^-1): the
@@ -1498,7 +1500,7 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
         const TfLinkShape* sh = &m->shape2;
         const float jx = m->j3_origin[0], jy = m->j3_origin[1], jz = m->j3_origin[2];
         const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
-        for (int fm = 0; fm < 3; ++fm) {
+        for (int o_ = 2; o_ >= 1; --o_) for (int fm = 0; fm < 3; ++fm) {
             const FK* km = &fr[fm].k;
             const float ex[3] = {km->c1, 0.0f, -km->s1};
             float g[3], xg[3], ey[3], ez[3], ab[3], bb[3], aw[3], bw[3];
@@ -1511,7 +1513,8 @@ static void substep(const struct TfHandle_* H, Env* e, float h) {
             }
             base_to_world(m, fm, ab, aw);
             base_to_world(m, fm, bb, bw);
-            for (int o = 1; o <= 2; ++o) {
+            {
+                const int o = o_;
                 const int fd = (fm + o) % 3;
                 float Pm[3], Pd[3], sp;
                 seg_seg_s(aw, bw, fr[fd].Aw, fr[fd].Bw, Pm, Pd, &sp);

@@ -313,10 +313,10 @@ def ref_substep(q, qd, cube, tau, h, gravity=(0.0, 0.0, -9.81), tol=1e-13, max_s
     # line between them; the row moves joints 1 and 2 of the middle finger (the point is a point of link 2) and all three of the distal one ----
     if ff_middle:
         sh2 = next(e[2] for e in SHAPES if e[0] == "shape" and e[1] == 2)
-        for fm in range(3):
+        for o, fm in ((2, 0), (2, 1), (2, 2), (1, 0), (1, 1), (1, 2)):         # the order the spec lists them in (it only orders the sums)
             qm = q[3 * fm:3 * fm + 3]
             am, bm = link_point_world(fm, qm, 2, sh2["a"]), link_point_world(fm, qm, 2, sh2["b"])
-            for o in (1, 2):
+            if True:
                 fd = (fm + o) % 3
                 Pm, Pd = segment_segment(am, bm, distal[fd][0], distal[fd][1])
                 dist = np.linalg.norm(Pd - Pm)
