@@ -16,8 +16,7 @@ _F = C.POINTER(C.c_float)
 
 
 def library_path():
-    """TFP_LIB: a developer build of the same sources (tools/experiments/*: timing variants)"""
-    return os.environ.get("TFP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_ppo.so")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrifinger_ppo.so")
 
 
 def load():

@@ -4,6 +4,8 @@ grouped launches, at the trainer's minibatch shapes; times per call inside a HIP
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import walk_bench_util  # noqa: F401  (honours TFP_LIB)
 from leibnizgym_amd import ppo_kernels as pk
 
 dev = "cuda:0"

@@ -1,7 +1,13 @@
 """helpers of walk_bench.py / walk_decompose.py"""
+import os
+
 import torch
 
+from leibnizgym_amd import ppo_kernels as _pk
+
 dev = "cuda:0"
+if os.environ.get("TFP_LIB"):          # a developer build of the trainer's kernels (timing variants): the package itself takes no environment override
+    _pk.library_path = lambda: os.environ["TFP_LIB"]
 
 
 def t_us(f, n=10, reps=5):

@@ -2,7 +2,7 @@
 of one workgroup, per wavefront):  python3 tools/experiments/walk_phases.py   (builds nothing: make the variant first, see tools/README.md)"""
 import os, sys, ctypes as C
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
-os.environ["TFP_LIB"] = os.path.join(REPO, "leibnizgym_amd", "csrc", "variants", "libppo_walk_timing.so")
+os.environ["TFP_LIB"] = os.path.join(REPO, "leibnizgym_amd", "csrc", "variants", "libppo_walk_timing.so")      # picked up by walk_bench_util
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.dirname(__file__))
 import torch
 from leibnizgym_amd import ppo_kernels as pk
