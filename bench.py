@@ -349,6 +349,11 @@ def main():
     # ---- the timed region: EXACTLY --steps steps, actions 2*U-1 generated on the device in every step by the
     # step itself (tf_step_random: Philox draws inside the launch) ----
     eng.enable_kernel_timing(8192 if args.time_window > 0 else 0, max(1, args.time_window))
+    # the driver's window is 20 steps = 1.4 ms: a cyclic-GC pass of the interpreter inside it (torch is loaded: a full collection takes milliseconds) would
+    # be most of the measurement - collect now, keep the collector off while the timed regions run (the loop itself allocates nothing that needs it)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -594,6 +599,7 @@ def main():
     if global_stats is not None:
         out["episode_stats_all_reduced"] = global_stats[:11]
         out["episode_stats_rank0"] = local_stats[:11]          # this rank's own statistics of the same step (equal to the reduced ones in a world of one)
+    gc.enable()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(asym)
