@@ -21,7 +21,8 @@
 // three) - a persistent form that pulls blocks from a queue, partial blocks as plain tiles, would come to ~45 us (not built).  Measured and not kept:
 // 128-row pieces, 8 steps of loads in flight instead of 4, a 2 x 2 arrangement of the wavefronts on 128 x 128 blocks with the second fetch of every
 // operand left to L1, and the same with both operands staged through LDS (one fetch per workgroup): all 75 - 85 us - the operand stream (5 TB/s) is not
-// what binds.
+// what binds.  Counters of the kept form (profiles/r6_zz_dw_pmc.txt): the matrix pipes are busy 72 % of the launch (98.6 M MFMA-busy cycles over 1024 SIMDs =
+// 96 k of 134 k cycles), L2 hit rate 71 %, L1 53 %.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
