@@ -38,9 +38,6 @@
 typedef float w4 __attribute__((ext_vector_type(4)));
 typedef float w4u __attribute__((ext_vector_type(4), aligned(4)));      // a dwordx4 load needs dword alignment only (rows of 41 / 113 floats)
 
-#ifndef WALK_ASM_MFMA
-#define WALK_ASM_MFMA 0
-#endif
 #ifndef WALK_DBG
 #define WALK_DBG 0     // developer builds (timing only, wrong results): 1 = the B loads do not advance along K (every step re-reads the first one: L1 hits),
 #endif                 // 2 = no MFMAs (loads, LDS traffic and epilogues only)
@@ -55,7 +52,6 @@ __device__ unsigned long long g_walk_t[4 * 32];
 #endif
 #define WALK_ROWS 32
 #define WALK_MAXL 4
-#define WALK_MAXT 7            // column tiles per wavefront: 4 x 7 x 16 = 448 >= the widest layer (416)
 
 struct WalkNet {
     const float* x;                    // forward: network input [M, dim[0]]; backward: gradient of the network output [M, dim[nl]]
@@ -144,13 +140,13 @@ struct StreamOut {
     }
 };
 
-// after the last MFMA of a layer, before anything but an MFMA touches the accumulators: an 8-pass MFMA needs 11 wait states before a vector instruction
-// may read its result (the compiler inserts them for its own MFMAs; it does not know these)
+// after the last MFMA of a layer, before anything but an MFMA touches the accumulators.  The compiler inserts the wait states an 8-pass MFMA needs before a
+// vector instruction reads its result; the explicit ones and the empty asm ties date from the inline-assembly form of the loop and are kept because they
+// keep the epilogue's reads behind the whole K loop (64 cycles per layer, under 0.5% of the walk) - the shape the parity tests and profiles were taken on.
 template <int NCT>
 __device__ __forceinline__ void walk_mfma_drain(w4 (&acc)[2][NCT]) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    // every accumulator passes through an (empty) volatile asm BEHIND the wait states: a vector instruction that reads one cannot be scheduled above them
-    // (it was: the last register of the last accumulator arrived in the epilogue before the MFMA had written it)
+    // every accumulator passes through an (empty) volatile asm behind the wait states: a vector instruction that reads one cannot be scheduled above them
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -180,11 +176,11 @@ __device__ __forceinline__ void walk_layer(const float* Xs, int px, const float*
     const float* xa = Xs + lr * px + 4 * kk;
     const bool ragged = !KMAJ && (K & 3) != 0;
     const int nvec = ragged ? (K >> 4) : ((K + 15) >> 4), tail = ragged ? (K & 15) : 0;     // steps of the uniform form; elements of the ragged step
-    // The MFMAs are written as inline assembly, in place (vdst = srcC) and volatile.  As builtins they came out of register allocation with accumulators
-    // rotating through the register file (vdst != srcC, copies, and - worse - B fragments landing in registers whose previous owner forces the next wait
-    // to vmcnt(0)); sched_barrier / sched_group_barrier either cut the region or did not stop it.  Volatile asm is neither reordered nor moved across by
-    // the loads around it, so the step below executes exactly as written: per column tile its 8 MFMAs, then the load of its next fragment.  What the
-    // compiler's hazard recogniser no longer sees is covered by hand: the accumulators are read by vector instructions only after walk_mfma_drain().
+    // The MFMAs are builtins and the order of a step is pinned with sched_group_barrier (the LDS reads of the next A fragments, then per column tile its
+    // 8 MFMAs followed by the load of its next B fragment).  Left to itself the scheduler hoisted all loads to the top of the step, which made every wait
+    // a vmcnt(0); sched_barrier(0) between tiles cut the region and brought accumulator copies (v_accvgpr shuffles) with it.  Writing the MFMAs as volatile
+    // inline assembly was tried and dropped: the hazard recogniser does not see them, and the compiler placed vector copies of accumulators behind MFMAs
+    // that had not finished (docs/HISTORY.md section 12).
     auto loadb = [&](int t, int j, w4& b) __attribute__((always_inline)) {
         const int k0 = WALK_DBG == 1 ? 0 : 16 * t;
         if (KMAJ) {
@@ -212,11 +208,7 @@ __device__ __forceinline__ void walk_layer(const float* Xs, int px, const float*
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (WALK_DBG == 2) { acc[i][j][0] += a[i][s] + b[s]; continue; }
-#if WALK_ASM_MFMA
-                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i][s]), "v"(b[s]));
-#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[s], acc[i][j], 0, 0, 0);
-#endif
                 }
             }
         }
@@ -244,14 +236,12 @@ __device__ __forceinline__ void walk_layer(const float* Xs, int px, const float*
             loadb(t + 1, j, b[j]);
         }
         if (SO) so.write(sv);
-#if !WALK_ASM_MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, SO ? 3 : 2, 0);
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, KMAJ ? 4 : 1, 0);
         }
-#endif
         a[0] = an[0]; a[1] = an[1];
     }
     if (tail) {
