@@ -52,13 +52,13 @@ ACTION_READ_BYTES = 36                            # ... of which the [N, 9] acti
 FLOPS_PER_ENV_STEP = 22.6e3
 
 
-def load_pmc_profile(n, asym, ext=False, wide=False):
+def load_pmc_profile(n, asym, ext=False, variant="narrow"):
     """Per-launch counters of the fused step kernel from the newest profiles/r*_pmc.txt whose header names this workload
     (written by tools/profile_round.sh; rocprofv3 --pmc passes, raw counter expressions).  Returns (dict, path) or
     (None, None): nothing is hard-coded here, a profile of another N / kernel is not used."""
     import glob
     import re
-    kname = kernel_name(asym, 9, ext, True, wide)
+    kname = kernel_name(asym, 9, ext, True, variant)
     want = f"# workload: N={n} asym={asym} kernel={kname}"
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.txt")), reverse=True):
         text = open(path).read()
@@ -128,11 +128,13 @@ FULL_DR = {"activate": True, "cube_mass": (0.7, 1.3), "cube_size": (0.9, 1.1), "
            "friction_robot": (0.8, 1.2), "friction_object": (0.8, 1.2), "friction_stage": (0.8, 1.2)}
 
 
-def kernel_name(asym, action_dim=9, ext=False, fused_actions=True, wide=False):
+def kernel_name(asym, action_dim=9, ext=False, fused_actions=True, variant="narrow"):
     """rocprofv3's name of the fused-step instantiation a workload launches (EXT: extended DR or the box object; MODE 127 = the step
     with the action source fused in - tf_step_random, what `value` times -, 63 = the step that reads a resident action tensor; the last
-    argument: the 256-register instantiation tf_create picks up to 32768 envs per handle)."""
-    return f"k_env<{action_dim}, false, {'true' if asym else 'false'}, {127 if fused_actions else 63}, {int(ext)}, {'true' if wide else 'false'}>"
+    two arguments: the 256-register instantiation tf_create picks up to 32768 envs per handle, and its form with helper wavefronts - up to
+    16384 envs; `variant` is TrifingerEngine.kernel_variant)."""
+    b = lambda x: "true" if x else "false"        # noqa: E731
+    return f"k_env<{action_dim}, false, {b(asym)}, {127 if fused_actions else 63}, {int(ext)}, {b(variant != 'narrow')}, {b(variant == 'wide_helpers')}>"
 
 
 def workload_kwargs(asym, difficulty=4, dr=False):
@@ -426,7 +428,7 @@ def main():
             elapsed_s = float(t[0].item())
         strong = {"global_envs": strong_total, "envs_per_gpu": cnt, "ms_per_step": elapsed_s / args.steps * 1e3,
                   "value": strong_total * args.steps / elapsed_s, "kernel_variant": eng_s.kernel_variant,
-                  "kernel": kernel_name(asym, eng_s.action_dim, 2 if args.box else (1 if args.dr else 0), True, eng_s.kernel_variant == "wide"),
+                  "kernel": kernel_name(asym, eng_s.action_dim, 2 if args.box else (1 if args.dr else 0), True, eng_s.kernel_variant),
                   "kernel_avg_us_rank0": (ks_ms / max(ks_n, 1)) * 1e3}
         eng_s.close()
 
@@ -474,8 +476,7 @@ def main():
     bytes_per_launch = alg_bytes * n
     achieved_gbs = bytes_per_launch / kern_avg_s / 1e9 if kern_n else 0.0
     ext = 2 if args.box else (1 if args.dr else 0)     # extended DR -> EXT = 1, box object -> EXT = 2 instantiation of the fused step
-    wide = eng.kernel_variant == "wide"
-    pmc, pmc_path = load_pmc_profile(n, asym, ext, wide) if (headline or ext) else (None, None)      # counters of the kernel `value` launches
+    pmc, pmc_path = load_pmc_profile(n, asym, ext, eng.kernel_variant) if (headline or ext) else (None, None)      # counters of the kernel `value` launches
     traffic = traffic_raw = issue = None
     traffic_how = None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -571,7 +572,7 @@ def main():
             "traffic": traffic,
             "traffic_raw": traffic_raw,
             "traffic_source": traffic_how,
-            "kernel": kernel_name(asym, eng.action_dim, ext, True, wide),
+            "kernel": kernel_name(asym, eng.action_dim, ext, True, eng.kernel_variant),
             "kernel_variant": eng.kernel_variant,
             "kernel_avg_us": kern_avg_s * 1e6,
             "kernel_launches_timed": kern_n,

@@ -358,9 +358,14 @@ int tf_set_frame_count(tf_handle h, int64_t frames);
  * workgroups on a CU (populations that fill the chip) and a 256-register one without spills or LDS parking for populations that never put more
  * than two workgroups on a CU (num_envs <= TF_WIDE_MAX_ENVS: shorter latency per step).  tf_create picks by num_envs (TF_KERNEL_AUTO); the parity
  * tests and the benchmarks force one or the other.  The oracle accepts and ignores the call.  tf_kernel_variant returns what the launches use
- * (TF_KERNEL_NARROW / TF_KERNEL_WIDE). */
-enum { TF_KERNEL_AUTO = 0, TF_KERNEL_NARROW = 1, TF_KERNEL_WIDE = 2 };
+ * (TF_KERNEL_NARROW / TF_KERNEL_WIDE / TF_KERNEL_WIDE_HELPERS). */
+enum { TF_KERNEL_AUTO = 0, TF_KERNEL_NARROW = 1, TF_KERNEL_WIDE = 2, TF_KERNEL_WIDE_HELPERS = 3 };
 #define TF_WIDE_MAX_ENVS 32768
+/* TF_KERNEL_WIDE_HELPERS (cube kernels; API 8, additive): the 256-register instantiation in workgroups of SEVEN wavefronts - three helper wavefronts build
+ * the middle-distal finger-finger rows (TfModel.ff_middle_pairs) beside the finger wavefronts' contact generation, in the second wavefront slot a CU
+ * that holds one workgroup leaves empty.  Same arithmetic, identical results.  TF_KERNEL_AUTO picks it for num_envs <= TF_HELPERS_MAX_ENVS when the
+ * model holds those rows; forcing it on a handle with the box object is TF_ERR_INVALID_ARG (the box kernels have no such instantiation). */
+#define TF_HELPERS_MAX_ENVS 16384
 int tf_set_kernel_variant(tf_handle h, int32_t variant);
 int tf_kernel_variant(tf_handle h);
 /* Workgroups of the handle's fused step that fit one CU at once, as the HIP runtime computes it from the kernel's registers and LDS (diagnostic; -1 if

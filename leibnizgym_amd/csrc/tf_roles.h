@@ -70,6 +70,14 @@ DEV constexpr int ffm_mbox(int fd, int k) {                  // k = 3 x message 
          : fd == 1 ? (k == 0 ? 148 : (k == 1 ? 59 : 153 + k))    //   finger 1: 148 (L_INIT + 1), 59 (tail of record 1), 155 .. 158
                    : 83 + k;                                 //   finger 2: 83 .. 88 (tail of record 2)
 }
+// The helper-wavefront instantiation of the 256-register cube kernels (HELP: workgroups of seven wavefronts, one workgroup per CU, populations of at most
+// 16384 envs): wavefronts 4..6 build the middle-distal rows of finger 0..2's middle link between S1 and S1b (helper_role) and post BOTH shares - the
+// distal finger's through ffm_mbox as above, the owning finger's through ffm_own_mbox; finger f hands them its restitution factor (L_HELP_DR + f).
+#define NT_HELP 448
+#define L_HELP_OWN 159                  //  18: velocity change of finger fm's own side, 3 x (o - 1) + j at 6 fm
+#define L_HELP_DR 177                   //   3: domain-randomisation value 5 (restitution) of the substep, published by finger f with its free motion
+#define LDS_SLOTS_HELP 180
+DEV constexpr int ffm_own_mbox(int fm, int k) { return L_HELP_OWN + 6 * fm + k; }
 #define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
 #define LDS_SLOTS_BOX 159
 // post phase (aliases the above)
@@ -387,8 +395,9 @@ struct TipContact {            // fingertip sphere against one feature of the ar
     float arm[3];             // contact point relative to the tip-link origin (fingertip wrench sensor)
 };
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, int X, bool WIDE>
+template <int A, bool IS_RESET, bool ASYM, int MODE, int X, bool WIDE, bool HELP = false>
 DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
+    static_assert(!HELP || (WIDE && X != 2), "helper wavefronts: 256-register cube kernels only");
     constexpr bool EXT = X != 0;      // X: 0 the headline kernels, 1 extended domain randomisation, 2 the same with the general box object
     // WIDE: the 256-register instantiation (2 wavefronts per SIMD) launched for populations that never put more than two workgroups on a
     // CU (num_envs <= 32768): nothing is parked in LDS or re-read from the state rows between substeps.  Same arithmetic, bit for bit.
@@ -658,6 +667,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 #pragma unroll
                 for (int j = 0; j < 6; ++j) LD(pb + P_MINV + j) = k.Minv[j];
                 LD(pb + P_S1) = k.s1; LD(pb + P_C1) = k.c1;
+                if (HELP) LD(L_HELP_DR + f) = dr[5];
             }
             STAMP(sb_ + 0);
             BAR();                                              // S1: free motion of every role published
@@ -776,7 +786,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             // all six on the fingers cost this role registers it has to spill (65536 envs: 73.0 us against 70.0 us with all six on the cube wavefront).
             const bool ffm_here = !BOXK && m.ff_middle_pairs != 0;     // wave-uniform
             constexpr int FFM_O_FIRST = WIDE ? 2 : 1;                  // this wavefront's groups: o = FFM_O_FIRST .. 1
-            if (ffm_here) {
+            if (ffm_here && !HELP) {                                   // (HELP: wavefront 4 + f builds them, helper_role)
                 const TfLinkShape& sh = m.shape2;
                 const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
                 const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
@@ -876,6 +886,10 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 // component skipped.  Within a group the rows are ordered by the finger that owns the middle link: this finger's own row (fm = f) and the
                 // one it received (first group: fm = f + 1, second group: fm = f + 2, mod 3).  (128-register kernels: the first group is in L_VQFF already.)
                 float mail[2][3];
+                if (HELP) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { ffm_own[0][j] = LD(ffm_own_mbox(f, j)); ffm_own[1][j] = LD(ffm_own_mbox(f, 3 + j)); }
+                }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     mail[0][j] = !WIDE ? 0.0f : ((f == 0) ? LD(ffm_mbox(0, j)) : ((f == 1) ? LD(ffm_mbox(1, j)) : LD(ffm_mbox(2, j))));
@@ -1360,6 +1374,135 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
     STAMP(35);
     STAMPV(40, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID
     STAMPV(41, __builtin_amdgcn_s_getreg((31 << 11) | 20));     // HW_REG_XCC_ID
+}
+
+// =====================================================================================================================
+// HELPER ROLE (HELP instantiation: wavefronts 4..6 of a seven-wavefront workgroup)
+// =====================================================================================================================
+// Up to 16384 envs a 256-register workgroup has a CU to itself and one wavefront on each SIMD: the second wavefront slot of a SIMD is empty, and the six
+// middle-distal finger-finger rows - independent of everything else between S1 and S1b, functions of what the fingers published before S1 - sat on the
+// finger wavefronts' critical path (contact generation).  Here wavefront 4 + fm builds the two rows of finger fm's middle link with the cube role's
+// formulation of them (the middle frame rebuilt from what finger fm publishes: the lines of cube_role's block, the same bits) and posts the velocity
+// changes; the finger roles add them behind S1b in the listed order exactly as they add the ones they computed themselves.  Apart from that the role
+// only keeps the workgroup's barriers company - every BAR() of the other roles has its twin here, in the same order under the same conditions.
+template <bool ASYM, int MODE, int X>
+DEV void helper_role(const DevParams& P, const StepArgs& sa, float* lds, const Ctx& cx) {
+    const TfModel& m = P.m;
+    const int lane = cx.lane;
+    const int fm = cx.role - 4;
+    BAR();                                                      // #1
+    if (!(MODE & (M_ACT_IN | M_RESETS))) BAR();                 // #1b
+    if (MODE & (M_ACT_IN | M_RESETS)) { BAR(); BAR(); }         // #2a, #2b
+    if (MODE & M_SIM) {
+        const float h = P.hsub, inv_h = 1.0f / h;
+        const int nsub = sa.nsim * P.substeps;
+        const TfLinkShape& sh = m.shape2;
+        const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
+        const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
+        const Yaw ym = {m.base_yaw_cos[fm], m.base_yaw_sin[fm], 0.0f, 0.0f, m.base_height};
+        for (int s = 0; s < nsub; ++s) {
+            BAR();                                              // S1
+            if (m.ff_middle_pairs != 0) {
+                const float rest_ff = m.restitution_ff * LD(L_HELP_DR + fm);
+                FingerPubRegs pm;
+                read_pub(lds, lane, fm, pm);
+                const float ex[3] = {pm.k.c1, 0.0f, -pm.k.s1};
+                float ey[3], aw[3], bw[3], vm[3];
+                {
+                    float g[3], xg[3], ez[3], ab[3], bb[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) g[i] = FMA(-jx, ex[i], pm.k.p3[i] - pm.k.p2[i]);
+                    cross3(ex, g, xg);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { ey[i] = FMA(jy, g[i], -(jz * xg[i])) * inv_j; ez[i] = FMA(jz, g[i], jy * xg[i]) * inv_j; }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        ab[i] = FMA(sh.a[2], ez[i], FMA(sh.a[1], ey[i], FMA(sh.a[0], ex[i], pm.k.p2[i])));
+                        bb[i] = FMA(sh.b[2], ez[i], FMA(sh.b[1], ey[i], FMA(sh.b[0], ex[i], pm.k.p2[i])));
+                    }
+                    base_to_world(ym, ab, aw);
+                    base_to_world(ym, bb, bw);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) vm[j] = LD(L_REC(fm) + P_VQ + j);      // the FREE velocities (API 8)
+#pragma unroll 1
+                for (int o = 2; o >= 1; --o) {
+                    const int fd = (fm + o >= 3) ? fm + o - 3 : fm + o;
+                    float dd[3] = {0.0f, 0.0f, 0.0f}, dm[3] = {0.0f, 0.0f, 0.0f};
+                    float Pm[3], Pd[3], sp;
+                    {
+                        float Ad[3], Bd[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { Ad[j] = LD(L_REC(fd) + P_AW + j); Bd[j] = LD(L_REC(fd) + P_BW + j); }
+                        seg_seg_s(aw, bw, Ad, Bd, Pm, Pd, sp);
+                    }
+                    const float dv[3] = {Pd[0] - Pm[0], Pd[1] - Pm[1], Pd[2] - Pm[2]};
+                    const float dist2 = dot3(dv, dv);
+                    const float inv = f_rsqrt(f_max(dist2, 1e-12f));
+                    const float dist = dist2 * inv;
+                    const float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};      // from the middle link to the distal capsule
+                    float nm[3];
+                    dir_world_to_base(ym, n, nm);
+                    const float u1 = dot3(nm, ex), u2 = dot3(nm, ey);
+                    const float rho = FMA(sp, sh.rho[1] - sh.rho[0], sh.rho[0]);
+                    const float h1 = FMA(sp, sh.w1[1] - sh.w1[0], sh.w1[0]) - rho, h2 = FMA(sp, sh.w2[1] - sh.w2[0], sh.w2[0]) - rho;
+                    const float o1 = FMA(sp, sh.o1[1] - sh.o1[0], sh.o1[0]), o2 = FMA(sp, sh.o2[1] - sh.o2[0], sh.o2[0]);
+                    const float ext = FMA(o2, u2, FMA(o1, u1, FMA(h2, f_abs(u2), FMA(h1, f_abs(u1), rho))));
+                    const float gap = dist - ext - m.cap_radius;
+                    const bool near_ff = (dist2 > 1e-12f) && (gap < m.contact_margin);
+                    if (__builtin_amdgcn_ballot_w64(near_ff) != 0ull) {
+                        float Jd[3], Wd[3], Jm[3], Wm[3], vd[3];
+                        {   // distal side: the point of the capsule surface that faces the middle link
+                            const Yaw yd = {m.base_yaw_cos[fd], m.base_yaw_sin[fd], 0.0f, 0.0f, m.base_height};
+                            FingerPubRegs pd;
+                            read_pub(lds, lane, fd, pd);
+                            float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) C[j] = FMA(-m.cap_radius, n[j], Pd[j]);
+                            world_to_base(yd, C, Cb_);
+                            levers(pd.k, Cb_, L1, L2, L3);
+                            dir_world_to_base(yd, n, nb);
+                            Jd[0] = dot3(L1, nb); Jd[1] = dot3(L2, nb); Jd[2] = dot3(L3, nb);
+                            sym3_mul(pd.k.Minv, Jd, Wd);
+                        }
+                        {   // middle side: joints 1 and 2 move it, joint 3 does not
+                            float C[3], Cb_[3], L1[3], L2[3], L3[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) C[j] = FMA(ext, n[j], Pm[j]);
+                            world_to_base(ym, C, Cb_);
+                            levers(pm.k, Cb_, L1, L2, L3);
+                            Jm[0] = dot3(L1, nm); Jm[1] = dot3(L2, nm); Jm[2] = 0.0f;
+                            sym3_mul(pm.k.Minv, Jm, Wm);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) vd[j] = LD(L_REC(fd) + P_VQ + j);
+                        const float vn0 = dot3(Jd, vd) - dot3(Jm, vm);
+                        if (near_ff && contact_live(m, gap, vn0, h)) {
+                            const float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
+                            const float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Jd, Wd) + dot3(Jm, Wm)), 0.0f);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) { dd[j] = Wd[j] * lam; dm[j] = Wm[j] * lam; }
+                        }
+                    }
+                    // fd's mailbox: message 0 is the row of the first group (o = 2), message 1 the row of the second (o = 1); fm's own: by group
+                    const int msg = 2 - o;
+                    if (fd == 0) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(0, 3 * msg + j)) = dd[j]; }
+                    else if (fd == 1) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(1, 3 * msg + j)) = dd[j]; }
+                    else { for (int j = 0; j < 3; ++j) LD(ffm_mbox(2, 3 * msg + j)) = dd[j]; }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) LD(ffm_own_mbox(fm, 3 * (o - 1) + j)) = dm[j];
+                }
+            }
+            BAR();                                              // S1b
+            BAR();                                              // S3
+            for (int it = 0; it < P.iters; ++it) { BAR(); BAR(); }     // W1, W2
+        }
+    }
+    if (MODE & M_POST) {
+        BAR();                                                  // P1
+        BAR();                                                  // P3
+        if (ASYM && P.dr_obs_noise > 0.0f) { BAR(); BAR(); }    // P4, P5
+    }
 }
 
 // =====================================================================================================================

@@ -111,7 +111,7 @@ struct TfHandle_ {
     int bound;
     int64_t frame_count;
     int action_dim;
-    int variant;             // TF_KERNEL_AUTO / NARROW / WIDE as asked for (tf_set_kernel_variant)
+    int variant;             // TF_KERNEL_AUTO / NARROW / WIDE / WIDE_HELPERS as asked for (tf_set_kernel_variant)
     bool wide;               // what the launches use
     // optional kernel timing (bench.py): event pairs around the fused step kernel
     hipEvent_t* ev;          // [2 * ev_cap]
@@ -449,21 +449,31 @@ int tf_set_gravity(tf_handle h, const float g[3]) {
     return TF_OK;
 }
 static int ext_kind(const TfConfig& c);
+// helper wavefronts (the WIDE = 2 units): asked for, or picked for a population that leaves every CU to one workgroup when the model holds the rows they build
+static bool use_helpers(const TfHandle_* h) {
+    if (!h->wide || ext_kind(h->cfg) == 2) return false;
+    if (h->variant == TF_KERNEL_WIDE_HELPERS) return true;
+    return h->variant == TF_KERNEL_AUTO && h->cfg.num_envs <= TF_HELPERS_MAX_ENVS && h->cfg.model.ff_middle_pairs != 0;
+}
 int tf_set_kernel_variant(tf_handle h, int32_t variant) {
-    if (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE) return TF_ERR_INVALID_ARG;
+    if (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE_HELPERS) return TF_ERR_INVALID_ARG;
+    if (variant == TF_KERNEL_WIDE_HELPERS && ext_kind(h->cfg) == 2) return TF_ERR_INVALID_ARG;      // the box kernels have no such instantiation
     h->variant = variant;
-    h->wide = (variant == TF_KERNEL_AUTO) ? (h->cfg.num_envs <= TF_WIDE_MAX_ENVS) : (variant == TF_KERNEL_WIDE);
+    h->wide = (variant == TF_KERNEL_AUTO) ? (h->cfg.num_envs <= TF_WIDE_MAX_ENVS) : (variant != TF_KERNEL_NARROW);
     return TF_OK;
 }
-int tf_kernel_variant(tf_handle h) { return h ? (h->wide ? TF_KERNEL_WIDE : TF_KERNEL_NARROW) : TF_ERR_INVALID_ARG; }
+int tf_kernel_variant(tf_handle h) { return h ? (h->wide ? (use_helpers(h) ? TF_KERNEL_WIDE_HELPERS : TF_KERNEL_WIDE) : TF_KERNEL_NARROW) : TF_ERR_INVALID_ARG; }
 int tf_kernel_occupancy(tf_handle h) {
     if (!h) return TF_ERR_INVALID_ARG;
     const bool asym = h->cfg.asymmetric_obs != 0;
+    const bool help = use_helpers(h);
 #if defined(TF_DEV_MIN)
+    if (help) return tf_occupancy_env_0_2(h->action_dim, asym);
     return h->wide ? tf_occupancy_env_0_1(h->action_dim, asym) : tf_occupancy_env_0_0(h->action_dim, asym);
 #else
     const int k = ext_kind(h->cfg);
     if (k == 2) return h->wide ? tf_occupancy_env_2_1(h->action_dim, asym) : tf_occupancy_env_2_0(h->action_dim, asym);
+    if (help) return k == 1 ? tf_occupancy_env_1_2(h->action_dim, asym) : tf_occupancy_env_0_2(h->action_dim, asym);
     if (k == 1) return h->wide ? tf_occupancy_env_1_1(h->action_dim, asym) : tf_occupancy_env_1_0(h->action_dim, asym);
     return h->wide ? tf_occupancy_env_0_1(h->action_dim, asym) : tf_occupancy_env_0_0(h->action_dim, asym);
 #endif
@@ -533,11 +543,14 @@ static void launch_env(TfHandle_* h, int lm, const float* action, hipStream_t s)
     EnvLaunch a;
     a.grid = (unsigned)n_waves(h); a.action_dim = h->action_dim; a.asym = h->cfg.asymmetric_obs != 0;
     a.d_params = h->d_params; a.sa = h->sa; a.action = action; a.stream = s;
+    // the helper units carry the launches that simulate; a launch of one of the other hooks (split path) is the plain 256-register kernel
+    const bool help = use_helpers(h) && (lm == TF_LM_STEP || lm == TF_LM_STEP_RAND || lm == TF_LM_RESET || lm == TF_LM_SIM);
 #if defined(TF_DEV_MIN)      // developer builds (tools/ab_bench.py, tools/variant_sweep.py): the headline kernels only
-    if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a);
+    if (help) tf_launch_env_0_2(lm, a); else if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a);
 #else
     const int k = ext_kind(h->cfg);
     if (k == 2) { if (h->wide) tf_launch_env_2_1(lm, a); else tf_launch_env_2_0(lm, a); }
+    else if (help) { if (k == 1) tf_launch_env_1_2(lm, a); else tf_launch_env_0_2(lm, a); }
     else if (k == 1) { if (h->wide) tf_launch_env_1_1(lm, a); else tf_launch_env_1_0(lm, a); }
     else { if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a); }
 #endif

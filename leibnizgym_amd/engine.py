@@ -273,15 +273,16 @@ class TrifingerEngine:
     def frame_count(self, v):
         check(self.lib, self.lib.tf_set_frame_count(self._handle, int(v)), "tf_set_frame_count")
 
-    KERNEL_VARIANTS = {"auto": 0, "narrow": 1, "wide": 2}       # TF_KERNEL_* of include/trifinger.h
+    KERNEL_VARIANTS = {"auto": 0, "narrow": 1, "wide": 2, "wide_helpers": 3}       # TF_KERNEL_* of include/trifinger.h
 
     @property
     def kernel_variant(self):
-        """which instantiation of the fused step the launches use: 'narrow' (128 registers, four workgroups per CU) or 'wide' (256
-        registers, picked for num_envs <= 32768); same results bit for bit"""
+        """which instantiation of the fused step the launches use: 'narrow' (128 registers, four workgroups per CU), 'wide' (256
+        registers, picked for num_envs <= 32768) or 'wide_helpers' (the same in workgroups of seven wavefronts, picked for num_envs <= 16384 when
+        the model holds the middle-distal finger-finger rows; cube kernels only); same results bit for bit"""
         v = int(self.lib.tf_kernel_variant(self._handle))
         check(self.lib, min(v, 0), "tf_kernel_variant")
-        return {1: "narrow", 2: "wide"}[v]
+        return {1: "narrow", 2: "wide", 3: "wide_helpers"}[v]
 
     @property
     def kernel_occupancy(self):

@@ -573,7 +573,7 @@ int tf_set_gravity(tf_handle h, const float g[3]) {
 int64_t tf_frame_count(tf_handle h) { return h ? h->frame_count : -1; }
 int tf_set_frame_count(tf_handle h, int64_t f) { if (!h) return TF_ERR_INVALID_ARG; h->frame_count = f; return TF_OK; }
 /* the product's two instantiations of the fused step share one arithmetic: the oracle has nothing to select (include/trifinger.h) */
-int tf_set_kernel_variant(tf_handle h, int32_t variant) { return (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE) ? TF_ERR_INVALID_ARG : TF_OK; }
+int tf_set_kernel_variant(tf_handle h, int32_t variant) { return (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE_HELPERS) ? TF_ERR_INVALID_ARG : TF_OK; }
 int tf_kernel_variant(tf_handle h) { return h ? TF_KERNEL_NARROW : TF_ERR_INVALID_ARG; }
 int tf_kernel_occupancy(tf_handle h) { return h ? 0 : TF_ERR_INVALID_ARG; }
 

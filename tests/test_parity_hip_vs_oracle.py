@@ -31,14 +31,21 @@ def test_both_instantiations_get_the_occupancy_they_are_built_for(hip):
         assert e.kernel_occupancy == 4, (extra.keys(), e.kernel_occupancy)
         e.kernel_variant = "wide"
         assert e.kernel_occupancy == 2, (extra.keys(), e.kernel_occupancy)
+        if "model" not in extra:                     # seven wavefronts of 256 registers: one workgroup per CU (the cube kernels; the box object has none)
+            e.kernel_variant = "wide_helpers"
+            assert e.kernel_variant == "wide_helpers" and e.kernel_occupancy == 1, (extra.keys(), e.kernel_occupancy)
+        else:
+            with pytest.raises(Exception):
+                e.kernel_variant = "wide_helpers"
         e.close()
 
 
 def test_kernel_variant_follows_the_population(hip):
-    """tf_create picks the 256-register instantiation up to TF_WIDE_MAX_ENVS envs and the 128-register one above (what bench.py's headline size
-    runs); the override is what the tests above use."""
+    """tf_create picks the 256-register instantiation up to TF_WIDE_MAX_ENVS envs - with helper wavefronts up to TF_HELPERS_MAX_ENVS when the model
+    holds the middle-distal rows (the default) - and the 128-register one above (what bench.py's headline size runs); the override is what the tests
+    above use."""
     from leibnizgym_amd.engine import TrifingerEngine, make_config
-    for n, want in ((64, "wide"), (32768, "wide"), (32769, "narrow"), (65536, "narrow")):
+    for n, want in ((64, "wide_helpers"), (16384, "wide_helpers"), (16385, "wide"), (32768, "wide"), (32769, "narrow"), (65536, "narrow")):
         e = TrifingerEngine(make_config(hip, n, **{k: v for k, v in pu.CONFIGS["d4_torque_asym"].items()}), device=DEV, lib=hip)
         assert e.kernel_variant == want, (n, e.kernel_variant)
         e.kernel_variant = "narrow"

@@ -9,7 +9,7 @@ run() {
   d=gpurun_out/pmc_$P/$1; shift
   rocprofv3 --pmc "$@" -d $d -o r -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
   echo "# rocprofv3 --pmc $* -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline" >> $OUT
-  python3 tools/rocprof_summary.py pmc $(find $d -name "*.db" | head -1) "k_env<9, false, true, 63, false" >> $OUT
+  python3 tools/rocprof_summary.py pmc $(find $d -name "*.db" | head -1) "k_env<9, false, true, 63" >> $OUT
   rm -rf $d
 }
 run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC

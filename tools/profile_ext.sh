@@ -7,7 +7,8 @@ T=${1:-rX}; O=gpurun_out
 mkdir -p $O
 for W in dr box; do
   for N in 16384 65536; do
-    K="k_env<9, false, true, 127, $([ $W = box ] && echo 2 || echo 1), $([ $N -le 32768 ] && echo true || echo false)>"      # <= 32768 envs: the 256-register instantiation
+    # <= 32768 envs: the 256-register instantiation; <= 16384 envs and not the box object: with helper wavefronts
+    K="k_env<9, false, true, 127, $([ $W = box ] && echo 2 || echo 1), $([ $N -le 32768 ] && echo true || echo false), $([ $N -le 16384 ] && [ $W != box ] && echo true || echo false)>"
     B="python3 bench.py --$W --envs $N --no-cpu-baseline --no-fast-contact-leg"
     P=$O/${T}_ext_${W}_${N}
     rocprofv3 --kernel-trace --stats -d $O/prof_$T/trace -o r -- $B --steps 300 --warmup 5 > /dev/null 2>&1

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}" || exit 1
 T=${1:-rX}
 O=gpurun_out
-K='k_env<9, false, true, 127, 0, false>'
+K='k_env<9, false, true, 127, 0, false, false>'
 mkdir -p $O
 CMD="python3 bench.py --steps 500 --warmup 5 --no-cpu-baseline --no-fast-contact-leg"
 rocprofv3 --kernel-trace --stats -d $O/prof_$T/trace -o r -- $CMD > /dev/null 2>&1

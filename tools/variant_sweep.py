@@ -18,7 +18,7 @@ SETTLE = int(os.environ.get("SETTLE", "400"))
 SOLVER = [int(x) for x in os.environ.get("SOLVER", "8,1").split(",")]      # SOLVER=16,1 / SOLVER=8,2: solver_iterations, solver_inner
 for asym in ([bool(int(os.environ["ASYM"]))] if os.environ.get("ASYM") else (True, False)):
     for n in sizes:
-        for variant in ("narrow", "wide"):
+        for variant in ("narrow", "wide", "wide_helpers"):
             kw = bench.workload_kwargs(asym)
             kw.update(solver_iterations=SOLVER[0], solver_inner=SOLVER[1])
             if os.environ.get("FF_MIDDLE"):                   # FF_MIDDLE=0: the fast contact set of API <= 7 (TfModel.ff_middle_pairs = 0; default model: 1)
@@ -41,5 +41,5 @@ for asym in ([bool(int(os.environ["ASYM"]))] if os.environ.get("ASYM") else (Tru
                 ms, cnt = eng.kernel_time_ms()
                 best = min(best, ms / cnt * 1e3)
             chk = float(eng.state.double().abs().sum())
-            print(f"N={n:6d} asym={int(asym)} {variant:6s}: k_env {best:7.2f} us   {n / best:8.1f} env-steps/us   state checksum {chk:.9e}", flush=True)
+            print(f"N={n:6d} asym={int(asym)} {variant:12s}: k_env {best:7.2f} us   {n / best:8.1f} env-steps/us   state checksum {chk:.9e}", flush=True)
             eng.close()
