@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(HELP ? NT_HELP : NT, HELP ? 1 : (WIDE ? 2 : 4)
 #elif defined(TF_ONLY_CUBE)
     cube_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
 #else
-    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, EXT, WIDE>(P, sa, action, lds, cx);
+    if (cx.role == 3) cube_role<A, IS_RESET, ASYM, MODE, EXT, WIDE, HELP>(P, sa, action, lds, cx);
     else if (HELP && cx.role > 3) helper_role<ASYM, MODE, EXT>(P, sa, lds, cx);
     else finger_role<A, IS_RESET, ASYM, MODE, EXT, WIDE, HELP>(P, sa, action, lds, cx);
 #endif

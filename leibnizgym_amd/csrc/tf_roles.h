@@ -70,10 +70,11 @@ DEV constexpr int ffm_mbox(int fd, int k) {                  // k = 3 x message 
          : fd == 1 ? (k == 0 ? 148 : (k == 1 ? 59 : 153 + k))    //   finger 1: 148 (L_INIT + 1), 59 (tail of record 1), 155 .. 158
                    : 83 + k;                                 //   finger 2: 83 .. 88 (tail of record 2)
 }
-// The helper-wavefront instantiation of the 256-register cube kernels (HELP: workgroups of seven wavefronts, one workgroup per CU, populations of at most
+// The helper-wavefront instantiation of the 256-register cube kernels (HELP: workgroups of eight wavefronts, one workgroup per CU, populations of at most
 // 16384 envs): wavefronts 4..6 build the middle-distal rows of finger 0..2's middle link between S1 and S1b (helper_role) and post BOTH shares - the
 // distal finger's through ffm_mbox as above, the owning finger's through ffm_own_mbox; finger f hands them its restitution factor (L_HELP_DR + f).
-#define NT_HELP 448
+// Wavefront 7 runs the distal finger-finger pass in the cube role's place, which builds its boundary corners meanwhile.
+#define NT_HELP 512
 #define L_HELP_OWN 159                  //  18: velocity change of finger fm's own side, 3 x (o - 1) + j at 6 fm
 #define L_HELP_DR 177                   //   3: domain-randomisation value 5 (restitution) of the substep, published by finger f with its free motion
 #define LDS_SLOTS_HELP 180
@@ -1377,7 +1378,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 }
 
 // =====================================================================================================================
-// HELPER ROLE (HELP instantiation: wavefronts 4..6 of a seven-wavefront workgroup)
+// HELPER ROLE (HELP instantiation: wavefronts 4..7 of an eight-wavefront workgroup)
 // =====================================================================================================================
 // Up to 16384 envs a 256-register workgroup has a CU to itself and one wavefront on each SIMD: the second wavefront slot of a SIMD is empty, and the six
 // middle-distal finger-finger rows - independent of everything else between S1 and S1b, functions of what the fingers published before S1 - sat on the
@@ -1399,10 +1400,14 @@ DEV void helper_role(const DevParams& P, const StepArgs& sa, float* lds, const C
         const TfLinkShape& sh = m.shape2;
         const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
         const float inv_j = f_rcp(FMA(jy, jy, jz * jz));
-        const Yaw ym = {m.base_yaw_cos[fm], m.base_yaw_sin[fm], 0.0f, 0.0f, m.base_height};
+        const int fmi = fm < 3 ? fm : 0;
+        const Yaw ym = {m.base_yaw_cos[fmi], m.base_yaw_sin[fmi], 0.0f, 0.0f, m.base_height};
         for (int s = 0; s < nsub; ++s) {
             BAR();                                              // S1
-            if (m.ff_middle_pairs != 0) {
+            if (fm == 3) {                                      // wavefront 7: the distal pass (cube_role runs the same lines when there are no helpers)
+                const float rest_ff = m.restitution_ff * LD(L_HELP_DR);
+#include "tf_ff_distal.inc"
+            } else if (m.ff_middle_pairs != 0) {
                 const float rest_ff = m.restitution_ff * LD(L_HELP_DR + fm);
                 FingerPubRegs pm;
                 read_pub(lds, lane, fm, pm);
@@ -1614,7 +1619,7 @@ DEV void wall_arms(bool box, const float* lds, int lane, const float r[3], const
     }
 }
 
-template <int A, bool IS_RESET, bool ASYM, int MODE, int X, bool WIDE>
+template <int A, bool IS_RESET, bool ASYM, int MODE, int X, bool WIDE, bool HELP = false>
 DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
     constexpr bool EXT = X != 0;
     constexpr bool BOXK = X == 2;
@@ -1855,103 +1860,8 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             // keeps their impulses between substeps (slots 2 and 3, practically never live, go through LDS as in the 128-register build)
             constexpr bool WREG = WIDE && !BOXK;
             float w_r[6], w_n[4], w_D[6], w_bias[2], w_lam[6], w_a[6], w_b[6];
-            {   // cube vs boundary wall: the four corners of the face that points outward most; rows go to LDS
-                const float cx_ = EXT ? cp[0] - soff[0] : cp[0], cy_ = EXT ? cp[1] - soff[1] : cp[1];      // relative to the stage centre
-                float rc2 = FMA(cx_, cx_, cy_ * cy_);
-                float irc = f_rsqrt(f_max(rc2, 1e-24f));
-                float rho_c = rc2 * irc;
-                bool any = rho_c > 1e-6f;
-                float dx = 0.0f, dy = 0.0f;
-                if (any) { dx = cx_ * irc; dy = cy_ * irc; }
-                float pr[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) pr[j] = FMA(R[j], dx, R[3 + j] * dy);
-                int k = 0;
-                float out[3] = {f_abs(pr[0]), f_abs(pr[1]), f_abs(pr[2])};
-                if (__builtin_expect(box, 0)) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) out[j] = out[j] * hc[j];
-                }
-                float best = out[0];
-                if (out[1] > best) { best = out[1]; k = 1; }
-                if (out[2] > best) { best = out[2]; k = 2; }
-                float pk = (k == 0) ? pr[0] : ((k == 1) ? pr[1] : pr[2]);
-                float sk = (pk < 0.0f) ? -1.0f : 1.0f;
-                // Slot order of the four corners: the LOWER pair of the face first (slots 0, 1), the upper pair behind it.  A cube that lies at
-                // the boundary touches it with its lower pair, so the lanes of a wavefront agree on which slots are live and the sweeps run two
-                // corner blocks instead of up to four (the step ends with its slowest workgroup: DESIGN.md section 4).  With a < b the two axes of
-                // the face, the "heavy" one is the axis whose corner offset has the larger vertical component; the pair is chosen by its sign,
-                // inside the lower pair the corner nearer to the boundary comes first (a cube usually touches the concave wall with one corner: it
-                // then sits in slot 0 in every lane), decided anew in every substep - the warm-start rows follow their corner when the order of
-                // the pair changes; the upper pair is ordered by the sign along the other axis.  The feature the warm start is keyed by is
-                // face + 8 x pair, stored with the order: + 32 x order.
-                const int a_ = (k == 0) ? 1 : 0, b_ = (k == 2) ? 1 : 2;
-                const float wa_ = hc[a_] * ((a_ == 0) ? R[6] : R[7]), wb_ = hc[b_] * ((b_ == 1) ? R[7] : R[8]);
-                const bool heavy_b = f_abs(wb_) > f_abs(wa_);
-                const int lowh = ((heavy_b ? wb_ : wa_) < 0.0f) ? 1 : 0;      // sign bit of the heavy axis that points down
-                const float face_pair = (float)(2 * k + 1 + ((sk > 0.0f) ? 1 : 0) + 8 * ((heavy_b ? 2 : 0) + lowh));
-                int order, swap01;
-                float keep, lam_old[6];
-                {
-                    const float prev_o = (cw_face >= 32.0f) ? 1.0f : 0.0f;
-                    float gl[2];
-#pragma unroll
-                    for (int lb = 0; lb < 2; ++lb) {             // horizontal gap of the two corners of the lower pair
-                        float rr[3];
-                        cube_corner(R, hc, k, sk, heavy_b ? (lb | (lowh << 1)) : (lowh | (lb << 1)), rr);
-                        const float qx = cx_ + rr[0], qy = cy_ + rr[1];
-                        const float q2 = FMA(qx, qx, qy * qy);
-                        gl[lb] = wall_radius_at(P, cp[2] + rr[2]) - q2 * f_rsqrt(f_max(q2, 1e-24f));
-                    }
-                    order = (gl[1] < gl[0]) ? 1 : 0;
-                    swap01 = order ^ (int)prev_o;
-                    keep = (FMA(-32.0f, prev_o, cw_face) == face_pair) ? ws : 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) lam_old[j] = LD(L_WALL + 12 * (j / 3) + 9 + (j % 3));      // slots 0 and 1 before they are rewritten
-                }
-                const float face = FMA(32.0f, (float)order, face_pair);
-                wall_lane = false;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int wb = L_WALL + 12 * c;
-                    float r[3], n[2] = {0.0f, 0.0f}, Dinv[3] = {0.0f, 0.0f, 0.0f}, bias = 0.0f, lam[3] = {0.0f, 0.0f, 0.0f};
-                    const int hbit = (c >> 1) ^ lowh, lbit = (c < 2) ? ((c & 1) ^ order) : (c & 1);
-                    cube_corner(R, hc, k, sk, heavy_b ? (lbit | (hbit << 1)) : (hbit | (lbit << 1)), r);
-                    float px = cx_ + r[0], py = cy_ + r[1], pz = cp[2] + r[2];
-                    float rho2 = FMA(px, px, py * py);
-                    float inv = f_rsqrt(f_max(rho2, 1e-24f));
-                    float rho = rho2 * inv;
-                    float gap = wall_radius_at(P, pz) - rho;
-                    if (__builtin_expect(any && gap < m.contact_margin && rho > 1e-6f, 0)) {
-                        float nn[2] = {-px * inv, -py * inv};
-                        float a[3], b[3], c3[3];
-                        wall_arms(box, lds, lane, r, nn, a, b, c3);
-                        const float vn0 = wn_vrel(nn, a, v, w);
-                        if (contact_live(m, gap, vn0, h)) {
-                            n[0] = nn[0]; n[1] = nn[1];
-                            Dinv[0] = f_rcp2(FMA(dot3(a, a), inv_I, inv_m));
-                            Dinv[1] = f_rcp2(FMA(dot3(b, b), inv_I, inv_m));
-                            Dinv[2] = box ? f_rcp2(FMA(dot3(c3, c3), inv_I, inv_m)) : f_rcp2(FMA(FMA(r[0], r[0], r[1] * r[1]), inv_I, inv_m));
-                            bias = contact_bias(m, gap, vn0, inv_h, 0.0f);
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) lam[d] = ((c < 2) ? (((c ^ swap01) == 0) ? lam_old[d] : lam_old[3 + d]) : LD(wb + 9 + d)) * keep;
-                        }
-                    }
-                    if (WREG && c < 2) {
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) { w_r[3 * c + j] = r[j]; w_D[3 * c + j] = Dinv[j]; w_lam[3 * c + j] = lam[j]; LD(wb + 9 + j) = lam[j]; }
-                        w_n[2 * c] = n[0]; w_n[2 * c + 1] = n[1]; w_bias[c] = bias;
-                        wall_arm_n(r, n, &w_a[3 * c]);
-                        wall_arm_t(r, n, &w_b[3 * c]);
-                    } else {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { LD(wb + j) = r[j]; LD(wb + 5 + j) = Dinv[j]; LD(wb + 9 + j) = lam[j]; }
-                    LD(wb + 3) = n[0]; LD(wb + 4) = n[1]; LD(wb + 8) = bias;
-                    }
-                    wall_lane = wall_lane || (Dinv[0] > 0.0f);
-                    slot_any[c] = __builtin_amdgcn_ballot_w64(Dinv[0] > 0.0f) != 0ull;
-                }
-                cw_face = wall_lane ? face : 0.0f;              // 0: no corner touches the boundary (the rows carry nothing)
+            if constexpr (!HELP) {
+#include "tf_wall_corners.inc"
             }
             // wave-uniform flags per corner slot: the sweeps enter the block of a slot only when a lane of this wavefront has a live corner
             // there - no LDS round trip for the others (with the lower pair in slots 0 and 1, slots 2 and 3 are practically never live)
@@ -1961,60 +1871,10 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             // ---- FF: finger-finger contacts (distal capsules), frictionless, resolved before the sweeps on the free
             // velocities: the pairs (0,1), (1,2), (2,0) in turn, one normal row each.  The velocities live in LDS (L_VQFF)
             // while the pairs are visited. ----
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) LD(L_VQFF + 3 * f + j) = LD(L_REC(f) + P_VQ + j);
-            }
-#pragma unroll 1                                                // (unrolling the three pairs in the 256-register build changes nothing: measured)
-            for (int p = 0; p < 3; ++p) {
-                const int fa = p, fb = (p == 2) ? 0 : p + 1;
-                float Pa[3], Pb[3];
-                {
-                    float Aa[3], Ba[3], Ab[3], Bb[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { Aa[j] = LD(L_REC(fa) + P_AW + j); Ba[j] = LD(L_REC(fa) + P_BW + j); Ab[j] = LD(L_REC(fb) + P_AW + j); Bb[j] = LD(L_REC(fb) + P_BW + j); }
-                    seg_seg(Aa, Ba, Ab, Bb, Pa, Pb);
-                }
-                float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
-                float dist2 = dot3(dv, dv);
-                float inv = f_rsqrt(f_max(dist2, 1e-12f));
-                float dist = dist2 * inv;
-                float gap = dist - 2.0f * m.cap_radius;
-                if ((dist2 > 1e-12f) && (gap < m.contact_margin)) {
-                    float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};       // from finger b to finger a
-                    float Ja[3], Wa[3], Jb[3], Wb[3], va[3], vb[3];
-#pragma unroll
-                    for (int side = 0; side < 2; ++side) {
-                        const int ff_ = side ? fb : fa;
-                        const Yaw yy = {m.base_yaw_cos[ff_], m.base_yaw_sin[ff_], 0.0f, 0.0f, m.base_height};
-                        FingerPubRegs pp;
-                        read_pub(lds, lane, ff_, pp);
-                        float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) C[j] = side ? FMA(m.cap_radius, n[j], Pb[j]) : FMA(-m.cap_radius, n[j], Pa[j]);
-                        world_to_base(yy, C, Cb_);
-                        levers(pp.k, Cb_, L1, L2, L3);
-                        dir_world_to_base(yy, n, nb);
-                        float* J = side ? Jb : Ja;
-                        float* W = side ? Wb : Wa;
-                        float* vv = side ? vb : va;
-                        J[0] = dot3(L1, nb); J[1] = dot3(L2, nb); J[2] = dot3(L3, nb);
-                        sym3_mul(pp.k.Minv, J, W);
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) vv[j] = LD(L_VQFF + 3 * ff_ + j);
-                    }
-                    float vn0 = dot3(Ja, va) - dot3(Jb, vb);
-                    if (contact_live(m, gap, vn0, h)) {
-                        float bias = contact_bias(m, gap, vn0, inv_h, rest_ff);
-                        float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja, Wa) + dot3(Jb, Wb)), 0.0f);
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            LD(L_VQFF + 3 * fa + j) = FMA(Wa[j], lam, va[j]);
-                            LD(L_VQFF + 3 * fb + j) = FMA(-Wb[j], lam, vb[j]);
-                        }
-                    }
-                }
+            if constexpr (HELP) {      // the distal pass runs on helper wavefront 7 (helper_role); this role builds the boundary corners in its place
+#include "tf_wall_corners.inc"
+            } else {
+#include "tf_ff_distal.inc"
             }
             // ---- FF, second part (TfModel.ff_middle_pairs, on by default since API 8; wave-uniform): the middle link of finger fm (shape2) against the distal
             // capsule of each other finger - six ordered pairs on the same velocities.  The middle frame is rebuilt from what finger fm publishes:
