@@ -1404,9 +1404,75 @@ DEV void helper_role(const DevParams& P, const StepArgs& sa, float* lds, const C
         const Yaw ym = {m.base_yaw_cos[fmi], m.base_yaw_sin[fmi], 0.0f, 0.0f, m.base_height};
         for (int s = 0; s < nsub; ++s) {
             BAR();                                              // S1
-            if (fm == 3) {                                      // wavefront 7: the distal pass (cube_role runs the same lines when there are no helpers)
+            if (fm == 3) {
+                // wavefront 7: the distal pass - the arithmetic of tf_ff_distal.inc (which the cube role runs when there are no helpers), laid out for a
+                // wavefront that has nothing else to do: what the fingers published is read once, the geometry of the three pairs (closest points,
+                // Jacobians, M^-1 J^T - independent of each other) is built side by side, and only the three velocity updates, each of which sees the
+                // one before it, run in turn, on registers; L_VQFF is written once at the end.  Same operations on the same operands: the same bits.
                 const float rest_ff = m.restitution_ff * LD(L_HELP_DR);
-#include "tf_ff_distal.inc"
+                float Aw_[3][3], Bw_[3][3], vel[3][3];
+                FingerPubRegs pp[3];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { Aw_[f][j] = LD(L_REC(f) + P_AW + j); Bw_[f][j] = LD(L_REC(f) + P_BW + j); vel[f][j] = LD(L_REC(f) + P_VQ + j); }
+                    read_pub(lds, lane, f, pp[f]);
+                }
+                float gapp[3], Ja[3][3], Wa[3][3], Jb[3][3], Wb[3][3];
+                bool nearp[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int fa = p, fb = (p == 2) ? 0 : p + 1;
+                    float Pa[3], Pb[3];
+                    seg_seg(Aw_[fa], Bw_[fa], Aw_[fb], Bw_[fb], Pa, Pb);
+                    float dv[3] = {Pa[0] - Pb[0], Pa[1] - Pb[1], Pa[2] - Pb[2]};
+                    float dist2 = dot3(dv, dv);
+                    float inv = f_rsqrt(f_max(dist2, 1e-12f));
+                    float dist = dist2 * inv;
+                    gapp[p] = dist - 2.0f * m.cap_radius;
+                    nearp[p] = (dist2 > 1e-12f) && (gapp[p] < m.contact_margin);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { Ja[p][j] = 0.0f; Wa[p][j] = 0.0f; Jb[p][j] = 0.0f; Wb[p][j] = 0.0f; }
+                    if (__builtin_amdgcn_ballot_w64(nearp[p]) != 0ull) {
+                        float n[3] = {dv[0] * inv, dv[1] * inv, dv[2] * inv};       // from finger b to finger a
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            const int ff_ = side ? fb : fa;
+                            const Yaw yy = {m.base_yaw_cos[ff_], m.base_yaw_sin[ff_], 0.0f, 0.0f, m.base_height};
+                            float C[3], Cb_[3], L1[3], L2[3], L3[3], nb[3];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) C[j] = side ? FMA(m.cap_radius, n[j], Pb[j]) : FMA(-m.cap_radius, n[j], Pa[j]);
+                            world_to_base(yy, C, Cb_);
+                            levers(pp[ff_].k, Cb_, L1, L2, L3);
+                            dir_world_to_base(yy, n, nb);
+                            float* J = side ? Jb[p] : Ja[p];
+                            float* W = side ? Wb[p] : Wa[p];
+                            J[0] = dot3(L1, nb); J[1] = dot3(L2, nb); J[2] = dot3(L3, nb);
+                            sym3_mul(pp[ff_].k.Minv, J, W);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int fa = p, fb = (p == 2) ? 0 : p + 1;
+                    if (nearp[p]) {
+                        const float vn0 = dot3(Ja[p], vel[fa]) - dot3(Jb[p], vel[fb]);
+                        if (contact_live(m, gapp[p], vn0, h)) {
+                            const float bias = contact_bias(m, gapp[p], vn0, inv_h, rest_ff);
+                            const float lam = f_max(-(vn0 + bias) * f_rcp2(dot3(Ja[p], Wa[p]) + dot3(Jb[p], Wb[p])), 0.0f);
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                vel[fa][j] = FMA(Wa[p][j], lam, vel[fa][j]);
+                                vel[fb][j] = FMA(-Wb[p][j], lam, vel[fb][j]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) LD(L_VQFF + 3 * f + j) = vel[f][j];
+                }
             } else if (m.ff_middle_pairs != 0) {
                 const float rest_ff = m.restitution_ff * LD(L_HELP_DR + fm);
                 FingerPubRegs pm;
