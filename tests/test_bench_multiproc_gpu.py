@@ -38,7 +38,7 @@ def test_single_process_line_carries_the_contract(hip):
               "roofline", "value_resident_actions", "value_with_torch_action_generation", "steady_state_prelude"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None
-    assert d["strong_scaling"]["value"] == d["value"] and d["roofline"]["kernel_variant"] == "wide"      # one rank: no second leg; 8192 envs: the 256-register kernel
+    assert d["strong_scaling"]["value"] == d["value"] and d["roofline"]["kernel_variant"] == "wide_helpers"      # one rank: no second leg; 8192 envs: the 256-register kernel with helper wavefronts
     assert abs(d["value"] - 8192 * 40 / (d["ms_per_step"] * 1e-3 * 40)) < 1e-6 * d["value"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_us", "kernel_launches_timed"):
@@ -59,9 +59,9 @@ def test_two_ranks_print_one_aggregate_line(hip):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 100 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert d["config"]["envs_per_gpu"] == 8192 and d["config"]["global_envs"] == 16384
-    # the strong-scaling leg beside it: --envs (8192) in total, 4096 per rank, the 256-register instantiation of the step kernel
+    # the strong-scaling leg beside it: --envs (8192) in total, 4096 per rank, the 256-register instantiation of the step kernel (with helper wavefronts)
     s = d["strong_scaling"]
-    assert s["global_envs"] == 8192 and s["envs_per_gpu"] == 4096 and s["kernel_variant"] == "wide" and s["kernel"].endswith("true>")
+    assert s["global_envs"] == 8192 and s["envs_per_gpu"] == 4096 and s["kernel_variant"] == "wide_helpers" and s["kernel"].endswith("true, true>")
     assert abs(s["value"] - 8192 * 100 / (s["ms_per_step"] * 1e-3 * 100)) < 1e-6 * s["value"]
     assert d["value_strong_65536_total"] is None               # only the headline total carries that key
     assert abs(d["value"] - 16384 * 100 / (d["ms_per_step"] * 1e-3 * 100)) < 1e-6 * d["value"]     # whole-job aggregate
@@ -81,7 +81,7 @@ def test_eight_ranks_on_one_device(hip):
     assert d["config"]["envs_per_gpu"] == 2048 and d["config"]["global_envs"] == 16384
     # the strong-scaling reading of the metric at the driver's 8-GPU command: the headline's 65536 envs partitioned into 8 x 8192
     s = d["strong_scaling"]
-    assert s["global_envs"] == 65536 and s["envs_per_gpu"] == 8192 and s["kernel_variant"] == "wide"
+    assert s["global_envs"] == 65536 and s["envs_per_gpu"] == 8192 and s["kernel_variant"] == "wide_helpers"
     assert d["value_strong_65536_total"] == s["value"] and abs(s["value"] - 65536 * 20 / (s["ms_per_step"] * 1e-3 * 20)) < 1e-6 * s["value"]
     assert abs(d["value"] - 16384 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d
