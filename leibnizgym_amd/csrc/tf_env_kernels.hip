@@ -2,7 +2,7 @@
 //
 // Compiled eight times (Makefile: -DTF_EXT=0|1|2 -DTF_WIDE=0|1, and -DTF_EXT=0|1 -DTF_WIDE=2): EXT 0 the headline kernels, 1 the extended domain
 // randomisation, 2 the general box object; WIDE 0 the 128-register instantiation (four workgroups per CU), 1 the 256-register one for populations of at
-// most 32768 envs, 2 the 256-register one with three helper wavefronts per workgroup (one workgroup per CU: at most 16384 envs; the launches that
+// most 32768 envs, 2 the 256-register one with four helper wavefronts per workgroup (one workgroup per CU: at most 16384 envs; the launches that
 // simulate only - the others are served by the WIDE = 1 unit).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,8 +18,8 @@
 // WIDE = false: 128 registers, 4 workgroups per CU (4 wavefronts per SIMD) - populations that fill the chip; WIDE = true: 256 registers, no spills,
 // nothing parked in LDS between substeps, the cube role's contact-space records in registers - populations of at most 32768 envs, which never put
 // more than two workgroups on a CU, so the occupancy the narrow build buys is not used (tf_create picks).  Same arithmetic.
-// HELP: the WIDE kernel in workgroups of seven wavefronts - 0..2 fingers, 3 cube, 4..6 helpers (tf_roles.h: helper_role) - for populations that leave a CU to
-// one workgroup: the second wavefront slot of three SIMDs, empty otherwise, carries the middle-distal finger-finger rows.  Same arithmetic again.
+// HELP: the WIDE kernel in workgroups of eight wavefronts - 0..2 fingers, 3 cube, 4..7 helpers (tf_roles.h: helper_role) - for populations that leave a CU to
+// one workgroup: the second wavefront slot of every SIMD, empty otherwise, carries the finger-finger rows (middle-distal: 4..6, distal pass: 7).  Same arithmetic again.
 template <int A, bool IS_RESET, bool ASYM, int MODE, int EXT, bool WIDE, bool HELP = false>
 __global__ void __launch_bounds__(HELP ? NT_HELP : NT, HELP ? 1 : (WIDE ? 2 : 4)) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
     __shared__ __attribute__((aligned(16))) float lds[(HELP ? LDS_SLOTS_HELP : ((EXT == 2) ? LDS_SLOTS_BOX : LDS_SLOTS)) * WAVE];

@@ -449,11 +449,12 @@ int tf_set_gravity(tf_handle h, const float g[3]) {
     return TF_OK;
 }
 static int ext_kind(const TfConfig& c);
-// helper wavefronts (the WIDE = 2 units): asked for, or picked for a population that leaves every CU to one workgroup when the model holds the rows they build
+// helper wavefronts (the WIDE = 2 units): asked for, or picked for a population that leaves every CU to one workgroup (with the fast contact set too: the
+// distal pass on wavefront 7 alone is worth 1.4 us at 8192 envs)
 static bool use_helpers(const TfHandle_* h) {
     if (!h->wide || ext_kind(h->cfg) == 2) return false;
     if (h->variant == TF_KERNEL_WIDE_HELPERS) return true;
-    return h->variant == TF_KERNEL_AUTO && h->cfg.num_envs <= TF_HELPERS_MAX_ENVS && h->cfg.model.ff_middle_pairs != 0;
+    return h->variant == TF_KERNEL_AUTO && h->cfg.num_envs <= TF_HELPERS_MAX_ENVS;
 }
 int tf_set_kernel_variant(tf_handle h, int32_t variant) {
     if (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE_HELPERS) return TF_ERR_INVALID_ARG;

@@ -278,8 +278,8 @@ class TrifingerEngine:
     @property
     def kernel_variant(self):
         """which instantiation of the fused step the launches use: 'narrow' (128 registers, four workgroups per CU), 'wide' (256
-        registers, picked for num_envs <= 32768) or 'wide_helpers' (the same in workgroups of seven wavefronts, picked for num_envs <= 16384 when
-        the model holds the middle-distal finger-finger rows; cube kernels only); same results bit for bit"""
+        registers, picked for num_envs <= 32768) or 'wide_helpers' (the same in workgroups of eight wavefronts - four helpers carry the finger-finger
+        rows -, picked for num_envs <= 16384; cube kernels only); same results bit for bit"""
         v = int(self.lib.tf_kernel_variant(self._handle))
         check(self.lib, min(v, 0), "tf_kernel_variant")
         return {1: "narrow", 2: "wide", 3: "wide_helpers"}[v]

@@ -31,7 +31,7 @@ def test_both_instantiations_get_the_occupancy_they_are_built_for(hip):
         assert e.kernel_occupancy == 4, (extra.keys(), e.kernel_occupancy)
         e.kernel_variant = "wide"
         assert e.kernel_occupancy == 2, (extra.keys(), e.kernel_occupancy)
-        if "model" not in extra:                     # seven wavefronts of 256 registers: one workgroup per CU (the cube kernels; the box object has none)
+        if "model" not in extra:                     # eight wavefronts of 256 registers: one workgroup per CU (the cube kernels; the box object has none)
             e.kernel_variant = "wide_helpers"
             assert e.kernel_variant == "wide_helpers" and e.kernel_occupancy == 1, (extra.keys(), e.kernel_occupancy)
         else:
@@ -56,7 +56,8 @@ def test_kernel_variant_follows_the_population(hip):
 
 
 @pytest.mark.parametrize("cfg_name,fused_actions,variant", [("d4_torque_asym", False, "narrow"), ("d4_domain_randomization", False, "narrow"), ("d4_torque_asym", True, "narrow"),
-                                                            ("d4_torque_asym", False, "wide"), ("d4_domain_randomization", True, "wide")])
+                                                            ("d4_torque_asym", False, "wide"), ("d4_domain_randomization", True, "wide"),
+                                                            ("d4_torque_asym", True, "wide_helpers"), ("d4_domain_randomization_extended", False, "wide_helpers")])
 def test_long_episodes_reach_the_boundary_and_stay_bit_exact(hip, oracle, cfg_name, fused_actions, variant):
     """The 40-step episodes above never let a cube reach the boundary of the arena.  With 750-step episodes under random actions the
     rollout arrives at the steady state of the bench workload - a third of the envs with a live boundary contact - which is where the slot
