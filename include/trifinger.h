@@ -361,11 +361,10 @@ int tf_set_frame_count(tf_handle h, int64_t frames);
  * (TF_KERNEL_NARROW / TF_KERNEL_WIDE / TF_KERNEL_WIDE_HELPERS). */
 enum { TF_KERNEL_AUTO = 0, TF_KERNEL_NARROW = 1, TF_KERNEL_WIDE = 2, TF_KERNEL_WIDE_HELPERS = 3 };
 #define TF_WIDE_MAX_ENVS 32768
-/* TF_KERNEL_WIDE_HELPERS (cube kernels; API 8, additive): the 256-register instantiation in workgroups of EIGHT wavefronts - three helper wavefronts build
+/* TF_KERNEL_WIDE_HELPERS (API 8, additive): the 256-register instantiation in workgroups of EIGHT wavefronts - three helper wavefronts build
  * the middle-distal finger-finger rows (TfModel.ff_middle_pairs) beside the finger wavefronts' contact generation, in the second wavefront slot a CU
  * that holds one workgroup leaves empty -, a fourth runs the distal finger-finger pass in the cube wavefront's place.  Same arithmetic, identical results.
- * TF_KERNEL_AUTO picks it for num_envs <= TF_HELPERS_MAX_ENVS (cube kernels); forcing it on a handle with the box object is TF_ERR_INVALID_ARG (the box
- * kernels have no such instantiation). */
+ * TF_KERNEL_AUTO picks it for num_envs <= TF_HELPERS_MAX_ENVS. */
 #define TF_HELPERS_MAX_ENVS 16384
 int tf_set_kernel_variant(tf_handle h, int32_t variant);
 int tf_kernel_variant(tf_handle h);

@@ -1,6 +1,6 @@
 // tf_env_kernels.hip - the fused TriFinger step kernel (roles: tf_roles.h) and its launcher for ONE (EXT, WIDE) pair.
 //
-// Compiled eight times (Makefile: -DTF_EXT=0|1|2 -DTF_WIDE=0|1, and -DTF_EXT=0|1 -DTF_WIDE=2): EXT 0 the headline kernels, 1 the extended domain
+// Compiled nine times (Makefile: -DTF_EXT=0|1|2 -DTF_WIDE=0|1, and -DTF_EXT=0|1|2 -DTF_WIDE=2): EXT 0 the headline kernels, 1 the extended domain
 // randomisation, 2 the general box object; WIDE 0 the 128-register instantiation (four workgroups per CU), 1 the 256-register one for populations of at
 // most 32768 envs, 2 the 256-register one with four helper wavefronts per workgroup (one workgroup per CU: at most 16384 envs; the launches that
 // simulate only - the others are served by the WIDE = 1 unit).
@@ -22,7 +22,7 @@
 // one workgroup: the second wavefront slot of every SIMD, empty otherwise, carries the finger-finger rows (middle-distal: 4..6, distal pass: 7).  Same arithmetic again.
 template <int A, bool IS_RESET, bool ASYM, int MODE, int EXT, bool WIDE, bool HELP = false>
 __global__ void __launch_bounds__(HELP ? NT_HELP : NT, HELP ? 1 : (WIDE ? 2 : 4)) k_env(const DevParams* __restrict__ Pp, const StepArgs sa, const float* __restrict__ action) {
-    __shared__ __attribute__((aligned(16))) float lds[(HELP ? LDS_SLOTS_HELP : ((EXT == 2) ? LDS_SLOTS_BOX : LDS_SLOTS)) * WAVE];
+    __shared__ __attribute__((aligned(16))) float lds[((EXT == 2) ? (WIDE ? LDS_SLOTS_BOX_WIDE : LDS_SLOTS_BOX) : (HELP ? LDS_SLOTS_HELP : LDS_SLOTS)) * WAVE];
     const DevParams& P = *Pp;
     {   // Warm the scalar cache with the parameter block (one dword per 64-byte line) BEFORE the state loads of every workgroup of the
         // launch saturate the L2: the model constants the free motion needs then come out of the constant cache instead of queueing

@@ -61,12 +61,13 @@ enum { M_ACT_IN = 1, M_RESETS = 2, M_TORQUE = 4, M_SIM = 8, M_POST = 16, M_FINIS
 #define L_DR0 32                        //  14: launch prologue only (behind the action tile, before any physics slot is live): the domain-randomisation rows of the
                                         //      env, loaded once by the cube role and handed to the three finger roles through barrier #1
 #define LDS_SLOTS 159                   //   (4 workgroups x 159 x 256 B = 159 KB of the CU's 160 KB)
-// Mailboxes of the middle-distal finger-finger rows built on the finger wavefronts (cube kernels only - the box kernels keep L_POSE_S at 150..155 and
-// leave these rows to the cube role): finger fd receives the velocity change of TWO rows, 2 x 3 floats.  Written between S1 and S1b by the finger that
+// Mailboxes of the middle-distal finger-finger rows built on the finger wavefronts (the 128-register box kernels keep L_POSE_S at 150..155 and leave
+// these rows to the cube role; the 256-register box kernels, which never share a CU with more than one other workgroup, use fresh slots): finger fd receives the velocity change of TWO rows, 2 x 3 floats.  Written between S1 and S1b by the finger that
 // owns the middle link, read by fd right behind S1b - so they must be slots nobody writes between S1b and S3 other than fd itself: fd's own L_INIT
 // slot, the free tail of its own record (the records are rewritten behind S1b, each by its owner), and the free slots 150..158.
-DEV constexpr int ffm_mbox(int fd, int k) {                  // k = 3 x message + component
-    return fd == 0 ? (k == 0 ? 147 : 149 + k)               //   finger 0: 147 (L_INIT + 0), 150 .. 154
+DEV constexpr int ffm_mbox(int fd, int k, bool boxw = false) {   // k = 3 x message + component
+    return boxw ? 180 + 6 * fd + k                           //   256-register box kernels (slots 150..155 hold L_POSE_S there): fresh slots 180 .. 197
+         : fd == 0 ? (k == 0 ? 147 : 149 + k)               //   finger 0: 147 (L_INIT + 0), 150 .. 154
          : fd == 1 ? (k == 0 ? 148 : (k == 1 ? 59 : 153 + k))    //   finger 1: 148 (L_INIT + 1), 59 (tail of record 1), 155 .. 158
                    : 83 + k;                                 //   finger 2: 83 .. 88 (tail of record 2)
 }
@@ -81,6 +82,7 @@ DEV constexpr int ffm_mbox(int fd, int k) {                  // k = 3 x message 
 DEV constexpr int ffm_own_mbox(int fm, int k) { return L_HELP_OWN + 6 * fm + k; }
 #define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
 #define LDS_SLOTS_BOX 159
+#define LDS_SLOTS_BOX_WIDE 198             //   256-register box kernels (at most two workgroups per CU): + helper slots 159..179, mailboxes 180..197
 // post phase (aliases the above)
 #define L_XCH (MAX_STATES)              //  18: fingertip position (3) and previous fingertip position (3) of finger f at 6 f
 #define L_NAN (MAX_STATES + 18)         //   4: non-finite flag of each role
@@ -398,7 +400,7 @@ struct TipContact {            // fingertip sphere against one feature of the ar
 
 template <int A, bool IS_RESET, bool ASYM, int MODE, int X, bool WIDE, bool HELP = false>
 DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __restrict__ action, float* lds, const Ctx& cx) {
-    static_assert(!HELP || (WIDE && X != 2), "helper wavefronts: 256-register cube kernels only");
+    static_assert(!HELP || WIDE, "helper wavefronts: 256-register kernels only");
     constexpr bool EXT = X != 0;      // X: 0 the headline kernels, 1 extended domain randomisation, 2 the same with the general box object
     // WIDE: the 256-register instantiation (2 wavefronts per SIMD) launched for populations that never put more than two workgroups on a
     // CU (num_envs <= 32768): nothing is parked in LDS or re-read from the state rows between substeps.  Same arithmetic, bit for bit.
@@ -785,7 +787,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
             // (65536 envs: 70.4 us there against 73.0 us here - this block costs the finger role registers it has to spill), and so do the box kernels.
             // The 128-register kernels build only the SECOND group here (fd = f + 1: one row per finger wavefront) and leave the first to the cube role:
             // all six on the fingers cost this role registers it has to spill (65536 envs: 73.0 us against 70.0 us with all six on the cube wavefront).
-            const bool ffm_here = !BOXK && m.ff_middle_pairs != 0;     // wave-uniform
+            const bool ffm_here = (!BOXK || WIDE) && m.ff_middle_pairs != 0;     // wave-uniform
             constexpr int FFM_O_FIRST = WIDE ? 2 : 1;                  // this wavefront's groups: o = FFM_O_FIRST .. 1
             if (ffm_here && !HELP) {                                   // (HELP: wavefront 4 + f builds them, helper_role)
                 const TfLinkShape& sh = m.shape2;
@@ -870,9 +872,9 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                     }
                     // fd's mailbox: message 0 is the row of the first group (o = 2), message 1 the row of the second (o = 1)
                     const int msg = 2 - o;
-                    if (fd == 0) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(0, 3 * msg + j)) = dd[j]; }
-                    else if (fd == 1) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(1, 3 * msg + j)) = dd[j]; }
-                    else { for (int j = 0; j < 3; ++j) LD(ffm_mbox(2, 3 * msg + j)) = dd[j]; }
+                    if (fd == 0) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(0, 3 * msg + j, BOXK && WIDE)) = dd[j]; }
+                    else if (fd == 1) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(1, 3 * msg + j, BOXK && WIDE)) = dd[j]; }
+                    else { for (int j = 0; j < 3; ++j) LD(ffm_mbox(2, 3 * msg + j, BOXK && WIDE)) = dd[j]; }
                 }
             }
             STAMP(sb_ + 2);
@@ -893,8 +895,8 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    mail[0][j] = !WIDE ? 0.0f : ((f == 0) ? LD(ffm_mbox(0, j)) : ((f == 1) ? LD(ffm_mbox(1, j)) : LD(ffm_mbox(2, j))));
-                    mail[1][j] = (f == 0) ? LD(ffm_mbox(0, 3 + j)) : ((f == 1) ? LD(ffm_mbox(1, 3 + j)) : LD(ffm_mbox(2, 3 + j)));
+                    mail[0][j] = !WIDE ? 0.0f : ((f == 0) ? LD(ffm_mbox(0, j, BOXK && WIDE)) : ((f == 1) ? LD(ffm_mbox(1, j, BOXK && WIDE)) : LD(ffm_mbox(2, j, BOXK && WIDE))));
+                    mail[1][j] = (f == 0) ? LD(ffm_mbox(0, 3 + j, BOXK && WIDE)) : ((f == 1) ? LD(ffm_mbox(1, 3 + j, BOXK && WIDE)) : LD(ffm_mbox(2, 3 + j, BOXK && WIDE)));
                 }
                 auto take = [&](const float d[3], bool minus) __attribute__((always_inline)) {
 #pragma unroll
@@ -1388,6 +1390,7 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
 // only keeps the workgroup's barriers company - every BAR() of the other roles has its twin here, in the same order under the same conditions.
 template <bool ASYM, int MODE, int X>
 DEV void helper_role(const DevParams& P, const StepArgs& sa, float* lds, const Ctx& cx) {
+    constexpr bool BOXK = X == 2;
     const TfModel& m = P.m;
     const int lane = cx.lane;
     const int fm = cx.role - 4;
@@ -1557,9 +1560,9 @@ DEV void helper_role(const DevParams& P, const StepArgs& sa, float* lds, const C
                     }
                     // fd's mailbox: message 0 is the row of the first group (o = 2), message 1 the row of the second (o = 1); fm's own: by group
                     const int msg = 2 - o;
-                    if (fd == 0) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(0, 3 * msg + j)) = dd[j]; }
-                    else if (fd == 1) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(1, 3 * msg + j)) = dd[j]; }
-                    else { for (int j = 0; j < 3; ++j) LD(ffm_mbox(2, 3 * msg + j)) = dd[j]; }
+                    if (fd == 0) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(0, 3 * msg + j, BOXK)) = dd[j]; }
+                    else if (fd == 1) { for (int j = 0; j < 3; ++j) LD(ffm_mbox(1, 3 * msg + j, BOXK)) = dd[j]; }
+                    else { for (int j = 0; j < 3; ++j) LD(ffm_mbox(2, 3 * msg + j, BOXK)) = dd[j]; }
 #pragma unroll
                     for (int j = 0; j < 3; ++j) LD(ffm_own_mbox(fm, 3 * (o - 1) + j)) = dm[j];
                 }
@@ -1948,7 +1951,7 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
             // (placement per instantiation, same bits: the 256-register cube kernels build all six rows on the finger wavefronts - the block above
             // their S1b; the 128-register cube kernels leave the FIRST group, fd = fm + 2, here and build the second on the finger wavefronts; the box
             // kernels, whose LDS has no room for the mailboxes, visit both groups here)
-            if ((BOXK || !WIDE) && m.ff_middle_pairs != 0) {
+            if (!WIDE && m.ff_middle_pairs != 0) {
                 const TfLinkShape& sh = m.shape2;
                 const float jx = m.j3_origin[0], jy = m.j3_origin[1], jz = m.j3_origin[2];
                 const float inv_j = f_rcp(FMA(jy, jy, jz * jz));

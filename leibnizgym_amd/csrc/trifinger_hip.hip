@@ -452,13 +452,12 @@ static int ext_kind(const TfConfig& c);
 // helper wavefronts (the WIDE = 2 units): asked for, or picked for a population that leaves every CU to one workgroup (with the fast contact set too: the
 // distal pass on wavefront 7 alone is worth 1.4 us at 8192 envs)
 static bool use_helpers(const TfHandle_* h) {
-    if (!h->wide || ext_kind(h->cfg) == 2) return false;
+    if (!h->wide) return false;
     if (h->variant == TF_KERNEL_WIDE_HELPERS) return true;
     return h->variant == TF_KERNEL_AUTO && h->cfg.num_envs <= TF_HELPERS_MAX_ENVS;
 }
 int tf_set_kernel_variant(tf_handle h, int32_t variant) {
     if (!h || variant < TF_KERNEL_AUTO || variant > TF_KERNEL_WIDE_HELPERS) return TF_ERR_INVALID_ARG;
-    if (variant == TF_KERNEL_WIDE_HELPERS && ext_kind(h->cfg) == 2) return TF_ERR_INVALID_ARG;      // the box kernels have no such instantiation
     h->variant = variant;
     h->wide = (variant == TF_KERNEL_AUTO) ? (h->cfg.num_envs <= TF_WIDE_MAX_ENVS) : (variant != TF_KERNEL_NARROW);
     return TF_OK;
@@ -473,8 +472,8 @@ int tf_kernel_occupancy(tf_handle h) {
     return h->wide ? tf_occupancy_env_0_1(h->action_dim, asym) : tf_occupancy_env_0_0(h->action_dim, asym);
 #else
     const int k = ext_kind(h->cfg);
+    if (help) return k == 2 ? tf_occupancy_env_2_2(h->action_dim, asym) : (k == 1 ? tf_occupancy_env_1_2(h->action_dim, asym) : tf_occupancy_env_0_2(h->action_dim, asym));
     if (k == 2) return h->wide ? tf_occupancy_env_2_1(h->action_dim, asym) : tf_occupancy_env_2_0(h->action_dim, asym);
-    if (help) return k == 1 ? tf_occupancy_env_1_2(h->action_dim, asym) : tf_occupancy_env_0_2(h->action_dim, asym);
     if (k == 1) return h->wide ? tf_occupancy_env_1_1(h->action_dim, asym) : tf_occupancy_env_1_0(h->action_dim, asym);
     return h->wide ? tf_occupancy_env_0_1(h->action_dim, asym) : tf_occupancy_env_0_0(h->action_dim, asym);
 #endif
@@ -550,8 +549,8 @@ static void launch_env(TfHandle_* h, int lm, const float* action, hipStream_t s)
     if (help) tf_launch_env_0_2(lm, a); else if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a);
 #else
     const int k = ext_kind(h->cfg);
-    if (k == 2) { if (h->wide) tf_launch_env_2_1(lm, a); else tf_launch_env_2_0(lm, a); }
-    else if (help) { if (k == 1) tf_launch_env_1_2(lm, a); else tf_launch_env_0_2(lm, a); }
+    if (help) { if (k == 2) tf_launch_env_2_2(lm, a); else if (k == 1) tf_launch_env_1_2(lm, a); else tf_launch_env_0_2(lm, a); }
+    else if (k == 2) { if (h->wide) tf_launch_env_2_1(lm, a); else tf_launch_env_2_0(lm, a); }
     else if (k == 1) { if (h->wide) tf_launch_env_1_1(lm, a); else tf_launch_env_1_0(lm, a); }
     else { if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a); }
 #endif

@@ -279,7 +279,7 @@ class TrifingerEngine:
     def kernel_variant(self):
         """which instantiation of the fused step the launches use: 'narrow' (128 registers, four workgroups per CU), 'wide' (256
         registers, picked for num_envs <= 32768) or 'wide_helpers' (the same in workgroups of eight wavefronts - four helpers carry the finger-finger
-        rows -, picked for num_envs <= 16384; cube kernels only); same results bit for bit"""
+        rows -, picked for num_envs <= 16384); same results bit for bit"""
         v = int(self.lib.tf_kernel_variant(self._handle))
         check(self.lib, min(v, 0), "tf_kernel_variant")
         return {1: "narrow", 2: "wide", 3: "wide_helpers"}[v]

@@ -92,7 +92,6 @@ def actions_for(step, n, a, seed):
 
 VARIANTS = ("narrow", "wide", "wide_helpers")     # the instantiations of the fused step (include/trifinger.h: tf_set_kernel_variant); at the sizes of these
                                                   # tests tf_create would always pick one of the 256-register ones, so the parity tests force each in turn
-                                                  # (the box kernels have no helper instantiation: `rollout` runs "wide" for them)
 
 _ORACLE_ROLLOUTS = {}
 
@@ -117,8 +116,6 @@ def rollout(lib, device, n, steps, cfg_name, seed=3, episode_length=40, extra=No
     cfg = make_config(lib, n, seed=seed, episode_length=episode_length, **kw)
     eng = TrifingerEngine(cfg, device=device, lib=lib)
     if variant is not None:
-        if variant == "wide_helpers" and bool(getattr(cfg.model, "box", 0)):
-            variant = "wide"
         eng.kernel_variant = variant
         assert eng.kernel_variant == variant
     if clipping:

@@ -31,12 +31,8 @@ def test_both_instantiations_get_the_occupancy_they_are_built_for(hip):
         assert e.kernel_occupancy == 4, (extra.keys(), e.kernel_occupancy)
         e.kernel_variant = "wide"
         assert e.kernel_occupancy == 2, (extra.keys(), e.kernel_occupancy)
-        if "model" not in extra:                     # eight wavefronts of 256 registers: one workgroup per CU (the cube kernels; the box object has none)
-            e.kernel_variant = "wide_helpers"
-            assert e.kernel_variant == "wide_helpers" and e.kernel_occupancy == 1, (extra.keys(), e.kernel_occupancy)
-        else:
-            with pytest.raises(Exception):
-                e.kernel_variant = "wide_helpers"
+        e.kernel_variant = "wide_helpers"            # eight wavefronts of 256 registers: one workgroup per CU
+        assert e.kernel_variant == "wide_helpers" and e.kernel_occupancy == 1, (extra.keys(), e.kernel_occupancy)
         e.close()
 
 
