@@ -17,6 +17,8 @@ if box:
 eng = TrifingerEngine(make_config(lib, n, seed=11, **kw), device="cuda:0", lib=lib)
 g = torch.Generator(device="cuda:0").manual_seed(3)
 ring = [(torch.rand(n, 9, device="cuda:0", generator=g) * 2 - 1) for _ in range(32)]
+if os.environ.get("VARIANT"):                               # force one instantiation of the step kernel (same bits: a check that an event is the physics')
+    eng.kernel_variant = os.environ["VARIANT"]
 eng.reset()
 nonfinite = torch.zeros((), device="cuda:0"); resets = torch.zeros((), device="cuda:0")
 t0 = time.perf_counter()
