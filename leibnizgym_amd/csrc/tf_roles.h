@@ -78,9 +78,7 @@ DEV constexpr int ffm_mbox(int fd, int k, bool boxw = false) {   // k = 3 x mess
 #define NT_HELP 512
 #define L_HELP_OWN 159                  //  18: velocity change of finger fm's own side, 3 x (o - 1) + j at 6 fm
 #define L_HELP_DR 177                   //   3: domain-randomisation value 5 (restitution) of the substep, published by finger f with its free motion
-#define L_HELP_NZ 160                   //  25: post phase (the mailboxes are dead by then): the uniform draws of the observation noise for slots 0..24, drawn
-                                        //      by the helpers during the sweeps of the last substep (they are functions of env id and frame: known all along)
-#define LDS_SLOTS_HELP 188
+#define LDS_SLOTS_HELP 180
 DEV constexpr int ffm_own_mbox(int fm, int k) { return L_HELP_OWN + 6 * fm + k; }
 #define L_POSE_S 150                    //   6: box kernels only: S = R diag(sqrt(I_ref / I_k)) R^T (00 01 02 11 12 22), published by the cube role
 #define LDS_SLOTS_BOX 159
@@ -1294,16 +1292,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 float nz[28];
 #pragma unroll
                 for (int b = 0; b < 28; ++b) nz[b] = 0.0f;
-                if (HELP) {                                     // drawn by the helper wavefronts during the last substep's sweeps (helper_role): the same numbers
-#pragma unroll
-                    for (int jj = 0; jj < 18; ++jj) nz[jj] = LD(L_HELP_NZ + jj);
-                } else {
 #pragma unroll
                 for (int b = 0; b < 5; ++b) {                   // only the Philox blocks that hold this finger's six slots (wave-uniform: f is)
                     const int lo = 4 * b, hi = 4 * b + 3;
                     const bool need = (lo <= 3 * f + 2 && hi >= 3 * f) || (lo <= 11 + 3 * f && hi >= 9 + 3 * f);
                     if (need) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
-                }
                 }
 #pragma unroll
                 for (int jj = 0; jj < 18; ++jj) {
@@ -1318,16 +1311,11 @@ DEV void finger_role(const DevParams& P, const StepArgs& sa, const float* __rest
                 float nz[28];
 #pragma unroll
                 for (int b = 0; b < 28; ++b) nz[b] = 0.0f;
-                if (HELP) {                                     // drawn by the helper wavefronts during the last substep's sweeps (helper_role): the same numbers
-#pragma unroll
-                    for (int jj = 0; jj < 18; ++jj) nz[jj] = LD(L_HELP_NZ + jj);
-                } else {
 #pragma unroll
                 for (int b = 0; b < 5; ++b) {                   // only the Philox blocks that hold this finger's six slots (wave-uniform: f is)
                     const int lo = 4 * b, hi = 4 * b + 3;
                     const bool need = (lo <= 3 * f + 2 && hi >= 3 * f) || (lo <= 11 + 3 * f && hi >= 9 + 3 * f);
                     if (need) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);
-                }
                 }
 #pragma unroll
                 for (int jj = 0; jj < 18; ++jj) {
@@ -1581,21 +1569,6 @@ DEV void helper_role(const DevParams& P, const StepArgs& sa, float* lds, const C
             }
             BAR();                                              // S1b
             BAR();                                              // S3
-            // the observation noise of this step (uniform draws keyed by env id and frame): drawn here, while the other roles sweep - helper h the
-            // Philox blocks 2 h and 2 h + 1 (wavefront 7: block 6) -, read from L_HELP_NZ by the roles that add it behind P3 / P4
-            if ((MODE & M_POST) && s == nsub - 1 && P.dr_obs_noise > 0.0f) {
-                const uint32_t gid = (uint32_t)(P.env_id_offset + cx.i);
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    const int b = 2 * fm + bb;
-                    if (b < 7 && !(fm == 3 && bb == 1)) {
-                        float u[4];
-                        rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, u);
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) { if (4 * b + k2 < 25) LD(L_HELP_NZ + 4 * b + k2) = u[k2]; }
-                    }
-                }
-            }
             for (int it = 0; it < P.iters; ++it) { BAR(); BAR(); }     // W1, W2
         }
     }
@@ -2578,13 +2551,8 @@ DEV void cube_role(const DevParams& P, const StepArgs& sa, const float* __restri
         }
         auto add_noise = [&]() {
             float nz[28];
-            if (HELP) {                                         // (drawn by the helper wavefronts: helper_role)
-#pragma unroll
-                for (int jj = 18; jj < 25; ++jj) nz[jj] = LD(L_HELP_NZ + jj);
-            } else {
 #pragma unroll
             for (int b = 4; b < 7; ++b) rng4(P, gid, sa.frame, RNG_OBS_NOISE + (uint32_t)b, &nz[4 * b]);      // the blocks that hold slots 18..24
-            }
 #pragma unroll
             for (int jj = 18; jj < 25; ++jj) row[jj] = f_clamp(FMA(P.dr_obs_noise, 2.0f * nz[jj] - 1.0f, row[jj]), -co, co);
         };
