@@ -354,7 +354,7 @@ int tf_set_clipping(tf_handle h, float clip_obs, float clip_actions);
  * after 2^32 frames (3.5 days at 14 000 steps/s; resets are keyed by the per-env reset count and are not affected). */
 int64_t tf_frame_count(tf_handle h);
 int tf_set_frame_count(tf_handle h, int64_t frames);
-/* The fused step exists in two instantiations with the SAME arithmetic (identical results, bit for bit): a 128-register one that puts four
+/* The fused step exists in several instantiations with the SAME arithmetic (identical results, bit for bit): a 128-register one that puts four
  * workgroups on a CU (populations that fill the chip) and a 256-register one without spills or LDS parking for populations that never put more
  * than two workgroups on a CU (num_envs <= TF_WIDE_MAX_ENVS: shorter latency per step).  tf_create picks by num_envs (TF_KERNEL_AUTO); the parity
  * tests and the benchmarks force one or the other.  The oracle accepts and ignores the call.  tf_kernel_variant returns what the launches use
