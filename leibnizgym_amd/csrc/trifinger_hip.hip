@@ -545,8 +545,8 @@ static void launch_env(TfHandle_* h, int lm, const float* action, hipStream_t s)
     a.d_params = h->d_params; a.sa = h->sa; a.action = action; a.stream = s;
     // the helper units carry the launches that simulate; a launch of one of the other hooks (split path) is the plain 256-register kernel
     const bool help = use_helpers(h) && (lm == TF_LM_STEP || lm == TF_LM_STEP_RAND || lm == TF_LM_RESET || lm == TF_LM_SIM);
-#if defined(TF_DEV_MIN)      // developer builds (tools/ab_bench.py, tools/variant_sweep.py): the headline kernels only
-    if (help) tf_launch_env_0_2(lm, a); else if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a);
+#if defined(TF_DEV_MIN)      // developer builds (tools/ab_bench.py, tools/variant_sweep.py): the headline kernels only (the fused launches: no split path)
+    if (help && lm != TF_LM_SIM) tf_launch_env_0_2(lm, a); else if (h->wide) tf_launch_env_0_1(lm, a); else tf_launch_env_0_0(lm, a);
 #else
     const int k = ext_kind(h->cfg);
     if (help) { if (k == 2) tf_launch_env_2_2(lm, a); else if (k == 1) tf_launch_env_1_2(lm, a); else tf_launch_env_0_2(lm, a); }
