@@ -65,6 +65,22 @@ int main(void) {
                      C.sizeof(capi.TfBuffers), capi.TfConfig.model.offset, capi.TfConfig.reward.offset]
 
 
+def test_kernel_variant_names_match_the_header(oracle):
+    """TrifingerEngine.KERNEL_VARIANTS against the TF_KERNEL_* enumerators of include/trifinger.h; the oracle accepts every one of them (and ignores it),
+    rejects what lies outside"""
+    from leibnizgym_amd.engine import TrifingerEngine, make_config
+    text = open(os.path.join(REPO, "include", "trifinger.h")).read()
+    enum = re.search(r"enum \{ (TF_KERNEL_AUTO[^}]*) \};", text).group(1)
+    vals = {k.strip().split(" = ")[0][len("TF_KERNEL_"):].lower(): int(k.strip().split(" = ")[1]) for k in enum.split(",")}
+    assert vals == TrifingerEngine.KERNEL_VARIANTS, (vals, TrifingerEngine.KERNEL_VARIANTS)
+    assert int(re.search(r"#define TF_HELPERS_MAX_ENVS (\d+)", text).group(1)) * 2 == int(re.search(r"#define TF_WIDE_MAX_ENVS (\d+)", text).group(1))
+    eng = TrifingerEngine(make_config(oracle, 8), device="cpu", lib=oracle)
+    for name in vals:
+        eng.kernel_variant = name
+    assert oracle.tf_set_kernel_variant(eng._handle, max(vals.values()) + 1) != 0
+    eng.close()
+
+
 def test_default_models_are_identical(oracle):
     a, b = hip_lib().default_model(), oracle.default_model()
     assert bytes(a) == bytes(b)
